@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the *imported* Python reference.
+
+Runs ONLY in the build container (needs /root/reference); the resulting small
+`.npz` fixtures are committed under tests/golden/ and are what travels to the GPU
+box.  Nothing from the reference's sources is copied: the fixtures hold inputs
+(trace-table windows as the reference constructed them, rack table, sized HVAC
+constants, initial state, the action sequence) and expected outputs (53 obs floats,
+3 rewards, done flag and ~35 info scalars per step).
+
+Determinism fixes applied to the reference:
+  * rack order frozen: `utils.dc_config_reader.as_completed` -> submission order
+    (the reference's ThreadPool `as_completed` order is non-deterministic,
+    /root/reference/utils/dc_config_reader.py:100-105);
+  * `reward_creator.energy_history.clear()` per fixture (module-global deque,
+    /root/reference/utils/reward_creator.py:5);
+  * `random.seed(s); np.random.seed(s)` per fixture (reset uses both:
+    /root/reference/sustaindc_env.py:454-455, utils/managers.py:45,601).
+
+Usage:  python tests/golden/gen_golden.py [--only NAME]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("SDC_REFERENCE", "/root/reference")
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+
+INFO_KEYS = [
+    "ls_original_workload", "ls_shifted_workload", "ls_tasks_in_queue", "ls_norm_tasks_in_queue",
+    "ls_tasks_dropped", "ls_tasks_processed", "ls_oldest_task_age", "ls_average_task_age",
+    "ls_overdue_penalty", "ls_computed_tasks", "ls_current_hour",
+    "dc_ITE_total_power_kW", "dc_CT_total_power_kW", "dc_Compressor_total_power_kW",
+    "dc_HVAC_total_power_kW", "dc_total_power_kW", "dc_crac_setpoint_delta", "dc_crac_setpoint",
+    "dc_cpu_workload_fraction", "dc_int_temperature", "dc_exterior_ambient_temp", "dc_water_usage",
+    "bat_action", "bat_SOC", "bat_CO2_footprint", "bat_avg_CI",
+    "bat_total_energy_without_battery_KWh", "bat_total_energy_with_battery_KWh",
+    "norm_CI", "outside_temp", "day", "hour",
+]
+
+
+def _install_shims():
+    sys.path.insert(0, os.path.join(HERE, "_shims"))
+    sys.path.insert(0, REF)
+    # sustaindc_env.py:32 imports the Dash dashboard through harl/envs/__init__.py, which
+    # pulls absl / dash_bootstrap_components (absent).  Pre-register a dummy module.
+    for name in ("harl", "harl.envs", "harl.envs.sustaindc"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    dash = types.ModuleType("harl.envs.sustaindc.dashboard_v2")
+
+    class Dashboard:  # pragma: no cover - never started
+        def __init__(self, *a, **k):
+            pass
+
+        def start(self):
+            pass
+
+    dash.Dashboard = Dashboard
+    sys.modules["harl.envs.sustaindc.dashboard_v2"] = dash
+    import utils.dc_config_reader as dcr
+    dcr.as_completed = lambda futures: list(futures)  # freeze rack order = JSON order
+
+
+def _static_block(env):
+    """As-constructed per-rack table and init-time constants."""
+    dc = env.dc_env
+    cfg = dc.DC_Config
+    racks = dc.dc.racks_list
+    out = {
+        "rack_n": np.array([r.num_CPUs for r in racks], dtype=np.float64),
+        "rack_full": np.array([r.full_load_pwr[0] for r in racks], dtype=np.float64),
+        "rack_idle": np.array([r.idle_pwr[0] for r in racks], dtype=np.float64),
+        "rack_supply": np.array(cfg.RACK_SUPPLY_APPROACH_TEMP_LIST, dtype=np.float64),
+        "rack_return": np.array(cfg.RACK_RETURN_APPROACH_TEMP_LIST, dtype=np.float64),
+        # every CPU in a rack is identical; record the scalars the rack model uses
+        "m_cpu": racks[0].m_cpu[0], "c_cpu": racks[0].c_cpu[0], "rs_cpu": racks[0].ratio_shift_max_cpu[0],
+        "m_fan": racks[0].m_itfan[0], "c_fan": racks[0].c_itfan[0], "rs_fan": racks[0].ratio_shift_max_itfan[0],
+        "itfan_ref_p": cfg.ITFAN_REF_P, "itfan_ref_v_ratio": cfg.ITFAN_REF_V_RATIO,
+        "it_fan_full_load_v": cfg.IT_FAN_FULL_LOAD_V,
+        "c_air": cfg.C_AIR, "rho_air": cfg.RHO_AIR,
+        "crac_supply_pu": cfg.CRAC_SUPPLY_AIR_FLOW_RATE_pu,
+        "ct_fan_ref_p": cfg.CT_FAN_REF_P,            # sized (make_envs_pyenv.py:159-161)
+        "ctafr": cfg.CT_REFRENCE_AIR_FLOW_RATE,      # sized
+        "min_temp": dc.min_temp, "max_temp": dc.max_temp,
+        "power_lb_kW": dc.power_lb_kW, "power_ub_kW": dc.power_ub_kW,
+        "bat_capacity": env.bat_env.battery.capacity,
+        "bat_dcload_min": env.bat_env.dcload_min, "bat_dcload_max": env.bat_env.dcload_max,
+        "range_zone_air": np.array(dc.ranges["Zone Air Temperature(West Zone)"], dtype=np.float64),
+        "range_hvac": np.array(dc.ranges["Facility Total HVAC Electricity Demand Rate(Whole Building)"], dtype=np.float64),
+        "range_total": np.array(dc.ranges["Facility Total Electricity Demand Rate(Whole Building)"], dtype=np.float64),
+        "range_it": np.array(dc.ranges["Facility Total Building Electricity Demand Rate(Whole Building)"], dtype=np.float64),
+        "init_day": env.init_day,
+        "queue_max_len": env.ls_env.queue_max_len,
+    }
+    return {k: np.asarray(v) for k, v in out.items()}
+
+
+def _policy(name, steps, rng):
+    a = rng.integers(0, 3, size=(steps, 3))
+    if name == "random":
+        pass
+    elif name == "defer":
+        a[:, 0] = 0
+    elif name == "process":
+        a[:, 0] = 2
+    elif name == "defer_drain":
+        a[:, 0] = 0
+        a[min(300, steps // 2):, 0] = 2
+    elif name == "stpt_up":
+        a[:, 1] = 2
+    elif name == "stpt_down":
+        a[:, 1] = 0
+    elif name == "stpt_saw":
+        blk = (np.arange(steps) // 9) % 2
+        a[:, 1] = np.where(blk == 0, 2, 0)
+    elif name == "bat_cycle":
+        blk = (np.arange(steps) // 50) % 2
+        a[:, 2] = np.where(blk == 0, 0, 1)
+    elif name == "idle":
+        a[:, 0] = 1
+        a[:, 1] = 1
+        a[:, 2] = 2
+    else:
+        raise ValueError(name)
+    return a.astype(np.int32)
+
+
+def _flat_obs(obs):
+    return np.concatenate([obs["agent_ls"], obs["agent_dc"], obs["agent_bat"]]).astype(np.float32)
+
+
+def _episode_inputs(env, steps):
+    """Trace-table windows exactly as the reference's managers hold them after reset()."""
+    c0 = env.ci_m.time_step
+    lo = max(0, c0 - 16)
+    hi = c0 + steps + 18
+    ci = env.ci_m
+    we = env.weather_m
+    wl = env.workload_m
+    assert hi <= len(ci.carbon_smooth), "episode runs past the year table (reference would raise IndexError)"
+    return {
+        "cursor0": c0, "win_lo": lo,
+        "W": np.array(wl.cpu_smooth[lo:hi], dtype=np.float64),
+        "C": np.array(ci.carbon_smooth[lo:hi], dtype=np.float64),
+        "NC": np.array(ci.norm_carbon[lo:hi], dtype=np.float64),
+        "T": np.array(we.temperature_data[lo:hi], dtype=np.float64),
+        "WB": np.array(we.wet_bulb_data[lo:hi], dtype=np.float64),
+        "NT": np.array(we.norm_temp_data[lo:hi], dtype=np.float64),
+        "ci_min30": np.min(ci.carbon_smooth[c0:c0 + 2880]), "ci_max30": np.max(ci.carbon_smooth[c0:c0 + 2880]),
+        "t_min30": np.min(we.temperature_data[c0:c0 + 2880]), "t_max30": np.max(we.temperature_data[c0:c0 + 2880]),
+        "init_day": env.t_m.day, "init_hour": env.t_m.hour,
+    }
+
+
+def run_fixture(spec):
+    from utils import reward_creator
+    from sustaindc_env import SustainDC
+
+    seed = spec["seed"]
+    reward_creator.energy_history.clear()
+    random.seed(seed)
+    np.random.seed(seed)
+    cfg = {
+        "location": spec["location"], "month": spec["month"],
+        "days_per_episode": spec.get("days", 7),
+        "datacenter_capacity_mw": spec.get("capacity_mw", 1),
+        "dc_config_file": spec.get("dc_config_file", "dc_config.json"),
+        "agents": ["agent_ls", "agent_dc", "agent_bat"],
+    }
+    env = SustainDC(cfg)
+    if "force_day_range" in spec:
+        env.ranges_day = list(spec["force_day_range"])   # public attribute (sustaindc_env.py:198)
+    steps = cfg["days_per_episode"] * 96
+    n_ep = spec.get("episodes", 1)
+    rng = np.random.default_rng(seed)
+    out = {f"static_{k}": v for k, v in _static_block(env).items()}
+    out["meta_location"] = np.array(spec["location"])
+    out["meta_month"] = np.array(spec["month"])
+    out["meta_steps"] = np.array(steps)
+    out["meta_episodes"] = np.array(n_ep)
+    out["meta_seed"] = np.array(seed)
+    out["meta_policy"] = np.array(spec["policy"])
+    out["meta_info_keys"] = np.array(INFO_KEYS)
+    out["init_stpt"] = np.array(env.dc_env.raw_curr_stpt, dtype=np.float64)
+
+    reset_obs = _flat_obs(env.reset())
+    for ep in range(n_ep):
+        if spec.get("need_early_cursor") and env.ci_m.time_step >= 15:
+            raise RuntimeError("seed does not give cursor < 15; pick another")
+        inputs = _episode_inputs(env, steps)
+        acts = _policy(spec["policy"], steps, rng)
+        obs = np.zeros((steps, 53), dtype=np.float32)
+        rew = np.zeros((steps, 3), dtype=np.float64)
+        done = np.zeros(steps, dtype=np.uint8)
+        info = np.zeros((steps, len(INFO_KEYS)), dtype=np.float64)
+        hist = np.zeros((steps, 5), dtype=np.float64)
+        hist_len0 = len(reward_creator.energy_history)
+        stpt0 = env.dc_env.raw_curr_stpt
+        for t in range(steps):
+            a = acts[t]
+            o, r, term, trunc, inf = env.step({"agent_ls": int(a[0]), "agent_dc": int(a[1]), "agent_bat": int(a[2])})
+            obs[t] = _flat_obs(o)
+            rew[t] = [r["agent_ls"], r["agent_dc"], r["agent_bat"]]
+            done[t] = 1 if (trunc["__all__"] or term["__all__"]) else 0
+            common = inf["agent_ls"]
+            info[t] = [float(common[k]) for k in INFO_KEYS]
+            hist[t] = np.asarray(common["ls_task_age_histogram"], dtype=np.float64)
+        assert done[-1] == 1 and done[:-1].sum() == 0
+        p = f"ep{ep}_"
+        for k, v in inputs.items():
+            out[p + k] = np.asarray(v)
+        out[p + "reset_obs"] = reset_obs
+        out[p + "actions"] = acts
+        out[p + "obs"] = obs
+        out[p + "rew"] = rew
+        out[p + "done"] = done
+        out[p + "info"] = info
+        out[p + "age_hist"] = hist
+        out[p + "hist_len0"] = np.array(hist_len0)
+        out[p + "stpt0"] = np.array(stpt0, dtype=np.float64)
+        # HARL auto-reset (harl/envs/env_wrappers.py:176-190): reset inside the same step call
+        reset_obs = _flat_obs(env.reset())
+    out["final_energy_history_tail"] = np.array(list(reward_creator.energy_history)[-64:], dtype=np.float64)
+    return out
+
+
+VARIANT_DIR = os.path.join(REPO, "dc-rl_amd", "configs")
+
+SPECS = {
+    # BASELINE.json config 1: NY, Alibaba trace, month 6, 7 days, seed 0, uniform-random actions
+    "ny_m6_random": dict(location="ny", month=6, seed=0, policy="random"),
+    "ny_m0_defer": dict(location="ny", month=0, seed=1, policy="defer"),
+    "ca_m3_defer_drain": dict(location="ca", month=3, seed=2, policy="defer_drain"),
+    "az_m7_stpt_saw": dict(location="az", month=7, seed=3, policy="stpt_saw"),
+    "wa_m11_bat_cycle": dict(location="wa", month=11, seed=4, policy="bat_cycle"),
+    "tx_m9_stpt_down_2mw": dict(location="tx", month=9, seed=5, policy="stpt_down", capacity_mw=2),
+    "il_m1_process": dict(location="il", month=1, seed=6, policy="process"),
+    # 0.5 MW: MAX_W_PER_RACK = 25 kW caps the CPUs per rack (datacenter.py:67-74) -> ragged n_r
+    "ga_m4_idle_halfmw": dict(location="ga", month=4, seed=11, policy="idle", capacity_mw=0.5),
+    # cursor < 16 edge (get_n_past_ci returns an empty slice, managers.py:482-483)
+    "ny_m0_early_cursor": dict(location="ny", month=0, seed=None, policy="random", force_day_range=(0, 0),
+                               need_early_cursor=True),
+    # history deque crosses 10 000, set-point carried across resets (16 x 672 = 10 752 steps)
+    "ny_m6_multi16": dict(location="ny", month=6, seed=7, policy="random", episodes=16),
+    # HARL YAML shape: 30-day episode, location ca
+    "ca_m6_30day": dict(location="ca", month=6, seed=8, policy="defer_drain", days=30),
+    # heterogeneous rack-count variants (our own JSONs; BASELINE config 4)
+    "ny_m5_r16": dict(location="ny", month=5, seed=9, policy="random",
+                      dc_config_file=os.path.join(VARIANT_DIR, "dc_config_r16.json")),
+    "ny_m5_r25": dict(location="ny", month=5, seed=10, policy="stpt_up",
+                      dc_config_file=os.path.join(VARIANT_DIR, "dc_config_r25.json")),
+}
+
+
+def _find_early_seed():
+    """Seed for which (day 0, hour < 4) -> cursor < 16; uses python `random` exactly like reset()."""
+    for s in range(1000):
+        random.seed(s)
+        d = random.randint(0, 0)
+        h = random.randint(0, 23)
+        if d == 0 and h < 2:
+            return s
+    raise RuntimeError
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    _install_shims()
+    SPECS["ny_m0_early_cursor"]["seed"] = _find_early_seed()
+    for name, spec in SPECS.items():
+        if args.only and name != args.only:
+            continue
+        if "dc_config_file" in spec and not os.path.exists(spec["dc_config_file"]):
+            print(f"skip {name}: {spec['dc_config_file']} missing")
+            continue
+        out = run_fixture(spec)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
