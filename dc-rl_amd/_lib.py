@@ -1,0 +1,139 @@
+"""ctypes binding of the C-ABI in include/sustaindc_hip.h (csrc/libsustaindc_hip.so).
+
+Loading fails loudly: there is no CPU fallback for the product path.  `import torch` must happen
+before the library is loaded so that the HIP runtime already mapped into the process (PyTorch-ROCm's
+libamdhip64.so.7) is the one our kernels launch through -- tensors and kernels then share one context.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+MAX_RACKS = 64
+N_AGENTS = 3
+OBS_PAD = 26
+SHARE_OBS_DIM = 29
+INFO_DIM = 40
+TABLE_LEN = 35040
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
+SOURCES = ["sdc_capi.hip", "sdc_step.hip", "sdc_reset.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+# info column names = the reference's info keys (sustaindc_hip.h enum sdc_info_col)
+INFO_COLS = [
+    "ls_original_workload", "ls_shifted_workload", "ls_tasks_in_queue", "ls_norm_tasks_in_queue",
+    "ls_tasks_dropped", "ls_tasks_processed", "ls_oldest_task_age", "ls_average_task_age",
+    "ls_overdue_penalty", "ls_computed_tasks", "ls_current_hour",
+    "ls_task_age_hist0", "ls_task_age_hist1", "ls_task_age_hist2", "ls_task_age_hist3", "ls_task_age_hist4",
+    "dc_ITE_total_power_kW", "dc_CT_total_power_kW", "dc_Compressor_total_power_kW",
+    "dc_HVAC_total_power_kW", "dc_total_power_kW", "dc_crac_setpoint_delta", "dc_crac_setpoint",
+    "dc_cpu_workload_fraction", "dc_int_temperature", "dc_exterior_ambient_temp", "dc_water_usage",
+    "bat_action", "bat_SOC", "bat_CO2_footprint", "bat_avg_CI",
+    "bat_total_energy_without_battery_KWh", "bat_total_energy_with_battery_KWh",
+    "norm_CI", "outside_temp", "day", "hour", "fault", "energy_z", "reserved",
+]
+INFO_IDX = {k: i for i, k in enumerate(INFO_COLS)}
+assert len(INFO_COLS) == INFO_DIM
+
+
+class SdcConfig(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32), ("device", C.c_int32), ("episode_steps", C.c_int32), ("hist_cap", C.c_int32),
+        ("queue_max_len", C.c_int32), ("n_locations", C.c_int32), ("n_dc_configs", C.c_int32),
+        ("auto_reset", C.c_int32), ("seed", C.c_uint64), ("weather_noise_std", C.c_double),
+        ("weather_noise_weight", C.c_double), ("max_roll_days", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class SdcDcParams(C.Structure):
+    _fields_ = [
+        ("n_racks", C.c_int32), ("reserved", C.c_int32),
+        ("rack_n", C.c_double * MAX_RACKS), ("rack_full", C.c_double * MAX_RACKS),
+        ("rack_idle", C.c_double * MAX_RACKS), ("rack_supply", C.c_double * MAX_RACKS),
+        ("rack_return", C.c_double * MAX_RACKS),
+        ("m_cpu", C.c_double), ("c_cpu", C.c_double), ("rs_cpu", C.c_double),
+        ("m_fan", C.c_double), ("c_fan", C.c_double), ("rs_fan", C.c_double),
+        ("itfan_ref_p", C.c_double), ("itfan_ref_v_ratio", C.c_double), ("it_fan_full_load_v", C.c_double),
+        ("c_air", C.c_double), ("rho_air", C.c_double), ("crac_supply_pu", C.c_double),
+        ("ct_fan_ref_p", C.c_double), ("ctafr", C.c_double),
+        ("min_temp", C.c_double), ("max_temp", C.c_double), ("init_setpoint", C.c_double),
+        ("bat_capacity_mwh", C.c_double),
+    ]
+
+
+class SdcResetOverride(C.Structure):
+    _fields_ = [
+        ("day", C.POINTER(C.c_int32)), ("hour", C.POINTER(C.c_int32)),
+        ("ci_min", C.POINTER(C.c_double)), ("ci_max", C.POINTER(C.c_double)),
+        ("t_min", C.POINTER(C.c_double)), ("t_max", C.POINTER(C.c_double)),
+        ("t_win", C.POINTER(C.c_double)), ("wb_win", C.POINTER(C.c_double)),
+    ]
+
+
+EXPORTS = [
+    "sdc_last_error", "sdc_version", "sdc_create", "sdc_destroy", "sdc_weather_window_len", "sdc_set_tables",
+    "sdc_set_dc_params", "sdc_assign_envs", "sdc_reset", "sdc_step", "sdc_get_state", "sdc_set_state",
+    "sdc_hist_stride", "sdc_queue_stride",
+]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "sdc_device.hpp"),
+                   os.path.join(CSRC, "..", "..", "include", "sustaindc_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Return the loaded library; raises RuntimeError if the extension is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (maps PyTorch-ROCm's HIP runtime first; see module docstring)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or dc_rl_amd._lib.build()). There is no CPU fallback for the SustainDC step.")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp, fp, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_uint8)
+    L.sdc_last_error.restype = C.c_char_p
+    L.sdc_version.restype = C.c_int
+    L.sdc_create.argtypes = [C.POINTER(SdcConfig), C.POINTER(vp)]
+    L.sdc_destroy.argtypes = [vp]
+    L.sdc_weather_window_len.argtypes = [vp]
+    L.sdc_hist_stride.argtypes = [vp]
+    L.sdc_queue_stride.argtypes = [vp]
+    L.sdc_set_tables.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_int]
+    L.sdc_set_dc_params.argtypes = [vp, C.c_int, C.POINTER(SdcDcParams)]
+    L.sdc_assign_envs.argtypes = [vp, ip, ip, ip, ip]
+    L.sdc_reset.argtypes = [vp, u8p, C.POINTER(SdcResetOverride), fp, fp, vp]
+    L.sdc_step.argtypes = [vp, vp, fp, fp, fp, vp, fp, fp, vp]
+    L.sdc_get_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    L.sdc_set_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    for name in EXPORTS:
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+class SdcError(RuntimeError):
+    pass
+
+
+def check(rc: int):
+    if rc != 0:
+        raise SdcError(load().sdc_last_error().decode())

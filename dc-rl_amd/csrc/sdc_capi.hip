@@ -1,0 +1,409 @@
+// sdc_capi.hip -- host side of the C-ABI declared in include/sustaindc_hip.h.
+//
+// Owns the device-resident struct-of-arrays state of N environments on one GPU and launches the two
+// kernels (sdc_step_kernel, sdc_reset_kernel) on the caller's stream.  No CPU fallback: every entry
+// point fails with an error code when HIP reports one.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sdc_device.hpp"
+
+extern "C" __global__ void sdc_step_kernel(SdcDev S, const int32_t* actions, float* obs, float* share_obs, float* rew,
+                                           unsigned char* done, float* info, float* final_obs);
+extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
+                                            const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
+                                            const double* ovr_t_max, int only_done, float* obs, float* share_obs);
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* what, hipError_t e) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return -1;
+}
+int fail_msg(const std::string& m) {
+  g_err = m;
+  return -2;
+}
+
+#define HIP_TRY(expr)                          \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) return fail(#expr, _e); \
+  } while (0)
+
+struct Field {
+  const char* name;
+  void** ptr;
+  size_t elem;    // bytes per env
+};
+
+}  // namespace
+
+struct sdc_handle {
+  sdc_config cfg;
+  SdcDev d;
+  int device;
+  std::vector<void*> allocs;
+  std::vector<Field> fields;
+  // override staging (device)
+  int* ovr_day = nullptr;
+  int* ovr_hour = nullptr;
+  double* ovr_ci_min = nullptr;
+  double* ovr_ci_max = nullptr;
+  double* ovr_t_min = nullptr;
+  double* ovr_t_max = nullptr;
+  // host mirror for auto-reset scheduling: steps left until the earliest env finishes
+  std::vector<int> host_t_rel;  // exact at the last sync point
+  int pending = 0;              // steps launched since then (every env advances by one per step)
+  int steps_to_terminal = 0;
+  bool tables_set = false, assigned = false, started = false;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(sdc_handle* h, T** p, size_t count, bool zero = true) {
+  void* q = nullptr;
+  HIP_TRY(hipMalloc(&q, count * sizeof(T)));
+  if (zero) HIP_TRY(hipMemset(q, 0, count * sizeof(T)));
+  h->allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return 0;
+}
+
+// fold the steps launched since the last sync point into the per-env mirror
+void sync_mirror(sdc_handle* h) {
+  if (h->pending) {
+    for (int e = 0; e < h->cfg.n_envs; e++) h->host_t_rel[e] += h->pending;
+    h->pending = 0;
+  }
+}
+
+void recompute_steps_to_terminal(sdc_handle* h) {
+  sync_mirror(h);
+  int m = 1 << 30;
+  for (int e = 0; e < h->cfg.n_envs; e++) {
+    const int left = h->cfg.episode_steps - h->host_t_rel[e];
+    if (left < m) m = left;
+  }
+  h->steps_to_terminal = m;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sdc_last_error(void) { return g_err.c_str(); }
+int sdc_version(void) { return 100; }
+
+int sdc_create(const sdc_config* cfg, sdc_handle** out) {
+  if (!cfg || !out) return fail_msg("sdc_create: null argument");
+  if (cfg->n_envs <= 0) return fail_msg("sdc_create: n_envs must be > 0");
+  if (cfg->episode_steps <= 0) return fail_msg("sdc_create: episode_steps must be > 0");
+  if (cfg->hist_cap < 2 || cfg->hist_cap > SDC_HIST_STRIDE)
+    return fail_msg("sdc_create: hist_cap must be in [2, 10240]");
+  if (cfg->n_locations <= 0 || cfg->n_dc_configs <= 0) return fail_msg("sdc_create: need >= 1 location and dc config");
+  if (cfg->queue_max_len <= 0 || cfg->queue_max_len > 65535) return fail_msg("sdc_create: bad queue_max_len");
+  if ((long long)cfg->episode_steps * 20 > 0x7FFFFFFFLL / cfg->episode_steps)
+    return fail_msg("sdc_create: episode too long for the 32-bit queue prefix sums");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail_msg("sdc_create: no such HIP device");
+  HIP_TRY(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail_msg(std::string("sdc_create: built for gfx950 (MI355X) only, device is ") + prop.gcnArchName);
+
+  sdc_handle* h = new sdc_handle();
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  SdcDev& d = h->d;
+  std::memset(&d, 0, sizeof(d));
+  const int N = cfg->n_envs;
+  d.n_envs = N;
+  d.episode_steps = cfg->episode_steps;
+  d.hist_cap = cfg->hist_cap;
+  d.queue_max = cfg->queue_max_len;
+  d.table_len = SDC_TABLE_LEN;
+  d.lw = cfg->episode_steps + 18;
+  d.qstride = (cfg->episode_steps + 63) / 64 * 64;
+  d.max_roll_days = cfg->max_roll_days;
+  d.seed = cfg->seed;
+  d.noise_std = cfg->weather_noise_std;
+  d.noise_weight = cfg->weather_noise_weight;
+
+#define A(ptr, count)                                              \
+  do {                                                             \
+    if (dev_alloc(h, &(ptr), (size_t)(count)) != 0) {              \
+      sdc_destroy(h);                                              \
+      return -1;                                                   \
+    }                                                              \
+  } while (0)
+  double *tabW, *tabC, *tabT, *tabWB, *hour_lut;
+  sdc_dc_params* dcp;
+  int *loc_id, *cfg_id, *day_lo, *day_hi;
+  A(tabW, (size_t)cfg->n_locations * SDC_TABLE_LEN);
+  A(tabC, (size_t)cfg->n_locations * SDC_TABLE_LEN);
+  A(tabT, (size_t)cfg->n_locations * SDC_TABLE_LEN);
+  A(tabWB, (size_t)cfg->n_locations * SDC_TABLE_LEN);
+  A(hour_lut, 96 * 2);
+  A(dcp, cfg->n_dc_configs);
+  A(loc_id, N);
+  A(cfg_id, N);
+  A(day_lo, N);
+  A(day_hi, N);
+  d.tabW = tabW; d.tabC = tabC; d.tabT = tabT; d.tabWB = tabWB; d.hour_lut = hour_lut; d.dc = dcp;
+  d.loc_id = loc_id; d.cfg_id = cfg_id; d.day_lo = day_lo; d.day_hi = day_hi;
+  A(d.cursor, N); A(d.t_rel, N); A(d.day, N); A(d.hourq, N);
+  A(d.q_popped, N); A(d.q_cum, N); A(d.q_cumT, N); A(d.q_head, N);
+  A(d.qtab, (size_t)N * d.qstride);
+  A(d.last_delta, N); A(d.consecutive, N); A(d.scale, N);
+  A(d.hist_len, N); A(d.hist_pos, N); A(d.episode, N); A(d.fault, N);
+  A(d.stpt, N); A(d.bat_load, N); A(d.ci_min, N); A(d.ci_den, N); A(d.t_min, N); A(d.t_den, N);
+  A(d.carry, (size_t)SDC_CARRY_DIM * N);
+  A(d.t_win, (size_t)N * d.lw);
+  A(d.wb_win, (size_t)N * d.lw);
+  {
+    const size_t w = (size_t)(d.lw > SDC_NORM_WINDOW ? d.lw : SDC_NORM_WINDOW);
+    A(d.walk_tmp, (size_t)N * w);
+  }
+  A(d.hist, (size_t)N * SDC_HIST_STRIDE);
+  A(d.reset_mask, N);
+  A(h->ovr_day, N); A(h->ovr_hour, N);
+  A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
+#undef A
+
+  // hour LUT: utils/managers.py:66-88 sc_obs -- round(hour/24, 3) * 2pi -> cos/sin * 0.5 + 0.5
+  {
+    double lut[192];
+    const double two_pi = 3.141592653589793 * 2;
+    for (int q = 0; q < 96; q++) {
+      const double hour = q * 0.25;
+      const double nh = (std::rint((hour / 24) * 1000.0) / 1000.0) * two_pi;
+      lut[2 * q] = std::cos(nh) * 0.5 + 0.5;
+      lut[2 * q + 1] = std::sin(nh) * 0.5 + 0.5;
+    }
+    if (hipMemcpy(hour_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) {
+      sdc_destroy(h);
+      return fail_msg("sdc_create: hour LUT upload failed");
+    }
+  }
+  // scale starts at 1, last_delta = None
+  {
+    std::vector<int> ones(N, 1), none(N, -2);
+    hipMemcpy(d.scale, ones.data(), sizeof(int) * N, hipMemcpyHostToDevice);
+    hipMemcpy(d.last_delta, none.data(), sizeof(int) * N, hipMemcpyHostToDevice);
+  }
+  h->host_t_rel.assign(N, cfg->episode_steps);  // "finished": a reset is required before stepping
+  h->fields = {
+      {"cursor", (void**)&d.cursor, 4}, {"t_rel", (void**)&d.t_rel, 4}, {"day", (void**)&d.day, 4},
+      {"hourq", (void**)&d.hourq, 4}, {"q_popped", (void**)&d.q_popped, 4}, {"q_cum", (void**)&d.q_cum, 4},
+      {"q_cumT", (void**)&d.q_cumT, 4}, {"q_head", (void**)&d.q_head, 4}, {"last_delta", (void**)&d.last_delta, 4},
+      {"consecutive", (void**)&d.consecutive, 4}, {"scale", (void**)&d.scale, 4}, {"hist_len", (void**)&d.hist_len, 4},
+      {"hist_pos", (void**)&d.hist_pos, 4}, {"episode", (void**)&d.episode, 4}, {"fault", (void**)&d.fault, 4},
+      {"stpt", (void**)&d.stpt, 8}, {"bat_load", (void**)&d.bat_load, 8}, {"ci_min", (void**)&d.ci_min, 8},
+      {"ci_den", (void**)&d.ci_den, 8}, {"t_min", (void**)&d.t_min, 8}, {"t_den", (void**)&d.t_den, 8},
+      {"carry", (void**)&d.carry, 8 * SDC_CARRY_DIM},
+      {"hist", (void**)&d.hist, sizeof(float) * SDC_HIST_STRIDE},
+      {"t_win", (void**)&d.t_win, sizeof(double) * (size_t)d.lw},
+      {"wb_win", (void**)&d.wb_win, sizeof(double) * (size_t)d.lw},
+      {"qtab", (void**)&d.qtab, sizeof(uint2) * (size_t)d.qstride},
+  };
+  *out = h;
+  return 0;
+}
+
+int sdc_destroy(sdc_handle* h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  for (void* p : h->allocs) hipFree(p);
+  delete h;
+  return 0;
+}
+
+int sdc_weather_window_len(const sdc_handle* h) { return h ? h->d.lw : -1; }
+int sdc_hist_stride(const sdc_handle* h) { return h ? SDC_HIST_STRIDE : -1; }
+int sdc_queue_stride(const sdc_handle* h) { return h ? h->d.qstride : -1; }
+
+int sdc_set_tables(sdc_handle* h, int loc_id, const double* W, const double* C, const double* T, const double* WB,
+                   int n) {
+  if (!h || !W || !C || !T || !WB) return fail_msg("sdc_set_tables: null argument");
+  if (loc_id < 0 || loc_id >= h->cfg.n_locations) return fail_msg("sdc_set_tables: loc_id out of range");
+  if (n != SDC_TABLE_LEN) return fail_msg("sdc_set_tables: tables must hold 35040 samples");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t off = (size_t)loc_id * SDC_TABLE_LEN, bytes = sizeof(double) * SDC_TABLE_LEN;
+  HIP_TRY(hipMemcpy(const_cast<double*>(h->d.tabW) + off, W, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(const_cast<double*>(h->d.tabC) + off, C, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(const_cast<double*>(h->d.tabT) + off, T, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(const_cast<double*>(h->d.tabWB) + off, WB, bytes, hipMemcpyHostToDevice));
+  h->tables_set = true;
+  return 0;
+}
+
+int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
+  if (!h || !p) return fail_msg("sdc_set_dc_params: null argument");
+  if (cfg_id < 0 || cfg_id >= h->cfg.n_dc_configs) return fail_msg("sdc_set_dc_params: cfg_id out of range");
+  if (p->n_racks <= 0 || p->n_racks > SDC_MAX_RACKS) return fail_msg("sdc_set_dc_params: n_racks must be in [1, 64]");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpy(const_cast<sdc_dc_params*>(h->d.dc) + cfg_id, p, sizeof(*p), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id, const int32_t* day_lo,
+                    const int32_t* day_hi) {
+  if (!h || !loc_id || !cfg_id || !day_lo || !day_hi) return fail_msg("sdc_assign_envs: null argument");
+  const int N = h->cfg.n_envs;
+  for (int e = 0; e < N; e++) {
+    if (loc_id[e] < 0 || loc_id[e] >= h->cfg.n_locations) return fail_msg("sdc_assign_envs: loc_id out of range");
+    if (cfg_id[e] < 0 || cfg_id[e] >= h->cfg.n_dc_configs) return fail_msg("sdc_assign_envs: cfg_id out of range");
+    if (day_lo[e] < 0 || day_hi[e] > 364 || day_lo[e] > day_hi[e]) return fail_msg("sdc_assign_envs: bad day range");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t b = sizeof(int) * (size_t)N;
+  HIP_TRY(hipMemcpy(const_cast<int*>(h->d.loc_id), loc_id, b, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(const_cast<int*>(h->d.cfg_id), cfg_id, b, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(const_cast<int*>(h->d.day_lo), day_lo, b, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(const_cast<int*>(h->d.day_hi), day_hi, b, hipMemcpyHostToDevice));
+  // the CRAC set-point starts at the config's initial value (make_envs_pyenv.py:124) and is never reset
+  if (!h->started) {
+    std::vector<sdc_dc_params> ps(h->cfg.n_dc_configs);
+    HIP_TRY(hipMemcpy(ps.data(), h->d.dc, sizeof(sdc_dc_params) * ps.size(), hipMemcpyDeviceToHost));
+    std::vector<double> st(N);
+    for (int e = 0; e < N; e++) st[e] = ps[cfg_id[e]].init_setpoint;
+    HIP_TRY(hipMemcpy(h->d.stpt, st.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+  }
+  h->assigned = true;
+  return 0;
+}
+
+int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override* ovr, float* obs, float* share_obs,
+              void* stream) {
+  if (!h) return fail_msg("sdc_reset: null handle");
+  if (!h->tables_set || !h->assigned) return fail_msg("sdc_reset: call sdc_set_tables / sdc_set_dc_params / sdc_assign_envs first");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int N = h->cfg.n_envs;
+  SdcDev d = h->d;
+  if (mask_host) {
+    HIP_TRY(hipMemcpyAsync(d.reset_mask, mask_host, (size_t)N, hipMemcpyHostToDevice, st));
+  } else {
+    d.reset_mask = nullptr;
+  }
+  if (ovr) {
+    if (!ovr->day || !ovr->hour || !ovr->ci_min || !ovr->ci_max || !ovr->t_min || !ovr->t_max || !ovr->t_win ||
+        !ovr->wb_win)
+      return fail_msg("sdc_reset: incomplete override");
+    for (int e = 0; e < N; e++) {
+      if (mask_host && !mask_host[e]) continue;
+      if (ovr->day[e] < 0 || ovr->day[e] > 364 || ovr->hour[e] < 0 || ovr->hour[e] > 23)
+        return fail_msg("sdc_reset: override day/hour out of range");
+    }
+    HIP_TRY(hipMemcpyAsync(h->ovr_day, ovr->day, sizeof(int) * (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->ovr_hour, ovr->hour, sizeof(int) * (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->ovr_ci_min, ovr->ci_min, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->ovr_ci_max, ovr->ci_max, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->ovr_t_min, ovr->t_min, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->ovr_t_max, ovr->t_max, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    const size_t row = sizeof(double) * (size_t)d.lw;
+    if (!mask_host) {
+      HIP_TRY(hipMemcpyAsync(d.t_win, ovr->t_win, row * N, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(d.wb_win, ovr->wb_win, row * N, hipMemcpyHostToDevice, st));
+    } else {
+      for (int e = 0; e < N; e++) {
+        if (!mask_host[e]) continue;
+        HIP_TRY(hipMemcpyAsync(d.t_win + (size_t)e * d.lw, ovr->t_win + (size_t)e * d.lw, row, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d.wb_win + (size_t)e * d.lw, ovr->wb_win + (size_t)e * d.lw, row, hipMemcpyHostToDevice, st));
+      }
+    }
+    // the host buffers may be pageable: the copies above must have consumed them before we return
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, ovr ? 1 : 0, h->ovr_day, h->ovr_hour,
+                     h->ovr_ci_min, h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 0, obs, share_obs);
+  HIP_TRY(hipGetLastError());
+  if (mask_host) HIP_TRY(hipStreamSynchronize(st));  // mask staging buffer is reused by the next call
+  sync_mirror(h);
+  for (int e = 0; e < N; e++)
+    if (!mask_host || mask_host[e]) h->host_t_rel[e] = 0;
+  recompute_steps_to_terminal(h);
+  h->started = true;
+  return 0;
+}
+
+int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs, float* rew, uint8_t* done,
+             float* info, float* final_obs, void* stream) {
+  if (!h || !actions || !obs || !rew || !done) return fail_msg("sdc_step: null argument");
+  if (!h->started) return fail_msg("sdc_step: sdc_reset must be called first");
+  if (h->steps_to_terminal <= 0)
+    return fail_msg("sdc_step: an environment has finished its episode; call sdc_reset (auto_reset is off)");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int N = h->cfg.n_envs;
+  hipLaunchKernelGGL(sdc_step_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, h->d, actions, obs, share_obs, rew, done, info,
+                     final_obs);
+  HIP_TRY(hipGetLastError());
+  h->steps_to_terminal -= 1;
+  h->pending += 1;
+  if (h->steps_to_terminal == 0) {
+    // At least one env just finished.  Episodes have a fixed length and every env advances one step per
+    // launch, so the host knows this from its mirror of the step counters -- no device read-back.
+    sync_mirror(h);
+    if (h->cfg.auto_reset) {
+      // harl/envs/env_wrappers.py:176-190: reset inside the same step call and return the reset obs
+      SdcDev d = h->d;
+      d.reset_mask = nullptr;
+      hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
+                         h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs, share_obs);
+      HIP_TRY(hipGetLastError());
+      for (int e = 0; e < N; e++)
+        if (h->host_t_rel[e] >= h->cfg.episode_steps) h->host_t_rel[e] = 0;
+      recompute_steps_to_terminal(h);
+    }
+  }
+  return 0;
+}
+
+static const Field* find_field(sdc_handle* h, const char* name) {
+  for (const Field& f : h->fields)
+    if (std::strcmp(f.name, name) == 0) return &f;
+  return nullptr;
+}
+
+int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes) {
+  if (!h || !field || !host_buf) return fail_msg("sdc_get_state: null argument");
+  const Field* f = find_field(h, field);
+  if (!f) return fail_msg(std::string("sdc_get_state: unknown field ") + field);
+  const size_t need = f->elem * (size_t)h->cfg.n_envs;
+  if (bytes != need) return fail_msg(std::string("sdc_get_state: size mismatch for ") + field);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_buf, *f->ptr, need, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t bytes) {
+  if (!h || !field || !host_buf) return fail_msg("sdc_set_state: null argument");
+  const Field* f = find_field(h, field);
+  if (!f) return fail_msg(std::string("sdc_set_state: unknown field ") + field);
+  const size_t need = f->elem * (size_t)h->cfg.n_envs;
+  if (bytes != need) return fail_msg(std::string("sdc_set_state: size mismatch for ") + field);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(*f->ptr, host_buf, need, hipMemcpyHostToDevice));
+  if (std::strcmp(field, "t_rel") == 0) {
+    h->pending = 0;
+    std::memcpy(h->host_t_rel.data(), host_buf, need);
+    recompute_steps_to_terminal(h);
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+// sdc_reset.hip -- SustainDC.reset() for the masked environments, one wavefront per environment.
+//
+// Two modes:
+//   * override: (day, hour, CI / temperature normalisation bounds, weather windows) were injected by the
+//     caller (parity tests feed what the reference's managers produced);
+//   * device:   the draws of sustaindc_env.py:454-455 and utils/managers.py:35-48, :596-613 are made on the
+//     GPU with a counter-based RNG (Philox4x32-10): start day / hour, the 0..13-day roll, and the
+//     35 040-step Gaussian random walk scaled to std 0.75 that is added to dry and wet bulb before
+//     the roll, clip to [0, 45] and 30-day min/max normalisation.  Same distributions as the reference,
+//     not the same stream (the reference uses MT19937 via `random` and `np.random`).
+//
+// What reset clears / keeps follows the reference: queue, battery SoC and the set-point scaling
+// counters are cleared (carbon_ls.py:85, battery_model.py:90-91, dc_gym.py:114-116); the CRAC set-point
+// and the energy history survive (dc_gym.py:91-140 never touches raw_curr_stpt; reward_creator.py:5).
+#include "sdc_device.hpp"
+
+namespace {
+
+struct ResetShared {
+  double nc[32];
+  double nt[32];
+  double tw[32];  // T[c0 .. c0+16] of a device-side reset
+  float obs[64];
+};
+
+__device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double u = __shfl_up(v, o);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
+// one standard normal per (env, episode, idx): Box-Muller on a Philox block shared by an index pair
+__device__ __forceinline__ double normal_at(const SdcDev& S, int env, int episode, int idx) {
+  const Philox4 r = philox4x32_10((unsigned)(idx >> 1), (unsigned)env, (unsigned)episode, 0x7E47u, (unsigned)S.seed,
+                                  (unsigned)(S.seed >> 32));
+  const double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
+  const double rad = sqrt(-2.0 * log(u1));
+  const double ang = 6.283185307179586 * u2;
+  return (idx & 1) ? rad * sin(ang) : rad * cos(ang);
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S, int use_override,
+                                                                          const int* __restrict__ ovr_day,
+                                                                          const int* __restrict__ ovr_hour,
+                                                                          const double* __restrict__ ovr_ci_min,
+                                                                          const double* __restrict__ ovr_ci_max,
+                                                                          const double* __restrict__ ovr_t_min,
+                                                                          const double* __restrict__ ovr_t_max,
+                                                                          int only_done, float* __restrict__ obs,
+                                                                          float* __restrict__ share_obs) {
+  __shared__ ResetShared sh;
+  const int env = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (S.reset_mask && !S.reset_mask[env]) return;
+  if (only_done && S.t_rel[env] < S.episode_steps) return;  // auto-reset: finished envs only
+  const int loc = S.loc_id[env];
+  const int TL = S.table_len;
+  const int episode = S.episode[env] + 1;
+  unsigned fault = S.fault[env];
+  int day, hour;
+  double ci_min, ci_den, t_min, t_den;
+  const double* tsrc;
+  if (use_override) {
+    day = ovr_day[env];
+    hour = ovr_hour[env];
+    ci_min = ovr_ci_min[env];
+    ci_den = ovr_ci_max[env] - ci_min;
+    t_min = ovr_t_min[env];
+    t_den = ovr_t_max[env] - t_min;
+    tsrc = S.t_win + (size_t)env * S.lw;  // copied in by the host before this launch
+    if (day * 96 + hour * 4 + S.episode_steps + 17 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
+  } else {
+    // ---- draws: sustaindc_env.py:454-455 (day in [lo, hi], hour in [0, 23]); managers.py:601 (roll) ----
+    const Philox4 r = philox4x32_10(0u, (unsigned)env, (unsigned)episode, 0xD4A7u, (unsigned)S.seed,
+                                    (unsigned)(S.seed >> 32));
+    const int lo = S.day_lo[env], hi = S.day_hi[env];
+    day = lo + (int)(((unsigned long long)r.x * (unsigned)(hi - lo + 1)) >> 32);
+    hour = (int)(((unsigned long long)r.y * 24u) >> 32);
+    const int roll_days = S.max_roll_days > 0 ? (int)(((unsigned long long)r.z * (unsigned)S.max_roll_days) >> 32) : 0;
+    // year-end fence: the reference reads table[cursor + 1 .. + 17] and raises IndexError at the end of the
+    // year; keep the whole episode inside the table instead
+    {
+      const int last_ok = TL - 1 - (S.episode_steps + 17);
+      if (day * 96 + hour * 4 > last_ok) {
+        const int c = last_ok < 0 ? 0 : last_ok;
+        day = c / 96;
+        hour = (c - day * 96) / 4;
+      }
+    }
+    const int c0 = day * 96 + hour * 4;
+    const int shift = roll_days * 96;
+    const int wlen = min(max(SDC_NORM_WINDOW, S.lw), TL - c0 + 0);  // samples of the rolled table we may touch
+    double* walk = S.walk_tmp + (size_t)env * max(SDC_NORM_WINDOW, S.lw);
+    double walk_std = 0.0;
+    if (S.noise_std > 0.0) {
+      // pass 1: CoherentNoise.generate (managers.py:35-48): random walk, its population std
+      double carry = 0.0, sum = 0.0, sumsq = 0.0;
+      for (int base = 0; base < TL; base += SDC_WAVE) {
+        const int j = base + lane;
+        const double step = j < TL ? S.noise_weight * normal_at(S, env, episode, j) : 0.0;
+        const double w = carry + wave_incl_scan_f64(step, lane);
+        carry = __shfl(w, 63);
+        if (j < TL) {
+          sum += w;
+          sumsq += w * w;
+          // base index j lands at rolled position (j + shift) mod TL (np.roll, managers.py:602)
+          int pos = j + shift;
+          if (pos >= TL) pos -= TL;
+          const int rel = pos - c0;
+          if (rel >= 0 && rel < wlen) walk[rel] = w;
+        }
+      }
+      sum = wave_sum_f64(sum);
+      sumsq = wave_sum_f64(sumsq);
+      const double mean = sum / (double)TL;
+      const double var = sumsq / (double)TL - mean * mean;
+      walk_std = sqrt(var);
+    }
+    __threadfence();  // walk[] is re-read by other lanes of this wave below
+    __syncthreads();
+    // pass 2: add noise, roll, clip [0, 45]; 30-day min / max from the cursor (managers.py:598-613)
+    const double* tT = S.tabT + (size_t)loc * TL;
+    const double* tWB = S.tabWB + (size_t)loc * TL;
+    const double* tC = S.tabC + (size_t)loc * TL;
+    double tmin = 1e300, tmax = -1e300, cmin = 1e300, cmax = -1e300;
+    double* tw = S.t_win + (size_t)env * S.lw;
+    double* wbw = S.wb_win + (size_t)env * S.lw;
+    for (int rel = lane; rel < wlen; rel += SDC_WAVE) {
+      int j = c0 + rel - shift;
+      if (j < 0) j += TL;
+      const double nz = walk_std > 0.0 ? (walk[rel] / walk_std) * S.noise_std : 0.0;  // managers.py:47
+      const double t = fmin(fmax(tT[j] + nz, 0.0), 45.0);
+      if (rel < SDC_NORM_WINDOW) {
+        tmin = fmin(tmin, t);
+        tmax = fmax(tmax, t);
+        const double c = tC[c0 + rel];
+        cmin = fmin(cmin, c);
+        cmax = fmax(cmax, c);
+      }
+      if (rel < S.lw) {
+        tw[rel] = t;
+        wbw[rel] = fmin(fmax(tWB[j] + nz, 0.0), 45.0);
+      }
+      if (rel < 17) sh.tw[rel] = t;
+    }
+    tmin = wave_min_f64(tmin);
+    tmax = wave_max_f64(tmax);
+    cmin = wave_min_f64(cmin);
+    cmax = wave_max_f64(cmax);
+    ci_min = cmin;
+    ci_den = cmax - cmin;
+    t_min = tmin;
+    t_den = tmax - tmin;
+    tsrc = sh.tw;
+  }
+  const int c0 = day * 96 + hour * 4;  // utils/managers.py:122
+  __syncthreads();
+  stage_windows(S, loc, c0, tsrc, ci_min, ci_den, t_min, t_den, lane, sh.nc, sh.nt);
+  __syncthreads();
+  if (lane == 0) {
+    const double* tW = S.tabW + (size_t)loc * TL;
+    auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
+    ObsScalars o;
+    const int hq = hour * 4;
+    o.cos_h = S.hour_lut[2 * hq];
+    o.sin_h = S.hour_lut[2 * hq + 1];
+    o.w_cur = tW[tix(c0)];
+    o.w_next = tW[tix(c0 + 1)];
+    o.soc = 0.0;
+    o.normq = 0.0;
+    o.oldest = 0.0;
+    o.avg = 0.0;
+    for (int b = 0; b < 5; b++) o.hist[b] = 0.0;
+    o.have_past = c0 >= 16;
+    build_obs_raw(sh.nc, sh.nt, o, sh.obs);
+    S.ci_min[env] = ci_min;
+    S.ci_den[env] = ci_den;
+    S.t_min[env] = t_min;
+    S.t_den[env] = t_den;
+    S.cursor[env] = c0;
+    S.t_rel[env] = 0;
+    S.day[env] = day;
+    S.hourq[env] = hq;
+    S.q_popped[env] = 0;
+    S.q_cum[env] = 0;
+    S.q_cumT[env] = 0u;
+    S.q_head[env] = 0;
+    S.last_delta[env] = -2;
+    S.consecutive[env] = 0;
+    S.scale[env] = 1;
+    S.bat_load[env] = 0.0;
+    S.episode[env] = episode;
+    S.fault[env] = fault;
+    for (int b = 0; b < SDC_CARRY_DIM; b++) S.carry[b * S.n_envs + env] = 0.0;
+  }
+  __syncthreads();
+  if (obs) {
+    obs[(size_t)env * SDC_OBS_OUT + lane] = obs_padded_at(sh.obs, lane);
+    if (lane < SDC_OBS_OUT - 64) obs[(size_t)env * SDC_OBS_OUT + 64 + lane] = obs_padded_at(sh.obs, 64 + lane);
+  }
+  if (share_obs && lane < SDC_SHARE_OBS_DIM) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = share_obs_at(sh.obs, lane);
+}

@@ -1,0 +1,201 @@
+"""SdcEngine: N SustainDC environment instances resident on one MI355X, driven through the C-ABI.
+
+PyTorch is plumbing here: it owns the obs / action / reward / info device buffers and the HIP stream;
+the dynamics run in the hand-written kernels of csrc/ (sdc_step_kernel, sdc_reset_kernel).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+_STATE_DTYPES = {
+    "cursor": (np.int32, 1), "t_rel": (np.int32, 1), "day": (np.int32, 1), "hourq": (np.int32, 1),
+    "q_popped": (np.int32, 1), "q_cum": (np.int32, 1), "q_cumT": (np.uint32, 1), "q_head": (np.int32, 1),
+    "last_delta": (np.int32, 1), "consecutive": (np.int32, 1), "scale": (np.int32, 1),
+    "hist_len": (np.int32, 1), "hist_pos": (np.int32, 1), "episode": (np.int32, 1), "fault": (np.uint32, 1),
+    "stpt": (np.float64, 1), "bat_load": (np.float64, 1), "ci_min": (np.float64, 1), "ci_den": (np.float64, 1),
+    "t_min": (np.float64, 1), "t_den": (np.float64, 1),
+}
+
+
+def dc_params_struct(p: dict) -> L.SdcDcParams:
+    """dict (see dc_config.size_datacenter) -> C struct."""
+    s = L.SdcDcParams()
+    R = len(p["rack_n"])
+    if not 1 <= R <= L.MAX_RACKS:
+        raise ValueError(f"n_racks must be in [1, {L.MAX_RACKS}], got {R}")
+    s.n_racks = R
+    for name in ("rack_n", "rack_full", "rack_idle", "rack_supply", "rack_return"):
+        dst = getattr(s, name)
+        src = p[name]
+        if len(src) != R:
+            raise ValueError(f"{name} has {len(src)} entries, expected {R}")
+        for i in range(R):
+            dst[i] = float(src[i])
+    for name in ("m_cpu", "c_cpu", "rs_cpu", "m_fan", "c_fan", "rs_fan", "itfan_ref_p", "itfan_ref_v_ratio",
+                 "it_fan_full_load_v", "c_air", "rho_air", "crac_supply_pu", "ct_fan_ref_p", "ctafr", "min_temp",
+                 "max_temp"):
+        setattr(s, name, float(p[name]))
+    s.init_setpoint = float(p.get("init_setpoint", 18.0))
+    s.bat_capacity_mwh = float(p["bat_capacity"])
+    return s
+
+
+class SdcEngine:
+    def __init__(self, n_envs: int, episode_steps: int = 672, device: int = 0, n_locations: int = 1,
+                 n_dc_configs: int = 1, auto_reset: bool = True, seed: int = 0, hist_cap: int = 10000,
+                 queue_max_len: int = 1000, weather_noise_std: float = 0.75, weather_noise_weight: float = 0.02,
+                 max_roll_days: int = 14):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("SdcEngine needs an MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = L.load()
+        self.torch = torch
+        self.n_envs = int(n_envs)
+        self.episode_steps = int(episode_steps)
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        cfg = L.SdcConfig(n_envs=self.n_envs, device=self.device_index, episode_steps=self.episode_steps,
+                          hist_cap=hist_cap, queue_max_len=queue_max_len, n_locations=n_locations,
+                          n_dc_configs=n_dc_configs, auto_reset=1 if auto_reset else 0, seed=seed,
+                          weather_noise_std=weather_noise_std, weather_noise_weight=weather_noise_weight,
+                          max_roll_days=max_roll_days, reserved=0)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.init()
+            L.check(self.lib.sdc_create(C.byref(cfg), C.byref(self._h)))
+        self.lw = self.lib.sdc_weather_window_len(self._h)
+        self.hist_stride = self.lib.sdc_hist_stride(self._h)
+        self.queue_stride = self.lib.sdc_queue_stride(self._h)
+        N = self.n_envs
+        kw = dict(device=self.device)
+        self.obs = torch.zeros((N, L.N_AGENTS, L.OBS_PAD), dtype=torch.float32, **kw)
+        self.share_obs = torch.zeros((N, L.SHARE_OBS_DIM), dtype=torch.float32, **kw)
+        self.rew = torch.zeros((N, L.N_AGENTS), dtype=torch.float32, **kw)
+        self.done = torch.zeros((N,), dtype=torch.uint8, **kw)
+        self.info = torch.zeros((N, L.INFO_DIM), dtype=torch.float32, **kw)
+        self.final_obs = torch.zeros((N, L.N_AGENTS, L.OBS_PAD), dtype=torch.float32, **kw)
+
+    # ------------------------------------------------------------------ setup
+    def set_tables(self, loc_id: int, W, Cc, T, WB):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (W, Cc, T, WB)]
+        for a in arrs:
+            if a.shape != (L.TABLE_LEN,):
+                raise ValueError(f"trace tables must have shape ({L.TABLE_LEN},), got {a.shape}")
+        dp = C.POINTER(C.c_double)
+        L.check(self.lib.sdc_set_tables(self._h, int(loc_id), *[a.ctypes.data_as(dp) for a in arrs], L.TABLE_LEN))
+
+    def set_dc_params(self, cfg_id: int, params: dict):
+        s = dc_params_struct(params)
+        L.check(self.lib.sdc_set_dc_params(self._h, int(cfg_id), C.byref(s)))
+
+    def assign(self, loc_id, cfg_id, day_lo, day_hi):
+        N = self.n_envs
+        arrs = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.int32), (N,))) for a in
+                (loc_id, cfg_id, day_lo, day_hi)]
+        ip = C.POINTER(C.c_int32)
+        L.check(self.lib.sdc_assign_envs(self._h, *[a.ctypes.data_as(ip) for a in arrs]))
+
+    # ------------------------------------------------------------------ run
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, mask: Optional[np.ndarray] = None, override: Optional[dict] = None):
+        """SustainDC.reset for the masked envs (all if mask is None).  Returns (obs, share_obs) device tensors
+        (views of the engine's buffers)."""
+        N = self.n_envs
+        mptr = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            if m.shape != (N,):
+                raise ValueError("mask must have shape (n_envs,)")
+            mptr = m.ctypes.data_as(C.POINTER(C.c_uint8))
+        optr = None
+        keep = None
+        if override is not None:
+            dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+            day = np.ascontiguousarray(override["day"], dtype=np.int32)
+            hour = np.ascontiguousarray(override["hour"], dtype=np.int32)
+            sc = [np.ascontiguousarray(override[k], dtype=np.float64) for k in ("ci_min", "ci_max", "t_min", "t_max")]
+            tw = np.ascontiguousarray(override["t_win"], dtype=np.float64)
+            wb = np.ascontiguousarray(override["wb_win"], dtype=np.float64)
+            for a in [day, hour] + sc:
+                if a.shape != (N,):
+                    raise ValueError("override scalars must have shape (n_envs,)")
+            if tw.shape != (N, self.lw) or wb.shape != (N, self.lw):
+                raise ValueError(f"override weather windows must have shape ({N}, {self.lw})")
+            o = L.SdcResetOverride(day.ctypes.data_as(ip), hour.ctypes.data_as(ip), *[a.ctypes.data_as(dp) for a in sc],
+                                   tw.ctypes.data_as(dp), wb.ctypes.data_as(dp))
+            keep = (day, hour, sc, tw, wb, o)
+            optr = C.byref(o)
+        with self.torch.cuda.device(self.device):
+            L.check(self.lib.sdc_reset(self._h, mptr, optr, C.c_void_p(self.obs.data_ptr()),
+                                       C.c_void_p(self.share_obs.data_ptr()), self._stream()))
+        del keep
+        return self.obs, self.share_obs
+
+    def step(self, actions, want_info: bool = True):
+        """actions: int32 device tensor [N, 3] (ls, dc, bat).  Returns views of the engine's buffers:
+        obs [N,3,26], share_obs [N,29], rew [N,3], done [N] (uint8), info [N,40]."""
+        t = self.torch
+        if not (isinstance(actions, t.Tensor) and actions.dtype == t.int32 and actions.is_cuda and
+                actions.is_contiguous() and tuple(actions.shape) == (self.n_envs, 3)):
+            raise ValueError("actions must be a contiguous int32 CUDA tensor of shape (n_envs, 3)")
+        with t.cuda.device(self.device):
+            L.check(self.lib.sdc_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                                      C.c_void_p(self.share_obs.data_ptr()), C.c_void_p(self.rew.data_ptr()),
+                                      C.c_void_p(self.done.data_ptr()),
+                                      C.c_void_p(self.info.data_ptr()) if want_info else None,
+                                      C.c_void_p(self.final_obs.data_ptr()), self._stream()))
+        return self.obs, self.share_obs, self.rew, self.done, self.info
+
+    # ------------------------------------------------------------------ state access (parity injection / checkpoint)
+    def _state_array(self, name):
+        N = self.n_envs
+        if name in _STATE_DTYPES:
+            dt, k = _STATE_DTYPES[name]
+            return np.zeros((N,) if k == 1 else (N, k), dtype=dt)
+        if name == "hist":
+            return np.zeros((N, self.hist_stride), dtype=np.float32)
+        if name in ("t_win", "wb_win"):
+            return np.zeros((N, self.lw), dtype=np.float64)
+        if name == "qtab":
+            return np.zeros((N, self.queue_stride, 2), dtype=np.uint32)
+        if name == "carry":
+            return np.zeros((8, N), dtype=np.float64)
+        raise KeyError(name)
+
+    def get_state(self, name: str) -> np.ndarray:
+        a = self._state_array(name)
+        L.check(self.lib.sdc_get_state(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a
+
+    def set_state(self, name: str, value):
+        a = self._state_array(name)
+        a[...] = value
+        L.check(self.lib.sdc_set_state(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def state_dict(self) -> dict:
+        """Full env checkpoint (the reference never checkpoints env state)."""
+        names = list(_STATE_DTYPES) + ["hist", "t_win", "wb_win", "qtab", "carry"]
+        return {n: self.get_state(n) for n in names}
+
+    def load_state_dict(self, sd: dict):
+        for n, v in sd.items():
+            self.set_state(n, v)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.sdc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,184 @@
+/*
+ * sustaindc_hip.h -- C-ABI of the MI355X-native vectorised SustainDC step.
+ *
+ * One handle = N environment instances resident on ONE GPU.  All obs / action / reward / info
+ * buffers are device memory owned by the caller (PyTorch-ROCm tensors in the Python host); the
+ * library borrows the raw pointers for the duration of a call and owns only its internal
+ * struct-of-arrays state, trace tables and history rings.  Launches are asynchronous on the
+ * caller's HIP stream.  No torch types, no C++ types: plain pointers and sizes.
+ *
+ * The reference (HewlettPackard/dc-rl) is pure Python and has no FFI for this path; each entry
+ * point below names the reference interface it replaces (file:line under /root/reference).
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Return value: 0 on success, negative on error; message via sdc_last_error().
+ * Threading: one host thread per handle; one handle per GPU.
+ */
+#ifndef SUSTAINDC_HIP_H
+#define SUSTAINDC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDC_MAX_RACKS 64
+#define SDC_N_AGENTS 3
+#define SDC_OBS_PAD 26       /* per-agent obs padded to 26 (harl/envs/sustaindc/harlsustaindc_env.py:25-26) */
+#define SDC_SHARE_OBS_DIM 29 /* harlsustaindc_env.py:78-80 */
+#define SDC_INFO_DIM 40
+#define SDC_TABLE_LEN 35040  /* 365 d x 96 steps (utils/managers.py:184) */
+
+/* info[N][SDC_INFO_DIM] columns; names are the reference's info keys
+ * (envs/carbon_ls.py:291-308, envs/dc_gym.py:213-229, envs/bat_env_fwd_view.py:111-122,
+ *  sustaindc_env.py:676-683) */
+enum sdc_info_col {
+  SDC_INFO_LS_ORIGINAL_WORKLOAD = 0,
+  SDC_INFO_LS_SHIFTED_WORKLOAD,
+  SDC_INFO_LS_TASKS_IN_QUEUE,
+  SDC_INFO_LS_NORM_TASKS_IN_QUEUE,
+  SDC_INFO_LS_TASKS_DROPPED,
+  SDC_INFO_LS_TASKS_PROCESSED,
+  SDC_INFO_LS_OLDEST_TASK_AGE,
+  SDC_INFO_LS_AVERAGE_TASK_AGE,
+  SDC_INFO_LS_OVERDUE_PENALTY,
+  SDC_INFO_LS_COMPUTED_TASKS,
+  SDC_INFO_LS_CURRENT_HOUR,
+  SDC_INFO_LS_AGE_HIST0, SDC_INFO_LS_AGE_HIST1, SDC_INFO_LS_AGE_HIST2, SDC_INFO_LS_AGE_HIST3, SDC_INFO_LS_AGE_HIST4,
+  SDC_INFO_DC_ITE_TOTAL_POWER_KW,
+  SDC_INFO_DC_CT_TOTAL_POWER_KW,
+  SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW,
+  SDC_INFO_DC_HVAC_TOTAL_POWER_KW,
+  SDC_INFO_DC_TOTAL_POWER_KW,
+  SDC_INFO_DC_CRAC_SETPOINT_DELTA,
+  SDC_INFO_DC_CRAC_SETPOINT,
+  SDC_INFO_DC_CPU_WORKLOAD_FRACTION,
+  SDC_INFO_DC_INT_TEMPERATURE,
+  SDC_INFO_DC_EXTERIOR_AMBIENT_TEMP,
+  SDC_INFO_DC_WATER_USAGE,
+  SDC_INFO_BAT_ACTION,
+  SDC_INFO_BAT_SOC,
+  SDC_INFO_BAT_CO2_FOOTPRINT,
+  SDC_INFO_BAT_AVG_CI,
+  SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH,
+  SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH,
+  SDC_INFO_NORM_CI,
+  SDC_INFO_OUTSIDE_TEMP,
+  SDC_INFO_DAY,
+  SDC_INFO_HOUR,
+  SDC_INFO_FAULT,    /* bit mask, see SDC_FAULT_* (the reference raises / asserts instead) */
+  SDC_INFO_ENERGY_Z, /* normalize_energy() output shared by the three rewards */
+  SDC_INFO_RESERVED
+};
+
+#define SDC_FAULT_OUTLET_DELTA 1u  /* envs/datacenter.py:295-300 raises */
+#define SDC_FAULT_CPU_LOAD 2u      /* envs/dc_gym.py:288-290 asserts */
+#define SDC_FAULT_BAT_DISCHARGE 4u /* envs/bat_env_fwd_view.py:237 asserts */
+#define SDC_FAULT_WORKLOAD 8u      /* envs/carbon_ls.py:333-336 raises */
+#define SDC_FAULT_TABLE_RANGE 16u  /* cursor would leave the year table (reference: IndexError) */
+
+typedef struct sdc_handle sdc_handle;
+
+/* replaces: EnvConfig / SustainDC.__init__ wiring (sustaindc_env.py:34-160) for N envs */
+typedef struct {
+  int32_t n_envs;
+  int32_t device;          /* HIP device ordinal */
+  int32_t episode_steps;   /* days_per_episode * 96 (utils/managers.py:113) */
+  int32_t hist_cap;        /* 10000 (utils/reward_creator.py:5) */
+  int32_t queue_max_len;   /* 1000 (sustaindc_env.py:149) */
+  int32_t n_locations;     /* number of trace-table sets */
+  int32_t n_dc_configs;    /* number of data-centre parameter sets */
+  int32_t auto_reset;      /* 1: reset finished envs inside sdc_step (harl/envs/env_wrappers.py:176-190) */
+  uint64_t seed;           /* counter-based RNG seed for device-side resets */
+  double weather_noise_std;   /* 0.75 (utils/managers.py:504) ; 0 disables the noise */
+  double weather_noise_weight;/* 0.02 (utils/managers.py:504) */
+  int32_t max_roll_days;   /* 14: roll in [0, 14) days (utils/managers.py:601) */
+  int32_t reserved;
+} sdc_config;
+
+/* replaces: DC_Config + Rack/CPU constants + sized HVAC values
+ * (utils/dc_config_reader.py:39-145, envs/datacenter.py:31-135, utils/make_envs_pyenv.py:139-197) */
+typedef struct {
+  int32_t n_racks;
+  int32_t reserved;
+  double rack_n[SDC_MAX_RACKS];      /* CPUs per rack after the MAX_W_PER_RACK cap (datacenter.py:67-74) */
+  double rack_full[SDC_MAX_RACKS];   /* full-load W per CPU */
+  double rack_idle[SDC_MAX_RACKS];   /* idle W per CPU */
+  double rack_supply[SDC_MAX_RACKS]; /* supply approach temperature, unclamped */
+  double rack_return[SDC_MAX_RACKS]; /* return approach temperature */
+  double m_cpu, c_cpu, rs_cpu;       /* datacenter.py:31-39 */
+  double m_fan, c_fan, rs_fan;       /* datacenter.py:41-49 */
+  double itfan_ref_p, itfan_ref_v_ratio, it_fan_full_load_v;
+  double c_air, rho_air, crac_supply_pu;
+  double ct_fan_ref_p, ctafr;        /* SIZED (make_envs_pyenv.py:159-161) */
+  double min_temp, max_temp;         /* CRAC set-point clamp (make_envs_pyenv.py:125-126) */
+  double init_setpoint;              /* 18 (make_envs_pyenv.py:124) */
+  double bat_capacity_mwh;           /* sized battery capacity (sustaindc_env.py:152) */
+} sdc_dc_params;
+
+/* replaces: the (day, hour, roll, noise) draws of SustainDC.reset / Weather_Manager.reset
+ * (sustaindc_env.py:454-461, utils/managers.py:581-628) when the caller wants to inject them
+ * (parity tests).  All pointers are HOST memory, indexed by env. */
+typedef struct {
+  const int32_t* day;   /* [N] */
+  const int32_t* hour;  /* [N] 0..23 */
+  const double* ci_min; /* [N] min of C over [cursor, cursor+2880) (managers.py:435-437) */
+  const double* ci_max;
+  const double* t_min;  /* [N] same for the noised/rolled/clipped temperature (managers.py:606-608) */
+  const double* t_max;
+  const double* t_win;  /* [N][weather_window_len]: T[cursor0 + k] after noise+roll+clip */
+  const double* wb_win; /* [N][weather_window_len]: wet bulb likewise */
+} sdc_reset_override;
+
+const char* sdc_last_error(void);
+int sdc_version(void);
+
+int sdc_create(const sdc_config* cfg, sdc_handle** out);
+int sdc_destroy(sdc_handle* h);
+
+/* episode_steps + 18: samples of per-env weather the step can touch */
+int sdc_weather_window_len(const sdc_handle* h);
+
+/* replaces: Workload_Manager / CI_Manager / Weather_Manager table construction
+ * (utils/managers.py:152-197, :318-388, :488-569).  Host arrays of length n (= SDC_TABLE_LEN):
+ * W = cpu_smooth after scale_array + 16-tap smoothing (managers.py:268-271), C = carbon_smooth,
+ * T / WB = interpolated dry / wet bulb BEFORE noise. */
+int sdc_set_tables(sdc_handle* h, int loc_id, const double* W, const double* C, const double* T, const double* WB,
+                   int n);
+
+int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p);
+
+/* per-env assignment (host arrays [N]): trace set, DC parameter set, and the inclusive range the
+ * random start day is drawn from (sustaindc_env.py:198, :454) */
+int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id, const int32_t* day_lo,
+                    const int32_t* day_hi);
+
+/* replaces: SustainDC.reset (sustaindc_env.py:436-531) / ShareVecEnv.reset (env_wrappers.py:275-280).
+ * mask_host: NULL = all envs, else [N] bytes (host).  ovr: NULL = draw on device.
+ * obs [N][3][26] f32, share_obs [N][29] f32 (device; may be NULL). */
+int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override* ovr, float* obs, float* share_obs,
+              void* stream);
+
+/* replaces: SustainDC.step (sustaindc_env.py:533-621) + HARL adaptation + auto-reset
+ * (harlsustaindc_env.py:106-131, env_wrappers.py:168-192) for all N envs.
+ * actions [N][3] int32 (ls, dc, bat) in {0,1,2}; obs [N][3][26]; share_obs [N][29]; rew [N][3];
+ * done [N] u8; info [N][SDC_INFO_DIM] f32; final_obs [N][3][26] receives the pre-reset observation of
+ * envs that finished ("original_obs"); info / final_obs / share_obs may be NULL. */
+int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs, float* rew, uint8_t* done,
+             float* info, float* final_obs, void* stream);
+
+/* parity injection + env checkpoint: copy one named state field to / from HOST memory.
+ * Fields: cursor t_rel day hourq q_popped q_cum q_head last_delta consecutive scale hist_len hist_pos
+ * episode (int32[N]);  stpt bat_load ci_min ci_den t_min t_den (double[N]);  hist (float[N][hist_stride]);
+ * t_win wb_win (double[N][weather_window_len]);  qtab (uint32[N][queue_stride][2]); fault (uint32[N]). */
+int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes);
+int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t bytes);
+int sdc_hist_stride(const sdc_handle* h);
+int sdc_queue_stride(const sdc_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -189,6 +189,9 @@ def run_fixture(spec):
     out["meta_episodes"] = np.array(n_ep)
     out["meta_seed"] = np.array(seed)
     out["meta_policy"] = np.array(spec["policy"])
+    out["meta_capacity_mw"] = np.array(float(cfg["datacenter_capacity_mw"]))
+    out["meta_dc_config"] = np.array(os.path.basename(cfg["dc_config_file"]))
+    out["meta_days"] = np.array(cfg["days_per_episode"])
     out["meta_info_keys"] = np.array(INFO_KEYS)
     out["init_stpt"] = np.array(env.dc_env.raw_curr_stpt, dtype=np.float64)
 

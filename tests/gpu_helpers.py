@@ -1,0 +1,78 @@
+"""Shared helpers for the -m gpu parity tests (drive the HIP path through the C-ABI via SdcEngine)."""
+import os
+
+import numpy as np
+
+from dc_rl_amd import _lib as L
+from dc_rl_amd.engine import SdcEngine
+from oracle import pyoracle as po
+from tests.conftest import GOLDEN_DIR
+
+TL = L.TABLE_LEN
+
+
+def load_fixture(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+def params_from_fixture(d):
+    p = {k[len("static_"):]: (d[k] if d[k].ndim else float(d[k])) for k in d.files if k.startswith("static_")}
+    p["init_setpoint"] = float(d["init_stpt"])
+    return p
+
+
+def tables_from_fixture(d, n_ep):
+    """Year tables holding the fixture's windows at their absolute offsets (zero elsewhere)."""
+    W = np.zeros(TL)
+    Cc = np.zeros(TL)
+    for ep in range(n_ep):
+        lo = int(d[f"ep{ep}_win_lo"])
+        n = len(d[f"ep{ep}_W"])
+        W[lo:lo + n] = d[f"ep{ep}_W"]
+        Cc[lo:lo + n] = d[f"ep{ep}_C"]
+    return W, Cc
+
+
+def override_from_fixture(d, ep, n_envs, lw):
+    pre = f"ep{ep}_"
+    c0, lo = int(d[pre + "cursor0"]), int(d[pre + "win_lo"])
+    tw = d[pre + "T"][c0 - lo:c0 - lo + lw]
+    wb = d[pre + "WB"][c0 - lo:c0 - lo + lw]
+    assert len(tw) == lw
+    rep = lambda v, dt: np.full(n_envs, v, dtype=dt)
+    return dict(day=rep(int(d[pre + "init_day"]), np.int32), hour=rep(int(d[pre + "init_hour"]), np.int32),
+                ci_min=rep(float(d[pre + "ci_min30"]), np.float64), ci_max=rep(float(d[pre + "ci_max30"]), np.float64),
+                t_min=rep(float(d[pre + "t_min30"]), np.float64), t_max=rep(float(d[pre + "t_max30"]), np.float64),
+                t_win=np.tile(tw, (n_envs, 1)), wb_win=np.tile(wb, (n_envs, 1)))
+
+
+def raw_obs(obs_padded):
+    """[.., 3, 26] padded -> [.., 53] raw (ls 26 | dc 14 | bat 13)."""
+    o = np.asarray(obs_padded)
+    return np.concatenate([o[..., 0, :26], o[..., 1, :14], o[..., 2, :13]], axis=-1)
+
+
+def share_from_raw(raw):
+    return np.concatenate([raw[..., :26], raw[..., 26 + 11:26 + 12], raw[..., 26 + 13:26 + 14], raw[..., 40 + 12:40 + 13]], axis=-1)
+
+
+def make_engine_for_fixture(d, n_envs=2, **kw):
+    steps = int(d["meta_steps"])
+    eng = SdcEngine(n_envs, episode_steps=steps, auto_reset=False, **kw)
+    W, Cc = tables_from_fixture(d, int(d["meta_episodes"]))
+    z = np.zeros(TL)
+    eng.set_tables(0, W, Cc, z, z)
+    eng.set_dc_params(0, params_from_fixture(d))
+    eng.assign(0, 0, 0, 364)
+    return eng
+
+
+# tolerances of the HIP path vs the fp64 reference values (north_star: 1e-5 relative fp32; abs where |ref| < 1)
+def rel_err(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+
+
+def oracle_params_from_dict(p):
+    return po.make_params(p["rack_n"], p["rack_full"], p["rack_idle"], p["rack_supply"], p["rack_return"], p)

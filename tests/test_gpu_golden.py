@@ -1,0 +1,89 @@
+"""HIP path (through the C-ABI) vs the golden vectors captured from the Python reference.
+
+Bar: obs and rewards within 1e-5 relative (absolute where |ref| < 1) -- BASELINE.json north_star; integer-valued
+outputs (queue counts, done flags, set-point) exact."""
+import numpy as np
+import pytest
+
+from dc_rl_amd import _lib as L
+from tests import gpu_helpers as G
+from tests.conftest import golden_names
+
+pytestmark = pytest.mark.gpu
+
+EXACT_INFO = ["ls_tasks_in_queue", "ls_tasks_dropped", "ls_tasks_processed", "ls_overdue_penalty", "ls_computed_tasks",
+              "dc_crac_setpoint_delta", "bat_action", "day", "hour", "ls_current_hour"]
+
+
+def _run(name, n_envs=2):
+    import torch
+    d = G.load_fixture(name)
+    eng = G.make_engine_for_fixture(d, n_envs=n_envs)
+    keys = [str(k) for k in d["meta_info_keys"]]
+    steps = int(d["meta_steps"])
+    worst = dict(obs=0.0, rew=0.0, info=0.0)
+    for ep in range(int(d["meta_episodes"])):
+        pre = f"ep{ep}_"
+        obs, share = eng.reset(override=G.override_from_fixture(d, ep, n_envs, eng.lw))
+        assert (eng.get_state("cursor") == int(d[pre + "cursor0"])).all()
+        assert (eng.get_state("hist_len") == int(d[pre + "hist_len0"])).all()
+        np.testing.assert_array_equal(eng.get_state("stpt"), float(d[pre + "stpt0"]))
+        raw = G.raw_obs(obs.cpu().numpy())
+        assert (raw == raw[0]).all(), "copies of one env diverged"
+        e = G.rel_err(raw[0], d[pre + "reset_obs"]).max()
+        assert e <= 1e-5, (name, ep, "reset obs", e)
+        np.testing.assert_array_equal(share.cpu().numpy(), G.share_from_raw(raw))
+        acts = torch.from_numpy(np.repeat(d[pre + "actions"][:, None, :], n_envs, axis=1)).to(eng.device)
+        gobs, grew, gdone, ginfo, ghist = (d[pre + k] for k in ("obs", "rew", "done", "info", "age_hist"))
+        O = np.zeros((steps, 53), np.float32)
+        R = np.zeros((steps, 3), np.float32)
+        D = np.zeros(steps, np.uint8)
+        I = np.zeros((steps, L.INFO_DIM), np.float32)
+        for t in range(steps):
+            obs, share, rew, done, info = eng.step(acts[t].contiguous())
+            if t % 97 == 0 or t == steps - 1:  # batch copies stay identical
+                o = obs.cpu().numpy()
+                assert (o == o[0]).all()
+                np.testing.assert_array_equal(share.cpu().numpy(), G.share_from_raw(G.raw_obs(o)))
+            O[t] = G.raw_obs(obs[0].cpu().numpy())
+            R[t] = rew[0].cpu().numpy()
+            D[t] = done[0].item()
+            I[t] = info[0].cpu().numpy()
+        np.testing.assert_array_equal(D, gdone)
+        eo = G.rel_err(O, gobs)
+        er = G.rel_err(R, grew)
+        worst["obs"] = max(worst["obs"], eo.max())
+        worst["rew"] = max(worst["rew"], er.max())
+        assert eo.max() <= 1e-5, (name, ep, "obs", np.unravel_index(eo.argmax(), eo.shape), eo.max())
+        assert er.max() <= 1e-5, (name, ep, "rew", np.unravel_index(er.argmax(), er.shape), er.max())
+        for j, k in enumerate(keys):
+            col = I[:, L.INFO_IDX[k]]
+            if k in EXACT_INFO:
+                np.testing.assert_array_equal(col, ginfo[:, j].astype(np.float32), err_msg=k)
+            else:
+                ei = G.rel_err(col, ginfo[:, j])
+                worst["info"] = max(worst["info"], ei.max())
+                assert ei.max() <= 2e-6, (name, ep, k, ei.argmax(), ei.max())
+        np.testing.assert_allclose(I[:, L.INFO_IDX["ls_task_age_hist0"]:L.INFO_IDX["ls_task_age_hist0"] + 5], ghist,
+                                   rtol=0, atol=1e-7)
+        assert (I[:, L.INFO_IDX["fault"]] == 0).all()
+        # final_obs holds the pre-reset observation of the finished episode ("original_obs")
+        fo = G.raw_obs(eng.final_obs[0].cpu().numpy())
+        np.testing.assert_array_equal(fo, O[-1])
+    eng.close()
+    return worst
+
+
+FAST = [n for n in golden_names() if n not in ("ny_m6_multi16", "ca_m6_30day")]
+
+
+@pytest.mark.parametrize("name", FAST)
+def test_hip_matches_reference_episode(name):
+    print(name, _run(name))
+
+
+@pytest.mark.parametrize("name", ["ca_m6_30day", "ny_m6_multi16"])
+def test_hip_matches_reference_long(name):
+    """30-day episode (2880 steps); 16 back-to-back episodes: history ring crosses 10 000 and wraps, set-point and
+    history carried across resets."""
+    print(name, _run(name))
