@@ -176,6 +176,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
     A(d.walk_tmp, (size_t)N * w);
   }
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
+  A(d.hist_ref, N);
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
@@ -212,7 +213,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
       {"stpt", (void**)&d.stpt, 8}, {"bat_load", (void**)&d.bat_load, 8}, {"ci_min", (void**)&d.ci_min, 8},
       {"ci_den", (void**)&d.ci_den, 8}, {"t_min", (void**)&d.t_min, 8}, {"t_den", (void**)&d.t_den, 8},
       {"carry", (void**)&d.carry, 8 * SDC_CARRY_DIM},
-      {"hist", (void**)&d.hist, sizeof(float) * SDC_HIST_STRIDE},
+      {"hist", (void**)&d.hist, sizeof(float) * SDC_HIST_STRIDE}, {"hist_ref", (void**)&d.hist_ref, 8},
       {"t_win", (void**)&d.t_win, sizeof(double) * (size_t)d.lw},
       {"wb_win", (void**)&d.wb_win, sizeof(double) * (size_t)d.lw},
       {"qtab", (void**)&d.qtab, sizeof(uint2) * (size_t)d.qstride},

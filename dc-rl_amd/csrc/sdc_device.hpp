@@ -73,7 +73,8 @@ struct SdcDev {
   double* t_win;  // [N][lw]
   double* wb_win;
   double* walk_tmp;  // [N][SDC_NORM_WINDOW] scratch of the device-side reset
-  float* hist;       // [N][SDC_HIST_STRIDE]
+  float* hist;       // [N][SDC_HIST_STRIDE]  energy - hist_ref, fp32
+  double* hist_ref;  // [N] first energy value of the env (fp64): the ring stores offsets from it
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
 };
 

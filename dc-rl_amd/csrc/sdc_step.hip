@@ -467,8 +467,12 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_step_kernel(SdcDev S
     if (share_obs) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + (tid - 128)] = share_obs_at(sh.obs, tid - 128);
   }
 
-  // (2) history append (utils/reward_creator.py:7-14): the new value replaces slot `slot`
-  const double energy = sh.energy;
+  // (2) history append (utils/reward_creator.py:7-14): the new value replaces slot `slot`.
+  // The ring holds fp32 OFFSETS from the env's first energy value (kept in fp64): normalize_energy is
+  // shift-invariant, and offsets keep the fp32 rounding error proportional to the spread of the history
+  // instead of to the ~300 kWh magnitude (two nearly equal energies would otherwise lose the z-score).
+  const double href = hist_len_old == 0 ? sh.energy : S.hist_ref[env];
+  const double energy = sh.energy - href;
   int n, slot, pos_new;
   if (hist_len_old < S.hist_cap) {
     slot = hist_len_old;
@@ -585,6 +589,7 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_step_kernel(SdcDev S
     rew[env * 3 + 2] = (float)foot;
     done[env] = (unsigned char)terminal;
     S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = energy_f;
+    if (hist_len_old == 0) S.hist_ref[env] = href;
     S.hist_len[env] = n;
     S.hist_pos[env] = pos_new;
     sh.info[SDC_INFO_ENERGY_Z] = (float)z;

@@ -18,7 +18,7 @@ _STATE_DTYPES = {
     "last_delta": (np.int32, 1), "consecutive": (np.int32, 1), "scale": (np.int32, 1),
     "hist_len": (np.int32, 1), "hist_pos": (np.int32, 1), "episode": (np.int32, 1), "fault": (np.uint32, 1),
     "stpt": (np.float64, 1), "bat_load": (np.float64, 1), "ci_min": (np.float64, 1), "ci_den": (np.float64, 1),
-    "t_min": (np.float64, 1), "t_den": (np.float64, 1),
+    "t_min": (np.float64, 1), "t_den": (np.float64, 1), "hist_ref": (np.float64, 1),
 }
 
 

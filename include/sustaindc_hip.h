@@ -171,7 +171,8 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
 
 /* parity injection + env checkpoint: copy one named state field to / from HOST memory.
  * Fields: cursor t_rel day hourq q_popped q_cum q_head last_delta consecutive scale hist_len hist_pos
- * episode (int32[N]);  stpt bat_load ci_min ci_den t_min t_den (double[N]);  hist (float[N][hist_stride]);
+ * episode (int32[N]);  stpt bat_load ci_min ci_den t_min t_den hist_ref (double[N]);
+ * hist (float[N][hist_stride], energy minus hist_ref);
  * t_win wb_win (double[N][weather_window_len]);  qtab (uint32[N][queue_stride][2]); fault (uint32[N]). */
 int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes);
 int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t bytes);
