@@ -14,12 +14,12 @@ MAX_RACKS = 64
 N_AGENTS = 3
 OBS_PAD = 26
 SHARE_OBS_DIM = 29
-INFO_DIM = 40
+INFO_DIM = 44
 TABLE_LEN = 35040
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
-SOURCES = ["sdc_capi.hip", "sdc_step.hip", "sdc_reset.hip"]
+SOURCES = ["sdc_capi.hip", "sdc_dynamics.hip", "sdc_reward.hip", "sdc_reset.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 # info column names = the reference's info keys (sustaindc_hip.h enum sdc_info_col)
@@ -34,6 +34,7 @@ INFO_COLS = [
     "bat_action", "bat_SOC", "bat_CO2_footprint", "bat_avg_CI",
     "bat_total_energy_without_battery_KWh", "bat_total_energy_with_battery_KWh",
     "norm_CI", "outside_temp", "day", "hour", "fault", "energy_z", "reserved",
+    "ep_return_ls", "ep_return_dc", "ep_return_bat", "episode_step",
 ]
 INFO_IDX = {k: i for i, k in enumerate(INFO_COLS)}
 assert len(INFO_COLS) == INFO_DIM

@@ -1,7 +1,7 @@
 // sdc_capi.hip -- host side of the C-ABI declared in include/sustaindc_hip.h.
 //
 // Owns the device-resident struct-of-arrays state of N environments on one GPU and launches the two
-// kernels (sdc_step_kernel, sdc_reset_kernel) on the caller's stream.  No CPU fallback: every entry
+// kernels (sdc_dynamics_kernel + sdc_reward_kernel per step, sdc_reset_kernel) on the caller's stream.  No CPU fallback: every entry
 // point fails with an error code when HIP reports one.
 #include <hip/hip_runtime.h>
 
@@ -13,8 +13,9 @@
 
 #include "sdc_device.hpp"
 
-extern "C" __global__ void sdc_step_kernel(SdcDev S, const int32_t* actions, float* obs, float* share_obs, float* rew,
-                                           unsigned char* done, float* info, float* final_obs);
+extern "C" __global__ void sdc_dynamics_kernel(SdcDev S, const int32_t* actions, float* obs, float* share_obs,
+                                               unsigned char* done, float* info, float* final_obs);
+extern "C" __global__ void sdc_reward_kernel(SdcDev S, float* rew, float* info);
 extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
                                             const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
                                             const double* ovr_t_max, int only_done, float* obs, float* share_obs);
@@ -177,6 +178,9 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   }
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
   A(d.hist_ref, N);
+  A(d.ep_return, (size_t)3 * N);
+  A(d.hand, (size_t)4 * N);
+  A(d.q_guess, (size_t)2 * N);
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
@@ -200,8 +204,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   // scale starts at 1, last_delta = None
   {
     std::vector<int> ones(N, 1), none(N, -2);
-    hipMemcpy(d.scale, ones.data(), sizeof(int) * N, hipMemcpyHostToDevice);
-    hipMemcpy(d.last_delta, none.data(), sizeof(int) * N, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d.scale, ones.data(), sizeof(int) * N, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d.last_delta, none.data(), sizeof(int) * N, hipMemcpyHostToDevice);
   }
   h->host_t_rel.assign(N, cfg->episode_steps);  // "finished": a reset is required before stepping
   h->fields = {
@@ -214,6 +218,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
       {"ci_den", (void**)&d.ci_den, 8}, {"t_min", (void**)&d.t_min, 8}, {"t_den", (void**)&d.t_den, 8},
       {"carry", (void**)&d.carry, 8 * SDC_CARRY_DIM},
       {"hist", (void**)&d.hist, sizeof(float) * SDC_HIST_STRIDE}, {"hist_ref", (void**)&d.hist_ref, 8},
+      {"ep_return", (void**)&d.ep_return, 8 * 3}, {"q_guess", (void**)&d.q_guess, 4 * 2},
       {"t_win", (void**)&d.t_win, sizeof(double) * (size_t)d.lw},
       {"wb_win", (void**)&d.wb_win, sizeof(double) * (size_t)d.lw},
       {"qtab", (void**)&d.qtab, sizeof(uint2) * (size_t)d.qstride},
@@ -224,8 +229,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
 
 int sdc_destroy(sdc_handle* h) {
   if (!h) return 0;
-  hipSetDevice(h->device);
-  for (void* p : h->allocs) hipFree(p);
+  (void)hipSetDevice(h->device);
+  for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return 0;
 }
@@ -348,8 +353,9 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int N = h->cfg.n_envs;
-  hipLaunchKernelGGL(sdc_step_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, h->d, actions, obs, share_obs, rew, done, info,
+  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(N), dim3(SDC_WAVE), 0, st, h->d, actions, obs, share_obs, done, info,
                      final_obs);
+  hipLaunchKernelGGL(sdc_reward_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, h->d, rew, info);
   HIP_TRY(hipGetLastError());
   h->steps_to_terminal -= 1;
   h->pending += 1;

@@ -1,9 +1,10 @@
 // sdc_device.hpp -- device-side state layout and shared device functions of the SustainDC step.
 //
-// Written for gfx950 (MI355X, CDNA4) only: 64-lane wavefronts, one workgroup of 4 wavefronts per
-// environment instance.  Wavefront 0 integrates the coupled dynamics (lanes = racks for the IT
-// model, wave shuffles for the rack reductions); all 4 wavefronts stream the env's 40 KB energy
-// history ring from HBM (16 B per lane, coalesced) and hold it in VGPRs for the order statistics
+// Written for gfx950 (MI355X, CDNA4) only: 64-lane wavefronts.  Two kernels per timestep:
+// sdc_dynamics_kernel -- one wavefront per environment instance integrates the coupled dynamics
+// (lanes = racks for the IT model, wave shuffles for the rack reductions) and writes obs / info;
+// sdc_reward_kernel -- one workgroup of 4 wavefronts per environment streams the env's 40 KB energy
+// history ring from HBM (16 B per lane, coalesced) and holds it in VGPRs for the order statistics
 // and the clipped mean / std of reward normalisation.
 //
 // Arithmetic: fp64 for the dynamics, observation features and reductions (the reference is Python
@@ -74,6 +75,9 @@ struct SdcDev {
   double* wb_win;
   double* walk_tmp;  // [N][SDC_NORM_WINDOW] scratch of the device-side reset
   float* hist;       // [N][SDC_HIST_STRIDE]  energy - hist_ref, fp32
+  double* hand;      // [4][N] dynamics -> reward kernel: energy, norm_CI next, oldest task age, overdue count
+  unsigned* q_guess; // [2][N] fp32 keys of last step's order statistics at floor((n-1)/4), floor(3(n-1)/4)
+  double* ep_return; // [3][N] running return of the current episode (cleared by reset)
   double* hist_ref;  // [N] first energy value of the env (fp64): the ring stores offsets from it
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
 };

@@ -1,75 +1,27 @@
-// sdc_step.hip -- the fused per-timestep kernel: one workgroup (4 wavefronts) per environment.
+// sdc_dynamics.hip -- coupled per-timestep dynamics, ONE WAVEFRONT PER ENVIRONMENT (block = 64 lanes).
 //
-//   phase A (256 threads): issue the 40 KB history-ring loads (10 x float4 per thread, coalesced), stage the
-//                          CI / temperature observation windows into LDS
-//   phase B (wavefront 0): coupled dynamics at cursor i -- load-shifting queue (O(1) prefix-count algebra +
-//                          a 64-ary wave search for the oldest task), CRAC set-point integrator, rack model
-//                          (lane = rack, wave-shuffle reductions), chiller / tower / water, battery --
-//                          then the 53 observation floats at i' = i + 1
-//   phase C (256 threads): order statistics of the energy history held in VGPRs (bisection on the fp32 key
-//                          space with packed block-wide counts), clipped mean / std, z-score, rewards,
-//                          ring append, coalesced obs / info stores
+//   * lanes 0..24 / 32..48 stage the carbon-intensity and temperature observation windows into LDS
+//     (coalesced reads of the struct-of-arrays trace tables);
+//   * the load-shifting queue is O(1) prefix-count algebra plus a 64-ary wave search for the oldest task;
+//   * the rack model runs lane = rack with per-rack constants read coalesced from the config table and
+//     wave-shuffle (DPP) reductions for total IT power, CRAC return and outlet temperature;
+//   * chiller / cooling tower / water / battery / set-point integrator are wave-uniform scalar fp64;
+//   * lane 0 assembles the 53 observation floats and the info block in LDS, all lanes store them coalesced.
+// The energy value and the three reward terms that need the history normaliser are handed to
+// sdc_reward_kernel (sdc_reward.hip) through a 32-byte per-env record.
 //
 // Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
 #include "sdc_device.hpp"
 
 namespace {
 
-struct StepShared {
+struct DynShared {
   double nc[32];
   double nt[32];
   float obs[64];
   float info[SDC_INFO_DIM];
-  double energy;       // bat_total_energy_with_battery_KWh
-  double norm_ci_next; // NC[i'+1]
-  double oldest_norm;
-  int overdue;
   int terminal;
-  int hist_len_new;
-  int hist_slot;
-  unsigned red_u[2][4];
-  unsigned red_v[2][4];
-  double red_d[2][4];
-  double red_e[2][4];
 };
-
-__device__ __forceinline__ unsigned f32_key(float f) {
-  const unsigned b = __float_as_uint(f);
-  return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
-}
-__device__ __forceinline__ float key_f32(unsigned k) {
-  const unsigned b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
-  return __uint_as_float(b);
-}
-
-// block-wide reductions over 4 wavefronts; `par` alternates the LDS slot so one barrier per call suffices
-__device__ __forceinline__ unsigned block_sum_u32(unsigned v, unsigned (*red)[4], int par, int wave, int lane) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if (lane == 0) red[par][wave] = v;
-  __syncthreads();
-  return red[par][0] + red[par][1] + red[par][2] + red[par][3];
-}
-__device__ __forceinline__ unsigned block_min_u32(unsigned v, unsigned (*red)[4], int par, int wave, int lane) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
-  if (lane == 0) red[par][wave] = v;
-  __syncthreads();
-  return min(min(red[par][0], red[par][1]), min(red[par][2], red[par][3]));
-}
-__device__ __forceinline__ unsigned block_max_u32(unsigned v, unsigned (*red)[4], int par, int wave, int lane) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
-  if (lane == 0) red[par][wave] = v;
-  __syncthreads();
-  return max(max(red[par][0], red[par][1]), max(red[par][2], red[par][3]));
-}
-__device__ __forceinline__ double block_sum_f64(double v, double (*red)[4], int par, int wave, int lane) {
-  v = wave_sum_f64(v);
-  if (lane == 0) red[par][wave] = v;
-  __syncthreads();
-  return (red[par][0] + red[par][1]) + (red[par][2] + red[par][3]);
-}
 
 // envs/datacenter.py:356-429 calculate_chiller_power
 __device__ __forceinline__ double chiller_power(double max_cooling_cap, double load, double ambient_temp) {
@@ -94,9 +46,9 @@ __device__ __forceinline__ double chiller_power(double max_cooling_cap, double l
 __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); }
 
 // ------------------------------------------------------------------------------------------------
-// phase B: executed by wavefront 0 only (lane in [0, 64))
+// the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
 __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, const int32_t* __restrict__ actions,
-                              StepShared& sh) {
+                              DynShared& sh) {
   const int loc = S.loc_id[env];
   const sdc_dc_params& P = S.dc[S.cfg_id[env]];
   const int TL = S.table_len;
@@ -382,12 +334,19 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
     inf[SDC_INFO_FAULT] = (float)f_all;
     inf[SDC_INFO_ENERGY_Z] = 0.0f;
     inf[SDC_INFO_RESERVED] = 0.0f;
+    inf[SDC_INFO_EP_RETURN_LS] = 0.0f;   // the four columns below are filled by sdc_reward_kernel
+    inf[SDC_INFO_EP_RETURN_DC] = 0.0f;
+    inf[SDC_INFO_EP_RETURN_BAT] = 0.0f;
+    inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
 
-    // ---- hand-off to phase C -------------------------------------------------------------------------
-    sh.energy = energy;
-    sh.norm_ci_next = sh.nc[17];
-    sh.oldest_norm = oldest_norm;
-    sh.overdue = overdue;
+    // ---- hand-off to the reward kernel (4 doubles per env, struct of arrays) ----------------------------
+    {
+      const int N = S.n_envs;
+      S.hand[env] = energy;                    // bat_total_energy_with_battery_KWh
+      S.hand[N + env] = sh.nc[17];             // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
+      S.hand[2 * N + env] = oldest_norm;       // ls_oldest_task_age
+      S.hand[3 * N + env] = (double)overdue;   // ls_overdue_penalty
+    }
     sh.terminal = terminal;
 
     // ---- state write-back ------------------------------------------------------------------------------
@@ -417,185 +376,33 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
 
 }  // namespace
 
-// ------------------------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_step_kernel(SdcDev S, const int32_t* __restrict__ actions,
-                                                                         float* __restrict__ obs,
-                                                                         float* __restrict__ share_obs,
-                                                                         float* __restrict__ rew,
-                                                                         unsigned char* __restrict__ done,
-                                                                         float* __restrict__ info,
-                                                                         float* __restrict__ final_obs) {
-  __shared__ StepShared sh;
+extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
+                                                                             float* __restrict__ obs,
+                                                                             float* __restrict__ share_obs,
+                                                                             unsigned char* __restrict__ done,
+                                                                             float* __restrict__ info,
+                                                                             float* __restrict__ final_obs) {
+  __shared__ DynShared sh;
   const int env = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-
-  // ---- phase A: get the 40 KB ring moving first, then stage the obs windows ---------------------------
-  const int hist_len_old = S.hist_len[env];
-  const int hist_pos_old = S.hist_pos[env];
-  unsigned key[SDC_HIST_PER_THREAD];
-  {
-    const float4* hp = reinterpret_cast<const float4*>(S.hist + (size_t)env * SDC_HIST_STRIDE);
-#pragma unroll
-    for (int k = 0; k < SDC_HIST_PER_THREAD / 4; k++) {
-      const float4 v = hp[k * SDC_BLOCK + tid];
-      key[4 * k + 0] = __float_as_uint(v.x);
-      key[4 * k + 1] = __float_as_uint(v.y);
-      key[4 * k + 2] = __float_as_uint(v.z);
-      key[4 * k + 3] = __float_as_uint(v.w);
-    }
-  }
-  if (tid < 64) {
-    stage_windows(S, S.loc_id[env], S.cursor[env] + 1, S.t_win + (size_t)env * S.lw + S.t_rel[env] + 1, S.ci_min[env],
-                  S.ci_den[env], S.t_min[env], S.t_den[env], tid, sh.nc, sh.nt);
-  }
+  const int lane = threadIdx.x;
+  stage_windows(S, S.loc_id[env], S.cursor[env] + 1, S.t_win + (size_t)env * S.lw + S.t_rel[env] + 1, S.ci_min[env],
+                S.ci_den[env], S.t_min[env], S.t_den[env], lane, sh.nc, sh.nt);
   __syncthreads();
-
-  // ---- phase B: coupled dynamics on wavefront 0 ----------------------------------------------------------
-  if (wave == 0) step_dynamics(S, env, lane, actions, sh);
+  step_dynamics(S, env, lane, actions, sh);
   __syncthreads();
-
-  // ---- phase C ----------------------------------------------------------------------------------------------
-  // (1) coalesced obs / share_obs / info stores (threads 0..77, 128..156, 192..231)
   const int terminal = sh.terminal;
-  if (tid < SDC_OBS_OUT) {
-    const float v = obs_padded_at(sh.obs, tid);
-    obs[(size_t)env * SDC_OBS_OUT + tid] = v;
-    if (terminal && final_obs) final_obs[(size_t)env * SDC_OBS_OUT + tid] = v;
-  } else if (tid >= 128 && tid < 128 + SDC_SHARE_OBS_DIM) {
-    if (share_obs) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + (tid - 128)] = share_obs_at(sh.obs, tid - 128);
-  }
-
-  // (2) history append (utils/reward_creator.py:7-14): the new value replaces slot `slot`.
-  // The ring holds fp32 OFFSETS from the env's first energy value (kept in fp64): normalize_energy is
-  // shift-invariant, and offsets keep the fp32 rounding error proportional to the spread of the history
-  // instead of to the ~300 kWh magnitude (two nearly equal energies would otherwise lose the z-score).
-  const double href = hist_len_old == 0 ? sh.energy : S.hist_ref[env];
-  const double energy = sh.energy - href;
-  int n, slot, pos_new;
-  if (hist_len_old < S.hist_cap) {
-    slot = hist_len_old;
-    n = hist_len_old + 1;
-    pos_new = hist_pos_old;
-  } else {
-    slot = hist_pos_old;
-    n = hist_len_old;
-    pos_new = hist_pos_old + 1 == S.hist_cap ? 0 : hist_pos_old + 1;
-  }
-  const float energy_f = (float)energy;
-#pragma unroll
-  for (int k = 0; k < SDC_HIST_PER_THREAD / 4; k++) {
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int idx = (k * SDC_BLOCK + tid) * 4 + c;
-      float f = __uint_as_float(key[4 * k + c]);
-      if (idx == slot) f = energy_f;
-      key[4 * k + c] = idx < n ? f32_key(f) : 0xFFFFFFFFu;
+  // coalesced stores: obs [3][26] (78 floats), share_obs [29], info [SDC_INFO_DIM]
+  {
+    const float v0 = obs_padded_at(sh.obs, lane);
+    obs[(size_t)env * SDC_OBS_OUT + lane] = v0;
+    if (terminal && final_obs) final_obs[(size_t)env * SDC_OBS_OUT + lane] = v0;
+    if (lane < SDC_OBS_OUT - SDC_WAVE) {
+      const float v1 = obs_padded_at(sh.obs, SDC_WAVE + lane);
+      obs[(size_t)env * SDC_OBS_OUT + SDC_WAVE + lane] = v1;
+      if (terminal && final_obs) final_obs[(size_t)env * SDC_OBS_OUT + SDC_WAVE + lane] = v1;
     }
   }
-
-  // (3) normalize_energy (utils/reward_creator.py:16-45)
-  double z = 0.0;
-  int par = 0;
-  if (n >= 2) {
-    // order statistics at floor((n-1)q) and +1 for q = .25, .75 by bisection on the key space
-    const int k1 = (n - 1) >> 2;                 // floor((n-1) * 0.25)
-    const double t1 = (double)((n - 1) & 3) * 0.25;
-    const int k3 = (3 * (n - 1)) >> 2;           // floor((n-1) * 0.75)
-    const double t3 = (double)((3 * (n - 1)) & 3) * 0.25;
-    unsigned kmin = 0xFFFFFFFFu, kmax = 0u;
-#pragma unroll
-    for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
-      kmin = min(kmin, key[j]);
-      kmax = max(kmax, key[j] == 0xFFFFFFFFu ? 0u : key[j]);
-    }
-    kmin = block_min_u32(kmin, sh.red_u, par, wave, lane);
-    kmax = block_max_u32(kmax, sh.red_v, par, wave, lane);
-    par ^= 1;
-    unsigned lo1 = kmin, hi1 = kmax, lo3 = kmin, hi3 = kmax;
-    while (lo1 < hi1 || lo3 < hi3) {
-      const unsigned m1 = lo1 + ((hi1 - lo1) >> 1);
-      const unsigned m3 = lo3 + ((hi3 - lo3) >> 1);
-      unsigned cnt = 0;  // packed: count(key <= m1) << 16 | count(key <= m3); each <= 10240
-#pragma unroll
-      for (int j = 0; j < SDC_HIST_PER_THREAD; j++) cnt += ((key[j] <= m1) ? 0x10000u : 0u) + ((key[j] <= m3) ? 1u : 0u);
-      cnt = block_sum_u32(cnt, sh.red_u, par, wave, lane);
-      par ^= 1;
-      const int c1 = (int)(cnt >> 16), c3 = (int)(cnt & 0xFFFFu);
-      if (lo1 < hi1) {
-        if (c1 >= k1 + 1) hi1 = m1; else lo1 = m1 + 1;
-      }
-      if (lo3 < hi3) {
-        if (c3 >= k3 + 1) hi3 = m3; else lo3 = m3 + 1;
-      }
-    }
-    // successors: value at rank k+1 = same value if count(<= v_k) >= k+2, else min{key > v_k}
-    unsigned cnt = 0, s1 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
-      cnt += ((key[j] <= lo1) ? 0x10000u : 0u) + ((key[j] <= lo3) ? 1u : 0u);
-      if (key[j] > lo1) s1 = min(s1, key[j]);
-      if (key[j] > lo3) s3 = min(s3, key[j]);
-    }
-    cnt = block_sum_u32(cnt, sh.red_u, par, wave, lane);
-    s1 = block_min_u32(s1, sh.red_v, par, wave, lane);
-    par ^= 1;
-    s3 = block_min_u32(s3, sh.red_u, par, wave, lane);
-    par ^= 1;
-    const double a1 = (double)key_f32(lo1), a3 = (double)key_f32(lo3);
-    const double b1 = ((int)(cnt >> 16) >= k1 + 2) ? a1 : (double)key_f32(s1);
-    const double b3 = ((int)(cnt & 0xFFFFu) >= k3 + 2) ? a3 : (double)key_f32(s3);
-    // numpy _lerp: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5
-    const double d1 = b1 - a1, d3 = b3 - a3;
-    const double q1 = (t1 == 0.0) ? a1 : ((t1 >= 0.5) ? b1 - d1 * (1.0 - t1) : a1 + d1 * t1);
-    const double q3 = (t3 == 0.0) ? a3 : ((t3 >= 0.5) ? b3 - d3 * (1.0 - t3) : a3 + d3 * t3);
-    const double iqr = q3 - q1;
-    const double lb = q1 - 1.5 * iqr, ub = q3 + 1.5 * iqr;
-    // clipped mean, then population std around it (two passes over the VGPR-resident ring)
-    double s = 0.0;
-#pragma unroll
-    for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
-      if (key[j] != 0xFFFFFFFFu) {
-        const double v = (double)key_f32(key[j]);
-        s += v < lb ? lb : (v > ub ? ub : v);
-      }
-    }
-    const double mean = block_sum_f64(s, sh.red_d, par, wave, lane) / (double)n;
-    double s2 = 0.0;
-#pragma unroll
-    for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
-      if (key[j] != 0xFFFFFFFFu) {
-        const double v = (double)key_f32(key[j]);
-        const double c = (v < lb ? lb : (v > ub ? ub : v)) - mean;
-        s2 += c * c;
-      }
-    }
-    const double var = block_sum_f64(s2, sh.red_e, par, wave, lane) / (double)n;
-    par ^= 1;
-    const double sd = sqrt(var);
-    z = (energy - mean) / (sd > 0 ? sd : 1.0);
-  }
-
-  // (4) rewards (utils/reward_creator.py:48-130), ring append, done flag, info
-  if (tid == 0) {
-    const double foot = -1.0 * (sh.norm_ci_next * z / 0.50);
-    const double overdue_pen = -0.3 * sqrt((double)sh.overdue) + 0.3;
-    const double age_pen = -0.1 * sh.oldest_norm;
-    double rls = foot + overdue_pen + age_pen;
-    rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
-    rew[env * 3 + 0] = (float)rls;
-    rew[env * 3 + 1] = (float)foot;
-    rew[env * 3 + 2] = (float)foot;
-    done[env] = (unsigned char)terminal;
-    S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = energy_f;
-    if (hist_len_old == 0) S.hist_ref[env] = href;
-    S.hist_len[env] = n;
-    S.hist_pos[env] = pos_new;
-    sh.info[SDC_INFO_ENERGY_Z] = (float)z;
-  }
-  if (info) {
-    __syncthreads();
-    if (tid >= 192 && tid < 192 + SDC_INFO_DIM) info[(size_t)env * SDC_INFO_DIM + (tid - 192)] = sh.info[tid - 192];
-  }
+  if (share_obs && lane < SDC_SHARE_OBS_DIM) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = share_obs_at(sh.obs, lane);
+  if (info && lane < SDC_INFO_DIM) info[(size_t)env * SDC_INFO_DIM + lane] = sh.info[lane];
+  if (lane == 0) done[env] = (unsigned char)terminal;
 }

@@ -197,6 +197,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     S.episode[env] = episode;
     S.fault[env] = fault;
     for (int b = 0; b < SDC_CARRY_DIM; b++) S.carry[b * S.n_envs + env] = 0.0;
+    for (int b = 0; b < 3; b++) S.ep_return[b * S.n_envs + env] = 0.0;
   }
   __syncthreads();
   if (obs) {

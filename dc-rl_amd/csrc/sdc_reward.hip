@@ -1,0 +1,337 @@
+// sdc_reward.hip -- history-normalised rewards: one workgroup (4 wavefronts, 256 lanes) per environment.
+//
+// utils/reward_creator.py:16-45 normalises the step's energy with the 25th / 75th percentiles, the IQR-clipped
+// mean and the clipped population std of a 10 000-entry sliding history, three times per step.  Here the
+// window is streamed ONCE per step: 40 KB per env as 10 x float4 per lane (coalesced, all loads issued before
+// anything else), held in VGPRs, and
+//   pass 1  certifies the four order statistics from last step's values: one sweep counts keys <= / >= the
+//           previous quartile (wave ballots + scalar popcounts) and tracks its predecessor and two successors;
+//           an insert + an evict move an order statistic by at most one position, so this almost always
+//           pins rank k and k+1.  If it does not (first steps, injected state), an exact bisection on the
+//           fp32 key space runs instead -- same result, more sweeps;
+//   pass 2  accumulates the clipped sum and sum of squares in fp64 around the inter-quartile midpoint.
+// Two workgroup-wide reductions through LDS, then lane 0 writes the three rewards, appends the energy to the
+// ring and updates the running episode return.
+#include "sdc_device.hpp"
+
+namespace {
+
+struct RewardShared {
+  unsigned red_u[2][4];
+  unsigned red_v[2][4];
+  unsigned p1[4][12];   // pass-1 per-wave partials
+  double red_d[4];
+  double red_e[4];
+};
+
+__device__ __forceinline__ unsigned f32_key(float f) {
+  const unsigned b = __float_as_uint(f);
+  return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+  const unsigned b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+  return __uint_as_float(b);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+  return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+  return v;
+}
+// two smallest of the union (as a multiset) of per-lane sorted pairs (a1 <= a2)
+__device__ __forceinline__ void wave_min2_u32(unsigned& a1, unsigned& a2) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned b1 = (unsigned)__shfl_xor((int)a1, o), b2 = (unsigned)__shfl_xor((int)a2, o);
+    const unsigned lo = min(a1, b1), hi = max(a1, b1);
+    a2 = min(hi, min(a2, b2));
+    a1 = lo;
+  }
+}
+
+// block-wide reductions over 4 wavefronts; `par` alternates the LDS slot so one barrier per call suffices
+__device__ __forceinline__ unsigned block_sum_u32(unsigned v, unsigned (*red)[4], int par, int wave, int lane) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane == 0) red[par][wave] = v;
+  __syncthreads();
+  return red[par][0] + red[par][1] + red[par][2] + red[par][3];
+}
+__device__ __forceinline__ unsigned block_min_u32(unsigned v, unsigned (*red)[4], int par, int wave, int lane) {
+  v = wave_min_u32(v);
+  if (lane == 0) red[par][wave] = v;
+  __syncthreads();
+  return min(min(red[par][0], red[par][1]), min(red[par][2], red[par][3]));
+}
+__device__ __forceinline__ unsigned block_max_u32(unsigned v, unsigned (*red)[4], int par, int wave, int lane) {
+  v = wave_max_u32(v);
+  if (lane == 0) red[par][wave] = v;
+  __syncthreads();
+  return max(max(red[par][0], red[par][1]), max(red[par][2], red[par][3]));
+}
+
+constexpr unsigned KEY_NONE = 0xFFFFFFFFu;  // marks ring slots beyond the current history length
+
+// Order statistics at ranks k and k+1 from the sweep around guess g:
+//   c_lt = #keys < g, c_le = #keys <= g, p = largest key < g, s1 <= s2 the two smallest keys > g (KEY_NONE if absent).
+// Ranks [c_lt-1] = p, [c_lt, c_le) = g, [c_le] = s1, [c_le+1] = s2.  Returns false when k or k+1 fall outside.
+__device__ __forceinline__ bool certify(int k, int n, unsigned g, int c_lt, int c_le, unsigned p, unsigned s1, unsigned s2,
+                                        unsigned& a, unsigned& b) {
+  auto at = [&](int r, unsigned& out) -> bool {
+    if (r >= c_lt && r < c_le) { out = g; return true; }
+    if (r == c_lt - 1 && p != KEY_NONE) { out = p; return true; }
+    if (r == c_le && s1 != KEY_NONE) { out = s1; return true; }
+    if (r == c_le + 1 && s2 != KEY_NONE) { out = s2; return true; }
+    return false;
+  };
+  if (!at(k, a)) return false;
+  if (k + 1 > n - 1) { b = a; return true; }
+  return at(k + 1, b);
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev S, float* __restrict__ rew,
+                                                                           float* __restrict__ info) {
+  __shared__ RewardShared sh;
+  const int env = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int N = S.n_envs;
+
+  // ---- stream the ring: every load of the workgroup is in flight before the first use -------------------------
+  unsigned key[SDC_HIST_PER_THREAD];
+  {
+    const float4* hp = reinterpret_cast<const float4*>(S.hist + (size_t)env * SDC_HIST_STRIDE);
+#pragma unroll
+    for (int k = 0; k < SDC_HIST_PER_THREAD / 4; k++) {
+      const float4 v = hp[k * SDC_BLOCK + tid];
+      key[4 * k + 0] = __float_as_uint(v.x);
+      key[4 * k + 1] = __float_as_uint(v.y);
+      key[4 * k + 2] = __float_as_uint(v.z);
+      key[4 * k + 3] = __float_as_uint(v.w);
+    }
+  }
+  const int hist_len_old = S.hist_len[env];
+  const int hist_pos_old = S.hist_pos[env];
+  const double e_abs = S.hand[env];
+  const double norm_ci_next = S.hand[N + env];
+  const double oldest_norm = S.hand[2 * N + env];
+  const double overdue = S.hand[3 * N + env];
+  const unsigned g1 = S.q_guess[env], g3 = S.q_guess[N + env];
+
+  // ---- history append (utils/reward_creator.py:7-14): the new value replaces slot `slot` -------------------------
+  // The ring holds fp32 OFFSETS from the env's first energy value (kept in fp64): normalize_energy is
+  // shift-invariant, and offsets keep the fp32 rounding error proportional to the spread of the history
+  // instead of to the ~300 kWh magnitude (two nearly equal energies would otherwise lose the z-score).
+  const double href = hist_len_old == 0 ? e_abs : S.hist_ref[env];
+  const double energy = e_abs - href;
+  int n, slot, pos_new;
+  if (hist_len_old < S.hist_cap) {
+    slot = hist_len_old;
+    n = hist_len_old + 1;
+    pos_new = hist_pos_old;
+  } else {
+    slot = hist_pos_old;
+    n = hist_len_old;
+    pos_new = hist_pos_old + 1 == S.hist_cap ? 0 : hist_pos_old + 1;
+  }
+  const float energy_f = (float)energy;
+#pragma unroll
+  for (int k = 0; k < SDC_HIST_PER_THREAD / 4; k++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int idx = (k * SDC_BLOCK + tid) * 4 + c;
+      float f = __uint_as_float(key[4 * k + c]);
+      if (idx == slot) f = energy_f;
+      key[4 * k + c] = idx < n ? f32_key(f) : KEY_NONE;
+    }
+  }
+
+  // ---- normalize_energy (utils/reward_creator.py:16-45) ------------------------------------------------------------
+  double z = 0.0;
+  unsigned ng1 = g1, ng3 = g3;
+  if (n >= 2) {
+    const int k1 = (n - 1) >> 2;                  // floor((n-1) * 0.25), np.percentile 'linear'
+    const double t1 = (double)((n - 1) & 3) * 0.25;
+    const int k3 = (3 * (n - 1)) >> 2;            // floor((n-1) * 0.75)
+    const double t3 = (double)((3 * (n - 1)) & 3) * 0.25;
+    unsigned a1 = 0, b1 = 0, a3 = 0, b3 = 0;
+    bool ok = false;
+    if (g1 != 0u && g1 != KEY_NONE && g3 != 0u && g3 != KEY_NONE) {
+      // pass 1: one sweep around last step's quartile keys
+      int cle1 = 0, cge1 = 0, cle3 = 0, cge3 = 0;  // wave-level counts (scalar unit)
+      unsigned pd1 = KEY_NONE, sd1a = KEY_NONE, sd1b = KEY_NONE, pd3 = KEY_NONE, sd3a = KEY_NONE, sd3b = KEY_NONE;
+#pragma unroll
+      for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
+        const unsigned x = key[j];
+        cle1 += __popcll(__ballot(x <= g1));
+        cge1 += __popcll(__ballot(x >= g1));
+        cle3 += __popcll(__ballot(x <= g3));
+        cge3 += __popcll(__ballot(x >= g3));
+        // distances in wrap-around arithmetic: a key on the wrong side wraps above every key on the right side
+        const unsigned ds1 = x - g1 - 1u, dp1 = g1 - 1u - x, ds3 = x - g3 - 1u, dp3 = g3 - 1u - x;
+        sd1b = min(max(sd1a, ds1), sd1b);
+        sd1a = min(sd1a, ds1);
+        pd1 = min(pd1, dp1);
+        sd3b = min(max(sd3a, ds3), sd3b);
+        sd3a = min(sd3a, ds3);
+        pd3 = min(pd3, dp3);
+      }
+      pd1 = wave_min_u32(pd1);
+      pd3 = wave_min_u32(pd3);
+      wave_min2_u32(sd1a, sd1b);
+      wave_min2_u32(sd3a, sd3b);
+      if (lane == 0) {
+        unsigned* w = sh.p1[wave];
+        w[0] = (unsigned)cle1; w[1] = (unsigned)cge1; w[2] = (unsigned)cle3; w[3] = (unsigned)cge3;
+        w[4] = pd1; w[5] = sd1a; w[6] = sd1b; w[7] = pd3; w[8] = sd3a; w[9] = sd3b;
+      }
+      __syncthreads();
+      int c_le1 = 0, c_ge1 = 0, c_le3 = 0, c_ge3 = 0;
+      unsigned P1 = KEY_NONE, S1a = KEY_NONE, S1b = KEY_NONE, P3 = KEY_NONE, S3a = KEY_NONE, S3b = KEY_NONE;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const unsigned* q = sh.p1[w];
+        c_le1 += (int)q[0]; c_ge1 += (int)q[1]; c_le3 += (int)q[2]; c_ge3 += (int)q[3];
+        P1 = min(P1, q[4]);
+        S1b = min(max(S1a, q[5]), min(S1b, q[6]));
+        S1a = min(S1a, q[5]);
+        P3 = min(P3, q[7]);
+        S3b = min(max(S3a, q[8]), min(S3b, q[9]));
+        S3a = min(S3a, q[8]);
+      }
+      // invalid slots (KEY_NONE) satisfy x >= g: remove them from the >= counts
+      const int n_invalid = SDC_HIST_STRIDE - n;
+      const int c_lt1 = n - (c_ge1 - n_invalid), c_lt3 = n - (c_ge3 - n_invalid);
+      // distances back to keys; a wrapped distance means "no such key"
+      const unsigned p1k = P1 < g1 ? g1 - 1u - P1 : KEY_NONE;               // legit pred distance < g
+      const unsigned s1ak = S1a < KEY_NONE - g1 - 1u ? g1 + 1u + S1a : KEY_NONE;  // legit succ distance <= 2^32-2-g
+      const unsigned s1bk = S1b < KEY_NONE - g1 - 1u ? g1 + 1u + S1b : KEY_NONE;
+      const unsigned p3k = P3 < g3 ? g3 - 1u - P3 : KEY_NONE;
+      const unsigned s3ak = S3a < KEY_NONE - g3 - 1u ? g3 + 1u + S3a : KEY_NONE;
+      const unsigned s3bk = S3b < KEY_NONE - g3 - 1u ? g3 + 1u + S3b : KEY_NONE;
+      ok = certify(k1, n, g1, c_lt1, c_le1, p1k, s1ak, s1bk, a1, b1) &&
+           certify(k3, n, g3, c_lt3, c_le3, p3k, s3ak, s3bk, a3, b3);
+    }
+    if (!ok) {
+      // exact fallback: bisection on the key space (block-uniform control flow)
+      int par = 0;
+      unsigned kmin = KEY_NONE, kmax = 0u;
+#pragma unroll
+      for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
+        kmin = min(kmin, key[j]);
+        kmax = max(kmax, key[j] == KEY_NONE ? 0u : key[j]);
+      }
+      __syncthreads();
+      kmin = block_min_u32(kmin, sh.red_u, par, wave, lane);
+      kmax = block_max_u32(kmax, sh.red_v, par, wave, lane);
+      par ^= 1;
+      unsigned lo1 = kmin, hi1 = kmax, lo3 = kmin, hi3 = kmax;
+      while (lo1 < hi1 || lo3 < hi3) {
+        const unsigned m1 = lo1 + ((hi1 - lo1) >> 1);
+        const unsigned m3 = lo3 + ((hi3 - lo3) >> 1);
+        unsigned cnt = 0;  // packed: count(key <= m1) << 16 | count(key <= m3); each <= 10240
+#pragma unroll
+        for (int j = 0; j < SDC_HIST_PER_THREAD; j++) cnt += ((key[j] <= m1) ? 0x10000u : 0u) + ((key[j] <= m3) ? 1u : 0u);
+        cnt = block_sum_u32(cnt, sh.red_u, par, wave, lane);
+        par ^= 1;
+        const int c1 = (int)(cnt >> 16), c3 = (int)(cnt & 0xFFFFu);
+        if (lo1 < hi1) {
+          if (c1 >= k1 + 1) hi1 = m1; else lo1 = m1 + 1;
+        }
+        if (lo3 < hi3) {
+          if (c3 >= k3 + 1) hi3 = m3; else lo3 = m3 + 1;
+        }
+      }
+      // successors: value at rank k+1 = same value if count(<= v_k) >= k+2, else min{key > v_k}
+      unsigned cnt = 0, s1 = KEY_NONE, s3 = KEY_NONE;
+#pragma unroll
+      for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
+        cnt += ((key[j] <= lo1) ? 0x10000u : 0u) + ((key[j] <= lo3) ? 1u : 0u);
+        if (key[j] > lo1) s1 = min(s1, key[j]);
+        if (key[j] > lo3) s3 = min(s3, key[j]);
+      }
+      cnt = block_sum_u32(cnt, sh.red_u, par, wave, lane);
+      s1 = block_min_u32(s1, sh.red_v, par, wave, lane);
+      par ^= 1;
+      s3 = block_min_u32(s3, sh.red_u, par, wave, lane);
+      par ^= 1;
+      a1 = lo1;
+      a3 = lo3;
+      b1 = ((int)(cnt >> 16) >= k1 + 2 || s1 == KEY_NONE) ? a1 : s1;
+      b3 = ((int)(cnt & 0xFFFFu) >= k3 + 2 || s3 == KEY_NONE) ? a3 : s3;
+    }
+    ng1 = a1;
+    ng3 = a3;
+    const double fa1 = (double)key_f32(a1), fb1 = (double)key_f32(b1);
+    const double fa3 = (double)key_f32(a3), fb3 = (double)key_f32(b3);
+    // numpy _lerp: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5
+    const double d1 = fb1 - fa1, d3 = fb3 - fa3;
+    const double q1 = (t1 == 0.0) ? fa1 : ((t1 >= 0.5) ? fb1 - d1 * (1.0 - t1) : fa1 + d1 * t1);
+    const double q3 = (t3 == 0.0) ? fa3 : ((t3 >= 0.5) ? fb3 - d3 * (1.0 - t3) : fa3 + d3 * t3);
+    const double iqr = q3 - q1;
+    const double lb = q1 - 1.5 * iqr, ub = q3 + 1.5 * iqr;
+    // pass 2: clipped sum and sum of squares around the inter-quartile midpoint, fp64
+    const double ctr = 0.5 * (q1 + q3);
+    double s = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
+      if (key[j] != KEY_NONE) {
+        const double v = (double)key_f32(key[j]);
+        const double c = fmin(fmax(v, lb), ub) - ctr;
+        s += c;
+        s2 += c * c;
+      }
+    }
+    s = wave_sum_f64(s);
+    s2 = wave_sum_f64(s2);
+    if (lane == 0) {
+      sh.red_d[wave] = s;
+      sh.red_e[wave] = s2;
+    }
+    __syncthreads();
+    const double S1 = (sh.red_d[0] + sh.red_d[1]) + (sh.red_d[2] + sh.red_d[3]);
+    const double S2 = (sh.red_e[0] + sh.red_e[1]) + (sh.red_e[2] + sh.red_e[3]);
+    const double m0 = S1 / (double)n;
+    const double mean = ctr + m0;
+    const double var = S2 / (double)n - m0 * m0;
+    const double sd = var > 0 ? sqrt(var) : 0.0;
+    z = (energy - mean) / (sd > 0 ? sd : 1.0);
+  }
+
+  // ---- rewards (utils/reward_creator.py:48-130), ring append, running episode return -------------------------------
+  if (tid == 0) {
+    const double foot = -1.0 * (norm_ci_next * z / 0.50);
+    const double overdue_pen = -0.3 * sqrt(overdue) + 0.3;
+    const double age_pen = -0.1 * oldest_norm;
+    double rls = foot + overdue_pen + age_pen;
+    rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
+    rew[env * 3 + 0] = (float)rls;
+    rew[env * 3 + 1] = (float)foot;
+    rew[env * 3 + 2] = (float)foot;
+    const double r0 = S.ep_return[env] + rls, r1 = S.ep_return[N + env] + foot, r2 = S.ep_return[2 * N + env] + foot;
+    S.ep_return[env] = r0;
+    S.ep_return[N + env] = r1;
+    S.ep_return[2 * N + env] = r2;
+    S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = energy_f;
+    if (hist_len_old == 0) S.hist_ref[env] = href;
+    S.hist_len[env] = n;
+    S.hist_pos[env] = pos_new;
+    S.q_guess[env] = ng1;
+    S.q_guess[N + env] = ng3;
+    if (info) {
+      float* inf = info + (size_t)env * SDC_INFO_DIM;
+      inf[SDC_INFO_ENERGY_Z] = (float)z;
+      inf[SDC_INFO_EP_RETURN_LS] = (float)r0;
+      inf[SDC_INFO_EP_RETURN_DC] = (float)r1;
+      inf[SDC_INFO_EP_RETURN_BAT] = (float)r2;
+    }
+  }
+}

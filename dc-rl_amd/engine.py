@@ -1,7 +1,8 @@
 """SdcEngine: N SustainDC environment instances resident on one MI355X, driven through the C-ABI.
 
 PyTorch is plumbing here: it owns the obs / action / reward / info device buffers and the HIP stream;
-the dynamics run in the hand-written kernels of csrc/ (sdc_step_kernel, sdc_reset_kernel).
+the dynamics run in the hand-written kernels of csrc/ (sdc_dynamics_kernel, sdc_reward_kernel,
+sdc_reset_kernel).
 """
 from __future__ import annotations
 
@@ -168,6 +169,10 @@ class SdcEngine:
             return np.zeros((N, self.queue_stride, 2), dtype=np.uint32)
         if name == "carry":
             return np.zeros((8, N), dtype=np.float64)
+        if name == "ep_return":
+            return np.zeros((3, N), dtype=np.float64)
+        if name == "q_guess":
+            return np.zeros((2, N), dtype=np.uint32)
         raise KeyError(name)
 
     def get_state(self, name: str) -> np.ndarray:
@@ -182,7 +187,7 @@ class SdcEngine:
 
     def state_dict(self) -> dict:
         """Full env checkpoint (the reference never checkpoints env state)."""
-        names = list(_STATE_DTYPES) + ["hist", "t_win", "wb_win", "qtab", "carry"]
+        names = list(_STATE_DTYPES) + ["hist", "t_win", "wb_win", "qtab", "carry", "ep_return", "q_guess"]
         return {n: self.get_state(n) for n in names}
 
     def load_state_dict(self, sd: dict):

@@ -28,7 +28,7 @@ extern "C" {
 #define SDC_N_AGENTS 3
 #define SDC_OBS_PAD 26       /* per-agent obs padded to 26 (harl/envs/sustaindc/harlsustaindc_env.py:25-26) */
 #define SDC_SHARE_OBS_DIM 29 /* harlsustaindc_env.py:78-80 */
-#define SDC_INFO_DIM 40
+#define SDC_INFO_DIM 44
 #define SDC_TABLE_LEN 35040  /* 365 d x 96 steps (utils/managers.py:184) */
 
 /* info[N][SDC_INFO_DIM] columns; names are the reference's info keys
@@ -70,7 +70,13 @@ enum sdc_info_col {
   SDC_INFO_HOUR,
   SDC_INFO_FAULT,    /* bit mask, see SDC_FAULT_* (the reference raises / asserts instead) */
   SDC_INFO_ENERGY_Z, /* normalize_energy() output shared by the three rewards */
-  SDC_INFO_RESERVED
+  SDC_INFO_RESERVED,
+  /* running return of the current episode INCLUDING this step (== the episode return on the done step);
+   * feeds the return statistics the runners log (harl/common/base_logger.py:75-88) without host sums */
+  SDC_INFO_EP_RETURN_LS,
+  SDC_INFO_EP_RETURN_DC,
+  SDC_INFO_EP_RETURN_BAT,
+  SDC_INFO_EPISODE_STEP /* steps taken in the current episode, including this one */
 };
 
 #define SDC_FAULT_OUTLET_DELTA 1u  /* envs/datacenter.py:295-300 raises */
@@ -171,7 +177,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
 
 /* parity injection + env checkpoint: copy one named state field to / from HOST memory.
  * Fields: cursor t_rel day hourq q_popped q_cum q_head last_delta consecutive scale hist_len hist_pos
- * episode (int32[N]);  stpt bat_load ci_min ci_den t_min t_den hist_ref (double[N]);
+ * episode (int32[N]);  stpt bat_load ci_min ci_den t_min t_den hist_ref (double[N]);  ep_return (double[3][N]);
  * hist (float[N][hist_stride], energy minus hist_ref);
  * t_win wb_win (double[N][weather_window_len]);  qtab (uint32[N][queue_stride][2]); fault (uint32[N]). */
 int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes);

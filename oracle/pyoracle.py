@@ -66,6 +66,7 @@ class Env(C.Structure):
         ("consecutive", C.c_int), ("scale", C.c_int),
         ("bat_load", C.c_double),
         ("hist", C.c_double * HIST_CAP), ("hist_len", C.c_int), ("hist_pos", C.c_int),
+        ("scratch", C.c_double * (2 * HIST_CAP)),
     ]
 
 

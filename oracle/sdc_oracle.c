@@ -108,9 +108,20 @@ double sdco_percentile_linear(double *s, int n, double q) {
 }
 
 /* utils/reward_creator.py:16-45 normalize_energy (history already contains `value`) */
+static double normalize_energy_scratch(const double *hist, int n, double value, double *s);
+
 double sdco_normalize_energy(const double *hist, int n, double value) {
   if (n < 2) return 0.0;
   double *s = (double *)malloc(sizeof(double) * (size_t)n * 2);
+  double z = normalize_energy_scratch(hist, n, value, s);
+  free(s);
+  return z;
+}
+
+/* same, on caller-provided scratch of 2n doubles (the per-step path: a 160 KB malloc per step would go
+ * through mmap/munmap and serialise the host threads of the CPU baseline on the kernel's mm lock) */
+static double normalize_energy_scratch(const double *hist, int n, double value, double *s) {
+  if (n < 2) return 0.0;
   double *sq = s + n;
   memcpy(s, hist, sizeof(double) * (size_t)n);
   double q1 = sdco_percentile_linear(s, n, 25.0);
@@ -124,7 +135,6 @@ double sdco_normalize_energy(const double *hist, int n, double value) {
   }
   double mean = np_mean(s, n);
   double sd = np_std(s, n, sq);
-  free(s);
   return (value - mean) / (sd > 0 ? sd : 1.0);
 }
 
@@ -565,7 +575,7 @@ int sdco_step(sdco_env *e, const sdco_params *p, const int32_t act[3], float *ob
     e->hist_pos = (e->hist_pos + 1) % SDCO_HIST_CAP;
   }
   /* numpy sees the deque in insertion order; order only affects the pairwise-sum tree (<=1e-16) */
-  double z = sdco_normalize_energy(e->hist, e->hist_len, energy);
+  double z = normalize_energy_scratch(e->hist, e->hist_len, energy, e->scratch);
   double norm_ci = NC[ip + 1];
   double foot = -1.0 * (norm_ci * z / 0.50);
   double overdue_pen = -0.3 * sqrt((double)overdue) + 0.3;

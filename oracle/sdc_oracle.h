@@ -91,6 +91,7 @@ typedef struct {
   /* energy history (utils/reward_creator.py:5), survives reset */
   double hist[SDCO_HIST_CAP];
   int hist_len, hist_pos;
+  double scratch[2 * SDCO_HIST_CAP]; /* work area of normalize_energy */
 } sdco_env;
 
 /* zero-initialise; stpt = 18 (utils/make_envs_pyenv.py:124) */
