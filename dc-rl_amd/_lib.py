@@ -77,7 +77,7 @@ class SdcResetOverride(C.Structure):
 EXPORTS = [
     "sdc_last_error", "sdc_version", "sdc_create", "sdc_destroy", "sdc_weather_window_len", "sdc_set_tables",
     "sdc_set_dc_params", "sdc_assign_envs", "sdc_reset", "sdc_step", "sdc_get_state", "sdc_set_state",
-    "sdc_hist_stride", "sdc_queue_stride",
+    "sdc_hist_stride", "sdc_queue_stride", "sdc_profile_enable", "sdc_profile_read",
 ]
 
 
@@ -125,6 +125,8 @@ def load():
     L.sdc_step.argtypes = [vp, vp, fp, fp, fp, vp, fp, fp, vp]
     L.sdc_get_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_set_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    L.sdc_profile_enable.argtypes = [vp, C.c_int]
+    L.sdc_profile_read.argtypes = [vp, dp, C.c_int]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

@@ -65,6 +65,12 @@ struct sdc_handle {
   int pending = 0;              // steps launched since then (every env advances by one per step)
   int steps_to_terminal = 0;
   bool tables_set = false, assigned = false, started = false;
+  // optional per-kernel timing (HIP events on the launch stream)
+  bool prof = false;
+  std::vector<hipEvent_t> ev;      // 3 per step: before dynamics, between, after reward
+  std::vector<hipEvent_t> ev_rst;  // 2 per auto-reset
+  size_t ev_used = 0, ev_rst_used = 0;
+  double acc_ms[5] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -177,6 +183,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
     A(d.walk_tmp, (size_t)N * w);
   }
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
+  (void)hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE);  // every slot empty
   A(d.hist_ref, N);
   A(d.ep_return, (size_t)3 * N);
   A(d.hand, (size_t)4 * N);
@@ -230,6 +237,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
 int sdc_destroy(sdc_handle* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
+  for (auto& e : h->ev) (void)hipEventDestroy(e);
+  for (auto& e : h->ev_rst) (void)hipEventDestroy(e);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return 0;
@@ -353,9 +362,16 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int N = h->cfg.n_envs;
+  const bool timed = h->prof && h->ev_used + 3 <= h->ev.size();
+  if (timed) (void)hipEventRecord(h->ev[h->ev_used], st);
   hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(N), dim3(SDC_WAVE), 0, st, h->d, actions, obs, share_obs, done, info,
                      final_obs);
+  if (timed) (void)hipEventRecord(h->ev[h->ev_used + 1], st);
   hipLaunchKernelGGL(sdc_reward_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, h->d, rew, info);
+  if (timed) {
+    (void)hipEventRecord(h->ev[h->ev_used + 2], st);
+    h->ev_used += 3;
+  }
   HIP_TRY(hipGetLastError());
   h->steps_to_terminal -= 1;
   h->pending += 1;
@@ -367,14 +383,58 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
       // harl/envs/env_wrappers.py:176-190: reset inside the same step call and return the reset obs
       SdcDev d = h->d;
       d.reset_mask = nullptr;
+      const bool rt = h->prof && h->ev_rst_used + 2 <= h->ev_rst.size();
+      if (rt) (void)hipEventRecord(h->ev_rst[h->ev_rst_used], st);
       hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
                          h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs, share_obs);
+      if (rt) {
+        (void)hipEventRecord(h->ev_rst[h->ev_rst_used + 1], st);
+        h->ev_rst_used += 2;
+      }
       HIP_TRY(hipGetLastError());
       for (int e = 0; e < N; e++)
         if (h->host_t_rel[e] >= h->cfg.episode_steps) h->host_t_rel[e] = 0;
       recompute_steps_to_terminal(h);
     }
   }
+  return 0;
+}
+
+int sdc_profile_enable(sdc_handle* h, int enable) {
+  if (!h) return fail_msg("sdc_profile_enable: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if (enable && h->ev.empty()) {
+    h->ev.resize(3 * 4096);
+    for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+    h->ev_rst.resize(2 * 64);
+    for (auto& e : h->ev_rst) HIP_TRY(hipEventCreate(&e));
+  }
+  h->prof = enable != 0;
+  return 0;
+}
+
+int sdc_profile_read(sdc_handle* h, double* out5, int reset) {
+  if (!h || !out5) return fail_msg("sdc_profile_read: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  for (size_t i = 0; i + 3 <= h->ev_used; i += 3) {
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, h->ev[i], h->ev[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&b, h->ev[i + 1], h->ev[i + 2]));
+    h->acc_ms[0] += a;
+    h->acc_ms[1] += b;
+    h->acc_ms[3] += 1;
+  }
+  for (size_t i = 0; i + 2 <= h->ev_rst_used; i += 2) {
+    float a = 0;
+    HIP_TRY(hipEventElapsedTime(&a, h->ev_rst[i], h->ev_rst[i + 1]));
+    h->acc_ms[2] += a;
+    h->acc_ms[4] += 1;
+  }
+  h->ev_used = h->ev_rst_used = 0;
+  for (int i = 0; i < 5; i++) out5[i] = h->acc_ms[i];
+  if (reset)
+    for (int i = 0; i < 5; i++) h->acc_ms[i] = 0;
   return 0;
 }
 
@@ -393,6 +453,10 @@ int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(host_buf, *f->ptr, need, hipMemcpyDeviceToHost));
+  if (std::strcmp(field, "hist") == 0) {  // device keys -> fp32 offsets (empty slot -> NaN)
+    unsigned* u = static_cast<unsigned*>(host_buf);
+    for (size_t i = 0; i < need / 4; i++) u[i] = sdc_key_f32(u[i]);
+  }
   return 0;
 }
 
@@ -404,6 +468,13 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
   if (bytes != need) return fail_msg(std::string("sdc_set_state: size mismatch for ") + field);
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (std::strcmp(field, "hist") == 0) {  // fp32 offsets -> device keys (NaN -> empty slot)
+    std::vector<unsigned> k(need / 4);
+    const unsigned* u = static_cast<const unsigned*>(host_buf);
+    for (size_t i = 0; i < k.size(); i++) k[i] = ((u[i] & 0x7FFFFFFFu) > 0x7F800000u) ? 0xFFFFFFFFu : sdc_f32_key(u[i]);
+    HIP_TRY(hipMemcpy(*f->ptr, k.data(), need, hipMemcpyHostToDevice));
+    return 0;
+  }
   HIP_TRY(hipMemcpy(*f->ptr, host_buf, need, hipMemcpyHostToDevice));
   if (std::strcmp(field, "t_rel") == 0) {
     h->pending = 0;

@@ -74,7 +74,7 @@ struct SdcDev {
   double* t_win;  // [N][lw]
   double* wb_win;
   double* walk_tmp;  // [N][SDC_NORM_WINDOW] scratch of the device-side reset
-  float* hist;       // [N][SDC_HIST_STRIDE]  energy - hist_ref, fp32
+  unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
   double* hand;      // [4][N] dynamics -> reward kernel: energy, norm_CI next, oldest task age, overdue count
   unsigned* q_guess; // [2][N] fp32 keys of last step's order statistics at floor((n-1)/4), floor(3(n-1)/4)
   double* ep_return; // [3][N] running return of the current episode (cleared by reset)
@@ -106,6 +106,10 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   return v;
 }
 
+// order-preserving map fp32 -> uint32 (and back); key(NaN 0x7FFFFFFF) = 0xFFFFFFFF marks an empty ring slot
+__host__ __device__ __forceinline__ unsigned sdc_f32_key(unsigned b) { return b ^ ((unsigned)((int)b >> 31) | 0x80000000u); }
+__host__ __device__ __forceinline__ unsigned sdc_key_f32(unsigned k) { return (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k; }
+
 // np.round(x, d) == rint(x * 10^d) / 10^d
 __device__ __forceinline__ double np_round(double x, double p10) { return rint(x * p10) / p10; }
 
@@ -114,68 +118,19 @@ __device__ __forceinline__ double np_round(double x, double p10) { return rint(x
 //   nc[0..24]  = NC[i'-16 .. i'+8]   (nc[16] = NC[i'];  entries for negative table indices unused)
 //   nt[0..16]  = NT[i' .. i'+16]
 
-__device__ __forceinline__ double lsq_slope(const double* y, int n) {
-  // np.polyfit(range(n), y, 1)[0] as the closed-form least-squares slope
-  const double xm = 0.5 * (double)(n - 1);
-  double ym = 0.0;
-  for (int i = 0; i < n; i++) ym += y[i];
-  ym /= (double)n;
-  double sxy = 0.0, sxx = 0.0;
-  for (int i = 0; i < n; i++) {
-    const double dx = (double)i - xm;
-    sxy += dx * (y[i] - ym);
-    sxx += dx * dx;
-  }
-  return sxy / sxx;
-}
+// Layout of the 29-float observation pool assembled in LDS (= the HARL shared observation,
+// harlsustaindc_env.py:78-80): [0..25] agent_ls state, [26] next workload, [27] next outside temperature, [28] SoC.
+//   ls (26): cos_h sin_h NC | 7 CI features | oldest_age avg_age queue | W NT | t_slope 5 temp features | 5 age bins
+enum { SDC_P_COS = 0, SDC_P_SIN, SDC_P_NC, SDC_P_CI7 = 3, SDC_P_OLDEST = 10, SDC_P_AVG, SDC_P_NORMQ, SDC_P_W, SDC_P_NT,
+       SDC_P_TSLOPE = 15, SDC_P_T5 = 16, SDC_P_HIST = 21, SDC_P_WNEXT = 26, SDC_P_NTNEXT, SDC_P_SOC, SDC_POOL_DIM };
 
-// NumPy's pairwise add.reduce for n in {8, 16} (8 accumulators, then a fixed tree) so that np.mean /
-// np.std of the 8 CI futures and the 16 temperature futures round exactly as in the reference.
-__device__ __forceinline__ double np_sum_8_16(const double* a, int n) {
-  double r[8];
+// segmented butterfly sum: lanes [0,16), [16,32) and [32,64) are three independent groups
+__device__ __forceinline__ double seg3_sum_f64(double v, int lane) {
 #pragma unroll
-  for (int j = 0; j < 8; j++) r[j] = a[j];
-  if (n == 16) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) r[j] += a[j + 8];
-  }
-  return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-}
-
-// extract_ci_features(values[n], cur) -> mean, std, (cur-mean)/(std+1e-8), first peak / n, first valley / n
-// n must be 8 or 16.
-__device__ __forceinline__ void extract_features(const double* vals, int n, double cur, double* out5) {
-  const double mean = np_sum_8_16(vals, n) / (double)n;
-  double sq[16];
-  for (int i = 0; i < n; i++) {
-    const double d = vals[i] - mean;
-    sq[i] = d * d;
-  }
-  const double sd = sqrt(np_sum_8_16(sq, n) / (double)n);
-  // np.gradient of [cur, vals...]: one-sided ends, central interior
-  int peak = n, valley = n;
-  double xm1 = cur, x0 = cur, x1 = vals[0];
-  double gprev = x1 - x0;  // g[0]
-  for (int i = 1; i <= n; i++) {
-    // g[i]
-    xm1 = x0;
-    x0 = x1;
-    double g;
-    if (i < n) {
-      x1 = vals[i];
-      g = (x1 - xm1) / 2.0;
-    } else {
-      g = x0 - xm1;
-    }
-    if (peak == n && gprev > 0 && g <= 0) peak = i - 1;
-    if (valley == n && gprev < 0 && g >= 0) valley = i - 1;
-    gprev = g;
-  }
-  out5[0] = mean;
-  out5[1] = sd;
-  out5[2] = (cur - mean) / (sd + 1e-8);
-  out5[3] = (double)peak / (double)n;
-  out5[4] = (double)valley / (double)n;
+  for (int o = 1; o <= 8; o <<= 1) v += __shfl_xor(v, o);
+  const double u = __shfl_xor(v, 16);
+  if (lane >= 32) v += u;
+  return v;
 }
 
 struct ObsScalars {
@@ -186,57 +141,121 @@ struct ObsScalars {
   int have_past;          // i' >= 16
 };
 
-// Writes the 53 raw observation floats (ls 26 | dc 14 | bat 13) to s_obs (LDS).  Uniform over the wave;
-// the caller guards the call with a single lane.
-__device__ __forceinline__ void build_obs_raw(const double* nc, const double* nt, const ObsScalars& o, float* s_obs) {
-  double sm[16], f7[7], tf[5];
-  const double cur = nc[16];
-  // future: 4-tap moving average of [cur, NC[i'+1..i'+8]] (9 -> 6 points), then slope (sustaindc_env.py:313,317)
-  for (int j = 0; j < 6; j++) sm[j] = (((nc[16 + j] + nc[17 + j]) + nc[18 + j]) + nc[19 + j]) / 4;
-  f7[0] = lsq_slope(sm, 6);
-  // past: [NC[i'-16..i'-1], cur] (17 -> 14 points); EMPTY past slice when i' < 16 (managers.py:482-483)
-  if (o.have_past) {
-    for (int j = 0; j < 14; j++) sm[j] = (((nc[j] + nc[j + 1]) + nc[j + 2]) + nc[j + 3]) / 4;
-    f7[1] = lsq_slope(sm, 14);
-  } else {
-    for (int j = 0; j < 4; j++) sm[j] = cur / 4;
-    f7[1] = lsq_slope(sm, 4);
+// Observation features (sustaindc_env.py:266-433), all 64 lanes of one wavefront cooperating.  LDS inputs:
+//   nc[0..24] = NC[i'-16 .. i'+8]  (nc[16] = NC[i']),   nt[0..16] = NT[i' .. i'+16].
+// Three least-squares slopes run side by side in lane groups [0,16) / [16,32) / [32,64); the mean / std of the
+// 8 CI futures (lanes 0..7) and the 16 temperature futures (lanes 32..47) use the butterfly order xor 8,1,2,4,
+// which is exactly NumPy's pairwise add.reduce tree for n = 8 and n = 16, so they round as in the reference.
+// Writes pool[0..28] (LDS floats); the caller synchronises before reading it.
+__device__ __forceinline__ void build_obs_pool(const double* nc, const double* nt, const ObsScalars& o, float* pool,
+                                               int lane) {
+  // ---- slopes: np.polyfit(range(n), y, 1)[0] as closed-form least squares --------------------------------
+  int n;            // points in this lane's group
+  double y = 0.0;   // this lane's point
+  const int j = lane & 15;
+  if (lane < 16) {  // future: 4-tap moving average of [NC[i'], NC[i'+1..i'+8]]: 9 -> 6 points (sustaindc_env.py:313,317)
+    n = 6;
+    if (j < 6) y = (((nc[16 + j] + nc[17 + j]) + nc[18 + j]) + nc[19 + j]) / 4;
+  } else if (lane < 32) {  // past: [NC[i'-16..i'-1], NC[i']]: 17 -> 14 points; EMPTY past slice when i' < 16
+    if (o.have_past) {     // (utils/managers.py:482-483): np.convolve then yields 4 copies of NC[i'] / 4
+      n = 14;
+      if (j < 14) y = (((nc[j] + nc[j + 1]) + nc[j + 2]) + nc[j + 3]) / 4;
+    } else {
+      n = 4;
+      if (j < 4) y = nc[16] / 4;
+    }
+  } else {  // temperature: [NT[i'], NT[i'+1..i'+16]], 17 points, no smoothing (sustaindc_env.py:331)
+    n = 17;
+    if (lane - 32 < 17) y = nt[lane - 32];
   }
-  extract_features(nc + 17, 8, cur, f7 + 2);
-  const double tslope = lsq_slope(nt, 17);
-  extract_features(nt + 1, 16, nt[0], tf);
-  int k = 0;
-  // agent_ls (26): sustaindc_env.py:342-353
-  s_obs[k++] = (float)o.cos_h; s_obs[k++] = (float)o.sin_h; s_obs[k++] = (float)cur;
-  for (int j = 0; j < 7; j++) s_obs[k++] = (float)f7[j];
-  s_obs[k++] = (float)o.oldest; s_obs[k++] = (float)o.avg; s_obs[k++] = (float)o.normq;
-  s_obs[k++] = (float)o.w_cur; s_obs[k++] = (float)nt[0]; s_obs[k++] = (float)tslope;
-  for (int j = 0; j < 5; j++) s_obs[k++] = (float)tf[j];
-  for (int j = 0; j < 5; j++) s_obs[k++] = (float)o.hist[j];
-  // agent_dc (14): sustaindc_env.py:386-393
-  s_obs[k++] = (float)o.cos_h; s_obs[k++] = (float)o.sin_h; s_obs[k++] = (float)cur;
-  for (int j = 0; j < 7; j++) s_obs[k++] = (float)f7[j];
-  s_obs[k++] = (float)o.w_cur; s_obs[k++] = (float)o.w_next; s_obs[k++] = (float)nt[0]; s_obs[k++] = (float)nt[1];
-  // agent_bat (13): sustaindc_env.py:426-432
-  s_obs[k++] = (float)o.cos_h; s_obs[k++] = (float)o.sin_h; s_obs[k++] = (float)cur;
-  for (int j = 0; j < 7; j++) s_obs[k++] = (float)f7[j];
-  s_obs[k++] = (float)o.w_cur; s_obs[k++] = (float)nt[0]; s_obs[k++] = (float)o.soc;
+  const int xi = lane < 32 ? j : lane - 32;
+  const bool act = xi < n;
+  const double xm = 0.5 * (double)(n - 1);
+  const double ym = seg3_sum_f64(y, lane) / (double)n;
+  const double dx = act ? (double)xi - xm : 0.0;
+  const double sxy = seg3_sum_f64(act ? dx * (y - ym) : 0.0, lane);
+  const double sxx = seg3_sum_f64(dx * dx, lane);
+  const double slope = sxy / sxx;
+  if (lane == 0) pool[SDC_P_CI7 + 0] = (float)slope;
+  if (lane == 16) pool[SDC_P_CI7 + 1] = (float)slope;
+  if (lane == 32) pool[SDC_P_TSLOPE] = (float)slope;
+
+  // ---- extract_ci_features on the 8 CI futures (lanes 0..8) and the 16 temperature futures (lanes 32..48) ----
+  const bool ci_grp = lane < 32;
+  const int q = ci_grp ? lane : lane - 32;      // point index within [cur, values...]
+  const int nv = ci_grp ? 8 : 16;               // number of values
+  const double* xs = ci_grp ? nc + 16 : nt;     // xs[0] = cur, xs[1..nv] = values
+  const double cur = xs[0];
+  const double v = q < nv ? xs[1 + q] : 0.0;    // lanes q >= nv contribute exact zeros
+  auto tree = [&](double a) {                   // NumPy pairwise order for n = 8 / 16
+    a += __shfl_xor(a, 8);
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    a += __shfl_xor(a, 4);
+    return a;
+  };
+  const double mean = tree(v) / (double)nv;
+  const double dv = q < nv ? v - mean : 0.0;
+  const double sd = sqrt(tree(dv * dv) / (double)nv);
+  // np.gradient of [cur, values...] (nv + 1 points): one-sided ends, central interior
+  double g = 0.0;
+  if (q == 0) g = xs[1] - xs[0];
+  else if (q < nv) g = (xs[q + 1] - xs[q - 1]) / 2.0;
+  else if (q == nv) g = xs[nv] - xs[nv - 1];
+  const double gn = __shfl_down(g, 1);
+  const bool in = q < nv;                        // pairs (g[q], g[q+1]) for q = 0 .. nv-1
+  const unsigned long long pk = __ballot(in && g > 0 && gn <= 0);
+  const unsigned long long vl = __ballot(in && g < 0 && gn >= 0);
+  if (lane == 0 || lane == 32) {
+    const unsigned pm = (unsigned)(ci_grp ? pk : pk >> 32), vm = (unsigned)(ci_grp ? vl : vl >> 32);
+    const int peak = pm ? __ffs((int)pm) - 1 : nv, valley = vm ? __ffs((int)vm) - 1 : nv;
+    float* f = pool + (ci_grp ? SDC_P_CI7 + 2 : SDC_P_T5);
+    f[0] = (float)mean;
+    f[1] = (float)sd;
+    f[2] = (float)((cur - mean) / (sd + 1e-8));
+    f[3] = (float)((double)peak / (double)nv);
+    f[4] = (float)((double)valley / (double)nv);
+  }
+  // ---- scalars -----------------------------------------------------------------------------------------------
+  if (lane == 1) {
+    pool[SDC_P_COS] = (float)o.cos_h;
+    pool[SDC_P_SIN] = (float)o.sin_h;
+    pool[SDC_P_NC] = (float)nc[16];
+    pool[SDC_P_OLDEST] = (float)o.oldest;
+    pool[SDC_P_AVG] = (float)o.avg;
+    pool[SDC_P_NORMQ] = (float)o.normq;
+    pool[SDC_P_W] = (float)o.w_cur;
+    pool[SDC_P_NT] = (float)nt[0];
+    for (int b = 0; b < 5; b++) pool[SDC_P_HIST + b] = (float)o.hist[b];
+    pool[SDC_P_WNEXT] = (float)o.w_next;
+    pool[SDC_P_NTNEXT] = (float)nt[1];
+    pool[SDC_P_SOC] = (float)o.soc;
+  }
 }
 
-// HARL layout (harlsustaindc_env.py:25-26, :78-80): obs [3][26] zero padded, share_obs [29].
-// idx in [0, 78) -> value
-__device__ __forceinline__ float obs_padded_at(const float* s_obs, int idx) {
+// HARL layout (harlsustaindc_env.py:25-26): obs [3][26] zero padded; idx in [0, 78) -> value from the pool.
+//   agent_dc (14): sustaindc_env.py:386-393   agent_bat (13): sustaindc_env.py:426-432
+__device__ __forceinline__ float obs_padded_at(const float* pool, int idx) {
   const int a = idx / SDC_OBS_PAD, k = idx - a * SDC_OBS_PAD;
-  if (a == 0) return s_obs[k];
-  if (a == 1) return k < 14 ? s_obs[26 + k] : 0.0f;
-  return k < 13 ? s_obs[40 + k] : 0.0f;
+  if (a == 0) return pool[k];
+  if (k < 10) return pool[k];
+  if (a == 1) {
+    switch (k) {
+      case 10: return pool[SDC_P_W];
+      case 11: return pool[SDC_P_WNEXT];
+      case 12: return pool[SDC_P_NT];
+      case 13: return pool[SDC_P_NTNEXT];
+      default: return 0.0f;
+    }
+  }
+  switch (k) {
+    case 10: return pool[SDC_P_W];
+    case 11: return pool[SDC_P_NT];
+    case 12: return pool[SDC_P_SOC];
+    default: return 0.0f;
+  }
 }
-__device__ __forceinline__ float share_obs_at(const float* s_obs, int idx) {
-  if (idx < 26) return s_obs[idx];
-  if (idx == 26) return s_obs[26 + 11];  // dc next workload
-  if (idx == 27) return s_obs[26 + 13];  // dc next outside temperature
-  return s_obs[40 + 12];                 // battery SoC
-}
+__device__ __forceinline__ float share_obs_at(const float* pool, int idx) { return pool[idx]; }
 
 // stage the obs windows for table cursor ip (= i') into LDS.  tsrc points at T[i'] of the env's weather
 // window (global memory, or LDS right after a device-side reset).  Called with tid = 0..63.

@@ -6,7 +6,8 @@
 //   * the rack model runs lane = rack with per-rack constants read coalesced from the config table and
 //     wave-shuffle (DPP) reductions for total IT power, CRAC return and outlet temperature;
 //   * chiller / cooling tower / water / battery / set-point integrator are wave-uniform scalar fp64;
-//   * lane 0 assembles the 53 observation floats and the info block in LDS, all lanes store them coalesced.
+//   * the observation features (3 least-squares slopes, 2 x mean/std/peak/valley) run lane-parallel with
+//     segmented butterfly reductions; lane 0 assembles the info block in LDS; all lanes store coalesced.
 // The energy value and the three reward terms that need the history normaliser are handed to
 // sdc_reward_kernel (sdc_reward.hip) through a 32-byte per-env record.
 //
@@ -280,8 +281,8 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
   const int terminal = (rel + 1 >= S.episode_steps) ? 1 : 0;
   const int ip = i + 1;
 
-  if (lane == 0) {
-    // ---- observations at i' (sustaindc_env.py:565-585) ----------------------------------------------
+  // ---- observations at i' (sustaindc_env.py:565-585): all lanes cooperate -------------------------------------
+  {
     ObsScalars o;
     o.cos_h = S.hour_lut[2 * hourq_n];
     o.sin_h = S.hour_lut[2 * hourq_n + 1];
@@ -293,8 +294,10 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
     o.avg = avg_norm;
     for (int b = 0; b < 5; b++) o.hist[b] = hist[b];
     o.have_past = ip >= 16;
-    build_obs_raw(sh.nc, sh.nt, o, sh.obs);
+    build_obs_pool(sh.nc, sh.nt, o, sh.obs, lane);
+  }
 
+  if (lane == 0) {
     // ---- info block --------------------------------------------------------------------------------
     float* inf = sh.info;
     inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)wl;
@@ -342,7 +345,24 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
     // ---- hand-off to the reward kernel (4 doubles per env, struct of arrays) ----------------------------
     {
       const int N = S.n_envs;
-      S.hand[env] = energy;                    // bat_total_energy_with_battery_KWh
+      // history append (utils/reward_creator.py:7-14).  The ring holds fp32 OFFSETS from the env's first energy
+      // value (kept in fp64): normalize_energy is shift-invariant, and offsets keep the fp32 rounding error
+      // proportional to the spread of the history instead of to the ~300 kWh magnitude (two nearly equal
+      // energies would otherwise lose the z-score).  Stored as order-preserving keys for the reward kernel.
+      const int hl = S.hist_len[env];
+      const double href = hl == 0 ? energy : S.hist_ref[env];
+      const double e_off = energy - href;
+      int slot;
+      if (hl < S.hist_cap) {
+        slot = hl;
+        S.hist_len[env] = hl + 1;
+        if (hl == 0) S.hist_ref[env] = href;
+      } else {
+        slot = S.hist_pos[env];
+        S.hist_pos[env] = slot + 1 == S.hist_cap ? 0 : slot + 1;
+      }
+      S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = sdc_f32_key(__float_as_uint((float)e_off));
+      S.hand[env] = e_off;                     // bat_total_energy_with_battery_KWh - hist_ref
       S.hand[N + env] = sh.nc[17];             // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
       S.hand[2 * N + env] = oldest_norm;       // ls_oldest_task_age
       S.hand[3 * N + env] = (double)overdue;   // ls_overdue_penalty
@@ -376,7 +396,7 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
+extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
                                                                              float* __restrict__ obs,
                                                                              float* __restrict__ share_obs,
                                                                              unsigned char* __restrict__ done,

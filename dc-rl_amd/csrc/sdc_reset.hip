@@ -162,7 +162,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
   __syncthreads();
   stage_windows(S, loc, c0, tsrc, ci_min, ci_den, t_min, t_den, lane, sh.nc, sh.nt);
   __syncthreads();
-  if (lane == 0) {
+  {
     const double* tW = S.tabW + (size_t)loc * TL;
     auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
     ObsScalars o;
@@ -177,7 +177,10 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     o.avg = 0.0;
     for (int b = 0; b < 5; b++) o.hist[b] = 0.0;
     o.have_past = c0 >= 16;
-    build_obs_raw(sh.nc, sh.nt, o, sh.obs);
+    build_obs_pool(sh.nc, sh.nt, o, sh.obs, lane);
+  }
+  if (lane == 0) {
+    const int hq = hour * 4;
     S.ci_min[env] = ci_min;
     S.ci_den[env] = ci_den;
     S.t_min[env] = t_min;

@@ -9,9 +9,13 @@
 //           an insert + an evict move an order statistic by at most one position, so this almost always
 //           pins rank k and k+1.  If it does not (first steps, injected state), an exact bisection on the
 //           fp32 key space runs instead -- same result, more sweeps;
-//   pass 2  accumulates the clipped sum and sum of squares in fp64 around the inter-quartile midpoint.
-// Two workgroup-wide reductions through LDS, then lane 0 writes the three rewards, appends the energy to the
-// ring and updates the running episode return.
+//   pass 2  clips in key space (one v_med3_u32), converts to fp32 and accumulates the clipped sum and sum of
+//           squares around the inter-quartile midpoint; per-lane partials (40 terms) are fp32, everything
+//           across lanes is fp64.
+// The ring is stored as order-preserving uint32 KEYS of the fp32 offsets (empty slots = 0xFFFFFFFF), and the
+// step's new energy has already been written into its slot by sdc_dynamics_kernel, so a load is ready for
+// comparison with no per-element fix-up.  Two workgroup-wide reductions through LDS, then lane 0 writes the
+// three rewards and the running episode return.
 #include "sdc_device.hpp"
 
 namespace {
@@ -29,8 +33,9 @@ __device__ __forceinline__ unsigned f32_key(float f) {
   return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
 }
 __device__ __forceinline__ float key_f32(unsigned k) {
-  const unsigned b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
-  return __uint_as_float(b);
+  // top bit set (was >= +0): clear it; else (was negative): flip all bits
+  const unsigned m = (unsigned)((int)k >> 31);
+  return __uint_as_float(k ^ (~m | 0x80000000u));
 }
 
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
@@ -108,51 +113,22 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev
   // ---- stream the ring: every load of the workgroup is in flight before the first use -------------------------
   unsigned key[SDC_HIST_PER_THREAD];
   {
-    const float4* hp = reinterpret_cast<const float4*>(S.hist + (size_t)env * SDC_HIST_STRIDE);
+    const uint4* hp = reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE);
 #pragma unroll
     for (int k = 0; k < SDC_HIST_PER_THREAD / 4; k++) {
-      const float4 v = hp[k * SDC_BLOCK + tid];
-      key[4 * k + 0] = __float_as_uint(v.x);
-      key[4 * k + 1] = __float_as_uint(v.y);
-      key[4 * k + 2] = __float_as_uint(v.z);
-      key[4 * k + 3] = __float_as_uint(v.w);
+      const uint4 v = hp[k * SDC_BLOCK + tid];
+      key[4 * k + 0] = v.x;
+      key[4 * k + 1] = v.y;
+      key[4 * k + 2] = v.z;
+      key[4 * k + 3] = v.w;
     }
   }
-  const int hist_len_old = S.hist_len[env];
-  const int hist_pos_old = S.hist_pos[env];
-  const double e_abs = S.hand[env];
+  const int n = S.hist_len[env];             // already includes this step's energy (appended by the dynamics kernel)
+  const double energy = S.hand[env];         // energy - hist_ref, fp64
   const double norm_ci_next = S.hand[N + env];
   const double oldest_norm = S.hand[2 * N + env];
   const double overdue = S.hand[3 * N + env];
   const unsigned g1 = S.q_guess[env], g3 = S.q_guess[N + env];
-
-  // ---- history append (utils/reward_creator.py:7-14): the new value replaces slot `slot` -------------------------
-  // The ring holds fp32 OFFSETS from the env's first energy value (kept in fp64): normalize_energy is
-  // shift-invariant, and offsets keep the fp32 rounding error proportional to the spread of the history
-  // instead of to the ~300 kWh magnitude (two nearly equal energies would otherwise lose the z-score).
-  const double href = hist_len_old == 0 ? e_abs : S.hist_ref[env];
-  const double energy = e_abs - href;
-  int n, slot, pos_new;
-  if (hist_len_old < S.hist_cap) {
-    slot = hist_len_old;
-    n = hist_len_old + 1;
-    pos_new = hist_pos_old;
-  } else {
-    slot = hist_pos_old;
-    n = hist_len_old;
-    pos_new = hist_pos_old + 1 == S.hist_cap ? 0 : hist_pos_old + 1;
-  }
-  const float energy_f = (float)energy;
-#pragma unroll
-  for (int k = 0; k < SDC_HIST_PER_THREAD / 4; k++) {
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int idx = (k * SDC_BLOCK + tid) * 4 + c;
-      float f = __uint_as_float(key[4 * k + c]);
-      if (idx == slot) f = energy_f;
-      key[4 * k + c] = idx < n ? f32_key(f) : KEY_NONE;
-    }
-  }
 
   // ---- normalize_energy (utils/reward_creator.py:16-45) ------------------------------------------------------------
   double z = 0.0;
@@ -165,18 +141,22 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev
     unsigned a1 = 0, b1 = 0, a3 = 0, b3 = 0;
     bool ok = false;
     if (g1 != 0u && g1 != KEY_NONE && g3 != 0u && g3 != KEY_NONE) {
-      // pass 1: one sweep around last step's quartile keys
-      int cle1 = 0, cge1 = 0, cle3 = 0, cge3 = 0;  // wave-level counts (scalar unit)
+      // pass 1: one sweep around last step's quartile keys.  Per key and quartile (8 VALU):
+      //   ds = x - (g+1)  borrows  <=> x <= g   (v_sub_co_u32 + v_addc_co_u32 count the borrow)
+      //   dp = (g-1) - x  borrows  <=> x >= g
+      // and in wrap-around arithmetic a key on the wrong side lands above every key on the right side, so
+      // plain unsigned minima of ds / dp find the two successors and the predecessor.
+      unsigned cle1 = 0, cge1 = 0, cle3 = 0, cge3 = 0;
       unsigned pd1 = KEY_NONE, sd1a = KEY_NONE, sd1b = KEY_NONE, pd3 = KEY_NONE, sd3a = KEY_NONE, sd3b = KEY_NONE;
+      const unsigned g1p = g1 + 1u, g1m = g1 - 1u, g3p = g3 + 1u, g3m = g3 - 1u;
 #pragma unroll
       for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
         const unsigned x = key[j];
-        cle1 += __popcll(__ballot(x <= g1));
-        cge1 += __popcll(__ballot(x >= g1));
-        cle3 += __popcll(__ballot(x <= g3));
-        cge3 += __popcll(__ballot(x >= g3));
-        // distances in wrap-around arithmetic: a key on the wrong side wraps above every key on the right side
-        const unsigned ds1 = x - g1 - 1u, dp1 = g1 - 1u - x, ds3 = x - g3 - 1u, dp3 = g3 - 1u - x;
+        unsigned ds1, dp1, ds3, dp3;
+        asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(ds1), "+v"(cle1) : "v"(x), "v"(g1p) : "vcc");
+        asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(dp1), "+v"(cge1) : "v"(g1m), "v"(x) : "vcc");
+        asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(ds3), "+v"(cle3) : "v"(x), "v"(g3p) : "vcc");
+        asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(dp3), "+v"(cge3) : "v"(g3m), "v"(x) : "vcc");
         sd1b = min(max(sd1a, ds1), sd1b);
         sd1a = min(sd1a, ds1);
         pd1 = min(pd1, dp1);
@@ -184,6 +164,10 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev
         sd3a = min(sd3a, ds3);
         pd3 = min(pd3, dp3);
       }
+      cle1 = wave_sum_i32((int)cle1);
+      cge1 = wave_sum_i32((int)cge1);
+      cle3 = wave_sum_i32((int)cle3);
+      cge3 = wave_sum_i32((int)cge3);
       pd1 = wave_min_u32(pd1);
       pd3 = wave_min_u32(pd3);
       wave_min2_u32(sd1a, sd1b);
@@ -278,20 +262,37 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev
     const double q3 = (t3 == 0.0) ? fa3 : ((t3 >= 0.5) ? fb3 - d3 * (1.0 - t3) : fa3 + d3 * t3);
     const double iqr = q3 - q1;
     const double lb = q1 - 1.5 * iqr, ub = q3 + 1.5 * iqr;
-    // pass 2: clipped sum and sum of squares around the inter-quartile midpoint, fp64
-    const double ctr = 0.5 * (q1 + q3);
-    double s = 0.0, s2 = 0.0;
+    // pass 2: clip in key space, accumulate (v - ctr) and (v - ctr)^2 around the inter-quartile midpoint;
+    // per-lane partial sums in fp32 (40 terms of magnitude <= 2 IQR), fp64 across lanes.  A register group k
+    // covers ring slots [1024 k, 1024 k + 1024): groups below the history length need no validity test
+    // (wave-uniform branch); in steady state only the last group (slots 10000..10239 are always empty) does.
+    const float lbf = (float)lb, ubf = (float)ub;
+    const float ctrf = (float)(0.5 * (q1 + q3));
+    const unsigned klb = f32_key(lbf), kub = f32_key(ubf);
+    float sf = 0.0f, sf2 = 0.0f;
 #pragma unroll
-    for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
-      if (key[j] != KEY_NONE) {
-        const double v = (double)key_f32(key[j]);
-        const double c = fmin(fmax(v, lb), ub) - ctr;
-        s += c;
-        s2 += c * c;
+    for (int k = 0; k < SDC_HIST_PER_THREAD / 4; k++) {
+      if (n >= (k + 1) * SDC_BLOCK * 4) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) {
+          const unsigned ck = min(max(key[4 * k + c4], klb), kub);   // v_med3_u32
+          const float c = key_f32(ck) - ctrf;
+          sf += c;
+          sf2 += c * c;
+        }
+      } else {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) {
+          const unsigned kk = key[4 * k + c4];
+          const unsigned ck = min(max(kk, klb), kub);
+          const float c = kk == KEY_NONE ? 0.0f : key_f32(ck) - ctrf;
+          sf += c;
+          sf2 += c * c;
+        }
       }
     }
-    s = wave_sum_f64(s);
-    s2 = wave_sum_f64(s2);
+    double s = wave_sum_f64((double)sf);
+    double s2 = wave_sum_f64((double)sf2);
     if (lane == 0) {
       sh.red_d[wave] = s;
       sh.red_e[wave] = s2;
@@ -299,6 +300,7 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev
     __syncthreads();
     const double S1 = (sh.red_d[0] + sh.red_d[1]) + (sh.red_d[2] + sh.red_d[3]);
     const double S2 = (sh.red_e[0] + sh.red_e[1]) + (sh.red_e[2] + sh.red_e[3]);
+    const double ctr = (double)ctrf;
     const double m0 = S1 / (double)n;
     const double mean = ctr + m0;
     const double var = S2 / (double)n - m0 * m0;
@@ -306,7 +308,7 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev
     z = (energy - mean) / (sd > 0 ? sd : 1.0);
   }
 
-  // ---- rewards (utils/reward_creator.py:48-130), ring append, running episode return -------------------------------
+  // ---- rewards (utils/reward_creator.py:48-130), running episode return -------------------------------
   if (tid == 0) {
     const double foot = -1.0 * (norm_ci_next * z / 0.50);
     const double overdue_pen = -0.3 * sqrt(overdue) + 0.3;
@@ -320,10 +322,6 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev
     S.ep_return[env] = r0;
     S.ep_return[N + env] = r1;
     S.ep_return[2 * N + env] = r2;
-    S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = energy_f;
-    if (hist_len_old == 0) S.hist_ref[env] = href;
-    S.hist_len[env] = n;
-    S.hist_pos[env] = pos_new;
     S.q_guess[env] = ng1;
     S.q_guess[N + env] = ng3;
     if (info) {

@@ -194,6 +194,16 @@ class SdcEngine:
         for n, v in sd.items():
             self.set_state(n, v)
 
+    def profile(self, enable: bool = True):
+        """Per-kernel HIP-event timing on the launch stream (measurement only)."""
+        L.check(self.lib.sdc_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset: bool = True) -> dict:
+        out = (C.c_double * 5)()
+        L.check(self.lib.sdc_profile_read(self._h, out, 1 if reset else 0))
+        return {"dynamics_ms": out[0], "reward_ms": out[1], "reset_ms": out[2], "steps": int(out[3]),
+                "resets": int(out[4])}
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.sdc_destroy(self._h)

@@ -178,12 +178,20 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
 /* parity injection + env checkpoint: copy one named state field to / from HOST memory.
  * Fields: cursor t_rel day hourq q_popped q_cum q_head last_delta consecutive scale hist_len hist_pos
  * episode (int32[N]);  stpt bat_load ci_min ci_den t_min t_den hist_ref (double[N]);  ep_return (double[3][N]);
- * hist (float[N][hist_stride], energy minus hist_ref);
+ * hist (float[N][hist_stride], energy minus hist_ref, NaN = empty slot: every slot >= hist_len must be NaN);
  * t_win wb_win (double[N][weather_window_len]);  qtab (uint32[N][queue_stride][2]); fault (uint32[N]). */
 int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes);
 int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t bytes);
 int sdc_hist_stride(const sdc_handle* h);
 int sdc_queue_stride(const sdc_handle* h);
+
+/* Per-kernel timing with HIP events recorded on the launch stream around each kernel of sdc_step
+ * (measurement only; off by default).  sdc_profile_read synchronises the device and returns accumulated
+ * milliseconds since the last read with reset != 0:
+ *   out[0] = sdc_dynamics_kernel total ms, out[1] = sdc_reward_kernel total ms,
+ *   out[2] = sdc_reset_kernel (auto-reset) total ms, out[3] = steps measured, out[4] = auto-resets measured. */
+int sdc_profile_enable(sdc_handle* h, int enable);
+int sdc_profile_read(sdc_handle* h, double* out5, int reset);
 
 #ifdef __cplusplus
 }

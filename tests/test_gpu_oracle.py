@@ -36,7 +36,7 @@ def test_full_history_ring_vs_oracle():
     N = 32
     rig = P.ParityRig(N, episode_steps=96, seed=7)
     rng = np.random.default_rng(7)
-    hist = np.zeros((N, rig.eng.hist_stride), np.float32)
+    hist = np.full((N, rig.eng.hist_stride), np.nan, np.float32)   # NaN = empty slot
     vals = (331 + 70 * rng.standard_normal((N, 10000))).clip(150, 650).astype(np.float32)
     vals[:, ::97] = vals[:, 5:6]          # duplicates on purpose
     hist[:, :10000] = vals
