@@ -41,8 +41,10 @@ int fail_msg(const std::string& m) {
 
 struct Field {
   const char* name;
-  void** ptr;
-  size_t elem;    // bytes per env
+  void** ptr;      // plain per-env array (ptr != nullptr) ...
+  size_t elem;     // ... of `elem` bytes per env,
+  int rec_idx;     // or a field of the 256-byte state record: first dword and
+  int rec_dwords;  // width in dwords
 };
 
 }  // namespace
@@ -91,6 +93,18 @@ void sync_mirror(sdc_handle* h) {
     for (int e = 0; e < h->cfg.n_envs; e++) h->host_t_rel[e] += h->pending;
     h->pending = 0;
   }
+}
+
+// one field of every env's 256-byte record <-> a dense host array
+int rec_put(sdc_handle* h, int idx, int dwords, const void* host) {
+  HIP_TRY(hipMemcpy2D(h->d.rec + idx, sizeof(unsigned) * SDC_REC_DWORDS, host, sizeof(unsigned) * dwords,
+                      sizeof(unsigned) * dwords, (size_t)h->cfg.n_envs, hipMemcpyHostToDevice));
+  return 0;
+}
+int rec_get(sdc_handle* h, int idx, int dwords, void* host) {
+  HIP_TRY(hipMemcpy2D(host, sizeof(unsigned) * dwords, h->d.rec + idx, sizeof(unsigned) * SDC_REC_DWORDS,
+                      sizeof(unsigned) * dwords, (size_t)h->cfg.n_envs, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 void recompute_steps_to_terminal(sdc_handle* h) {
@@ -156,26 +170,15 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   } while (0)
   double *tabW, *tabC, *tabT, *tabWB, *hour_lut;
   sdc_dc_params* dcp;
-  int *loc_id, *cfg_id, *day_lo, *day_hi;
   A(tabW, (size_t)cfg->n_locations * SDC_TABLE_LEN);
   A(tabC, (size_t)cfg->n_locations * SDC_TABLE_LEN);
   A(tabT, (size_t)cfg->n_locations * SDC_TABLE_LEN);
   A(tabWB, (size_t)cfg->n_locations * SDC_TABLE_LEN);
   A(hour_lut, 96 * 2);
   A(dcp, cfg->n_dc_configs);
-  A(loc_id, N);
-  A(cfg_id, N);
-  A(day_lo, N);
-  A(day_hi, N);
   d.tabW = tabW; d.tabC = tabC; d.tabT = tabT; d.tabWB = tabWB; d.hour_lut = hour_lut; d.dc = dcp;
-  d.loc_id = loc_id; d.cfg_id = cfg_id; d.day_lo = day_lo; d.day_hi = day_hi;
-  A(d.cursor, N); A(d.t_rel, N); A(d.day, N); A(d.hourq, N);
-  A(d.q_popped, N); A(d.q_cum, N); A(d.q_cumT, N); A(d.q_head, N);
+  A(d.rec, (size_t)N * SDC_REC_DWORDS);
   A(d.qtab, (size_t)N * d.qstride);
-  A(d.last_delta, N); A(d.consecutive, N); A(d.scale, N);
-  A(d.hist_len, N); A(d.hist_pos, N); A(d.episode, N); A(d.fault, N);
-  A(d.stpt, N); A(d.bat_load, N); A(d.ci_min, N); A(d.ci_den, N); A(d.t_min, N); A(d.t_den, N);
-  A(d.carry, (size_t)SDC_CARRY_DIM * N);
   A(d.t_win, (size_t)N * d.lw);
   A(d.wb_win, (size_t)N * d.lw);
   {
@@ -184,10 +187,10 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   }
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
   (void)hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE);  // every slot empty
-  A(d.hist_ref, N);
-  A(d.ep_return, (size_t)3 * N);
   A(d.hand, (size_t)4 * N);
+  A(d.hist_n, N);
   A(d.q_guess, (size_t)2 * N);
+  A(d.ep_return, (size_t)3 * N);
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
@@ -208,28 +211,35 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
       return fail_msg("sdc_create: hour LUT upload failed");
     }
   }
-  // scale starts at 1, last_delta = None
-  {
-    std::vector<int> ones(N, 1), none(N, -2);
-    (void)hipMemcpy(d.scale, ones.data(), sizeof(int) * N, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d.last_delta, none.data(), sizeof(int) * N, hipMemcpyHostToDevice);
-  }
   h->host_t_rel.assign(N, cfg->episode_steps);  // "finished": a reset is required before stepping
   h->fields = {
-      {"cursor", (void**)&d.cursor, 4}, {"t_rel", (void**)&d.t_rel, 4}, {"day", (void**)&d.day, 4},
-      {"hourq", (void**)&d.hourq, 4}, {"q_popped", (void**)&d.q_popped, 4}, {"q_cum", (void**)&d.q_cum, 4},
-      {"q_cumT", (void**)&d.q_cumT, 4}, {"q_head", (void**)&d.q_head, 4}, {"last_delta", (void**)&d.last_delta, 4},
-      {"consecutive", (void**)&d.consecutive, 4}, {"scale", (void**)&d.scale, 4}, {"hist_len", (void**)&d.hist_len, 4},
-      {"hist_pos", (void**)&d.hist_pos, 4}, {"episode", (void**)&d.episode, 4}, {"fault", (void**)&d.fault, 4},
-      {"stpt", (void**)&d.stpt, 8}, {"bat_load", (void**)&d.bat_load, 8}, {"ci_min", (void**)&d.ci_min, 8},
-      {"ci_den", (void**)&d.ci_den, 8}, {"t_min", (void**)&d.t_min, 8}, {"t_den", (void**)&d.t_den, 8},
-      {"carry", (void**)&d.carry, 8 * SDC_CARRY_DIM},
-      {"hist", (void**)&d.hist, sizeof(float) * SDC_HIST_STRIDE}, {"hist_ref", (void**)&d.hist_ref, 8},
-      {"ep_return", (void**)&d.ep_return, 8 * 3}, {"q_guess", (void**)&d.q_guess, 4 * 2},
-      {"t_win", (void**)&d.t_win, sizeof(double) * (size_t)d.lw},
-      {"wb_win", (void**)&d.wb_win, sizeof(double) * (size_t)d.lw},
-      {"qtab", (void**)&d.qtab, sizeof(uint2) * (size_t)d.qstride},
+      {"cursor", nullptr, 4, R_CURSOR, 1}, {"t_rel", nullptr, 4, R_TREL, 1}, {"day", nullptr, 4, R_DAY, 1},
+      {"hourq", nullptr, 4, R_HOURQ, 1}, {"q_popped", nullptr, 4, R_QPOPPED, 1}, {"q_cum", nullptr, 4, R_QCUM, 1},
+      {"q_cumT", nullptr, 4, R_QCUMT, 1}, {"q_head", nullptr, 4, R_QHEAD, 1}, {"q_cum_hm1", nullptr, 4, R_QCUM_HM1, 1},
+      {"q_cumT_hm1", nullptr, 4, R_QCUMT_HM1, 1}, {"last_delta", nullptr, 4, R_LAST_DELTA, 1},
+      {"consecutive", nullptr, 4, R_CONSEC, 1}, {"scale", nullptr, 4, R_SCALE, 1}, {"hist_len", nullptr, 4, R_HIST_LEN, 1},
+      {"hist_pos", nullptr, 4, R_HIST_POS, 1}, {"episode", nullptr, 4, R_EPISODE, 1}, {"fault", nullptr, 4, R_FAULT, 1},
+      {"loc_id", nullptr, 4, R_LOC, 1}, {"cfg_id", nullptr, 4, R_CFG, 1}, {"day_lo", nullptr, 4, R_DAY_LO, 1},
+      {"day_hi", nullptr, 4, R_DAY_HI, 1},
+      {"stpt", nullptr, 8, R_STPT, 2}, {"bat_load", nullptr, 8, R_BAT, 2}, {"ci_min", nullptr, 8, R_CI_MIN, 2},
+      {"ci_den", nullptr, 8, R_CI_DEN, 2}, {"t_min", nullptr, 8, R_T_MIN, 2}, {"t_den", nullptr, 8, R_T_DEN, 2},
+      {"hist_ref", nullptr, 8, R_HIST_REF, 2},
+      {"record", (void**)&d.rec, 4 * SDC_REC_DWORDS, 0, 0},
+      {"hist", (void**)&d.hist, sizeof(unsigned) * SDC_HIST_STRIDE, 0, 0},
+      {"hist_n", (void**)&d.hist_n, 4, 0, 0},
+      {"ep_return", (void**)&d.ep_return, 8 * 3, 0, 0}, {"q_guess", (void**)&d.q_guess, 4 * 2, 0, 0},
+      {"t_win", (void**)&d.t_win, sizeof(double) * (size_t)d.lw, 0, 0},
+      {"wb_win", (void**)&d.wb_win, sizeof(double) * (size_t)d.lw, 0, 0},
+      {"qtab", (void**)&d.qtab, sizeof(uint2) * (size_t)d.qstride, 0, 0},
   };
+  // scale starts at 1, last_delta = None (envs/dc_gym.py:81-83)
+  {
+    std::vector<int> ones(N, 1), none(N, -2);
+    if (rec_put(h, R_SCALE, 1, ones.data()) != 0 || rec_put(h, R_LAST_DELTA, 1, none.data()) != 0) {
+      sdc_destroy(h);
+      return -1;
+    }
+  }
   *out = h;
   return 0;
 }
@@ -282,18 +292,17 @@ int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id,
     if (day_lo[e] < 0 || day_hi[e] > 364 || day_lo[e] > day_hi[e]) return fail_msg("sdc_assign_envs: bad day range");
   }
   HIP_TRY(hipSetDevice(h->device));
-  const size_t b = sizeof(int) * (size_t)N;
-  HIP_TRY(hipMemcpy(const_cast<int*>(h->d.loc_id), loc_id, b, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(const_cast<int*>(h->d.cfg_id), cfg_id, b, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(const_cast<int*>(h->d.day_lo), day_lo, b, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(const_cast<int*>(h->d.day_hi), day_hi, b, hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  if (rec_put(h, R_LOC, 1, loc_id) || rec_put(h, R_CFG, 1, cfg_id) || rec_put(h, R_DAY_LO, 1, day_lo) ||
+      rec_put(h, R_DAY_HI, 1, day_hi))
+    return -1;
   // the CRAC set-point starts at the config's initial value (make_envs_pyenv.py:124) and is never reset
   if (!h->started) {
     std::vector<sdc_dc_params> ps(h->cfg.n_dc_configs);
     HIP_TRY(hipMemcpy(ps.data(), h->d.dc, sizeof(sdc_dc_params) * ps.size(), hipMemcpyDeviceToHost));
     std::vector<double> st(N);
     for (int e = 0; e < N; e++) st[e] = ps[cfg_id[e]].init_setpoint;
-    HIP_TRY(hipMemcpy(h->d.stpt, st.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+    if (rec_put(h, R_STPT, 2, st.data())) return -1;
   }
   h->assigned = true;
   return 0;
@@ -452,6 +461,7 @@ int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes
   if (bytes != need) return fail_msg(std::string("sdc_get_state: size mismatch for ") + field);
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (!f->ptr) return rec_get(h, f->rec_idx, f->rec_dwords, host_buf);
   HIP_TRY(hipMemcpy(host_buf, *f->ptr, need, hipMemcpyDeviceToHost));
   if (std::strcmp(field, "hist") == 0) {  // device keys -> fp32 offsets (empty slot -> NaN)
     unsigned* u = static_cast<unsigned*>(host_buf);
@@ -468,17 +478,23 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
   if (bytes != need) return fail_msg(std::string("sdc_set_state: size mismatch for ") + field);
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
-  if (std::strcmp(field, "hist") == 0) {  // fp32 offsets -> device keys (NaN -> empty slot)
+  if (!f->ptr) {
+    if (rec_put(h, f->rec_idx, f->rec_dwords, host_buf)) return -1;
+    if (std::strcmp(field, "hist_len") == 0)   // the reward kernel's copy of the length
+      HIP_TRY(hipMemcpy(h->d.hist_n, host_buf, need, hipMemcpyHostToDevice));
+  } else if (std::strcmp(field, "hist") == 0) {  // fp32 offsets -> device keys (NaN -> empty slot)
     std::vector<unsigned> k(need / 4);
     const unsigned* u = static_cast<const unsigned*>(host_buf);
     for (size_t i = 0; i < k.size(); i++) k[i] = ((u[i] & 0x7FFFFFFFu) > 0x7F800000u) ? 0xFFFFFFFFu : sdc_f32_key(u[i]);
     HIP_TRY(hipMemcpy(*f->ptr, k.data(), need, hipMemcpyHostToDevice));
-    return 0;
+  } else {
+    HIP_TRY(hipMemcpy(*f->ptr, host_buf, need, hipMemcpyHostToDevice));
   }
-  HIP_TRY(hipMemcpy(*f->ptr, host_buf, need, hipMemcpyHostToDevice));
-  if (std::strcmp(field, "t_rel") == 0) {
+  if (std::strcmp(field, "t_rel") == 0 || std::strcmp(field, "record") == 0) {
+    std::vector<int> tr(h->cfg.n_envs);
+    if (rec_get(h, R_TREL, 1, tr.data())) return -1;
     h->pending = 0;
-    std::memcpy(h->host_t_rel.data(), host_buf, need);
+    h->host_t_rel = tr;
     recompute_steps_to_terminal(h);
   }
   return 0;

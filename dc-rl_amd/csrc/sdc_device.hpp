@@ -28,8 +28,44 @@
 #define SDC_OBS_RAW 53
 #define SDC_OBS_OUT (SDC_N_AGENTS * SDC_OBS_PAD)
 
-// per-env carried load-shifting info (sustaindc_env.py:569-573): 8 doubles
-enum { SDC_C_NORMQ = 0, SDC_C_OLDEST, SDC_C_AVG, SDC_C_H0, SDC_C_H1, SDC_C_H2, SDC_C_H3, SDC_C_H4, SDC_CARRY_DIM };
+// ------------------------------------------------------------------------------------------------
+// Per-environment state RECORD: 64 dwords (256 B, one per lane) so that the wavefront that owns an env loads its
+// whole state with ONE coalesced global_load_dword and stores it back with one coalesced store.  Fields are read
+// out with v_readlane.  (Struct-of-arrays would make every field of a one-wavefront-per-env kernel a separate
+// wave-uniform scalar load -- ~30 dependent cache misses per step.)
+enum SdcRec {
+  R_CURSOR = 0,   // trace-table index i = day*96 + hour*4 (utils/managers.py:122)
+  R_TREL,         // steps since the episode started
+  R_DAY,
+  R_HOURQ,        // quarter-hour of the day 0..95
+  R_QPOPPED,      // load-shifting queue: tasks ever removed this episode
+  R_QCUM,         // tasks ever enqueued up to the previous step
+  R_QCUMT,        // sum over enqueued tasks of their enqueue step
+  R_QHEAD,        // enqueue step of the oldest task still queued
+  R_QCUM_HM1,     // cum[head - 1], cumT[head - 1] (cached so the average-age algebra needs no load)
+  R_QCUMT_HM1,
+  R_LAST_DELTA,   // -2 = None (envs/dc_gym.py:115)
+  R_CONSEC,
+  R_SCALE,
+  R_HIST_LEN,
+  R_HIST_POS,
+  R_EPISODE,
+  R_FAULT,
+  R_LOC,          // assignment: trace-table set
+  R_CFG,          //             data-centre parameter set
+  R_DAY_LO,       //             inclusive range of the random start day
+  R_DAY_HI,
+  R_F64 = 24,     // doubles from here, two dwords each
+  R_STPT = 24,
+  R_BAT = 26,
+  R_CI_MIN = 28,
+  R_CI_DEN = 30,
+  R_T_MIN = 32,
+  R_T_DEN = 34,
+  R_HIST_REF = 36,
+  R_END = 38,
+  SDC_REC_DWORDS = 64
+};
 
 struct SdcDev {
   int n_envs, episode_steps, hist_cap, queue_max, table_len, lw, qstride, max_roll_days;
@@ -42,45 +78,28 @@ struct SdcDev {
   const double* tabWB;  // pre-noise wet bulb
   const sdc_dc_params* dc;  // [n_cfg]
   const double* hour_lut;   // [96][2] = cos, sin (utils/managers.py:66-88)
-  // per-env assignment
-  const int* loc_id;
-  const int* cfg_id;
-  const int* day_lo;
-  const int* day_hi;
-  // per-env state (struct of arrays)
-  int* cursor;
-  int* t_rel;
-  int* day;
-  int* hourq;
-  int* q_popped;
-  int* q_cum;
-  unsigned* q_cumT;
-  int* q_head;
-  uint2* qtab;  // [N][qstride] {cum, cumT}
-  int* last_delta;  // -2 = None
-  int* consecutive;
-  int* scale;
-  int* hist_len;
-  int* hist_pos;
-  int* episode;
-  unsigned* fault;
-  double* stpt;
-  double* bat_load;
-  double* ci_min;
-  double* ci_den;
-  double* t_min;
-  double* t_den;
-  double* carry;  // [SDC_CARRY_DIM][N]
-  double* t_win;  // [N][lw]
-  double* wb_win;
-  double* walk_tmp;  // [N][SDC_NORM_WINDOW] scratch of the device-side reset
+  // per-env state
+  unsigned* rec;     // [N][SDC_REC_DWORDS] state records (see SdcRec)
+  uint2* qtab;       // [N][qstride] {cum, cumT} per enqueue step of the episode
+  double* t_win;     // [N][lw] dry bulb after noise + roll + clip, from the episode's first cursor
+  double* wb_win;    // [N][lw] wet bulb likewise
+  double* walk_tmp;  // [N][max(SDC_NORM_WINDOW, lw)] scratch of the device-side reset
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
-  double* hand;      // [4][N] dynamics -> reward kernel: energy, norm_CI next, oldest task age, overdue count
+  // dynamics -> reward kernel hand-off and reward-kernel-owned state (struct of arrays: one lane reads them)
+  double* hand;      // [4][N] energy - hist_ref, norm_CI next, oldest task age, overdue count
+  int* hist_n;       // [N] history length including this step's value
   unsigned* q_guess; // [2][N] fp32 keys of last step's order statistics at floor((n-1)/4), floor(3(n-1)/4)
   double* ep_return; // [3][N] running return of the current episode (cleared by reset)
-  double* hist_ref;  // [N] first energy value of the env (fp64): the ring stores offsets from it
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
 };
+
+// record field access: every lane holds dword `lane` of the record in `r`
+__device__ __forceinline__ int rec_i32(unsigned r, int idx) { return (int)__builtin_amdgcn_readlane((int)r, idx); }
+__device__ __forceinline__ double rec_f64(unsigned r, int idx) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)r, idx);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)r, idx + 1);
+  return __hiloint2double((int)hi, (int)lo);
+}
 
 // ------------------------------------------------------------------------------------------------
 // wave helpers (64 lanes)

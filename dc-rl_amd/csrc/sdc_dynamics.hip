@@ -1,27 +1,45 @@
 // sdc_dynamics.hip -- coupled per-timestep dynamics, ONE WAVEFRONT PER ENVIRONMENT (block = 64 lanes).
 //
-//   * lanes 0..24 / 32..48 stage the carbon-intensity and temperature observation windows into LDS
-//     (coalesced reads of the struct-of-arrays trace tables);
-//   * the load-shifting queue is O(1) prefix-count algebra plus a 64-ary wave search for the oldest task;
-//   * the rack model runs lane = rack with per-rack constants read coalesced from the config table and
-//     wave-shuffle (DPP) reductions for total IT power, CRAC return and outlet temperature;
+// Memory plan (two dependent round trips per step instead of one per field):
+//   level 0  the env's 256-byte state record, one dword per lane (coalesced), + the 3 actions;
+//   level 1  ONE 8-byte gather per lane: the workload / carbon / weather samples of the step, the 25-sample CI
+//            and 17-sample temperature observation windows, the 5 queue prefix-count probes and the hour LUT
+//            entry -- staged through LDS and read back wave-uniformly; the per-rack constants (lane = rack);
+//   (level 2 only on steps that pop tasks: the 64-ary search for the new oldest task in the queue.)
+// Compute:
+//   * the load-shifting queue is O(1) prefix-count algebra (see below);
+//   * the rack model runs lane = rack with wave-shuffle (DPP) reductions for total IT power, CRAC return and
+//     outlet temperature;
 //   * chiller / cooling tower / water / battery / set-point integrator are wave-uniform scalar fp64;
-//   * the observation features (3 least-squares slopes, 2 x mean/std/peak/valley) run lane-parallel with
-//     segmented butterfly reductions; lane 0 assembles the info block in LDS; all lanes store coalesced.
-// The energy value and the three reward terms that need the history normaliser are handed to
-// sdc_reward_kernel (sdc_reward.hip) through a 32-byte per-env record.
+//   * the observation features (3 least-squares slopes, 2 x mean/std/peak/valley) run lane-parallel with segmented
+//     butterfly reductions; lane 0 assembles the info block and the new state record in LDS; all lanes store
+//     obs / share_obs / info / record coalesced.
+// The energy value and the reward terms that need the history normaliser are handed to sdc_reward_kernel
+// (sdc_reward.hip) through a 32-byte per-env record; the energy is appended to the history ring here.
 //
 // Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
 #include "sdc_device.hpp"
 
 namespace {
 
+// gather slots (one 8-byte load per lane)
+enum {
+  G_W0 = 0, G_W1, G_W2,   // W[i], W[i+1], W[i+2]
+  G_C0,                   // C[i]
+  G_T0, G_WB0, G_T1,      // T[i], WB[i], T[i+1] from the env's weather window
+  G_LUT,                  // hour LUT {cos, sin} is 16 bytes: two slots
+  G_LUT2,
+  G_Q97, G_Q24, G_Q48, G_Q72, G_Q96,   // queue prefix counts cum[now - a]
+  G_NC = 16,              // 25 slots: C[i'-16 .. i'+8]
+  G_NT = 41,              // 17 slots: T[i' .. i'+16]
+  G_END = 58
+};
+
 struct DynShared {
-  double nc[32];
-  double nt[32];
-  float obs[64];
+  double g[64];     // gathered raw values; g[G_NC..] / g[G_NT..] are normalised in place to NC / NT
+  float pool[32];   // observation pool (see build_obs_pool)
   float info[SDC_INFO_DIM];
-  int terminal;
+  unsigned rec[SDC_REC_DWORDS];
 };
 
 // envs/datacenter.py:356-429 calculate_chiller_power
@@ -48,28 +66,20 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 
 // ------------------------------------------------------------------------------------------------
 // the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
-__device__ void step_dynamics(const SdcDev& S, const int env, const int lane, const int32_t* __restrict__ actions,
-                              DynShared& sh) {
-  const int loc = S.loc_id[env];
-  const sdc_dc_params& P = S.dc[S.cfg_id[env]];
-  const int TL = S.table_len;
-  const int i = S.cursor[env];
-  const int rel = S.t_rel[env];
-  const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
-  unsigned fault = 0;
-  if (i + 9 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
-  auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
-  const double* tW = S.tabW + (size_t)loc * TL;
-  const double* tC = S.tabC + (size_t)loc * TL;
-  const double wl = tW[tix(i)];
-  const double w_ip = tW[tix(i + 1)], w_ip1 = tW[tix(i + 2)];
-  const double ci_i = tC[tix(i)];
-  const double* tw = S.t_win + (size_t)env * S.lw;
-  const double* wbw = S.wb_win + (size_t)env * S.lw;
-  const double amb = tw[rel], wet_bulb = wbw[rel], amb_next = tw[rel + 1];
-  const int day = S.day[env];
-  const int hourq = S.hourq[env];
+__device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_params& P, const int env, const int lane,
+                                              const unsigned r, const int a_ls, const int a_dc, const int a_bat,
+                                              unsigned fault, DynShared& sh) {
+  const int N = S.n_envs;
+  const int i = rec_i32(r, R_CURSOR);
+  const int rel = rec_i32(r, R_TREL);
+  const int day = rec_i32(r, R_DAY);
+  const int hourq = rec_i32(r, R_HOURQ);
   const double hour = (double)hourq * 0.25;
+  const double wl = sh.g[G_W0], w_ip = sh.g[G_W1], w_ip1 = sh.g[G_W2];
+  const double ci_i = sh.g[G_C0];
+  const double amb = sh.g[G_T0], wet_bulb = sh.g[G_WB0], amb_next = sh.g[G_T1];
+  const double* nc = sh.g + G_NC;
+  const double* nt = sh.g + G_NT;
 
   // ---- load shifting: envs/carbon_ls.py:172-324 ------------------------------------------------
   // The reference keeps a deque of per-task enqueue timestamps and only ever removes a FIFO prefix
@@ -83,12 +93,13 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
   const int shf = (int)floor(wl * flex * 100);
   const uint2* qt = S.qtab + (size_t)env * S.qstride;
   const int now = rel;
-  int popped = S.q_popped[env];
-  const int cum_prev = S.q_cum[env];
-  const unsigned cumT_prev = S.q_cumT[env];
-  auto cum_at = [&](int t) -> int { return t < 0 ? 0 : (int)qt[t].x; };  // t <= now - 1
+  const int popped0 = rec_i32(r, R_QPOPPED);
+  int popped = popped0;
+  const int cum_prev = rec_i32(r, R_QCUM);
+  const unsigned cumT_prev = (unsigned)rec_i32(r, R_QCUMT);
+  auto cum_g = [&](int slot) -> int { return (int)(unsigned)__double2loint(sh.g[slot]); };  // .x of the gathered uint2 (0 if t < 0)
   // overdue: age > 24 h  <=>  enqueued at step <= now - 97  (carbon_ls.py:208)
-  const int overdue = max(0, cum_at(now - 97) - popped);
+  const int overdue = max(0, cum_g(G_Q97) - popped);
   int avail = 90 - (ns + shf);
   int od_proc = 0;
   if (avail > 0 && overdue > 0) od_proc = min(overdue, avail);
@@ -117,8 +128,8 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
   const unsigned cumT_now = cumT_prev + (unsigned)add * (unsigned)now;
   const int total = cum_now - popped;
   // age histogram, bins [0,6,12,18,24,inf] hours = [0,24,48,72,96,inf) steps (carbon_ls.py:63-73)
-  auto older_eq = [&](int a) -> int { return max(0, cum_at(now - a) - popped); };  // tasks with age >= a steps (a > 0)
-  const int a24 = older_eq(24), a48 = older_eq(48), a72 = older_eq(72), a96 = older_eq(96);
+  const int a24 = max(0, cum_g(G_Q24) - popped), a48 = max(0, cum_g(G_Q48) - popped);
+  const int a72 = max(0, cum_g(G_Q72) - popped), a96 = max(0, cum_g(G_Q96) - popped);
   double hist[5];
   {
     const double den = (double)max(total, 1);
@@ -128,34 +139,42 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
     hist[3] = (double)(a72 - a96) / den;
     hist[4] = a96 > 0 ? 1.0 : 0.0;
   }
-  // oldest task: smallest step h in [head, now] with cum[h] > popped (64-ary search, <= 2 rounds)
-  int head = S.q_head[env];
+  // oldest task: smallest step h in [head, now] with cum[h] > popped.  It only moves when tasks were popped
+  // (or the queue was empty): then a 64-ary wave search (<= 2 rounds) finds it and cum/cumT[h-1] are cached.
+  int head = rec_i32(r, R_QHEAD);
+  int cum_hm1 = rec_i32(r, R_QCUM_HM1);
+  unsigned cumT_hm1 = (unsigned)rec_i32(r, R_QCUMT_HM1);
   double oldest = 0.0, avg = 0.0;
   if (total > 0) {
-    int lo = head, hi = now;
-    while (hi - lo + 1 > SDC_WAVE) {
-      const int len = hi - lo + 1;
-      const int stride = (len + SDC_WAVE - 1) / SDC_WAVE;
-      const int t = min(lo + (lane + 1) * stride - 1, hi);
-      const int c = (t == now) ? cum_now : (int)qt[t].x;
-      const unsigned long long m = __ballot(c > popped);
-      const int f = __ffsll((long long)m) - 1;  // exists: cum[now] > popped
-      const int nlo = lo + f * stride;
-      hi = min(lo + (f + 1) * stride - 1, hi);
-      lo = nlo;
-    }
-    {
-      const int t = lo + lane;
-      int c = 0;
-      if (t <= hi) c = (t == now) ? cum_now : (int)qt[t].x;
-      const unsigned long long m = __ballot(t <= hi && c > popped);
-      head = lo + (__ffsll((long long)m) - 1);
-    }
-    // sum of enqueue steps over the queued tasks = cumT[now] - cumT[h-1] - (popped - cum[h-1]) * h
-    int cum_hm1 = 0;
-    unsigned cumT_hm1 = 0;
-    if (head > 0) {
-      if (head == now) {
+    const bool was_empty = (cum_prev - popped0) == 0;
+    if (was_empty) {          // everything queued was enqueued now
+      head = now;
+      cum_hm1 = cum_prev;
+      cumT_hm1 = cumT_prev;
+    } else if (popped != popped0) {
+      int lo = head, hi = now;
+      while (hi - lo + 1 > SDC_WAVE) {
+        const int len = hi - lo + 1;
+        const int stride = (len + SDC_WAVE - 1) / SDC_WAVE;
+        const int t = min(lo + (lane + 1) * stride - 1, hi);
+        const int c = (t == now) ? cum_now : (int)qt[t].x;
+        const unsigned long long m = __ballot(c > popped);
+        const int f = __ffsll((long long)m) - 1;  // exists: cum[now] > popped
+        const int nlo = lo + f * stride;
+        hi = min(lo + (f + 1) * stride - 1, hi);
+        lo = nlo;
+      }
+      {
+        const int t = lo + lane;
+        int c = 0;
+        if (t <= hi) c = (t == now) ? cum_now : (int)qt[t].x;
+        const unsigned long long m = __ballot(t <= hi && c > popped);
+        head = lo + (__ffsll((long long)m) - 1);
+      }
+      if (head == 0) {
+        cum_hm1 = 0;
+        cumT_hm1 = 0;
+      } else if (head == now) {
         cum_hm1 = cum_prev;
         cumT_hm1 = cumT_prev;
       } else {
@@ -164,12 +183,15 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
         cumT_hm1 = e.y;
       }
     }
+    // sum of enqueue steps over the queued tasks = cumT[now] - cumT[h-1] - (popped - cum[h-1]) * h
     const long long sum_t = (long long)cumT_now - (long long)cumT_hm1 - (long long)(popped - cum_hm1) * head;
     const long long sum_age_steps = (long long)total * now - sum_t;
-    oldest = (double)(now - head) * 0.25;             // hours, exact
+    oldest = (double)(now - head) * 0.25;                  // hours, exact
     avg = ((double)sum_age_steps * 0.25) / (double)total;  // sum(ages) is exact in the reference too
   } else {
     head = now;
+    cum_hm1 = cum_now;
+    cumT_hm1 = cumT_now;
   }
   const double normq = (double)total / (double)S.queue_max;
   const double oldest_norm = oldest / 24, avg_norm = avg / 24;
@@ -177,7 +199,7 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 ----------------------------------------
   if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
   const int delta = a_dc - 1;  // make_envs_pyenv.py:127-131
-  int last_delta = S.last_delta[env], consecutive = S.consecutive[env], scale = S.scale[env];
+  int last_delta = rec_i32(r, R_LAST_DELTA), consecutive = rec_i32(r, R_CONSEC), scale = rec_i32(r, R_SCALE);
   if (last_delta != -2 && delta == last_delta && a_dc != 0) {
     consecutive += 1;
   } else {
@@ -185,7 +207,7 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
     scale = 1;
   }
   if (consecutive > 3) scale += 1;
-  double stpt = S.stpt[env] + (double)(delta * scale);
+  double stpt = rec_f64(r, R_STPT) + (double)(delta * scale);
   stpt = fmax(fmin(stpt, P.max_temp), P.min_temp);
 
   // ---- rack model, lane = rack: envs/datacenter.py:250-317, :157-181 ------------------------------
@@ -245,7 +267,7 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
   // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ----------------------
   const double cap = P.bat_capacity_mwh;
   const double dcload = total_kw / 1e3;  // MW (sustaindc_env.py:652)
-  double bat_load = S.bat_load[env];
+  double bat_load = rec_f64(r, R_BAT);
   double energy, co2;
   if (a_bat == 0) {  // charge
     const double soc = (bat_load - 0) / (cap - 0);
@@ -278,14 +300,13 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
     hourq_n = 0;
     day_n += 1;
   }
-  const int terminal = (rel + 1 >= S.episode_steps) ? 1 : 0;
   const int ip = i + 1;
 
   // ---- observations at i' (sustaindc_env.py:565-585): all lanes cooperate -------------------------------------
   {
     ObsScalars o;
-    o.cos_h = S.hour_lut[2 * hourq_n];
-    o.sin_h = S.hour_lut[2 * hourq_n + 1];
+    o.cos_h = sh.g[G_LUT];
+    o.sin_h = sh.g[G_LUT2];
     o.w_cur = w_ip;
     o.w_next = w_ip1;
     o.soc = soc_after;
@@ -294,9 +315,12 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
     o.avg = avg_norm;
     for (int b = 0; b < 5; b++) o.hist[b] = hist[b];
     o.have_past = ip >= 16;
-    build_obs_pool(sh.nc, sh.nt, o, sh.obs, lane);
+    build_obs_pool(nc, nt, o, sh.pool, lane);
   }
 
+  // every lane keeps its own dword of the record; lane 0 patches the fields that changed (below)
+  sh.rec[lane] = r;
+  __syncthreads();
   if (lane == 0) {
     // ---- info block --------------------------------------------------------------------------------
     float* inf = sh.info;
@@ -329,100 +353,147 @@ __device__ void step_dynamics(const SdcDev& S, const int env, const int lane, co
     inf[SDC_INFO_BAT_AVG_CI] = (float)ci_i;
     inf[SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH] = (float)(dcload * 1e3 * 0.25);
     inf[SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH] = (float)energy;
-    inf[SDC_INFO_NORM_CI] = (float)sh.nc[17];
+    inf[SDC_INFO_NORM_CI] = (float)nc[17];
     inf[SDC_INFO_OUTSIDE_TEMP] = (float)amb_next;
     inf[SDC_INFO_DAY] = (float)day_n;
     inf[SDC_INFO_HOUR] = (float)((double)hourq_n * 0.25);
-    const unsigned f_all = S.fault[env] | fault;
+    const unsigned f_all = (unsigned)rec_i32(r, R_FAULT) | fault;
     inf[SDC_INFO_FAULT] = (float)f_all;
-    inf[SDC_INFO_ENERGY_Z] = 0.0f;
+    inf[SDC_INFO_ENERGY_Z] = 0.0f;       // the five columns below are filled by sdc_reward_kernel
     inf[SDC_INFO_RESERVED] = 0.0f;
-    inf[SDC_INFO_EP_RETURN_LS] = 0.0f;   // the four columns below are filled by sdc_reward_kernel
+    inf[SDC_INFO_EP_RETURN_LS] = 0.0f;
     inf[SDC_INFO_EP_RETURN_DC] = 0.0f;
     inf[SDC_INFO_EP_RETURN_BAT] = 0.0f;
     inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
 
-    // ---- hand-off to the reward kernel (4 doubles per env, struct of arrays) ----------------------------
-    {
-      const int N = S.n_envs;
-      // history append (utils/reward_creator.py:7-14).  The ring holds fp32 OFFSETS from the env's first energy
-      // value (kept in fp64): normalize_energy is shift-invariant, and offsets keep the fp32 rounding error
-      // proportional to the spread of the history instead of to the ~300 kWh magnitude (two nearly equal
-      // energies would otherwise lose the z-score).  Stored as order-preserving keys for the reward kernel.
-      const int hl = S.hist_len[env];
-      const double href = hl == 0 ? energy : S.hist_ref[env];
-      const double e_off = energy - href;
-      int slot;
-      if (hl < S.hist_cap) {
-        slot = hl;
-        S.hist_len[env] = hl + 1;
-        if (hl == 0) S.hist_ref[env] = href;
-      } else {
-        slot = S.hist_pos[env];
-        S.hist_pos[env] = slot + 1 == S.hist_cap ? 0 : slot + 1;
-      }
-      S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = sdc_f32_key(__float_as_uint((float)e_off));
-      S.hand[env] = e_off;                     // bat_total_energy_with_battery_KWh - hist_ref
-      S.hand[N + env] = sh.nc[17];             // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
-      S.hand[2 * N + env] = oldest_norm;       // ls_oldest_task_age
-      S.hand[3 * N + env] = (double)overdue;   // ls_overdue_penalty
+    // ---- history append (utils/reward_creator.py:7-14) ------------------------------------------------------
+    // The ring holds fp32 OFFSETS from the env's first energy value (kept in fp64): normalize_energy is
+    // shift-invariant, and offsets keep the fp32 rounding error proportional to the spread of the history
+    // instead of to the ~300 kWh magnitude (two nearly equal energies would otherwise lose the z-score).
+    // Stored as order-preserving keys for the reward kernel.
+    int hl = rec_i32(r, R_HIST_LEN), hpos = rec_i32(r, R_HIST_POS);
+    const double href = hl == 0 ? energy : rec_f64(r, R_HIST_REF);
+    const double e_off = energy - href;
+    int slot;
+    if (hl < S.hist_cap) {
+      slot = hl;
+      hl += 1;
+    } else {
+      slot = hpos;
+      hpos = hpos + 1 == S.hist_cap ? 0 : hpos + 1;
     }
-    sh.terminal = terminal;
-
-    // ---- state write-back ------------------------------------------------------------------------------
-    S.cursor[env] = ip;
-    S.t_rel[env] = rel + 1;
-    S.day[env] = day_n;
-    S.hourq[env] = hourq_n;
-    S.q_popped[env] = popped;
-    S.q_cum[env] = cum_now;
-    S.q_cumT[env] = cumT_now;
-    S.q_head[env] = head;
+    S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = sdc_f32_key(__float_as_uint((float)e_off));
+    // ---- hand-off to the reward kernel ------------------------------------------------------------------------
+    S.hand[env] = e_off;                     // bat_total_energy_with_battery_KWh - hist_ref
+    S.hand[N + env] = nc[17];                // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
+    S.hand[2 * N + env] = oldest_norm;       // ls_oldest_task_age
+    S.hand[3 * N + env] = (double)overdue;   // ls_overdue_penalty
+    S.hist_n[env] = hl;
     S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
-    S.last_delta[env] = delta;
-    S.consecutive[env] = consecutive;
-    S.scale[env] = scale;
-    S.stpt[env] = stpt;
-    S.bat_load[env] = bat_load;
-    S.fault[env] = f_all;
-    double* cr = S.carry;
-    const int N = S.n_envs;
-    cr[SDC_C_NORMQ * N + env] = normq;
-    cr[SDC_C_OLDEST * N + env] = oldest_norm;
-    cr[SDC_C_AVG * N + env] = avg_norm;
-    for (int b = 0; b < 5; b++) cr[(SDC_C_H0 + b) * N + env] = hist[b];
+
+    // ---- new state record ------------------------------------------------------------------------------------
+    unsigned* o = sh.rec;
+    o[R_CURSOR] = (unsigned)ip;
+    o[R_TREL] = (unsigned)(rel + 1);
+    o[R_DAY] = (unsigned)day_n;
+    o[R_HOURQ] = (unsigned)hourq_n;
+    o[R_QPOPPED] = (unsigned)popped;
+    o[R_QCUM] = (unsigned)cum_now;
+    o[R_QCUMT] = cumT_now;
+    o[R_QHEAD] = (unsigned)head;
+    o[R_QCUM_HM1] = (unsigned)cum_hm1;
+    o[R_QCUMT_HM1] = cumT_hm1;
+    o[R_LAST_DELTA] = (unsigned)delta;
+    o[R_CONSEC] = (unsigned)consecutive;
+    o[R_SCALE] = (unsigned)scale;
+    o[R_HIST_LEN] = (unsigned)hl;
+    o[R_HIST_POS] = (unsigned)hpos;
+    o[R_FAULT] = f_all;
+    o[R_STPT] = (unsigned)__double2loint(stpt);
+    o[R_STPT + 1] = (unsigned)__double2hiint(stpt);
+    o[R_BAT] = (unsigned)__double2loint(bat_load);
+    o[R_BAT + 1] = (unsigned)__double2hiint(bat_load);
+    o[R_HIST_REF] = (unsigned)__double2loint(href);
+    o[R_HIST_REF + 1] = (unsigned)__double2hiint(href);
   }
 }
 
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
-                                                                             float* __restrict__ obs,
-                                                                             float* __restrict__ share_obs,
-                                                                             unsigned char* __restrict__ done,
-                                                                             float* __restrict__ info,
-                                                                             float* __restrict__ final_obs) {
+                                                                                float* __restrict__ obs,
+                                                                                float* __restrict__ share_obs,
+                                                                                unsigned char* __restrict__ done,
+                                                                                float* __restrict__ info,
+                                                                                float* __restrict__ final_obs) {
   __shared__ DynShared sh;
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
-  stage_windows(S, S.loc_id[env], S.cursor[env] + 1, S.t_win + (size_t)env * S.lw + S.t_rel[env] + 1, S.ci_min[env],
-                S.ci_den[env], S.t_min[env], S.t_den[env], lane, sh.nc, sh.nt);
-  __syncthreads();
-  step_dynamics(S, env, lane, actions, sh);
-  __syncthreads();
-  const int terminal = sh.terminal;
-  // coalesced stores: obs [3][26] (78 floats), share_obs [29], info [SDC_INFO_DIM]
+  const int N = S.n_envs;
+  const int TL = S.table_len;
+
+  // ---- level 0: state record (coalesced) + actions ---------------------------------------------------------------
+  unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
+  const unsigned r = recp[lane];
+  const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
+  const int i = rec_i32(r, R_CURSOR), rel = rec_i32(r, R_TREL);
+  const int loc = rec_i32(r, R_LOC);
+  const sdc_dc_params& P = S.dc[rec_i32(r, R_CFG)];
+  const double ci_min = rec_f64(r, R_CI_MIN), ci_den = rec_f64(r, R_CI_DEN);
+  const double t_min = rec_f64(r, R_T_MIN), t_den = rec_f64(r, R_T_DEN);
+  const int hourq = rec_i32(r, R_HOURQ);
+  const int hourq_n = hourq + 1 >= 96 ? 0 : hourq + 1;
+  unsigned fault = 0;
+  if (i + 9 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
+
+  // ---- level 1: one 8-byte gather per lane -------------------------------------------------------------------------
   {
-    const float v0 = obs_padded_at(sh.obs, lane);
+    auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
+    const double* tW = S.tabW + (size_t)loc * TL;
+    const double* tC = S.tabC + (size_t)loc * TL;
+    const double* tw = S.t_win + (size_t)env * S.lw + rel;
+    const double* wbw = S.wb_win + (size_t)env * S.lw + rel;
+    const uint2* qt = S.qtab + (size_t)env * S.qstride;
+    const double* src = nullptr;
+    if (lane <= G_W2) src = tW + tix(i + lane);
+    else if (lane == G_C0) src = tC + tix(i);
+    else if (lane == G_T0) src = tw;
+    else if (lane == G_WB0) src = wbw;
+    else if (lane == G_T1) src = tw + 1;
+    else if (lane == G_LUT) src = S.hour_lut + 2 * hourq_n;
+    else if (lane == G_LUT2) src = S.hour_lut + 2 * hourq_n + 1;
+    else if (lane >= G_Q97 && lane <= G_Q96) {
+      const int back = lane == G_Q97 ? 97 : 24 * (lane - G_Q97);   // 97, 24, 48, 72, 96
+      const int t = rel - back;
+      if (t >= 0) src = reinterpret_cast<const double*>(qt + t);
+    } else if (lane >= G_NC && lane < G_NC + 25) src = tC + tix(i + 1 - 16 + (lane - G_NC));
+    else if (lane >= G_NT && lane < G_NT + 17) src = tw + 1 + (lane - G_NT);
+    double v = 0.0;
+    if (src) v = *src;
+    if (lane >= G_NC && lane < G_NC + 25) v = (v - ci_min) / ci_den;   // utils/managers.py:437
+    if (lane >= G_NT && lane < G_NT + 17) v = (v - t_min) / t_den;     // utils/managers.py:608
+    sh.g[lane] = v;
+  }
+  __syncthreads();
+
+  step_dynamics(S, P, env, lane, r, a_ls, a_dc, a_bat, fault, sh);
+  __syncthreads();
+
+  // ---- coalesced stores: record, obs [3][26] (78 floats), share_obs [29], info --------------------------------------
+  recp[lane] = sh.rec[lane];
+  const int terminal = (rel + 1 >= S.episode_steps) ? 1 : 0;
+  {
+    const float v0 = obs_padded_at(sh.pool, lane);
     obs[(size_t)env * SDC_OBS_OUT + lane] = v0;
     if (terminal && final_obs) final_obs[(size_t)env * SDC_OBS_OUT + lane] = v0;
     if (lane < SDC_OBS_OUT - SDC_WAVE) {
-      const float v1 = obs_padded_at(sh.obs, SDC_WAVE + lane);
+      const float v1 = obs_padded_at(sh.pool, SDC_WAVE + lane);
       obs[(size_t)env * SDC_OBS_OUT + SDC_WAVE + lane] = v1;
       if (terminal && final_obs) final_obs[(size_t)env * SDC_OBS_OUT + SDC_WAVE + lane] = v1;
     }
   }
-  if (share_obs && lane < SDC_SHARE_OBS_DIM) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = share_obs_at(sh.obs, lane);
+  if (share_obs && lane < SDC_SHARE_OBS_DIM) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = sh.pool[lane];
   if (info && lane < SDC_INFO_DIM) info[(size_t)env * SDC_INFO_DIM + lane] = sh.info[lane];
   if (lane == 0) done[env] = (unsigned char)terminal;
+  (void)N;
 }

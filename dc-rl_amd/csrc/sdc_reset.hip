@@ -21,6 +21,7 @@ struct ResetShared {
   double nt[32];
   double tw[32];  // T[c0 .. c0+16] of a device-side reset
   float obs[64];
+  unsigned rec[SDC_REC_DWORDS];
 };
 
 __device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
@@ -57,11 +58,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
   if (S.reset_mask && !S.reset_mask[env]) return;
-  if (only_done && S.t_rel[env] < S.episode_steps) return;  // auto-reset: finished envs only
-  const int loc = S.loc_id[env];
+  unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
+  const unsigned r = recp[lane];  // the env's state record, one dword per lane
+  if (only_done && rec_i32(r, R_TREL) < S.episode_steps) return;  // auto-reset: finished envs only
+  const int loc = rec_i32(r, R_LOC);
   const int TL = S.table_len;
-  const int episode = S.episode[env] + 1;
-  unsigned fault = S.fault[env];
+  const int episode = rec_i32(r, R_EPISODE) + 1;
+  unsigned fault = (unsigned)rec_i32(r, R_FAULT);
   int day, hour;
   double ci_min, ci_den, t_min, t_den;
   const double* tsrc;
@@ -76,12 +79,12 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     if (day * 96 + hour * 4 + S.episode_steps + 17 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
   } else {
     // ---- draws: sustaindc_env.py:454-455 (day in [lo, hi], hour in [0, 23]); managers.py:601 (roll) ----
-    const Philox4 r = philox4x32_10(0u, (unsigned)env, (unsigned)episode, 0xD4A7u, (unsigned)S.seed,
-                                    (unsigned)(S.seed >> 32));
-    const int lo = S.day_lo[env], hi = S.day_hi[env];
-    day = lo + (int)(((unsigned long long)r.x * (unsigned)(hi - lo + 1)) >> 32);
-    hour = (int)(((unsigned long long)r.y * 24u) >> 32);
-    const int roll_days = S.max_roll_days > 0 ? (int)(((unsigned long long)r.z * (unsigned)S.max_roll_days) >> 32) : 0;
+    const Philox4 px = philox4x32_10(0u, (unsigned)env, (unsigned)episode, 0xD4A7u, (unsigned)S.seed,
+                                     (unsigned)(S.seed >> 32));
+    const int lo = rec_i32(r, R_DAY_LO), hi = rec_i32(r, R_DAY_HI);
+    day = lo + (int)(((unsigned long long)px.x * (unsigned)(hi - lo + 1)) >> 32);
+    hour = (int)(((unsigned long long)px.y * 24u) >> 32);
+    const int roll_days = S.max_roll_days > 0 ? (int)(((unsigned long long)px.z * (unsigned)S.max_roll_days) >> 32) : 0;
     // year-end fence: the reference reads table[cursor + 1 .. + 17] and raises IndexError at the end of the
     // year; keep the whole episode inside the table instead
     {
@@ -179,29 +182,38 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     o.have_past = c0 >= 16;
     build_obs_pool(sh.nc, sh.nt, o, sh.obs, lane);
   }
+  sh.rec[lane] = r;
+  __syncthreads();
   if (lane == 0) {
-    const int hq = hour * 4;
-    S.ci_min[env] = ci_min;
-    S.ci_den[env] = ci_den;
-    S.t_min[env] = t_min;
-    S.t_den[env] = t_den;
-    S.cursor[env] = c0;
-    S.t_rel[env] = 0;
-    S.day[env] = day;
-    S.hourq[env] = hq;
-    S.q_popped[env] = 0;
-    S.q_cum[env] = 0;
-    S.q_cumT[env] = 0u;
-    S.q_head[env] = 0;
-    S.last_delta[env] = -2;
-    S.consecutive[env] = 0;
-    S.scale[env] = 1;
-    S.bat_load[env] = 0.0;
-    S.episode[env] = episode;
-    S.fault[env] = fault;
-    for (int b = 0; b < SDC_CARRY_DIM; b++) S.carry[b * S.n_envs + env] = 0.0;
+    unsigned* o = sh.rec;
+    auto put64 = [&](int idx, double v) {
+      o[idx] = (unsigned)__double2loint(v);
+      o[idx + 1] = (unsigned)__double2hiint(v);
+    };
+    put64(R_CI_MIN, ci_min);
+    put64(R_CI_DEN, ci_den);
+    put64(R_T_MIN, t_min);
+    put64(R_T_DEN, t_den);
+    put64(R_BAT, 0.0);                 // battery_model.py:90-91
+    o[R_CURSOR] = (unsigned)c0;
+    o[R_TREL] = 0u;
+    o[R_DAY] = (unsigned)day;
+    o[R_HOURQ] = (unsigned)(hour * 4);
+    o[R_QPOPPED] = 0u;                 // carbon_ls.py:85
+    o[R_QCUM] = 0u;
+    o[R_QCUMT] = 0u;
+    o[R_QHEAD] = 0u;
+    o[R_QCUM_HM1] = 0u;
+    o[R_QCUMT_HM1] = 0u;
+    o[R_LAST_DELTA] = (unsigned)-2;    // dc_gym.py:114-116 (the set-point itself is kept)
+    o[R_CONSEC] = 0u;
+    o[R_SCALE] = 1u;
+    o[R_EPISODE] = (unsigned)episode;
+    o[R_FAULT] = fault;
     for (int b = 0; b < 3; b++) S.ep_return[b * S.n_envs + env] = 0.0;
   }
+  __syncthreads();
+  recp[lane] = sh.rec[lane];
   __syncthreads();
   if (obs) {
     obs[(size_t)env * SDC_OBS_OUT + lane] = obs_padded_at(sh.obs, lane);

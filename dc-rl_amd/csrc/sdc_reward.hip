@@ -123,7 +123,7 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev
       key[4 * k + 3] = v.w;
     }
   }
-  const int n = S.hist_len[env];             // already includes this step's energy (appended by the dynamics kernel)
+  const int n = S.hist_n[env];               // already includes this step's energy (appended by the dynamics kernel)
   const double energy = S.hand[env];         // energy - hist_ref, fp64
   const double norm_ci_next = S.hand[N + env];
   const double oldest_norm = S.hand[2 * N + env];

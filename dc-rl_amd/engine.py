@@ -16,11 +16,16 @@ from . import _lib as L
 _STATE_DTYPES = {
     "cursor": (np.int32, 1), "t_rel": (np.int32, 1), "day": (np.int32, 1), "hourq": (np.int32, 1),
     "q_popped": (np.int32, 1), "q_cum": (np.int32, 1), "q_cumT": (np.uint32, 1), "q_head": (np.int32, 1),
+    "q_cum_hm1": (np.int32, 1), "q_cumT_hm1": (np.uint32, 1),
     "last_delta": (np.int32, 1), "consecutive": (np.int32, 1), "scale": (np.int32, 1),
     "hist_len": (np.int32, 1), "hist_pos": (np.int32, 1), "episode": (np.int32, 1), "fault": (np.uint32, 1),
+    "loc_id": (np.int32, 1), "cfg_id": (np.int32, 1), "day_lo": (np.int32, 1), "day_hi": (np.int32, 1),
+    "hist_n": (np.int32, 1),
     "stpt": (np.float64, 1), "bat_load": (np.float64, 1), "ci_min": (np.float64, 1), "ci_den": (np.float64, 1),
     "t_min": (np.float64, 1), "t_den": (np.float64, 1), "hist_ref": (np.float64, 1),
 }
+# a full checkpoint: the raw records + every array the kernels own
+_CHECKPOINT = ["record", "hist", "hist_n", "t_win", "wb_win", "qtab", "ep_return", "q_guess"]
 
 
 def dc_params_struct(p: dict) -> L.SdcDcParams:
@@ -167,8 +172,8 @@ class SdcEngine:
             return np.zeros((N, self.lw), dtype=np.float64)
         if name == "qtab":
             return np.zeros((N, self.queue_stride, 2), dtype=np.uint32)
-        if name == "carry":
-            return np.zeros((8, N), dtype=np.float64)
+        if name == "record":
+            return np.zeros((N, 64), dtype=np.uint32)
         if name == "ep_return":
             return np.zeros((3, N), dtype=np.float64)
         if name == "q_guess":
@@ -187,8 +192,7 @@ class SdcEngine:
 
     def state_dict(self) -> dict:
         """Full env checkpoint (the reference never checkpoints env state)."""
-        names = list(_STATE_DTYPES) + ["hist", "t_win", "wb_win", "qtab", "carry", "ep_return", "q_guess"]
-        return {n: self.get_state(n) for n in names}
+        return {n: self.get_state(n) for n in _CHECKPOINT}
 
     def load_state_dict(self, sd: dict):
         for n, v in sd.items():
