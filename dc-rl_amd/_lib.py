@@ -75,7 +75,7 @@ class SdcResetOverride(C.Structure):
 
 
 EXPORTS = [
-    "sdc_last_error", "sdc_version", "sdc_create", "sdc_destroy", "sdc_weather_window_len", "sdc_set_tables",
+    "sdc_last_error", "sdc_version", "sdc_create", "sdc_destroy", "sdc_set_seed", "sdc_weather_window_len", "sdc_set_tables",
     "sdc_set_dc_params", "sdc_assign_envs", "sdc_reset", "sdc_step", "sdc_get_state", "sdc_set_state",
     "sdc_hist_stride", "sdc_queue_stride", "sdc_profile_enable", "sdc_profile_read",
 ]
@@ -115,6 +115,7 @@ def load():
     L.sdc_version.restype = C.c_int
     L.sdc_create.argtypes = [C.POINTER(SdcConfig), C.POINTER(vp)]
     L.sdc_destroy.argtypes = [vp]
+    L.sdc_set_seed.argtypes = [vp, C.c_uint64]
     L.sdc_weather_window_len.argtypes = [vp]
     L.sdc_hist_stride.argtypes = [vp]
     L.sdc_queue_stride.argtypes = [vp]

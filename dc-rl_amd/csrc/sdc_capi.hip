@@ -254,6 +254,13 @@ int sdc_destroy(sdc_handle* h) {
   return 0;
 }
 
+int sdc_set_seed(sdc_handle* h, uint64_t seed) {
+  if (!h) return fail_msg("sdc_set_seed: null handle");
+  h->cfg.seed = seed;
+  h->d.seed = seed;
+  return 0;
+}
+
 int sdc_weather_window_len(const sdc_handle* h) { return h ? h->d.lw : -1; }
 int sdc_hist_stride(const sdc_handle* h) { return h ? SDC_HIST_STRIDE : -1; }
 int sdc_queue_stride(const sdc_handle* h) { return h ? h->d.qstride : -1; }

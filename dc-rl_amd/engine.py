@@ -107,6 +107,9 @@ class SdcEngine:
         ip = C.POINTER(C.c_int32)
         L.check(self.lib.sdc_assign_envs(self._h, *[a.ctypes.data_as(ip) for a in arrs]))
 
+    def set_seed(self, seed: int):
+        L.check(self.lib.sdc_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
     # ------------------------------------------------------------------ run
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)

@@ -1,0 +1,305 @@
+"""The vector-env boundary HARL runners call (`ShareVecEnv`, harl/envs/env_wrappers.py:53-165), backed by one
+MI355X batch instead of one OS process per environment.
+
+`SustainDCVecEnv(env_args, n_envs, ...)` presents N coupled SustainDC environments:
+  reset() -> (obs [N,3,26] f32, share_obs [N,3,29] f32, available_actions [N,3,3])        (env_wrappers.py:275-280)
+  step(actions [N,3,1] | [N,3]) -> (obs, share_obs, rews [N,3,1], dones [N,3] bool, infos, available_actions)
+                                                                                          (env_wrappers.py:262-273)
+with the reference's auto-reset semantics (env_wrappers.py:176-190): an env whose episode ends is reset inside
+the same step call, the returned obs are the reset obs, and `infos[i][0]["original_obs" | "original_state" |
+"original_avail_actions"]` hold the pre-reset values.
+
+Outputs are NumPy arrays by default (what `ShareSubprocVecEnv` returns after `np.stack`); with
+`return_torch=True` they are device tensors (views of the engine's buffers, valid until the next call) so that a
+GPU policy never round-trips through the host.  `infos` is a lazy sequence: the N x 3 dicts of the reference are
+materialised only for the entries a caller touches; `info_sums()` gives the logger's per-step sums
+(harl/envs/sustaindc/sustaindc_logger.py:87-101) as one device reduction.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from collections.abc import Mapping, Sequence
+from typing import List, Optional, Union
+
+import numpy as np
+
+from . import _lib as L
+from . import dc_config, traces
+from .engine import SdcEngine
+from .make_envs_pyenv import make_bat_fwd_env, make_dc_pyeplus_env, make_ls_env
+from .spaces import Box, Discrete
+
+AGENTS = ["agent_ls", "agent_dc", "agent_bat"]
+OBS_DIMS = (26, 14, 13)
+
+# the 10 info keys the SustainDC logger sums every step (sustaindc_logger.py:87-101)
+LOGGER_KEYS = ["bat_total_energy_with_battery_KWh", "bat_CO2_footprint", "dc_water_usage",
+               "ls_unasigned_day_load_left", "ls_tasks_in_queue", "ls_tasks_dropped", "dc_ITE_total_power_kW",
+               "dc_CT_total_power_kW", "dc_Compressor_total_power_kW", "dc_HVAC_total_power_kW"]
+
+DEFAULT_ENV_ARGS = {  # EnvConfig.DEFAULT_CONFIG (sustaindc_env.py:38-80)
+    "agents": list(AGENTS), "location": "ny", "cintensity_file": "NYIS_NG_&_avgCI.csv",
+    "weather_file": "USA_NY_New.York-Kennedy.epw", "workload_file": "Alibaba_CPU_Data_Hourly_1.csv",
+    "datacenter_capacity_mw": 1, "timezone_shift": 0, "days_per_episode": 7, "max_bat_cap_Mw": 2,
+    "dc_config_file": "dc_config.json", "individual_reward_weight": 0.8, "flexible_load": 0.1,
+    "ls_reward": "default_ls_reward", "dc_reward": "default_dc_reward", "bat_reward": "default_bat_reward",
+    "evaluation": False, "actions_are_logits": False,
+}
+_SUPPORTED_REWARDS = {"ls_reward": "default_ls_reward", "dc_reward": "default_dc_reward", "bat_reward": "default_bat_reward"}
+
+
+class ShareVecEnv(ABC):
+    """Abstract vectorised multi-agent env (same surface as harl/envs/env_wrappers.py:53)."""
+
+    closed = False
+    viewer = None
+    metadata = {"render.modes": []}
+
+    def __init__(self, num_envs, observation_space, share_observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.share_observation_space = share_observation_space
+        self.action_space = action_space
+
+    @abstractmethod
+    def reset(self):
+        pass
+
+    @abstractmethod
+    def step_async(self, actions):
+        pass
+
+    @abstractmethod
+    def step_wait(self):
+        pass
+
+    def close_extras(self):
+        pass
+
+    def close(self):
+        if self.closed:
+            return
+        self.close_extras()
+        self.closed = True
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+class _InfoDict(Mapping):
+    """One agent's info dict of one env, read lazily from the step's info row."""
+
+    def __init__(self, owner: "LazyInfos", env: int, agent: int):
+        self._o, self._e, self._a = owner, env, agent
+
+    def _extra(self):
+        return self._o.extra.get((self._e, self._a), {})
+
+    def __getitem__(self, key):
+        ex = self._extra()
+        if key in ex:
+            return ex[key]
+        o = self._o
+        if key in L.INFO_IDX:
+            return float(o.rows()[self._e, L.INFO_IDX[key]])
+        if key == "ls_task_age_histogram":
+            j = L.INFO_IDX["ls_task_age_hist0"]
+            return np.array(o.rows()[self._e, j:j + 5], dtype=np.float64)
+        if key in o.const[self._e]:
+            return o.const[self._e][key]
+        if key == "ls_action":
+            return int(o.actions[self._e, 0])
+        if key == "bat_a_t":
+            return ("charge", "discharge", "idle")[int(o.rows()[self._e, L.INFO_IDX["bat_action"]])]
+        if key == "isterminal":
+            return bool(o.done[self._e])
+        raise KeyError(key)
+
+    def __iter__(self):
+        yield from L.INFO_COLS
+        yield "ls_task_age_histogram"
+        yield from self._o.const[self._e]
+        yield from ("ls_action", "bat_a_t", "isterminal")
+        yield from self._extra()
+
+    def __len__(self):
+        return sum(1 for _ in self)
+
+
+class LazyInfos(Sequence):
+    """`infos` of a step: tuple[N] of list[3] of dict in the reference; here views over one [N, K] array."""
+
+    def __init__(self, info_tensor, actions, done, const, extra):
+        self._t = info_tensor
+        self._rows = None
+        self.actions = actions
+        self.done = done
+        self.const = const
+        self.extra = extra
+
+    def rows(self):
+        if self._rows is None:
+            self._rows = self._t.detach().cpu().numpy() if hasattr(self._t, "detach") else np.asarray(self._t)
+        return self._rows
+
+    def __len__(self):
+        return len(self.done)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return [_InfoDict(self, i, a) for a in range(3)]
+
+
+def _merge_args(env_args: Optional[dict]) -> dict:
+    a = dict(DEFAULT_ENV_ARGS)
+    if env_args:
+        a.update(env_args)
+    for k, v in _SUPPORTED_REWARDS.items():
+        if a.get(k, v) != v:
+            raise NotImplementedError(f"{k}={a[k]!r}: only the default reward methods run on the device "
+                                      "(utils/reward_creator.py:48-130); alternates are listed as 'next' in DESIGN.md")
+    if list(a["agents"]) != AGENTS:
+        raise NotImplementedError("all three agents must be active (base do-nothing agents are not implemented)")
+    return a
+
+
+class SustainDCVecEnv(ShareVecEnv):
+    def __init__(self, env_args: Union[dict, List[dict], None] = None, n_envs: int = 1, seed: int = 0,
+                 months: Optional[Sequence[int]] = None, device: int = 0, return_torch: bool = False,
+                 auto_reset: bool = True, data_root: Optional[str] = None):
+        per_env = [_merge_args(a) for a in env_args] if isinstance(env_args, (list, tuple)) else [_merge_args(env_args)] * n_envs
+        if len(per_env) != n_envs:
+            raise ValueError("env_args list must have n_envs entries")
+        days = {a["days_per_episode"] for a in per_env}
+        if len(days) != 1:
+            raise ValueError("all envs of one batch must share days_per_episode")
+        self.n_agents = 3
+        self.agents = list(AGENTS)
+        self.return_torch = return_torch
+        self.episode_steps = int(days.pop()) * 96
+        if months is None:
+            months = [a.get("month", 0) if a.get("month") is not None else 0 for a in per_env]
+        self.months = [int(m) for m in months]
+        # unique trace sets and data-centre parameter sets
+        loc_keys, cfg_keys, loc_id, cfg_id = [], [], [], []
+        for a in per_env:
+            lk = (a["location"].lower(), a["workload_file"], int(a["timezone_shift"]))
+            ci_loc, _ = traces.obtain_paths(a["location"])
+            ck = (a["dc_config_file"], float(a["datacenter_capacity_mw"]), ci_loc)
+            if lk not in loc_keys:
+                loc_keys.append(lk)
+            if ck not in cfg_keys:
+                cfg_keys.append(ck)
+            loc_id.append(loc_keys.index(lk))
+            cfg_id.append(cfg_keys.index(ck))
+        self.tables = [traces.get_tables(lk[0], lk[1], lk[2], data_root=data_root) for lk in loc_keys]
+        self.data_source = self.tables[0]["source"]
+        # the same factory calls SustainDC.__init__ makes (sustaindc_env.py:148-160)
+        self.ls_env = make_ls_env(month=self.months[0], n_vars_ci=8, n_vars_energy=0, n_vars_battery=0, queue_max_len=1000)
+        self.dc_envs = [make_dc_pyeplus_env(month=self.months[0] + 1, location=ck[2], dc_config_file=ck[0],
+                                            datacenter_capacity_mw=ck[1], max_bat_cap_Mw=per_env[0]["max_bat_cap_Mw"],
+                                            use_ls_cpu_load=True, add_cpu_usage=False)[0] for ck in cfg_keys]
+        self.dc_env = self.dc_envs[0]
+        tot = self.dc_env.ranges["Facility Total Electricity Demand Rate(Whole Building)"]
+        self.bat_env = make_bat_fwd_env(month=self.months[0], max_bat_cap_Mwh=self.dc_env.ranges["max_battery_energy_Mwh"],
+                                        max_dc_pw_MW=tot[1] / 1e6, dcload_max=tot[1], dcload_min=tot[0], n_fwd_steps=8)
+        self.bat_env.dcload_max = self.dc_env.power_ub_kW / 4   # sustaindc_env.py:158-160
+        self.bat_env.dcload_min = self.dc_env.power_lb_kW / 4
+        self.engine = SdcEngine(n_envs, episode_steps=self.episode_steps, device=device, n_locations=len(loc_keys),
+                                n_dc_configs=len(cfg_keys), auto_reset=auto_reset, seed=seed, queue_max_len=1000)
+        for i, tb in enumerate(self.tables):
+            self.engine.set_tables(i, tb["W"], tb["C"], tb["T"], tb["WB"])
+        for i, e in enumerate(self.dc_envs):
+            self.engine.set_dc_params(i, e.sized)
+        init_day = np.array([traces.get_init_day(m) for m in self.months])
+        self.engine.assign(np.array(loc_id), np.array(cfg_id), np.maximum(0, init_day - 7), np.minimum(364, init_day + 7))
+        self._cfg_id = cfg_id
+        # per-env constant info entries (envs/dc_gym.py:224-227, envs/bat_env_fwd_view.py:118-121, carbon_ls.py:294-297)
+        self._const = []
+        for i in range(n_envs):
+            e = self.dc_envs[cfg_id[i]]
+            c = e.DC_Config
+            self._const.append({
+                "ls_queue_max_len": 1000, "ls_norm_load_left": 0, "ls_unasigned_day_load_left": 0, "ls_penalty_flag": 0,
+                "ls_enforced": 0, "dc_power_lb_kW": e.power_lb_kW, "dc_power_ub_kW": e.power_ub_kW,
+                "dc_CW_pump_power_kW": (c.CW_PRESSURE_DROP * c.CW_WATER_FLOW_RATE) / c.CW_PUMP_EFFICIENCY,
+                "dc_CT_pump_power_kW": (c.CT_PRESSURE_DROP * c.CT_WATER_FLOW_RATE) / c.CT_PUMP_EFFICIENCY,
+                "bat_max_bat_cap": e.sized["bat_capacity"], "bat_dcload_min": e.power_lb_kW / 4,
+                "bat_dcload_max": e.power_ub_kW / 4,
+            })
+        # HARL pads every agent to the widest space (harlsustaindc_env.py:25-26, :30-33)
+        obs_space = [Box(low=-2.0, high=2.0, shape=(L.OBS_PAD,), dtype=np.float32) for _ in AGENTS]
+        share_space = [Box(low=-2.0, high=2.0, shape=(L.SHARE_OBS_DIM,), dtype=np.float32) for _ in AGENTS]
+        act_space = [Discrete(3) for _ in AGENTS]
+        ShareVecEnv.__init__(self, n_envs, obs_space, share_space, act_space)
+        import torch
+        self._torch = torch
+        self._avail = torch.ones((n_envs, 3, 3), dtype=torch.float32, device=self.engine.device)
+        self._avail_np = np.ones((n_envs, 3, 3), dtype=np.float32)
+        self._actions = None
+        self._need_reset = True
+
+    # ------------------------------------------------------------------ helpers
+    def _out(self, t):
+        return t if self.return_torch else t.cpu().numpy()
+
+    def _share3(self, share):
+        # the same 29-vector for the three agents (harlsustaindc_env.py:85 `repeat`)
+        return share.unsqueeze(1).expand(-1, 3, -1)
+
+    def seed(self, seed: int):
+        self.engine.set_seed(seed)
+
+    # ------------------------------------------------------------------ ShareVecEnv API
+    def reset(self):
+        obs, share = self.engine.reset()
+        self._need_reset = False
+        return self._out(obs), self._out(self._share3(share)), (self._avail if self.return_torch else self._avail_np)
+
+    def step_async(self, actions):
+        t = self._torch
+        if not isinstance(actions, t.Tensor):
+            actions = t.as_tensor(np.asarray(actions))
+        a = actions.reshape(self.num_envs, 3).to(device=self.engine.device, dtype=t.int32).contiguous()
+        self._actions = a
+
+    def step_wait(self):
+        if self._need_reset:
+            raise RuntimeError("call reset() before step()")
+        a = self._actions
+        self._actions = None
+        obs, share, rew, done, info = self.engine.step(a)
+        done_h = done.cpu().numpy().astype(bool)
+        extra = {}
+        if done_h.any():
+            fo = self.engine.final_obs.cpu().numpy()
+            for i in np.nonzero(done_h)[0]:
+                raw = np.concatenate([fo[i, 0, :26], fo[i, 1, 11:12], fo[i, 1, 13:14], fo[i, 2, 12:13]])
+                extra[(int(i), 0)] = {"original_obs": fo[i].copy(),
+                                      "original_state": np.repeat(raw[None, :], 3, axis=0),
+                                      "original_avail_actions": np.ones((3, 3), dtype=np.float32)}
+        infos = LazyInfos(info, a, done_h, self._const, extra)
+        dones3 = done.bool().unsqueeze(1).expand(-1, 3)
+        if self.return_torch:
+            return obs, self._share3(share), rew.unsqueeze(-1), dones3, infos, self._avail
+        return (obs.cpu().numpy(), self._share3(share).cpu().numpy(), rew.cpu().numpy()[..., None],
+                np.repeat(done_h[:, None], 3, axis=1), infos, self._avail_np)
+
+    def info_sums(self, keys: Sequence[str] = LOGGER_KEYS):
+        """Sum over envs of the given info columns for the last step, computed on the device."""
+        idx = [L.INFO_IDX[k] for k in keys if k in L.INFO_IDX]
+        s = self.engine.info[:, idx].sum(0).cpu().numpy()
+        out = {k: 0.0 for k in keys}
+        out.update({k: float(v) for k, v in zip([k for k in keys if k in L.INFO_IDX], s)})
+        return out
+
+    def close_extras(self):
+        self.engine.close()

@@ -144,6 +144,9 @@ int sdc_version(void);
 int sdc_create(const sdc_config* cfg, sdc_handle** out);
 int sdc_destroy(sdc_handle* h);
 
+/* replaces: SustainDC.seed (sustaindc_env.py:241-251): re-key the counter-based RNG of device-side resets */
+int sdc_set_seed(sdc_handle* h, uint64_t seed);
+
 /* episode_steps + 18: samples of per-env weather the step can touch */
 int sdc_weather_window_len(const sdc_handle* h);
 

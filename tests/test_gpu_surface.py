@@ -1,0 +1,103 @@
+"""The drop-in surface on the GPU: SustainDC (single env, dict API), SustainDCVecEnv (ShareVecEnv API with the
+reference's auto-reset semantics), make_train_env."""
+import numpy as np
+import pytest
+
+from dc_rl_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+ENV_ARGS = {"location": "ny", "month": 6, "days_per_episode": 1, "partial_obs": True,
+            "nonoverlapping_shared_obs_space": True}
+
+
+def test_single_env_dict_api():
+    from dc_rl_amd import SustainDC
+    env = SustainDC(dict(ENV_ARGS), seed=3)
+    assert env.agents == ["agent_ls", "agent_dc", "agent_bat"]
+    assert [s.shape for s in env.observation_space] == [(26,), (14,), (13,)]
+    assert [s.n for s in env.action_space] == [3, 3, 3]
+    obs = env.reset()
+    assert set(obs) == set(env.agents)
+    assert obs["agent_ls"].shape == (26,) and obs["agent_dc"].shape == (14,) and obs["agent_bat"].shape == (13,)
+    assert obs["agent_ls"].dtype == np.float32
+    np.testing.assert_array_equal(obs["agent_ls"][:10], obs["agent_dc"][:10])   # shared time / CI features
+    rng = np.random.default_rng(0)
+    for t in range(96):
+        a = {k: int(rng.integers(0, 3)) for k in env.agents}
+        o, r, term, trunc, info = env.step(a)
+        assert set(o) == set(env.agents) and set(r) == set(env.agents)
+        assert term["__all__"] is False and trunc["__all__"] == (t == 95)
+        assert all(trunc[k] == (t == 95) for k in env.agents)
+        assert r["agent_dc"] == r["agent_bat"]
+        c = info["__common__"]
+        assert c["bat_action"] == a["agent_bat"] and c["ls_action"] == a["agent_ls"]
+        assert 0.0 <= c["ls_shifted_workload"] <= 1.0 and c["dc_total_power_kW"] > 0
+        assert c["bat_total_energy_with_battery_KWh"] >= 0 and c["isterminal"] == (t == 95)
+        assert info["agent_ls"]["dc_crac_setpoint"] == c["dc_crac_setpoint"]
+    with pytest.raises(Exception):
+        env.step(a)            # episode over: the single-env surface requires reset(), like the reference
+    env.reset()
+    env.step(a)
+    env.close()
+
+
+def test_vec_env_shapes_and_auto_reset():
+    from dc_rl_amd import make_train_env
+    N = 24
+    args = {k: v for k, v in ENV_ARGS.items() if k != "month"}
+    envs = make_train_env("sustaindc", seed=5, n_threads=N, env_args=args)
+    assert envs.num_envs == N and envs.n_agents == 3
+    assert len(envs.observation_space) == 3 and envs.observation_space[0].shape == (26,)
+    assert envs.share_observation_space[0].shape == (29,) and envs.action_space[0].n == 3
+    assert envs.months[:14] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 5, 6]
+    obs, share, avail = envs.reset()
+    assert obs.shape == (N, 3, 26) and share.shape == (N, 3, 29) and avail.shape == (N, 3, 3)
+    assert obs.dtype == np.float32 and (avail == 1).all()
+    assert (obs[:, 1, 14:] == 0).all() and (obs[:, 2, 13:] == 0).all()     # zero padding
+    np.testing.assert_array_equal(share[:, 0], share[:, 2])
+    np.testing.assert_array_equal(share[:, 0, :26], obs[:, 0])
+    np.testing.assert_array_equal(share[:, 0, 26], obs[:, 1, 11])
+    np.testing.assert_array_equal(share[:, 0, 27], obs[:, 1, 13])
+    np.testing.assert_array_equal(share[:, 0, 28], obs[:, 2, 12])
+    day = envs.engine.get_state("day")
+    from dc_rl_amd import traces
+    for i, m in enumerate(envs.months):
+        d0 = traces.get_init_day(m)
+        assert max(0, d0 - 7) <= day[i] <= min(364, d0 + 7)
+    rng = np.random.default_rng(1)
+    sums = {k: 0.0 for k in ("bat_CO2_footprint", "dc_water_usage")}
+    for t in range(96):
+        acts = rng.integers(0, 3, size=(N, 3, 1))
+        obs, share, rew, dones, infos, avail = envs.step(acts)
+        assert rew.shape == (N, 3, 1) and dones.shape == (N, 3) and dones.dtype == bool
+        assert len(infos) == N and len(infos[0]) == 3
+        s = envs.info_sums()
+        manual = sum(infos[i][0]["bat_CO2_footprint"] for i in range(N))
+        assert s["bat_CO2_footprint"] == pytest.approx(manual, rel=1e-5)
+        assert s["ls_unasigned_day_load_left"] == 0.0
+        if t < 95:
+            assert not dones.any()
+    assert dones.all()
+    # auto-reset inside the same call: returned obs are reset obs, originals are in infos[i][0]
+    i0 = infos[0][0]
+    assert i0["original_obs"].shape == (3, 26) and i0["original_state"].shape == (3, 29)
+    assert i0["original_avail_actions"].shape == (3, 3)
+    assert not np.array_equal(i0["original_obs"], obs[0])
+    assert "original_obs" not in infos[0][1]
+    assert (envs.engine.get_state("t_rel") == 0).all()
+    np.testing.assert_array_equal(obs[:, 0, 10:13], 0)   # queue empty after reset: age / queue features are 0
+    obs, *_ = envs.step(rng.integers(0, 3, size=(N, 3)))  # [N,3] actions accepted too; no explicit reset needed
+    envs.close()
+
+
+def test_vec_env_torch_outputs_stay_on_device():
+    import torch
+    from dc_rl_amd import SustainDCVecEnv
+    envs = SustainDCVecEnv(dict(ENV_ARGS), n_envs=8, seed=1, months=[6] * 8, return_torch=True)
+    obs, share, avail = envs.reset()
+    assert obs.is_cuda and share.is_cuda and share.shape == (8, 3, 29)
+    a = torch.randint(0, 3, (8, 3, 1), device="cuda")
+    obs, share, rew, dones, infos, avail = envs.step(a)
+    assert rew.is_cuda and rew.shape == (8, 3, 1) and dones.dtype == torch.bool and dones.shape == (8, 3)
+    envs.close()

@@ -1,0 +1,110 @@
+"""CPU tests of the host-side drop-in surface: factories, config defaults, month / seed rules, sharding,
+lazy infos.  No GPU, no compute calls into the HIP library."""
+import os
+
+import numpy as np
+import pytest
+
+from dc_rl_amd import make_envs_pyenv as M
+from dc_rl_amd import traces
+from dc_rl_amd.distributed import ReturnStats, shard_range
+from dc_rl_amd.envs_tools import months_for_ranks
+from dc_rl_amd.vec_env import DEFAULT_ENV_ARGS, LOGGER_KEYS, LazyInfos, _merge_args
+from dc_rl_amd import _lib as L
+from tests.conftest import GOLDEN_DIR
+
+
+def test_factories_expose_what_sustaindc_init_reads():
+    d = np.load(os.path.join(GOLDEN_DIR, "ny_m6_random.npz"))
+    ls = M.make_ls_env(month=6, test_mode=False, n_vars_ci=8, n_vars_energy=0, n_vars_battery=0, queue_max_len=1000)
+    assert ls.observation_space.shape == (26,) and ls.action_space.n == 3 and ls.queue_max_len == 1000
+    assert ls.flexible_workload_ratio == 0.2
+    dc, max_pw = M.make_dc_pyeplus_env(month=7, location="NY", max_bat_cap_Mw=2, use_ls_cpu_load=True,
+                                       datacenter_capacity_mw=1, dc_config_file="dc_config.json", add_cpu_usage=False)
+    assert dc.observation_space.shape == (14,) and dc.action_space.n == 3
+    assert dc.action_mapping == {0: -1, 1: 0, 2: 1} and dc.min_temp == 15.0 and dc.max_temp == 21.6
+    np.testing.assert_allclose(dc.power_ub_kW, float(d["static_power_ub_kW"]), rtol=1e-13)
+    np.testing.assert_allclose(dc.power_lb_kW, float(d["static_power_lb_kW"]), rtol=1e-13)
+    np.testing.assert_allclose(dc.ranges["max_battery_energy_Mwh"], float(d["static_bat_capacity"]), rtol=1e-13)
+    tot = dc.ranges["Facility Total Electricity Demand Rate(Whole Building)"]
+    np.testing.assert_allclose(tot, d["static_range_total"], rtol=1e-13)
+    assert max_pw == pytest.approx(dc.ranges["Facility Total HVAC Electricity Demand Rate(Whole Building)"][1]
+                                   + dc.ranges["Facility Total Building Electricity Demand Rate(Whole Building)"][1])
+    bat = M.make_bat_fwd_env(month=6, max_bat_cap_Mwh=dc.ranges["max_battery_energy_Mwh"], max_dc_pw_MW=tot[1] / 1e6,
+                             dcload_max=tot[1], dcload_min=tot[0], n_fwd_steps=8)
+    assert bat.observation_space.shape == (13,) and bat.action_space.n == 3
+    assert bat._action_to_direction == {0: "charge", 1: "discharge", 2: "idle"}
+
+
+def test_env_config_defaults_match_reference_keys():
+    for k in ("agents", "location", "workload_file", "datacenter_capacity_mw", "timezone_shift", "days_per_episode",
+              "max_bat_cap_Mw", "dc_config_file", "individual_reward_weight", "flexible_load", "ls_reward", "dc_reward",
+              "bat_reward", "evaluation", "actions_are_logits"):
+        assert k in DEFAULT_ENV_ARGS
+    assert DEFAULT_ENV_ARGS["days_per_episode"] == 7 and DEFAULT_ENV_ARGS["location"] == "ny"
+    a = _merge_args({"location": "ca", "days_per_episode": 30, "month": 6, "partial_obs": True,
+                     "nonoverlapping_shared_obs_space": True})
+    assert a["location"] == "ca" and a["dc_config_file"] == "dc_config.json"
+    with pytest.raises(NotImplementedError):
+        _merge_args({"ls_reward": "tou_reward"})
+    with pytest.raises(NotImplementedError):
+        _merge_args({"agents": ["agent_ls", "agent_dc"]})
+
+
+def test_month_rule_of_make_train_env():
+    # harl/utils/envs_tools.py:56-62
+    assert months_for_ranks(14, {}) == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12 % 3 + 5, 13 % 3 + 5]
+    assert months_for_ranks(4, {"month": 6}) == [6, 6, 6, 6]
+    assert months_for_ranks(3, {}, rank_offset=11) == [11, 5, 6]
+    assert [traces.get_init_day(m) for m in range(12)] == [0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334]
+
+
+def test_location_mapping_and_errors():
+    assert traces.obtain_paths("ny") == ["NY", "USA_NY_New.York-LaGuardia.epw"]
+    assert traces.obtain_paths("CA")[0] == "CA" and traces.obtain_paths("wa")[0] == "WA"
+    with pytest.raises(ValueError):
+        traces.obtain_paths("zz")
+    assert traces.max_ambient_for_sizing("NY") == 30.0 and traces.max_ambient_for_sizing("AZ") == 50.0
+    assert traces.max_ambient_for_sizing("WA") == 20.0 and traces.max_ambient_for_sizing("CA") == 50.0
+
+
+@pytest.mark.parametrize("n,world", [(4096, 1), (32768, 8), (10, 4), (7, 8), (0, 2)])
+def test_shard_range_partitions_the_env_index_space(n, world):
+    rs = [shard_range(n, r, world) for r in range(world)]
+    assert rs[0][0] == 0 and rs[-1][1] == n
+    for (a, b), (c, d) in zip(rs, rs[1:]):
+        assert b == c
+    sizes = [b - a for a, b in rs]
+    assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(n, world, world)
+
+
+def test_return_stats_accumulate():
+    st = ReturnStats.zeros()
+    r = np.array([[1.0, 2.0, 3.0], [3.0, 2.0, 1.0]])
+    st.add_episode_returns(r)
+    mean, std, n = st.all_reduce().mean_std()
+    assert n == 2
+    np.testing.assert_allclose(mean, [2, 2, 2])
+    np.testing.assert_allclose(std, [1, 0, 1])
+
+
+def test_lazy_infos_views():
+    N = 3
+    rows = np.zeros((N, L.INFO_DIM), np.float32)
+    rows[:, L.INFO_IDX["bat_total_energy_with_battery_KWh"]] = [300, 310, 320]
+    rows[:, L.INFO_IDX["bat_action"]] = [0, 1, 2]
+    rows[1, L.INFO_IDX["ls_task_age_hist0"]:L.INFO_IDX["ls_task_age_hist0"] + 5] = [.5, .25, .25, 0, 1]
+    const = [{"ls_queue_max_len": 1000, "ls_unasigned_day_load_left": 0}] * N
+    extra = {(2, 0): {"original_obs": np.ones((3, 26))}}
+    infos = LazyInfos(rows, np.array([[0, 1, 2]] * N), np.array([False, False, True]), const, extra)
+    assert len(infos) == N and len(infos[0]) == 3
+    assert infos[1][0]["bat_total_energy_with_battery_KWh"] == 310.0
+    assert infos[1][2]["bat_a_t"] == "discharge" and infos[0][0]["ls_action"] == 0
+    np.testing.assert_array_equal(infos[1][0]["ls_task_age_histogram"], [.5, .25, .25, 0, 1])
+    assert "original_obs" in infos[2][0] and "original_obs" not in infos[2][1] and "original_obs" not in infos[0][0]
+    for k in LOGGER_KEYS:
+        assert k in infos[0][0], k
+    with pytest.raises(KeyError):
+        infos[0][0]["nope"]
