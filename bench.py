@@ -195,6 +195,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     faults = int((eng.info[:, 37] != 0).sum().item())
+    fallbacks = int((eng.info[:, 39] != 0).sum().item())
 
     if rank == 0:
         total_envs = N * world
@@ -224,7 +225,8 @@ def main():
                        if world == 1 else f"BASELINE configs[4]: {total_envs} envs sharded {world}xMI355X (4096/GPU)",
                        "envs_per_gpu": N, "episode_steps": args.episode_steps, "history_len": hlen,
                        "history_fill_steps": fill, "auto_reset": True, "actions": "uniform {0,1,2}, device-resident",
-                       "parallelism": f"env-shard x{world}", "faults": faults},
+                       "parallelism": f"env-shard x{world}", "faults": faults,
+                       "order_stat_fallbacks_last_step": fallbacks},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": "sdc_reward_kernel", "kernel_avg_us": round(k_rew * 1e6, 2),

@@ -5,6 +5,7 @@
 // point fails with an error code when HIP reports one.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -43,8 +44,9 @@ struct Field {
   const char* name;
   void** ptr;      // plain per-env array (ptr != nullptr) ...
   size_t elem;     // ... of `elem` bytes per env,
-  int rec_idx;     // or a field of the 256-byte state record: first dword and
-  int rec_dwords;  // width in dwords
+  int rec_idx;     // or a field of a strided per-env record: first dword,
+  int rec_dwords;  // width in dwords,
+  int in_hdr = 0;  // 0: the 256-byte state record, 1: the 64-byte hand-off header
 };
 
 }  // namespace
@@ -95,15 +97,19 @@ void sync_mirror(sdc_handle* h) {
   }
 }
 
-// one field of every env's 256-byte record <-> a dense host array
-int rec_put(sdc_handle* h, int idx, int dwords, const void* host) {
-  HIP_TRY(hipMemcpy2D(h->d.rec + idx, sizeof(unsigned) * SDC_REC_DWORDS, host, sizeof(unsigned) * dwords,
-                      sizeof(unsigned) * dwords, (size_t)h->cfg.n_envs, hipMemcpyHostToDevice));
+// one field of every env's record (256-byte state record, or 64-byte hand-off header) <-> a dense host array
+int rec_put(sdc_handle* h, int idx, int dwords, const void* host, int in_hdr = 0) {
+  unsigned* base = in_hdr ? h->d.hdr : h->d.rec;
+  const size_t pitch = sizeof(unsigned) * (in_hdr ? SDC_HDR_DWORDS : SDC_REC_DWORDS);
+  HIP_TRY(hipMemcpy2D(base + idx, pitch, host, sizeof(unsigned) * dwords, sizeof(unsigned) * dwords,
+                      (size_t)h->cfg.n_envs, hipMemcpyHostToDevice));
   return 0;
 }
-int rec_get(sdc_handle* h, int idx, int dwords, void* host) {
-  HIP_TRY(hipMemcpy2D(host, sizeof(unsigned) * dwords, h->d.rec + idx, sizeof(unsigned) * SDC_REC_DWORDS,
-                      sizeof(unsigned) * dwords, (size_t)h->cfg.n_envs, hipMemcpyDeviceToHost));
+int rec_get(sdc_handle* h, int idx, int dwords, void* host, int in_hdr = 0) {
+  const unsigned* base = in_hdr ? h->d.hdr : h->d.rec;
+  const size_t pitch = sizeof(unsigned) * (in_hdr ? SDC_HDR_DWORDS : SDC_REC_DWORDS);
+  HIP_TRY(hipMemcpy2D(host, sizeof(unsigned) * dwords, base + idx, pitch, sizeof(unsigned) * dwords,
+                      (size_t)h->cfg.n_envs, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -187,10 +193,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   }
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
   (void)hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE);  // every slot empty
-  A(d.hand, (size_t)4 * N);
-  A(d.hist_n, N);
-  A(d.q_guess, (size_t)2 * N);
-  A(d.ep_return, (size_t)3 * N);
+  A(d.hdr, (size_t)N * SDC_HDR_DWORDS);
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
@@ -226,8 +229,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
       {"hist_ref", nullptr, 8, R_HIST_REF, 2},
       {"record", (void**)&d.rec, 4 * SDC_REC_DWORDS, 0, 0},
       {"hist", (void**)&d.hist, sizeof(unsigned) * SDC_HIST_STRIDE, 0, 0},
-      {"hist_n", (void**)&d.hist_n, 4, 0, 0},
-      {"ep_return", (void**)&d.ep_return, 8 * 3, 0, 0}, {"q_guess", (void**)&d.q_guess, 4 * 2, 0, 0},
+      {"hist_n", nullptr, 4, H_N, 1, 1}, {"q_guess", nullptr, 8, H_G1, 2, 1}, {"ep_return", nullptr, 24, H_RET, 6, 1},
+      {"header", (void**)&d.hdr, 4 * SDC_HDR_DWORDS, 0, 0},
       {"t_win", (void**)&d.t_win, sizeof(double) * (size_t)d.lw, 0, 0},
       {"wb_win", (void**)&d.wb_win, sizeof(double) * (size_t)d.lw, 0, 0},
       {"qtab", (void**)&d.qtab, sizeof(uint2) * (size_t)d.qstride, 0, 0},
@@ -468,7 +471,7 @@ int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes
   if (bytes != need) return fail_msg(std::string("sdc_get_state: size mismatch for ") + field);
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
-  if (!f->ptr) return rec_get(h, f->rec_idx, f->rec_dwords, host_buf);
+  if (!f->ptr) return rec_get(h, f->rec_idx, f->rec_dwords, host_buf, f->in_hdr);
   HIP_TRY(hipMemcpy(host_buf, *f->ptr, need, hipMemcpyDeviceToHost));
   if (std::strcmp(field, "hist") == 0) {  // device keys -> fp32 offsets (empty slot -> NaN)
     unsigned* u = static_cast<unsigned*>(host_buf);
@@ -486,9 +489,7 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   if (!f->ptr) {
-    if (rec_put(h, f->rec_idx, f->rec_dwords, host_buf)) return -1;
-    if (std::strcmp(field, "hist_len") == 0)   // the reward kernel's copy of the length
-      HIP_TRY(hipMemcpy(h->d.hist_n, host_buf, need, hipMemcpyHostToDevice));
+    if (rec_put(h, f->rec_idx, f->rec_dwords, host_buf, f->in_hdr)) return -1;
   } else if (std::strcmp(field, "hist") == 0) {  // fp32 offsets -> device keys (NaN -> empty slot)
     std::vector<unsigned> k(need / 4);
     const unsigned* u = static_cast<const unsigned*>(host_buf);

@@ -67,6 +67,20 @@ enum SdcRec {
   SDC_REC_DWORDS = 64
 };
 
+// 64-byte per-env hand-off header: written by the dynamics kernel (N, OVERDUE, EOFF, NORM_CI, OLDEST) and by the
+// reward kernel (G1, G3, RET); every wavefront of the reward workgroup loads it with lanes 0..15.
+enum SdcHdr {
+  H_N = 0,        // history length including this step's value
+  H_G1,           // fp32 keys of last step's order statistics at floor((n-1)/4) and floor(3(n-1)/4)
+  H_G3,
+  H_OVERDUE,      // ls_overdue_penalty (int)
+  H_EOFF = 4,     // f64: bat_total_energy_with_battery_KWh - hist_ref
+  H_NORM_CI = 6,  // f64: norm_CI = NC[i'+1]
+  H_OLDEST = 8,   // f64: ls_oldest_task_age
+  H_RET = 10,     // 3 x f64: running return of the current episode (cleared by reset)
+  SDC_HDR_DWORDS = 16
+};
+
 struct SdcDev {
   int n_envs, episode_steps, hist_cap, queue_max, table_len, lw, qstride, max_roll_days;
   unsigned long long seed;
@@ -85,11 +99,7 @@ struct SdcDev {
   double* wb_win;    // [N][lw] wet bulb likewise
   double* walk_tmp;  // [N][max(SDC_NORM_WINDOW, lw)] scratch of the device-side reset
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
-  // dynamics -> reward kernel hand-off and reward-kernel-owned state (struct of arrays: one lane reads them)
-  double* hand;      // [4][N] energy - hist_ref, norm_CI next, oldest task age, overdue count
-  int* hist_n;       // [N] history length including this step's value
-  unsigned* q_guess; // [2][N] fp32 keys of last step's order statistics at floor((n-1)/4), floor(3(n-1)/4)
-  double* ep_return; // [3][N] running return of the current episode (cleared by reset)
+  unsigned* hdr;     // [N][SDC_HDR_DWORDS] dynamics -> reward kernel hand-off + reward-kernel state (see SdcHdr)
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
 };
 

@@ -15,7 +15,7 @@
 //     butterfly reductions; lane 0 assembles the info block and the new state record in LDS; all lanes store
 //     obs / share_obs / info / record coalesced.
 // The energy value and the reward terms that need the history normaliser are handed to sdc_reward_kernel
-// (sdc_reward.hip) through a 32-byte per-env record; the energy is appended to the history ring here.
+// (sdc_reward.hip) through a 64-byte per-env header; the energy is appended to the history ring here.
 //
 // Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
 #include "sdc_device.hpp"
@@ -69,7 +69,6 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_params& P, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
                                               unsigned fault, DynShared& sh) {
-  const int N = S.n_envs;
   const int i = rec_i32(r, R_CURSOR);
   const int rel = rec_i32(r, R_TREL);
   const int day = rec_i32(r, R_DAY);
@@ -384,11 +383,12 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     }
     S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = sdc_f32_key(__float_as_uint((float)e_off));
     // ---- hand-off to the reward kernel ------------------------------------------------------------------------
-    S.hand[env] = e_off;                     // bat_total_energy_with_battery_KWh - hist_ref
-    S.hand[N + env] = nc[17];                // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
-    S.hand[2 * N + env] = oldest_norm;       // ls_oldest_task_age
-    S.hand[3 * N + env] = (double)overdue;   // ls_overdue_penalty
-    S.hist_n[env] = hl;
+    unsigned* hw = S.hdr + (size_t)env * SDC_HDR_DWORDS;
+    hw[H_N] = (unsigned)hl;
+    hw[H_OVERDUE] = (unsigned)overdue;                               // ls_overdue_penalty
+    reinterpret_cast<double*>(hw + H_EOFF)[0] = e_off;               // bat_total_energy_with_battery_KWh - hist_ref
+    reinterpret_cast<double*>(hw + H_NORM_CI)[0] = nc[17];           // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
+    reinterpret_cast<double*>(hw + H_OLDEST)[0] = oldest_norm;       // ls_oldest_task_age
     S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
 
     // ---- new state record ------------------------------------------------------------------------------------

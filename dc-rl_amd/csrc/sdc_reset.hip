@@ -210,7 +210,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     o[R_SCALE] = 1u;
     o[R_EPISODE] = (unsigned)episode;
     o[R_FAULT] = fault;
-    for (int b = 0; b < 3; b++) S.ep_return[b * S.n_envs + env] = 0.0;
+    for (int b = 0; b < 3; b++) reinterpret_cast<double*>(S.hdr + (size_t)env * SDC_HDR_DWORDS + H_RET)[b] = 0.0;
   }
   __syncthreads();
   recp[lane] = sh.rec[lane];

@@ -25,7 +25,7 @@ _STATE_DTYPES = {
     "t_min": (np.float64, 1), "t_den": (np.float64, 1), "hist_ref": (np.float64, 1),
 }
 # a full checkpoint: the raw records + every array the kernels own
-_CHECKPOINT = ["record", "hist", "hist_n", "t_win", "wb_win", "qtab", "ep_return", "q_guess"]
+_CHECKPOINT = ["record", "header", "hist", "t_win", "wb_win", "qtab"]
 
 
 def dc_params_struct(p: dict) -> L.SdcDcParams:
@@ -178,9 +178,11 @@ class SdcEngine:
         if name == "record":
             return np.zeros((N, 64), dtype=np.uint32)
         if name == "ep_return":
-            return np.zeros((3, N), dtype=np.float64)
+            return np.zeros((N, 3), dtype=np.float64)
         if name == "q_guess":
-            return np.zeros((2, N), dtype=np.uint32)
+            return np.zeros((N, 2), dtype=np.uint32)
+        if name == "header":
+            return np.zeros((N, 16), dtype=np.uint32)
         raise KeyError(name)
 
     def get_state(self, name: str) -> np.ndarray:

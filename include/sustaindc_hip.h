@@ -182,7 +182,8 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
  * int32[N]:  cursor t_rel day hourq q_popped q_cum q_cumT q_head q_cum_hm1 q_cumT_hm1 last_delta consecutive
  *            scale hist_len hist_pos episode fault loc_id cfg_id day_lo day_hi hist_n
  * double[N]: stpt bat_load ci_min ci_den t_min t_den hist_ref
- * record (uint32[N][64], the raw 256-byte state records);  ep_return (double[3][N]);  q_guess (uint32[2][N]);
+ * record (uint32[N][64], the raw 256-byte state records);  header (uint32[N][16], the hand-off headers);
+ * ep_return (double[N][3]);  q_guess (uint32[N][2]);
  * hist (float[N][hist_stride], energy minus hist_ref, NaN = empty slot: every slot >= hist_len must be NaN);
  * t_win wb_win (double[N][weather_window_len]);  qtab (uint32[N][queue_stride][2]). */
 int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes);
