@@ -195,7 +195,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     faults = int((eng.info[:, 37] != 0).sum().item())
-    fallbacks = int((eng.info[:, 39] != 0).sum().item())
+    fallbacks = [int((eng.info[:, 39] == v).sum().item()) for v in (1, 2)]
 
     if rank == 0:
         total_envs = N * world
@@ -226,7 +226,7 @@ def main():
                        "envs_per_gpu": N, "episode_steps": args.episode_steps, "history_len": hlen,
                        "history_fill_steps": fill, "auto_reset": True, "actions": "uniform {0,1,2}, device-resident",
                        "parallelism": f"env-shard x{world}", "faults": faults,
-                       "order_stat_fallbacks_last_step": fallbacks},
+                       "order_stat_paths_last_step": {"rebuild_sweep": fallbacks[0], "bisection": fallbacks[1]}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": "sdc_reward_kernel", "kernel_avg_us": round(k_rew * 1e6, 2),

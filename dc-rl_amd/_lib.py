@@ -45,7 +45,7 @@ class SdcConfig(C.Structure):
         ("n_envs", C.c_int32), ("device", C.c_int32), ("episode_steps", C.c_int32), ("hist_cap", C.c_int32),
         ("queue_max_len", C.c_int32), ("n_locations", C.c_int32), ("n_dc_configs", C.c_int32),
         ("auto_reset", C.c_int32), ("seed", C.c_uint64), ("weather_noise_std", C.c_double),
-        ("weather_noise_weight", C.c_double), ("max_roll_days", C.c_int32), ("reserved", C.c_int32),
+        ("weather_noise_weight", C.c_double), ("max_roll_days", C.c_int32), ("debug_flags", C.c_int32),
     ]
 
 

@@ -113,6 +113,13 @@ int rec_get(sdc_handle* h, int idx, int dwords, void* host, int in_hdr = 0) {
   return 0;
 }
 
+// the reward kernel's order-statistic trackers describe the ring contents: drop them when the ring is injected
+int invalidate_trackers(sdc_handle* h) {
+  std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
+  if (rec_put(h, H_Q1 + T_G, 1, z.data(), 1) || rec_put(h, H_Q3 + T_G, 1, z.data(), 1)) return -1;
+  return 0;
+}
+
 void recompute_steps_to_terminal(sdc_handle* h) {
   sync_mirror(h);
   int m = 1 << 30;
@@ -163,6 +170,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   d.lw = cfg->episode_steps + 18;
   d.qstride = (cfg->episode_steps + 63) / 64 * 64;
   d.max_roll_days = cfg->max_roll_days;
+  d.debug_flags = cfg->debug_flags;
   d.seed = cfg->seed;
   d.noise_std = cfg->weather_noise_std;
   d.noise_weight = cfg->weather_noise_weight;
@@ -229,7 +237,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
       {"hist_ref", nullptr, 8, R_HIST_REF, 2},
       {"record", (void**)&d.rec, 4 * SDC_REC_DWORDS, 0, 0},
       {"hist", (void**)&d.hist, sizeof(unsigned) * SDC_HIST_STRIDE, 0, 0},
-      {"hist_n", nullptr, 4, H_N, 1, 1}, {"q_guess", nullptr, 8, H_G1, 2, 1}, {"ep_return", nullptr, 24, H_RET, 6, 1},
+      {"hist_n", nullptr, 4, H_N, 1, 1}, {"ep_return", nullptr, 24, H_RET, 6, 1},
+      {"order_stat_sticky", nullptr, 4, H_STICKY, 1, 1},
       {"header", (void**)&d.hdr, 4 * SDC_HDR_DWORDS, 0, 0},
       {"t_win", (void**)&d.t_win, sizeof(double) * (size_t)d.lw, 0, 0},
       {"wb_win", (void**)&d.wb_win, sizeof(double) * (size_t)d.lw, 0, 0},
@@ -490,7 +499,12 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
   HIP_TRY(hipDeviceSynchronize());
   if (!f->ptr) {
     if (rec_put(h, f->rec_idx, f->rec_dwords, host_buf, f->in_hdr)) return -1;
+    if (std::strcmp(field, "hist_len") == 0 || std::strcmp(field, "hist_pos") == 0) {
+      if (std::strcmp(field, "hist_len") == 0 && rec_put(h, H_N, 1, host_buf, 1)) return -1;
+      if (invalidate_trackers(h)) return -1;
+    }
   } else if (std::strcmp(field, "hist") == 0) {  // fp32 offsets -> device keys (NaN -> empty slot)
+    if (invalidate_trackers(h)) return -1;
     std::vector<unsigned> k(need / 4);
     const unsigned* u = static_cast<const unsigned*>(host_buf);
     for (size_t i = 0; i < k.size(); i++) k[i] = ((u[i] & 0x7FFFFFFFu) > 0x7F800000u) ? 0xFFFFFFFFu : sdc_f32_key(u[i]);

@@ -67,22 +67,29 @@ enum SdcRec {
   SDC_REC_DWORDS = 64
 };
 
-// 64-byte per-env hand-off header: written by the dynamics kernel (N, OVERDUE, EOFF, NORM_CI, OLDEST) and by the
-// reward kernel (G1, G3, RET); every wavefront of the reward workgroup loads it with lanes 0..15.
+// 256-byte per-env hand-off header (one dword per lane): written by the dynamics kernel (N .. OLDEST) and by the
+// reward kernel (RET, the two order-statistic trackers); every wavefront of the reward workgroup loads it whole.
 enum SdcHdr {
   H_N = 0,        // history length including this step's value
-  H_G1,           // fp32 keys of last step's order statistics at floor((n-1)/4) and floor(3(n-1)/4)
-  H_G3,
   H_OVERDUE,      // ls_overdue_penalty (int)
+  H_XNEW,         // key of the value appended this step
+  H_XOLD,         // key of the value it evicted (0xFFFFFFFF: ring was not full)
   H_EOFF = 4,     // f64: bat_total_energy_with_battery_KWh - hist_ref
   H_NORM_CI = 6,  // f64: norm_CI = NC[i'+1]
   H_OLDEST = 8,   // f64: ls_oldest_task_age
   H_RET = 10,     // 3 x f64: running return of the current episode (cleared by reset)
-  SDC_HDR_DWORDS = 16
+  H_Q1 = 16,      // order-statistic tracker of the lower quartile (SdcTrack, 13 dwords)
+  H_Q3 = 32,      // ... of the upper quartile
+  H_STICKY = 48,  // sticky diagnostics (bit 0: a verify-mode mismatch was seen)
+  SDC_HDR_DWORDS = 64
 };
+// tracker: a window of consecutive order statistics of the history around anchor key G
+enum SdcTrack { T_G = 0, T_CLT, T_CLE, T_NP, T_NS, T_P = 5, T_S = 9, SDC_TRACK_DWORDS = 13 };
+#define SDC_QW 4   // cached neighbours on each side of the anchor
 
 struct SdcDev {
   int n_envs, episode_steps, hist_cap, queue_max, table_len, lw, qstride, max_roll_days;
+  int debug_flags;  // bit 0: cross-check the tracked order statistics against the bisection every step
   unsigned long long seed;
   double noise_std, noise_weight;
   // shared, read-only

@@ -68,7 +68,7 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 // the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
 __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_params& P, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
-                                              unsigned fault, DynShared& sh) {
+                                              unsigned fault, const unsigned x_old, DynShared& sh) {
   const int i = rec_i32(r, R_CURSOR);
   const int rel = rec_i32(r, R_TREL);
   const int day = rec_i32(r, R_DAY);
@@ -381,11 +381,14 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
       slot = hpos;
       hpos = hpos + 1 == S.hist_cap ? 0 : hpos + 1;
     }
-    S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = sdc_f32_key(__float_as_uint((float)e_off));
+    const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
+    S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
     // ---- hand-off to the reward kernel ------------------------------------------------------------------------
     unsigned* hw = S.hdr + (size_t)env * SDC_HDR_DWORDS;
     hw[H_N] = (unsigned)hl;
     hw[H_OVERDUE] = (unsigned)overdue;                               // ls_overdue_penalty
+    hw[H_XNEW] = x_new;
+    hw[H_XOLD] = x_old;
     reinterpret_cast<double*>(hw + H_EOFF)[0] = e_off;               // bat_total_energy_with_battery_KWh - hist_ref
     reinterpret_cast<double*>(hw + H_NORM_CI)[0] = nc[17];           // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
     reinterpret_cast<double*>(hw + H_OLDEST)[0] = oldest_norm;       // ls_oldest_task_age
@@ -445,6 +448,12 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   const int hourq_n = hourq + 1 >= 96 ? 0 : hourq + 1;
   unsigned fault = 0;
   if (i + 9 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
+  // the ring slot this step's energy will overwrite: its current key is the evicted value the reward kernel's
+  // order-statistic trackers need (issued with the gather below; 0xFFFFFFFF while the ring is still filling)
+  const int hl0 = rec_i32(r, R_HIST_LEN);
+  const int slot0 = hl0 < S.hist_cap ? hl0 : rec_i32(r, R_HIST_POS);
+  unsigned x_old_l = 0xFFFFFFFFu;
+  if (lane == 63 && hl0 >= S.hist_cap) x_old_l = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
 
   // ---- level 1: one 8-byte gather per lane -------------------------------------------------------------------------
   {
@@ -476,7 +485,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   }
   __syncthreads();
 
-  step_dynamics(S, P, env, lane, r, a_ls, a_dc, a_bat, fault, sh);
+  const unsigned x_old = (unsigned)__builtin_amdgcn_readlane((int)x_old_l, 63);
+  step_dynamics(S, P, env, lane, r, a_ls, a_dc, a_bat, fault, x_old, sh);
   __syncthreads();
 
   // ---- coalesced stores: record, obs [3][26] (78 floats), share_obs [29], info --------------------------------------

@@ -2,36 +2,43 @@
 //
 // utils/reward_creator.py:16-45 normalises the step's energy with the 25th / 75th percentiles, the IQR-clipped
 // mean and the clipped population std of a 10 000-entry sliding history, three times per step.  Here the
-// window is streamed ONCE per step: 40 KB per env as 10 x float4 per lane (coalesced, all loads issued before
-// anything else), held in VGPRs, and
-//   pass 1  certifies the four order statistics from last step's values: one sweep counts keys <= / >= the
-//           previous quartile (wave ballots + scalar popcounts) and tracks its predecessor and two successors;
-//           an insert + an evict move an order statistic by at most one position, so this almost always
-//           pins rank k and k+1.  If it does not (first steps, injected state), an exact bisection on the
-//           fp32 key space runs instead -- same result, more sweeps;
-//   pass 2  clips in key space (one v_med3_u32), converts to fp32 and accumulates the clipped sum and sum of
-//           squares around the inter-quartile midpoint; per-lane partials (40 terms) are fp32, everything
-//           across lanes is fp64.
-// The ring is stored as order-preserving uint32 KEYS of the fp32 offsets (empty slots = 0xFFFFFFFF), and the
-// step's new energy has already been written into its slot by sdc_dynamics_kernel, so a load is ready for
-// comparison with no per-element fix-up.  Two workgroup-wide reductions through LDS, then lane 0 writes the
-// three rewards and the running episode return.
+// window is streamed ONCE per step: 40 KB per env as 10 x dwordx4 per lane (coalesced, all loads issued before
+// anything else) and held in VGPRs.
 //
-// Measured alternative (round 1, kept out of tree): a persistent grid of 4 workgroups per CU with the next env's
-// ring prefetched into a second register set ran SLOWER (54 us vs 39 us per launch at 4096 envs): at 128 VGPRs
-// only 4 x 40 KB per CU are in flight and each workgroup's chain (wait for ring -> compute -> wait) is serial,
-// whereas one workgroup per env at 5-6 workgroups per CU keeps 200+ KB per CU in flight.
+// Order statistics.  The ring holds order-preserving uint32 keys (empty slot = 0xFFFFFFFF).  Per quartile the
+// env keeps a TRACKER: an anchor key G, the exact counts #{x < G}, #{x <= G}, and the (up to) 4 largest keys below
+// and 4 smallest keys above G -- a window of ~9 consecutive order statistics.  A step inserts one key and evicts at
+// most one (both handed over by the dynamics kernel), which updates the tracker in O(1) scalar work; the wanted
+// ranks floor((n-1)q) and +1 random-walk inside the window.  Only when they leave it (every few dozen steps) the
+// anchor SLIDES to the last listed key on that side with a one-sided sweep over the VGPR-resident keys for what
+// lies beyond it: `x - (G+1)` / `(G-1) - x` give the <= / >= predicate as a borrow (v_sub_co_u32 + v_addc_co_u32)
+// and, in wrap-around arithmetic, a distance whose 4 smallest values are the neighbours (v_med3_u32 insertion
+// network).  An exact bisection on the key space (re-reading the L2-hot ring) followed by a two-sided rebuild
+// sweep bootstraps the trackers (first steps, injected state) and serves tiny histories.
+//
+// Moments.  One pass: clip in key space (v_med3_u32), convert, accumulate sum(v-c) and sum((v-c)^2) around the
+// inter-quartile midpoint; per-lane partials (40 terms) are fp32, everything across lanes is fp64.
+//
+// Measured (tools/ablate/kbench_reward.hip, 4096 envs): streaming the rings alone takes 23 us; the previous
+// version, which swept for the order statistics every step, was VALU-bound at 35 us of compute.
+// A persistent grid with the next env's ring prefetched into a second register set was slower (54 us): at 128
+// VGPRs only 4 x 40 KB per CU are in flight and each workgroup's wait -> compute chain is serial.
 #include "sdc_device.hpp"
 
 namespace {
 
+constexpr unsigned KEY_NONE = 0xFFFFFFFFu;  // empty ring slot; also "+infinity" in ascending neighbour lists
+constexpr int QW = SDC_QW;
+constexpr int SMALL_N = 32;                 // below this the bisection is used directly
+
 struct RewardShared {
   unsigned red_u[2][4];
   unsigned red_v[2][4];
-  unsigned p1[4][12];   // pass-1 per-wave partials
+  unsigned sweep[4][2][2 + 2 * QW];  // per wave, per quartile: count <=, count >=, QW pred distances, QW succ distances
   double red_d[4];
   double red_e[4];
 };
+
 
 __device__ __forceinline__ unsigned f32_key(float f) {
   const unsigned b = __float_as_uint(f);
@@ -41,6 +48,11 @@ __device__ __forceinline__ float key_f32(unsigned k) {
   // top bit set (was >= +0): clear it; else (was negative): flip all bits
   const unsigned m = (unsigned)((int)k >> 31);
   return __uint_as_float(k ^ (~m | 0x80000000u));
+}
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
@@ -52,16 +64,6 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
   return v;
-}
-// two smallest of the union (as a multiset) of per-lane sorted pairs (a1 <= a2)
-__device__ __forceinline__ void wave_min2_u32(unsigned& a1, unsigned& a2) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned b1 = (unsigned)__shfl_xor((int)a1, o), b2 = (unsigned)__shfl_xor((int)a2, o);
-    const unsigned lo = min(a1, b1), hi = max(a1, b1);
-    a2 = min(hi, min(a2, b2));
-    a1 = lo;
-  }
 }
 
 // block-wide reductions over 4 wavefronts; `par` alternates the LDS slot so one barrier per call suffices
@@ -85,31 +87,173 @@ __device__ __forceinline__ unsigned block_max_u32(unsigned v, unsigned (*red)[4]
   return max(max(red[par][0], red[par][1]), max(red[par][2], red[par][3]));
 }
 
-constexpr unsigned KEY_NONE = 0xFFFFFFFFu;  // marks ring slots beyond the current history length
+// ------------------------------------------------------------------------------------------------
+// tracker: O(1) maintenance (wave-uniform scalar code)
 
-// Order statistics at ranks k and k+1 from the sweep around guess g:
-//   c_lt = #keys < g, c_le = #keys <= g, p = largest key < g, s1 <= s2 the two smallest keys > g (KEY_NONE if absent).
-// Ranks [c_lt-1] = p, [c_lt, c_le) = g, [c_le] = s1, [c_le+1] = s2.  Returns false when k or k+1 fall outside.
-__device__ __forceinline__ bool certify(int k, int n, unsigned g, int c_lt, int c_le, unsigned p, unsigned s1, unsigned s2,
-                                        unsigned& a, unsigned& b) {
-  auto at = [&](int r, unsigned& out) -> bool {
-    if (r >= c_lt && r < c_le) { out = g; return true; }
-    if (r == c_lt - 1 && p != KEY_NONE) { out = p; return true; }
-    if (r == c_le && s1 != KEY_NONE) { out = s1; return true; }
-    if (r == c_le + 1 && s2 != KEY_NONE) { out = s2; return true; }
-    return false;
-  };
-  if (!at(k, a)) return false;
-  if (k + 1 > n - 1) { b = a; return true; }
-  return at(k + 1, b);
+// 4-entry sorted lists kept as four named scalars (not arrays: LLVM turns unrolled select chains over an array
+// back into a dynamically indexed load, which would push the whole tracker into scratch memory).
+struct L4 {
+  unsigned e0, e1, e2, e3;
+};
+static_assert(QW == 4, "the tracker lists are written out for 4 entries");
+
+// ascending list of the 4 smallest: insert x (keeps the 4 smallest of list + x)
+__device__ __forceinline__ void asc_insert(L4& L, unsigned x) {
+  L.e3 = min(max(L.e2, x), L.e3);  // clamp x into [e2, e3] (old values)
+  L.e2 = min(max(L.e1, x), L.e2);
+  L.e1 = min(max(L.e0, x), L.e1);
+  L.e0 = min(L.e0, x);
+}
+// descending list of the 4 largest
+__device__ __forceinline__ void desc_insert(L4& L, unsigned x) {
+  L.e3 = max(min(L.e2, x), L.e3);
+  L.e2 = max(min(L.e1, x), L.e2);
+  L.e1 = max(min(L.e0, x), L.e1);
+  L.e0 = max(L.e0, x);
+}
+__device__ __forceinline__ unsigned lget(const L4& L, int j) {
+  return j == 0 ? L.e0 : (j == 1 ? L.e1 : (j == 2 ? L.e2 : L.e3));
+}
+// remove one occurrence of x from the first `cnt` entries; `fill` pads the tail.  Returns false if absent.
+__device__ __forceinline__ bool list_remove(L4& L, int& cnt, unsigned x, unsigned fill) {
+  int j = -1;
+  if (3 < cnt && L.e3 == x) j = 3;
+  if (2 < cnt && L.e2 == x) j = 2;
+  if (1 < cnt && L.e1 == x) j = 1;
+  if (0 < cnt && L.e0 == x) j = 0;
+  if (j < 0) return false;
+  if (j <= 0) L.e0 = L.e1;
+  if (j <= 1) L.e1 = L.e2;
+  if (j <= 2) L.e2 = L.e3;
+  L.e3 = fill;
+  cnt -= 1;
+  return true;
 }
 
-// Exact fallback for the order statistics at ranks k1, k1+1, k3, k3+1: bisection on the key space with block-wide
-// counts.  Rare (first steps of a history, injected state, >= 3 duplicates at a quartile), so it re-reads the ring
-// from memory (L2-hot) instead of holding live ranges in the main path's registers.  Block-uniform control flow.
+struct QTrack {
+  unsigned g;          // anchor key; 0 = invalid (no tracker)
+  int c_lt, c_le;      // #{x < g}, #{x <= g} over the current ring
+  int np, ns;          // valid entries of P / S
+  L4 P;                // the np largest keys below g, descending; unused entries 0
+  L4 S;                // the ns smallest keys above g, ascending; unused entries KEY_NONE
+};
+
+__device__ __forceinline__ QTrack qt_load(unsigned hd, int base) {
+  QTrack q;
+  q.g = (unsigned)rec_i32(hd, base + T_G);
+  q.c_lt = rec_i32(hd, base + T_CLT);
+  q.c_le = rec_i32(hd, base + T_CLE);
+  q.np = rec_i32(hd, base + T_NP);
+  q.ns = rec_i32(hd, base + T_NS);
+  q.P.e0 = (unsigned)rec_i32(hd, base + T_P + 0);
+  q.P.e1 = (unsigned)rec_i32(hd, base + T_P + 1);
+  q.P.e2 = (unsigned)rec_i32(hd, base + T_P + 2);
+  q.P.e3 = (unsigned)rec_i32(hd, base + T_P + 3);
+  q.S.e0 = (unsigned)rec_i32(hd, base + T_S + 0);
+  q.S.e1 = (unsigned)rec_i32(hd, base + T_S + 1);
+  q.S.e2 = (unsigned)rec_i32(hd, base + T_S + 2);
+  q.S.e3 = (unsigned)rec_i32(hd, base + T_S + 3);
+  return q;
+}
+__device__ __forceinline__ void qt_store(const QTrack& q, unsigned* w) {
+  w[T_G] = q.g;
+  w[T_CLT] = (unsigned)q.c_lt;
+  w[T_CLE] = (unsigned)q.c_le;
+  w[T_NP] = (unsigned)q.np;
+  w[T_NS] = (unsigned)q.ns;
+  w[T_P + 0] = q.P.e0;
+  w[T_P + 1] = q.P.e1;
+  w[T_P + 2] = q.P.e2;
+  w[T_P + 3] = q.P.e3;
+  w[T_S + 0] = q.S.e0;
+  w[T_S + 1] = q.S.e1;
+  w[T_S + 2] = q.S.e2;
+  w[T_S + 3] = q.S.e3;
+}
+
+// Apply this step's eviction (x_old, if has_old) and insertion (x_new) to a tracker that described the ring of
+// the previous step, which held n_prev keys.  Sets q.g = 0 if the tracker turns out to be inconsistent.
+__device__ __forceinline__ void qt_update(QTrack& q, unsigned x_new, unsigned x_old, bool has_old, int n_prev) {
+  int m = n_prev;
+  if (has_old) {
+    m -= 1;
+    if (x_old < q.g) {
+      q.c_lt -= 1;
+      q.c_le -= 1;
+      // the list holds exactly the np largest keys below g: the evicted key is in it iff it is >= the smallest listed
+      if (q.np > 0 && x_old >= lget(q.P, q.np - 1)) {
+        if (!list_remove(q.P, q.np, x_old, 0u)) q.g = 0u;
+      }
+    } else if (x_old == q.g) {
+      q.c_le -= 1;
+    } else {
+      if (q.ns > 0 && x_old <= lget(q.S, q.ns - 1)) {
+        if (!list_remove(q.S, q.ns, x_old, KEY_NONE)) q.g = 0u;
+      }
+    }
+  }
+  if (x_new < q.g) {
+    const bool complete = q.np == q.c_lt;  // every key below g is listed
+    q.c_lt += 1;
+    q.c_le += 1;
+    if (complete || (q.np > 0 && x_new > lget(q.P, q.np - 1))) {
+      desc_insert(q.P, x_new);
+      q.np = min(QW, q.np + 1);
+    }
+  } else if (x_new == q.g) {
+    q.c_le += 1;
+  } else {
+    const bool complete = q.ns == m - q.c_le;  // every key above g is listed
+    if (complete || (q.ns > 0 && x_new < lget(q.S, q.ns - 1))) {
+      asc_insert(q.S, x_new);
+      q.ns = min(QW, q.ns + 1);
+    }
+  }
+}
+
+// key at rank r, if the window covers it
+__device__ __forceinline__ bool qt_value_at(const QTrack& q, int r, unsigned& out) {
+  if (r >= q.c_lt && r < q.c_le) {
+    out = q.g;
+    return true;
+  }
+  if (r < q.c_lt) {
+    const int j = q.c_lt - 1 - r;
+    if (j >= q.np) return false;
+    out = lget(q.P, j);
+    return true;
+  }
+  const int j = r - q.c_le;
+  if (j >= q.ns) return false;
+  out = lget(q.S, j);
+  return true;
+}
+// ranks k and k+1 (the second only if it exists)
+__device__ __forceinline__ bool qt_resolve(const QTrack& q, int k, int n, unsigned& a, unsigned& b) {
+  if (q.g == 0u || q.g == KEY_NONE) return false;
+  if (!qt_value_at(q, k, a)) return false;
+  if (k + 1 > n - 1) {
+    b = a;
+    return true;
+  }
+  return qt_value_at(q, k + 1, b);
+}
+// the listed key whose rank is nearest to k: the anchor of a rebuild
+__device__ __forceinline__ unsigned qt_nearest(const QTrack& q, int k) {
+  const int lo = q.c_lt - q.np, hi = q.c_le + q.ns - 1;
+  const int r = k < lo ? lo : (k > hi ? hi : k);
+  unsigned v = q.g;
+  if (qt_value_at(q, r, v)) return v;
+  return q.g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact order statistics at ranks k1, k1+1, k3, k3+1 by bisection on the key space with block-wide counts.
+// Rare (bootstrap, tiny histories, verify mode): re-reads the ring from memory (L2-hot) in rolled loops so that it
+// adds no register pressure to the main path.  Block-uniform control flow.
 __device__ __forceinline__ void quartiles_by_bisection(const unsigned* __restrict__ ring, const int k1, const int k3,
-                                                    RewardShared& sh, const int tid, const int lane, const int wave,
-                                                    unsigned& a1, unsigned& b1, unsigned& a3, unsigned& b3) {
+                                                       RewardShared& sh, const int tid, const int lane, const int wave,
+                                                       unsigned& a1, unsigned& b1, unsigned& a3, unsigned& b3) {
   const uint4* hp = reinterpret_cast<const uint4*>(ring);
   int par = 0;
   unsigned kmin = KEY_NONE, kmax = 0u;
@@ -172,115 +316,347 @@ __device__ __forceinline__ void quartiles_by_bisection(const unsigned* __restric
   __syncthreads();
 }
 
+// merge the four wavefronts' partial results of a rebuild sweep (quartile slot t of sh.sweep) into tracker q
+__device__ __forceinline__ void rebuild_finish(const RewardShared& sh, const int t, const unsigned g, const int n, QTrack& q) {
+  unsigned c_le = 0, c_ge = 0;
+  L4 P = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE}, Sx = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const unsigned* v = sh.sweep[w][t];
+    c_le += v[0];
+    c_ge += v[1];
+#pragma unroll
+    for (int i = 0; i < QW; i++) {
+      asc_insert(P, v[2 + i]);
+      asc_insert(Sx, v[2 + QW + i]);
+    }
+  }
+  q.g = g;
+  // empty slots (KEY_NONE) satisfy x >= g: take them out of the >= count
+  const int n_empty = SDC_HIST_STRIDE - n;
+  q.c_le = (int)c_le;
+  q.c_lt = n - ((int)c_ge - n_empty);
+  // a legitimate predecessor distance is < g; a legitimate successor distance is < KEY_NONE - g - 1
+  const unsigned smax = KEY_NONE - g - 1u;
+  q.np = (P.e0 < g) + (P.e1 < g) + (P.e2 < g) + (P.e3 < g);
+  q.ns = (Sx.e0 < smax) + (Sx.e1 < smax) + (Sx.e2 < smax) + (Sx.e3 < smax);
+  q.P.e0 = P.e0 < g ? g - 1u - P.e0 : 0u;
+  q.P.e1 = P.e1 < g ? g - 1u - P.e1 : 0u;
+  q.P.e2 = P.e2 < g ? g - 1u - P.e2 : 0u;
+  q.P.e3 = P.e3 < g ? g - 1u - P.e3 : 0u;
+  q.S.e0 = Sx.e0 < smax ? g + 1u + Sx.e0 : KEY_NONE;
+  q.S.e1 = Sx.e1 < smax ? g + 1u + Sx.e1 : KEY_NONE;
+  q.S.e2 = Sx.e2 < smax ? g + 1u + Sx.e2 : KEY_NONE;
+  q.S.e3 = Sx.e3 < smax ? g + 1u + Sx.e3 : KEY_NONE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rebuild sweep: re-anchor both trackers (anchors g1, g3 must be valid keys in (0, KEY_NONE)).
+// Per key and quartile: ds = x - (g+1) borrows <=> x <= g;  dp = (g-1) - x borrows <=> x >= g;  a key on the wrong
+// side of g wraps to a distance above every legitimate one, so the QW smallest ds / dp are the neighbours.
+__device__ __forceinline__ void rebuild_trackers(const unsigned (&key)[SDC_HIST_PER_THREAD], const unsigned g1,
+                                                 const unsigned g3, const int n, RewardShared& sh, const int lane,
+                                                 const int wave, QTrack& q1, QTrack& q3) {
+  unsigned cle1 = 0u, cge1 = 0u, cle3 = 0u, cge3 = 0u;
+  L4 pd1 = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE}, sd1 = pd1, pd3 = pd1, sd3 = pd1;
+  const unsigned g1p = g1 + 1u, g1m = g1 - 1u, g3p = g3 + 1u, g3m = g3 - 1u;
+#pragma unroll
+  for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
+    const unsigned x = key[j];
+    unsigned ds1, dp1, ds3, dp3;
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(ds1), "+v"(cle1) : "v"(x), "v"(g1p) : "vcc");
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(dp1), "+v"(cge1) : "v"(g1m), "v"(x) : "vcc");
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(ds3), "+v"(cle3) : "v"(x), "v"(g3p) : "vcc");
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(dp3), "+v"(cge3) : "v"(g3m), "v"(x) : "vcc");
+    sd1.e3 = umed3(sd1.e2, ds1, sd1.e3); sd1.e2 = umed3(sd1.e1, ds1, sd1.e2); sd1.e1 = umed3(sd1.e0, ds1, sd1.e1); sd1.e0 = min(sd1.e0, ds1);
+    pd1.e3 = umed3(pd1.e2, dp1, pd1.e3); pd1.e2 = umed3(pd1.e1, dp1, pd1.e2); pd1.e1 = umed3(pd1.e0, dp1, pd1.e1); pd1.e0 = min(pd1.e0, dp1);
+    sd3.e3 = umed3(sd3.e2, ds3, sd3.e3); sd3.e2 = umed3(sd3.e1, ds3, sd3.e2); sd3.e1 = umed3(sd3.e0, ds3, sd3.e1); sd3.e0 = min(sd3.e0, ds3);
+    pd3.e3 = umed3(pd3.e2, dp3, pd3.e3); pd3.e2 = umed3(pd3.e1, dp3, pd3.e2); pd3.e1 = umed3(pd3.e0, dp3, pd3.e1); pd3.e0 = min(pd3.e0, dp3);
+  }
+  // across lanes: butterfly merge of the sorted distance lists (insert the partner's 4 entries), counts summed
+  cle1 = (unsigned)wave_sum_i32((int)cle1);
+  cge1 = (unsigned)wave_sum_i32((int)cge1);
+  cle3 = (unsigned)wave_sum_i32((int)cle3);
+  cge3 = (unsigned)wave_sum_i32((int)cge3);
+  auto merge = [&](L4& A) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned b0 = (unsigned)__shfl_xor((int)A.e0, o), b1 = (unsigned)__shfl_xor((int)A.e1, o);
+      const unsigned b2 = (unsigned)__shfl_xor((int)A.e2, o), b3 = (unsigned)__shfl_xor((int)A.e3, o);
+      asc_insert(A, b0);
+      asc_insert(A, b1);
+      asc_insert(A, b2);
+      asc_insert(A, b3);
+    }
+  };
+  merge(pd1);
+  merge(sd1);
+  merge(pd3);
+  merge(sd3);
+  if (lane == 0) {
+    unsigned* w = sh.sweep[wave][0];
+    w[0] = cle1; w[1] = cge1;
+    w[2] = pd1.e0; w[3] = pd1.e1; w[4] = pd1.e2; w[5] = pd1.e3;
+    w[6] = sd1.e0; w[7] = sd1.e1; w[8] = sd1.e2; w[9] = sd1.e3;
+    w = sh.sweep[wave][1];
+    w[0] = cle3; w[1] = cge3;
+    w[2] = pd3.e0; w[3] = pd3.e1; w[4] = pd3.e2; w[5] = pd3.e3;
+    w[6] = sd3.e0; w[7] = sd3.e1; w[8] = sd3.e2; w[9] = sd3.e3;
+  }
+  __syncthreads();
+  rebuild_finish(sh, 0, g1, n, q1);
+  rebuild_finish(sh, 1, g3, n, q3);
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SLIDE: when the wanted rank has walked off one end of a tracker's window, move the anchor to the last listed key
+// on that side and sweep only for what lies beyond it -- one quartile, one side: per key one v_sub_co_u32 /
+// v_addc_co_u32 pair (distance + predicate count) and the 4-entry insertion network.  Everything on the near side
+// of the new anchor is already known from the old window.
+template <bool UP>
+__device__ __forceinline__ void one_sided_sweep(const unsigned (&key)[SDC_HIST_PER_THREAD], const unsigned pivot,
+                                                RewardShared& sh, const int lane, const int wave, unsigned& count,
+                                                L4& dist) {
+  unsigned cnt = 0u;
+  L4 d4 = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+  const unsigned pp = pivot + 1u, pm = pivot - 1u;
+#pragma unroll
+  for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
+    const unsigned x = key[j];
+    unsigned d;
+    if (UP)   // d = x - (pivot+1): borrows <=> x <= pivot; legitimate d = distance of a key above the pivot
+      asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(d), "+v"(cnt) : "v"(x), "v"(pp) : "vcc");
+    else      // d = (pivot-1) - x: borrows <=> x >= pivot; legitimate d = distance of a key below the pivot
+      asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(d), "+v"(cnt) : "v"(pm), "v"(x) : "vcc");
+    d4.e3 = umed3(d4.e2, d, d4.e3);
+    d4.e2 = umed3(d4.e1, d, d4.e2);
+    d4.e1 = umed3(d4.e0, d, d4.e1);
+    d4.e0 = min(d4.e0, d);
+  }
+  cnt = (unsigned)wave_sum_i32((int)cnt);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned b0 = (unsigned)__shfl_xor((int)d4.e0, o), b1 = (unsigned)__shfl_xor((int)d4.e1, o);
+    const unsigned b2 = (unsigned)__shfl_xor((int)d4.e2, o), b3 = (unsigned)__shfl_xor((int)d4.e3, o);
+    asc_insert(d4, b0);
+    asc_insert(d4, b1);
+    asc_insert(d4, b2);
+    asc_insert(d4, b3);
+  }
+  if (lane == 0) {
+    unsigned* w = sh.sweep[wave][0];
+    w[0] = cnt;
+    w[2] = d4.e0; w[3] = d4.e1; w[4] = d4.e2; w[5] = d4.e3;
+  }
+  __syncthreads();
+  count = 0u;
+  dist = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const unsigned* v = sh.sweep[w][0];
+    count += v[0];
+    asc_insert(dist, v[2]);
+    asc_insert(dist, v[3]);
+    asc_insert(dist, v[4]);
+    asc_insert(dist, v[5]);
+  }
+  __syncthreads();
+}
+
+// first index of `x` in a sorted 4-list (it is present)
+__device__ __forceinline__ int first_index(const L4& L, unsigned x) {
+  return L.e0 == x ? 0 : (L.e1 == x ? 1 : (L.e2 == x ? 2 : 3));
+}
+
+// move the anchor up to the largest listed key above it (requires q.ns >= 1)
+__device__ __forceinline__ void qt_slide_up(QTrack& q, const unsigned (&key)[SDC_HIST_PER_THREAD], const int n,
+                                            RewardShared& sh, const int lane, const int wave) {
+  const unsigned g2 = lget(q.S, q.ns - 1);
+  const int e0 = first_index(q.S, g2);          // keys S[0..e0) lie strictly between the old and the new anchor
+  const int c_eq = q.c_le - q.c_lt;
+  unsigned c_le2;
+  L4 dist;
+  one_sided_sweep<true>(key, g2, sh, lane, wave, c_le2, dist);
+  // new lower list (descending): S[e0-1] .. S[0], then the old anchor c_eq times, then the old lower list
+  L4 P2 = {0u, 0u, 0u, 0u};
+  int cnt = 0;
+  auto push = [&](unsigned v) {
+    if (cnt == 0) P2.e0 = v;
+    if (cnt == 1) P2.e1 = v;
+    if (cnt == 2) P2.e2 = v;
+    if (cnt == 3) P2.e3 = v;
+    cnt += 1;
+  };
+  if (e0 >= 3) push(q.S.e2);
+  if (e0 >= 2) push(q.S.e1);
+  if (e0 >= 1) push(q.S.e0);
+#pragma unroll
+  for (int r = 0; r < QW; r++)
+    if (r < c_eq) push(q.g);
+  if (q.np > 0) push(q.P.e0);
+  if (q.np > 1) push(q.P.e1);
+  if (q.np > 2) push(q.P.e2);
+  if (q.np > 3) push(q.P.e3);
+  const unsigned smax = KEY_NONE - g2 - 1u;
+  q.c_lt = q.c_le + e0;
+  q.c_le = (int)c_le2;
+  q.g = g2;
+  q.P = P2;
+  q.np = min(QW, cnt);
+  q.ns = (dist.e0 < smax) + (dist.e1 < smax) + (dist.e2 < smax) + (dist.e3 < smax);
+  q.S.e0 = dist.e0 < smax ? g2 + 1u + dist.e0 : KEY_NONE;
+  q.S.e1 = dist.e1 < smax ? g2 + 1u + dist.e1 : KEY_NONE;
+  q.S.e2 = dist.e2 < smax ? g2 + 1u + dist.e2 : KEY_NONE;
+  q.S.e3 = dist.e3 < smax ? g2 + 1u + dist.e3 : KEY_NONE;
+}
+
+// move the anchor down to the smallest listed key below it (requires q.np >= 1)
+__device__ __forceinline__ void qt_slide_down(QTrack& q, const unsigned (&key)[SDC_HIST_PER_THREAD], const int n,
+                                              RewardShared& sh, const int lane, const int wave) {
+  const unsigned g2 = lget(q.P, q.np - 1);
+  const int e0 = first_index(q.P, g2);          // keys P[0..e0) lie strictly between the new and the old anchor
+  const int c_eq = q.c_le - q.c_lt;
+  unsigned c_ge2;
+  L4 dist;
+  one_sided_sweep<false>(key, g2, sh, lane, wave, c_ge2, dist);
+  // new upper list (ascending): P[e0-1] .. P[0], then the old anchor c_eq times, then the old upper list
+  L4 S2 = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+  int cnt = 0;
+  auto push = [&](unsigned v) {
+    if (cnt == 0) S2.e0 = v;
+    if (cnt == 1) S2.e1 = v;
+    if (cnt == 2) S2.e2 = v;
+    if (cnt == 3) S2.e3 = v;
+    cnt += 1;
+  };
+  if (e0 >= 3) push(q.P.e2);
+  if (e0 >= 2) push(q.P.e1);
+  if (e0 >= 1) push(q.P.e0);
+#pragma unroll
+  for (int r = 0; r < QW; r++)
+    if (r < c_eq) push(q.g);
+  if (q.ns > 0) push(q.S.e0);
+  if (q.ns > 1) push(q.S.e1);
+  if (q.ns > 2) push(q.S.e2);
+  if (q.ns > 3) push(q.S.e3);
+  const int n_empty = SDC_HIST_STRIDE - n;      // empty slots (KEY_NONE) satisfy x >= pivot
+  q.c_le = q.c_lt - e0;
+  q.c_lt = n - ((int)c_ge2 - n_empty);
+  q.g = g2;
+  q.S = S2;
+  q.ns = min(QW, cnt);
+  q.np = (dist.e0 < g2) + (dist.e1 < g2) + (dist.e2 < g2) + (dist.e3 < g2);
+  q.P.e0 = dist.e0 < g2 ? g2 - 1u - dist.e0 : 0u;
+  q.P.e1 = dist.e1 < g2 ? g2 - 1u - dist.e1 : 0u;
+  q.P.e2 = dist.e2 < g2 ? g2 - 1u - dist.e2 : 0u;
+  q.P.e3 = dist.e3 < g2 ? g2 - 1u - dist.e3 : 0u;
+}
+
+// the tracker is wave-uniform: pin it to scalar registers after it was recomputed from LDS / vector values, so
+// that the 26 tracker words do not occupy vector registers next to the 40 ring keys
+__device__ __forceinline__ unsigned sfl(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void qt_uniform(QTrack& q) {
+  q.g = sfl(q.g);
+  q.c_lt = (int)sfl((unsigned)q.c_lt);
+  q.c_le = (int)sfl((unsigned)q.c_le);
+  q.np = (int)sfl((unsigned)q.np);
+  q.ns = (int)sfl((unsigned)q.ns);
+  q.P.e0 = sfl(q.P.e0); q.P.e1 = sfl(q.P.e1); q.P.e2 = sfl(q.P.e2); q.P.e3 = sfl(q.P.e3);
+  q.S.e0 = sfl(q.S.e0); q.S.e1 = sfl(q.S.e1); q.S.e2 = sfl(q.S.e2); q.S.e3 = sfl(q.S.e3);
+}
+
+// bring ranks k, k+1 inside the window by sliding (block-uniform); false if the tracker cannot get there
+__device__ __forceinline__ bool qt_chase(QTrack& q, const int k, const int n, const unsigned (&key)[SDC_HIST_PER_THREAD],
+                                         RewardShared& sh, const int lane, const int wave, unsigned& a, unsigned& b) {
+  if (q.g == 0u || q.g == KEY_NONE) return false;
+  for (int it = 0; it < 3; it++) {
+    if (qt_resolve(q, k, n, a, b)) return true;
+    const int hi_rank = (k + 1 > n - 1) ? k : k + 1;
+    if (hi_rank >= q.c_le + q.ns) {
+      if (q.ns < 1) return false;
+      qt_slide_up(q, key, n, sh, lane, wave);
+    } else {
+      if (q.np < 1) return false;
+      qt_slide_down(q, key, n, sh, lane, wave);
+    }
+    qt_uniform(q);
+  }
+  return qt_resolve(q, k, n, a, b);
+}
+
+// ------------------------------------------------------------------------------------------------
 // one env: order statistics + clipped moments + rewards.  `key` = this lane's 40 ring slots, `hd` = this lane's
-// dword of the env's 64-byte hand-off header (lanes 0..15).
-__device__ __forceinline__ void reward_one_env(const SdcDev& S, RewardShared& sh, const int env, unsigned (&key)[SDC_HIST_PER_THREAD],
-                                               const unsigned hd, float* __restrict__ rew, float* __restrict__ info,
-                                               const int tid, const int lane, const int wave) {
+// dword of the env's 256-byte hand-off header.
+__device__ __forceinline__ void reward_one_env(const SdcDev& S, RewardShared& sh, const int env,
+                                               const unsigned (&key)[SDC_HIST_PER_THREAD], const unsigned hd,
+                                               float* __restrict__ rew, float* __restrict__ info, const int tid,
+                                               const int lane, const int wave) {
   const int n = rec_i32(hd, H_N);            // already includes this step's energy (appended by the dynamics kernel)
   const double energy = rec_f64(hd, H_EOFF); // energy - hist_ref, fp64
   const double norm_ci_next = rec_f64(hd, H_NORM_CI);
   const double oldest_norm = rec_f64(hd, H_OLDEST);
   const double overdue = (double)rec_i32(hd, H_OVERDUE);
-  const unsigned g1 = (unsigned)rec_i32(hd, H_G1), g3 = (unsigned)rec_i32(hd, H_G3);
+  const unsigned x_new = (unsigned)rec_i32(hd, H_XNEW), x_old = (unsigned)rec_i32(hd, H_XOLD);
+  const bool has_old = x_old != KEY_NONE;
+  const unsigned* ring = S.hist + (size_t)env * SDC_HIST_STRIDE;
 
   // ---- normalize_energy (utils/reward_creator.py:16-45) ------------------------------------------------------------
   double z = 0.0;
-  unsigned ng1 = g1, ng3 = g3;
-  bool used_fallback = false;
-  if (n >= 2) {
+  QTrack q1 = qt_load(hd, H_Q1), q3 = qt_load(hd, H_Q3);
+  int path = 0;  // diagnostics: 0 tracker only, 1 anchor slid (one-sided sweep), 2 bisection + rebuild
+  unsigned mismatch = 0u;
+  if (n < 2) {
+    q1.g = q3.g = 0u;
+  } else {
     const int k1 = (n - 1) >> 2;                  // floor((n-1) * 0.25), np.percentile 'linear'
     const double t1 = (double)((n - 1) & 3) * 0.25;
     const int k3 = (3 * (n - 1)) >> 2;            // floor((n-1) * 0.75)
     const double t3 = (double)((3 * (n - 1)) & 3) * 0.25;
     unsigned a1 = 0, b1 = 0, a3 = 0, b3 = 0;
-    bool ok = false;
-    if (g1 != 0u && g1 != KEY_NONE && g3 != 0u && g3 != KEY_NONE) {
-      // pass 1: one sweep around last step's quartile keys.  Per key and quartile (8 VALU):
-      //   ds = x - (g+1)  borrows  <=> x <= g   (v_sub_co_u32 + v_addc_co_u32 count the borrow)
-      //   dp = (g-1) - x  borrows  <=> x >= g
-      // and in wrap-around arithmetic a key on the wrong side lands above every key on the right side, so
-      // plain unsigned minima of ds / dp find the two successors and the predecessor.
-      unsigned cle1 = 0, cge1 = 0, cle3 = 0, cge3 = 0;
-      unsigned pd1 = KEY_NONE, sd1a = KEY_NONE, sd1b = KEY_NONE, pd3 = KEY_NONE, sd3a = KEY_NONE, sd3b = KEY_NONE;
-      const unsigned g1p = g1 + 1u, g1m = g1 - 1u, g3p = g3 + 1u, g3m = g3 - 1u;
-#pragma unroll
-      for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
-        const unsigned x = key[j];
-        unsigned ds1, dp1, ds3, dp3;
-        asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(ds1), "+v"(cle1) : "v"(x), "v"(g1p) : "vcc");
-        asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(dp1), "+v"(cge1) : "v"(g1m), "v"(x) : "vcc");
-        asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(ds3), "+v"(cle3) : "v"(x), "v"(g3p) : "vcc");
-        asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(dp3), "+v"(cge3) : "v"(g3m), "v"(x) : "vcc");
-        sd1b = min(max(sd1a, ds1), sd1b);
-        sd1a = min(sd1a, ds1);
-        pd1 = min(pd1, dp1);
-        sd3b = min(max(sd3a, ds3), sd3b);
-        sd3a = min(sd3a, ds3);
-        pd3 = min(pd3, dp3);
-        __builtin_amdgcn_sched_barrier(0);   // keep the per-key temporaries short-lived (register budget: 128)
+    if (n < SMALL_N) {
+      quartiles_by_bisection(ring, k1, k3, sh, tid, lane, wave, a1, b1, a3, b3);
+      q1.g = q3.g = 0u;
+      path = 2;
+    } else {
+      const int n_prev = has_old ? n : n - 1;
+      const bool v1 = q1.g != 0u && q1.g != KEY_NONE, v3 = q3.g != 0u && q3.g != KEY_NONE;
+      if (v1) qt_update(q1, x_new, x_old, has_old, n_prev);
+      if (v3) qt_update(q3, x_new, x_old, has_old, n_prev);
+      // each tracker answers from its window, or slides its anchor (one-sided sweep) until the ranks are inside
+      const bool ok1 = qt_chase(q1, k1, n, key, sh, lane, wave, a1, b1);
+      const bool ok3 = qt_chase(q3, k3, n, key, sh, lane, wave, a3, b3);
+      if (!(v1 && v3)) path = 2;
+      else if (q1.g != (unsigned)rec_i32(hd, H_Q1 + T_G) || q3.g != (unsigned)rec_i32(hd, H_Q3 + T_G)) path = 1;
+      if (!ok1 || !ok3) {
+        // bootstrap (or a tracker that lost its window): exact bisection for the anchors, then a full rebuild sweep
+        quartiles_by_bisection(ring, k1, k3, sh, tid, lane, wave, a1, b1, a3, b3);
+        rebuild_trackers(key, sfl(a1), sfl(a3), n, sh, lane, wave, q1, q3);
+        qt_uniform(q1);
+        qt_uniform(q3);
+        path = 2;
       }
-      cle1 = wave_sum_i32((int)cle1);
-      cge1 = wave_sum_i32((int)cge1);
-      cle3 = wave_sum_i32((int)cle3);
-      cge3 = wave_sum_i32((int)cge3);
-      pd1 = wave_min_u32(pd1);
-      pd3 = wave_min_u32(pd3);
-      wave_min2_u32(sd1a, sd1b);
-      wave_min2_u32(sd3a, sd3b);
-      if (lane == 0) {
-        unsigned* w = sh.p1[wave];
-        w[0] = (unsigned)cle1; w[1] = (unsigned)cge1; w[2] = (unsigned)cle3; w[3] = (unsigned)cge3;
-        w[4] = pd1; w[5] = sd1a; w[6] = sd1b; w[7] = pd3; w[8] = sd3a; w[9] = sd3b;
+      if (S.debug_flags & 1) {
+        unsigned va1, vb1, va3, vb3;
+        __syncthreads();
+        quartiles_by_bisection(ring, k1, k3, sh, tid, lane, wave, va1, vb1, va3, vb3);
+        if (va1 != a1 || vb1 != b1 || va3 != a3 || vb3 != b3) mismatch = SDC_FAULT_ORDER_STAT;
       }
-      __syncthreads();
-      int c_le1 = 0, c_ge1 = 0, c_le3 = 0, c_ge3 = 0;
-      unsigned P1 = KEY_NONE, S1a = KEY_NONE, S1b = KEY_NONE, P3 = KEY_NONE, S3a = KEY_NONE, S3b = KEY_NONE;
-#pragma unroll
-      for (int w = 0; w < 4; w++) {
-        const unsigned* q = sh.p1[w];
-        c_le1 += (int)q[0]; c_ge1 += (int)q[1]; c_le3 += (int)q[2]; c_ge3 += (int)q[3];
-        P1 = min(P1, q[4]);
-        S1b = min(max(S1a, q[5]), min(S1b, q[6]));
-        S1a = min(S1a, q[5]);
-        P3 = min(P3, q[7]);
-        S3b = min(max(S3a, q[8]), min(S3b, q[9]));
-        S3a = min(S3a, q[8]);
-      }
-      // invalid slots (KEY_NONE) satisfy x >= g: remove them from the >= counts
-      const int n_invalid = SDC_HIST_STRIDE - n;
-      const int c_lt1 = n - (c_ge1 - n_invalid), c_lt3 = n - (c_ge3 - n_invalid);
-      // distances back to keys; a wrapped distance means "no such key"
-      const unsigned p1k = P1 < g1 ? g1 - 1u - P1 : KEY_NONE;               // legit pred distance < g
-      const unsigned s1ak = S1a < KEY_NONE - g1 - 1u ? g1 + 1u + S1a : KEY_NONE;  // legit succ distance <= 2^32-2-g
-      const unsigned s1bk = S1b < KEY_NONE - g1 - 1u ? g1 + 1u + S1b : KEY_NONE;
-      const unsigned p3k = P3 < g3 ? g3 - 1u - P3 : KEY_NONE;
-      const unsigned s3ak = S3a < KEY_NONE - g3 - 1u ? g3 + 1u + S3a : KEY_NONE;
-      const unsigned s3bk = S3b < KEY_NONE - g3 - 1u ? g3 + 1u + S3b : KEY_NONE;
-      ok = certify(k1, n, g1, c_lt1, c_le1, p1k, s1ak, s1bk, a1, b1) &&
-           certify(k3, n, g3, c_lt3, c_le3, p3k, s3ak, s3bk, a3, b3);
     }
-    if (!ok) {
-      used_fallback = true;
-      __syncthreads();
-      quartiles_by_bisection(S.hist + (size_t)env * SDC_HIST_STRIDE, k1, k3, sh, tid, lane, wave, a1, b1, a3, b3);
-    }
-    ng1 = a1;
-    ng3 = a3;
     const double fa1 = (double)key_f32(a1), fb1 = (double)key_f32(b1);
     const double fa3 = (double)key_f32(a3), fb3 = (double)key_f32(b3);
     // numpy _lerp: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5
     const double d1 = fb1 - fa1, d3 = fb3 - fa3;
-    const double q1 = (t1 == 0.0) ? fa1 : ((t1 >= 0.5) ? fb1 - d1 * (1.0 - t1) : fa1 + d1 * t1);
-    const double q3 = (t3 == 0.0) ? fa3 : ((t3 >= 0.5) ? fb3 - d3 * (1.0 - t3) : fa3 + d3 * t3);
-    const double iqr = q3 - q1;
-    const double lb = q1 - 1.5 * iqr, ub = q3 + 1.5 * iqr;
-    // pass 2: clip in key space, accumulate (v - ctr) and (v - ctr)^2 around the inter-quartile midpoint;
+    const double qv1 = (t1 == 0.0) ? fa1 : ((t1 >= 0.5) ? fb1 - d1 * (1.0 - t1) : fa1 + d1 * t1);
+    const double qv3 = (t3 == 0.0) ? fa3 : ((t3 >= 0.5) ? fb3 - d3 * (1.0 - t3) : fa3 + d3 * t3);
+    const double iqr = qv3 - qv1;
+    const double lb = qv1 - 1.5 * iqr, ub = qv3 + 1.5 * iqr;
+    // clipped moments: clip in key space, accumulate (v - ctr) and (v - ctr)^2 around the inter-quartile midpoint;
     // per-lane partial sums in fp32 (40 terms of magnitude <= 2 IQR), fp64 across lanes.  A register group k
     // covers ring slots [1024 k, 1024 k + 1024): groups below the history length need no validity test
     // (wave-uniform branch); in steady state only the last group (slots 10000..10239 are always empty) does.
     const float lbf = (float)lb, ubf = (float)ub;
-    const float ctrf = (float)(0.5 * (q1 + q3));
+    const float ctrf = (float)(0.5 * (qv1 + qv3));
     const unsigned klb = f32_key(lbf), kub = f32_key(ubf);
     float sf = 0.0f, sf2 = 0.0f;
 #pragma unroll
@@ -288,25 +664,22 @@ __device__ __forceinline__ void reward_one_env(const SdcDev& S, RewardShared& sh
       if (n >= (k + 1) * SDC_BLOCK * 4) {
 #pragma unroll
         for (int c4 = 0; c4 < 4; c4++) {
-          const unsigned ck = min(max(key[4 * k + c4], klb), kub);   // v_med3_u32
-          const float c = key_f32(ck) - ctrf;
+          const float c = key_f32(umed3(key[4 * k + c4], klb, kub)) - ctrf;
           sf += c;
-          sf2 += c * c;
-          __builtin_amdgcn_sched_barrier(0);
+          sf2 = __builtin_fmaf(c, c, sf2);
         }
       } else {
 #pragma unroll
         for (int c4 = 0; c4 < 4; c4++) {
           const unsigned kk = key[4 * k + c4];
-          const unsigned ck = min(max(kk, klb), kub);
-          const float c = kk == KEY_NONE ? 0.0f : key_f32(ck) - ctrf;
+          const float c = kk == KEY_NONE ? 0.0f : key_f32(umed3(kk, klb, kub)) - ctrf;
           sf += c;
-          sf2 += c * c;
+          sf2 = __builtin_fmaf(c, c, sf2);
         }
       }
     }
-    double s = wave_sum_f64((double)sf);
-    double s2 = wave_sum_f64((double)sf2);
+    const double s = wave_sum_f64((double)sf);
+    const double s2 = wave_sum_f64((double)sf2);
     if (lane == 0) {
       sh.red_d[wave] = s;
       sh.red_e[wave] = s2;
@@ -322,7 +695,7 @@ __device__ __forceinline__ void reward_one_env(const SdcDev& S, RewardShared& sh
     z = (energy - mean) / (sd > 0 ? sd : 1.0);
   }
 
-  // ---- rewards (utils/reward_creator.py:48-130), running episode return -------------------------------
+  // ---- rewards (utils/reward_creator.py:48-130), running episode return, tracker write-back -------------------------
   if (tid == 0) {
     const double foot = -1.0 * (norm_ci_next * z / 0.50);
     const double overdue_pen = -0.3 * sqrt(overdue) + 0.3;
@@ -334,26 +707,28 @@ __device__ __forceinline__ void reward_one_env(const SdcDev& S, RewardShared& sh
     rew[env * 3 + 2] = (float)foot;
     const double r0 = rec_f64(hd, H_RET) + rls, r1 = rec_f64(hd, H_RET + 2) + foot, r2 = rec_f64(hd, H_RET + 4) + foot;
     unsigned* hw = S.hdr + (size_t)env * SDC_HDR_DWORDS;
-    hw[H_G1] = ng1;
-    hw[H_G3] = ng3;
     double* hr = reinterpret_cast<double*>(hw + H_RET);
     hr[0] = r0;
     hr[1] = r1;
     hr[2] = r2;
+    qt_store(q1, hw + H_Q1);
+    qt_store(q3, hw + H_Q3);
+    if (mismatch) hw[H_STICKY] = (unsigned)rec_i32(hd, H_STICKY) | 1u;
     if (info) {
       float* inf = info + (size_t)env * SDC_INFO_DIM;
       inf[SDC_INFO_ENERGY_Z] = (float)z;
-      inf[SDC_INFO_RESERVED] = used_fallback ? 1.0f : 0.0f;   // diagnostic: order statistics came from the bisection fallback
+      inf[SDC_INFO_RESERVED] = (float)path;   // diagnostic: 0 tracker, 1 slide, 2 bisection + rebuild
       inf[SDC_INFO_EP_RETURN_LS] = (float)r0;
       inf[SDC_INFO_EP_RETURN_DC] = (float)r1;
       inf[SDC_INFO_EP_RETURN_BAT] = (float)r2;
+      if (mismatch) inf[SDC_INFO_FAULT] = (float)((unsigned)inf[SDC_INFO_FAULT] | mismatch);
     }
   }
 }
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev S, float* __restrict__ rew,
+extern "C" __global__ __launch_bounds__(SDC_BLOCK, 5) void sdc_reward_kernel(SdcDev S, float* __restrict__ rew,
                                                                            float* __restrict__ info) {
   __shared__ RewardShared sh;
   const int env = blockIdx.x;
@@ -374,6 +749,6 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK) void sdc_reward_kernel(SdcDev
       key[4 * q + 3] = v.w;
     }
   }
-  const unsigned hd = S.hdr[(size_t)env * SDC_HDR_DWORDS + (lane & (SDC_HDR_DWORDS - 1))];
+  const unsigned hd = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];
   reward_one_env(S, sh, env, key, hd, rew, info, tid, lane, wave);
 }

@@ -20,12 +20,13 @@ _STATE_DTYPES = {
     "last_delta": (np.int32, 1), "consecutive": (np.int32, 1), "scale": (np.int32, 1),
     "hist_len": (np.int32, 1), "hist_pos": (np.int32, 1), "episode": (np.int32, 1), "fault": (np.uint32, 1),
     "loc_id": (np.int32, 1), "cfg_id": (np.int32, 1), "day_lo": (np.int32, 1), "day_hi": (np.int32, 1),
-    "hist_n": (np.int32, 1),
+    "hist_n": (np.int32, 1), "order_stat_sticky": (np.uint32, 1),
     "stpt": (np.float64, 1), "bat_load": (np.float64, 1), "ci_min": (np.float64, 1), "ci_den": (np.float64, 1),
     "t_min": (np.float64, 1), "t_den": (np.float64, 1), "hist_ref": (np.float64, 1),
 }
 # a full checkpoint: the raw records + every array the kernels own
-_CHECKPOINT = ["record", "header", "hist", "t_win", "wb_win", "qtab"]
+# "hist" first: injecting the ring drops the order-statistic trackers, which "header" then restores
+_CHECKPOINT = ["hist", "record", "header", "t_win", "wb_win", "qtab"]
 
 
 def dc_params_struct(p: dict) -> L.SdcDcParams:
@@ -55,7 +56,7 @@ class SdcEngine:
     def __init__(self, n_envs: int, episode_steps: int = 672, device: int = 0, n_locations: int = 1,
                  n_dc_configs: int = 1, auto_reset: bool = True, seed: int = 0, hist_cap: int = 10000,
                  queue_max_len: int = 1000, weather_noise_std: float = 0.75, weather_noise_weight: float = 0.02,
-                 max_roll_days: int = 14):
+                 max_roll_days: int = 14, debug_flags: int = 0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("SdcEngine needs an MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is False); "
@@ -70,7 +71,7 @@ class SdcEngine:
                           hist_cap=hist_cap, queue_max_len=queue_max_len, n_locations=n_locations,
                           n_dc_configs=n_dc_configs, auto_reset=1 if auto_reset else 0, seed=seed,
                           weather_noise_std=weather_noise_std, weather_noise_weight=weather_noise_weight,
-                          max_roll_days=max_roll_days, reserved=0)
+                          max_roll_days=max_roll_days, debug_flags=debug_flags)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             torch.cuda.init()
@@ -179,10 +180,8 @@ class SdcEngine:
             return np.zeros((N, 64), dtype=np.uint32)
         if name == "ep_return":
             return np.zeros((N, 3), dtype=np.float64)
-        if name == "q_guess":
-            return np.zeros((N, 2), dtype=np.uint32)
         if name == "header":
-            return np.zeros((N, 16), dtype=np.uint32)
+            return np.zeros((N, 64), dtype=np.uint32)
         raise KeyError(name)
 
     def get_state(self, name: str) -> np.ndarray:

@@ -84,6 +84,7 @@ enum sdc_info_col {
 #define SDC_FAULT_BAT_DISCHARGE 4u /* envs/bat_env_fwd_view.py:237 asserts */
 #define SDC_FAULT_WORKLOAD 8u      /* envs/carbon_ls.py:333-336 raises */
 #define SDC_FAULT_TABLE_RANGE 16u  /* cursor would leave the year table (reference: IndexError) */
+#define SDC_FAULT_ORDER_STAT 32u   /* debug_flags bit 0: tracked order statistics disagreed with the bisection */
 
 typedef struct sdc_handle sdc_handle;
 
@@ -101,7 +102,8 @@ typedef struct {
   double weather_noise_std;   /* 0.75 (utils/managers.py:504) ; 0 disables the noise */
   double weather_noise_weight;/* 0.02 (utils/managers.py:504) */
   int32_t max_roll_days;   /* 14: roll in [0, 14) days (utils/managers.py:601) */
-  int32_t reserved;
+  int32_t debug_flags;     /* bit 0: verify the incrementally tracked order statistics against an exact
+                              bisection every step (slow; a mismatch sets SDC_FAULT_ORDER_STAT) */
 } sdc_config;
 
 /* replaces: DC_Config + Rack/CPU constants + sized HVAC values
@@ -182,8 +184,8 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
  * int32[N]:  cursor t_rel day hourq q_popped q_cum q_cumT q_head q_cum_hm1 q_cumT_hm1 last_delta consecutive
  *            scale hist_len hist_pos episode fault loc_id cfg_id day_lo day_hi hist_n
  * double[N]: stpt bat_load ci_min ci_den t_min t_den hist_ref
- * record (uint32[N][64], the raw 256-byte state records);  header (uint32[N][16], the hand-off headers);
- * ep_return (double[N][3]);  q_guess (uint32[N][2]);
+ * record (uint32[N][64], the raw 256-byte state records);  header (uint32[N][64], the hand-off headers);
+ * ep_return (double[N][3]);
  * hist (float[N][hist_stride], energy minus hist_ref, NaN = empty slot: every slot >= hist_len must be NaN);
  * t_win wb_win (double[N][weather_window_len]);  qtab (uint32[N][queue_stride][2]). */
 int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes);

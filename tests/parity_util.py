@@ -42,7 +42,7 @@ class ParityRig:
     """N envs on the engine + N scalar oracle envs fed the same inputs."""
 
     def __init__(self, n_envs, episode_steps=672, seed=0, locations=("ny",), dc_files=("dc_config.json",),
-                 capacity_mw=1.0, months=None, hist_cap=10000, with_oracle=True, oracle_envs=None):
+                 capacity_mw=1.0, months=None, hist_cap=10000, with_oracle=True, oracle_envs=None, debug_flags=1):
         self.N = n_envs
         self.steps = episode_steps
         self.rng = np.random.default_rng(seed)
@@ -53,7 +53,7 @@ class ParityRig:
             ci_loc, _ = traces.obtain_paths(locations[li])
             self.params.append(dc_config.size_datacenter(f, capacity_mw, traces.max_ambient_for_sizing(ci_loc)))
         self.eng = SdcEngine(n_envs, episode_steps=episode_steps, auto_reset=False, n_locations=len(locations),
-                             n_dc_configs=len(combos), seed=seed, hist_cap=hist_cap)
+                             n_dc_configs=len(combos), seed=seed, hist_cap=hist_cap, debug_flags=debug_flags)
         for li, tb in enumerate(self.tables):
             self.eng.set_tables(li, tb["W"], tb["C"], tb["T"], tb["WB"])
         for ci, p in enumerate(self.params):

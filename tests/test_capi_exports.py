@@ -37,7 +37,7 @@ def test_fails_loudly_without_gpu_or_bad_args():
     h = C.c_void_p()
     cfg = L.SdcConfig(n_envs=0, device=0, episode_steps=672, hist_cap=10000, queue_max_len=1000, n_locations=1,
                       n_dc_configs=1, auto_reset=1, seed=0, weather_noise_std=0.75, weather_noise_weight=0.02,
-                      max_roll_days=14)
+                      max_roll_days=14, debug_flags=0)
     assert lib.sdc_create(C.byref(cfg), C.byref(h)) != 0
     assert b"n_envs" in lib.sdc_last_error()
     if not torch.cuda.is_available():

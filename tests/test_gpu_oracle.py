@@ -58,6 +58,45 @@ def test_full_history_ring_vs_oracle():
     rig.eng.close()
 
 
+def test_order_statistic_tracker_stress():
+    """The O(1) order-statistic trackers of the reward kernel against the exact bisection (debug_flags bit 0) on
+    histories built to stress them: heavy duplicates, monotone drifts, constant runs, values straddling zero (sign
+    change of the fp32 offsets), a small history capacity so evictions start early."""
+    import torch
+    N, steps, cap = 64, 96, 257
+    rig = P.ParityRig(N, episode_steps=steps, seed=21, hist_cap=cap, with_oracle=False)
+    eng = rig.eng
+    rng = np.random.default_rng(21)
+    hist = np.full((N, eng.hist_stride), np.nan, np.float32)
+    L0 = 200
+    base = rng.standard_normal((N, L0)).astype(np.float32) * 40
+    base[0::4] = np.round(base[0::4] / 20) * 20            # few distinct values
+    base[1::4] = np.sort(base[1::4], axis=1)               # monotone
+    base[2::4, 50:150] = 7.0                               # long constant run
+    hist[:, :L0] = base
+    eng.set_state("hist", hist)
+    eng.set_state("hist_len", np.full(N, L0, np.int32))
+    eng.set_state("hist_pos", np.zeros(N, np.int32))
+    rig.reset_all()
+    paths = np.zeros(3, np.int64)
+    for ep in range(6):
+        for t in range(steps):
+            a = torch.randint(0, 3, (N, 3), dtype=torch.int32, device=eng.device)
+            if ep % 2 == 1:
+                a[:, :] = 1
+                a[:, 2] = 2                                # idle policy: near-constant energies -> duplicates
+            obs, share, rew, done, info = eng.step(a)
+            inf = info.cpu().numpy()
+            assert (inf[:, L.INFO_IDX["fault"]] == 0).all(), (ep, t, inf[:, L.INFO_IDX["fault"]])
+            paths += np.bincount(inf[:, 39].astype(int), minlength=3)[:3]
+        rig.reset_all()
+    assert (eng.get_state("order_stat_sticky") == 0).all()
+    assert (eng.get_state("hist_len") == cap).all()
+    print("tracker paths (tracker-only, anchor slide, bisection + rebuild):", paths)
+    assert paths[0] > 3 * paths[1]                         # the window usually answers without a sweep
+    eng.close()
+
+
 def test_device_reset_and_auto_reset():
     """Device-side reset (Philox draws, coherent noise, roll, clip, 30-day min/max): distributional checks and
     the reset observation recomputed by the oracle from the windows the device produced."""

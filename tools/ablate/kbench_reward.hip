@@ -74,6 +74,10 @@ int main(int argc, char** argv) {
     }
     unsigned* h = &hdr[(size_t)e * SDC_HDR_DWORDS];
     h[H_N] = 10000;
+    // steady-state emulation: the "new" key equals the "evicted" key (ring unchanged between launches), so the
+    // order-statistic trackers stay valid after the bootstrap launch and the timed launches take the fast path
+    h[H_XNEW] = hist[(size_t)e * SDC_HIST_STRIDE + 17];
+    h[H_XOLD] = hist[(size_t)e * SDC_HIST_STRIDE + 17];
     double eo = 12.5, nci = 0.4, old = 0.1;
     std::memcpy(h + H_EOFF, &eo, 8); std::memcpy(h + H_NORM_CI, &nci, 8); std::memcpy(h + H_OLDEST, &old, 8);
   }
@@ -88,8 +92,13 @@ int main(int argc, char** argv) {
   CK(hipStreamSynchronize(st));
   std::vector<float> inf((size_t)N * SDC_INFO_DIM);
   CK(hipMemcpy(inf.data(), info, inf.size() * 4, hipMemcpyDeviceToHost));
-  int fb = 0; for (int e = 0; e < N; e++) fb += inf[(size_t)e * SDC_INFO_DIM + SDC_INFO_RESERVED] != 0;
-  printf("N=%d  fallbacks on the timed path: %d  bytes/launch=%.1f MB\n", N, fb, N * 40124.0 / 1e6);
+  int p1 = 0, p2 = 0;
+  for (int e = 0; e < N; e++) {
+    p1 += inf[(size_t)e * SDC_INFO_DIM + SDC_INFO_RESERVED] == 1.f;
+    p2 += inf[(size_t)e * SDC_INFO_DIM + SDC_INFO_RESERVED] == 2.f;
+  }
+  printf("N=%d  envs on the rebuild / bisection path in the timed launches: %d / %d   bytes/launch=%.1f MB\n", N, p1, p2,
+         N * 40124.0 / 1e6);
   float tf = time_kernel("full", iters, st, [&] { hipLaunchKernelGGL(sdc_reward_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, S, rew, info); });
   float tr = time_kernel("read", iters, st, [&] { hipLaunchKernelGGL(k_read, dim3(N), dim3(SDC_BLOCK), 0, st, S, sink); });
   float tc = time_kernel("compute", iters, st, [&] { hipLaunchKernelGGL(k_compute, dim3(N), dim3(SDC_BLOCK), 0, st, S, rew, info); });
