@@ -5,7 +5,8 @@
 //     caller (parity tests feed what the reference's managers produced);
 //   * device:   the draws of sustaindc_env.py:454-455 and utils/managers.py:35-48, :596-613 are made on the
 //     GPU with a counter-based RNG (Philox4x32-10): start day / hour, the 0..13-day roll, and the
-//     35 040-step Gaussian random walk scaled to std 0.75 that is added to dry and wet bulb before
+//     35 040-step Gaussian random walk (fp32 Box-Muller, fp64 accumulation) scaled to std 0.75 that is added
+//     to dry and wet bulb before
 //     the roll, clip to [0, 45] and 30-day min/max normalisation.  Same distributions as the reference,
 //     not the same stream (the reference uses MT19937 via `random` and `np.random`).
 //
@@ -33,14 +34,20 @@ __device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
   return v;
 }
 
-// one standard normal per (env, episode, idx): Box-Muller on a Philox block shared by an index pair
-__device__ __forceinline__ double normal_at(const SdcDev& S, int env, int episode, int idx) {
-  const Philox4 r = philox4x32_10((unsigned)(idx >> 1), (unsigned)env, (unsigned)episode, 0x7E47u, (unsigned)S.seed,
+// four standard normals per Philox4x32-10 block: two Box-Muller pairs in fp32 (hardware log2 / sin / cos); the
+// random walk itself is accumulated in fp64.  Block c of (env, episode) yields the normals of samples 4c .. 4c+3.
+__device__ __forceinline__ void normals4(const SdcDev& S, int env, int episode, int c, float (&nz)[4]) {
+  const Philox4 r = philox4x32_10((unsigned)c, (unsigned)env, (unsigned)episode, 0x7E47u, (unsigned)S.seed,
                                   (unsigned)(S.seed >> 32));
-  const double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
-  const double rad = sqrt(-2.0 * log(u1));
-  const double ang = 6.283185307179586 * u2;
-  return (idx & 1) ? rad * sin(ang) : rad * cos(ang);
+  const float k24 = 1.0f / 16777216.0f;
+  const float u1 = ((float)(r.x >> 8) + 0.5f) * k24, u2 = ((float)(r.y >> 8) + 0.5f) * k24;   // (0, 1)
+  const float u3 = ((float)(r.z >> 8) + 0.5f) * k24, u4 = ((float)(r.w >> 8) + 0.5f) * k24;
+  const float r1 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+  const float r2 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
+  nz[0] = r1 * __builtin_amdgcn_cosf(u2);   // v_cos_f32 / v_sin_f32 take revolutions: cos(2 pi u)
+  nz[1] = r1 * __builtin_amdgcn_sinf(u2);
+  nz[2] = r2 * __builtin_amdgcn_cosf(u4);
+  nz[3] = r2 * __builtin_amdgcn_sinf(u4);
 }
 
 }  // namespace
@@ -101,21 +108,36 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     double* walk = S.walk_tmp + (size_t)env * max(SDC_NORM_WINDOW, S.lw);
     double walk_std = 0.0;
     if (S.noise_std > 0.0) {
-      // pass 1: CoherentNoise.generate (managers.py:35-48): random walk, its population std
+      // pass 1: CoherentNoise.generate (managers.py:35-48): random walk, its population std.
+      // 256 samples per iteration: 4 per lane (one Philox block), lane-local prefix + wave scan of the lane totals.
       double carry = 0.0, sum = 0.0, sumsq = 0.0;
-      for (int base = 0; base < TL; base += SDC_WAVE) {
-        const int j = base + lane;
-        const double step = j < TL ? S.noise_weight * normal_at(S, env, episode, j) : 0.0;
-        const double w = carry + wave_incl_scan_f64(step, lane);
-        carry = __shfl(w, 63);
-        if (j < TL) {
-          sum += w;
-          sumsq += w * w;
-          // base index j lands at rolled position (j + shift) mod TL (np.roll, managers.py:602)
-          int pos = j + shift;
-          if (pos >= TL) pos -= TL;
-          const int rel = pos - c0;
-          if (rel >= 0 && rel < wlen) walk[rel] = w;
+      for (int base = 0; base < TL; base += 4 * SDC_WAVE) {
+        float nz[4];
+        normals4(S, env, episode, (base >> 2) + lane, nz);
+        const int j0 = base + 4 * lane;
+        double p[4];
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          acc += (j0 + k < TL) ? S.noise_weight * (double)nz[k] : 0.0;
+          p[k] = acc;
+        }
+        const double incl = wave_incl_scan_f64(acc, lane);
+        const double off = carry + (incl - acc);
+        carry += __shfl(incl, 63);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int j = j0 + k;
+          if (j < TL) {
+            const double w = off + p[k];
+            sum += w;
+            sumsq += w * w;
+            // base index j lands at rolled position (j + shift) mod TL (np.roll, managers.py:602)
+            int pos = j + shift;
+            if (pos >= TL) pos -= TL;
+            const int rel = pos - c0;
+            if (rel >= 0 && rel < wlen) walk[rel] = w;
+          }
         }
       }
       sum = wave_sum_f64(sum);
