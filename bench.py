@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--mixed-racks", action="store_true", help="BASELINE configs[3]: 16/20/25-rack mix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fill", action="store_true", help="skip the history fill (debug only; invalid as a result)")
+    ap.add_argument("--profile-every", type=int, default=8, help="record per-kernel HIP events every k-th step (0 = off)")
     args = ap.parse_args()
 
     import torch
@@ -177,7 +178,7 @@ def main():
         one_step(i)
     hlen = int(eng.get_state("hist_len").min())
 
-    eng.profile(True)          # HIP events on the launch stream around each kernel (first 4096 timed steps)
+    eng.profile(args.profile_every)   # HIP events on the launch stream around each kernel of every k-th timed step
     eng.profile_read(reset=True)
     if world > 1:
         dist.barrier()
@@ -190,6 +191,12 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = eng.profile_read(reset=True)
+    if prof["steps"] == 0:     # profiling was off in the timed region: sample the kernels in a short extra pass
+        eng.profile(1)
+        for i in range(64):
+            one_step(i)
+        prof = eng.profile_read(reset=True)
+        eng.profile(0)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

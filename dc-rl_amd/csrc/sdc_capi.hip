@@ -69,15 +69,19 @@ struct sdc_handle {
   int pending = 0;              // steps launched since then (every env advances by one per step)
   int steps_to_terminal = 0;
   bool tables_set = false, assigned = false, started = false;
-  // optional per-kernel timing (HIP events on the launch stream)
-  bool prof = false;
-  std::vector<hipEvent_t> ev;      // 3 per step: before dynamics, between, after reward
-  std::vector<hipEvent_t> ev_rst;  // 2 per auto-reset
-  size_t ev_used = 0, ev_rst_used = 0;
-  double acc_ms[5] = {0, 0, 0, 0, 0};
+  // optional per-kernel timing: the kernels stamp the device wall clock per workgroup into one slot per sampled step
+  int prof = 0;       // sample every `prof`-th step (0 = off)
+  long prof_tick = 0;
+  unsigned long long* prof_buf = nullptr;  // [PROF_SLOTS][3][N][2]
+  int prof_used = 0;
+  std::vector<unsigned char> prof_has_reset;
+  double wall_clock_khz = 100000.0;
+  double acc_ms[5] = {0, 0, 0, 0, 0};      // dynamics, reward, reset, steps, resets
 };
 
 namespace {
+
+constexpr int PROF_SLOTS = 256;
 
 template <typename T>
 int dev_alloc(sdc_handle* h, T** p, size_t count, bool zero = true) {
@@ -259,8 +263,6 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
 int sdc_destroy(sdc_handle* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
-  for (auto& e : h->ev) (void)hipEventDestroy(e);
-  for (auto& e : h->ev_rst) (void)hipEventDestroy(e);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return 0;
@@ -390,16 +392,15 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int N = h->cfg.n_envs;
-  const bool timed = h->prof && h->ev_used + 3 <= h->ev.size();
-  if (timed) (void)hipEventRecord(h->ev[h->ev_used], st);
-  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(N), dim3(SDC_WAVE), 0, st, h->d, actions, obs, share_obs, done, info,
-                     final_obs);
-  if (timed) (void)hipEventRecord(h->ev[h->ev_used + 1], st);
-  hipLaunchKernelGGL(sdc_reward_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, h->d, rew, info);
+  const bool timed = h->prof > 0 && (h->prof_tick++ % h->prof) == 0 && h->prof_used < PROF_SLOTS;
+  SdcDev d = h->d;
   if (timed) {
-    (void)hipEventRecord(h->ev[h->ev_used + 2], st);
-    h->ev_used += 3;
+    d.prof_ts = h->prof_buf + (size_t)h->prof_used * 3 * N * 2;
+    h->prof_has_reset[h->prof_used] = 0;
   }
+  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, actions, obs, share_obs, done, info,
+                     final_obs);
+  hipLaunchKernelGGL(sdc_reward_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, rew, info);
   HIP_TRY(hipGetLastError());
   h->steps_to_terminal -= 1;
   h->pending += 1;
@@ -409,35 +410,32 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
     sync_mirror(h);
     if (h->cfg.auto_reset) {
       // harl/envs/env_wrappers.py:176-190: reset inside the same step call and return the reset obs
-      SdcDev d = h->d;
       d.reset_mask = nullptr;
-      const bool rt = h->prof && h->ev_rst_used + 2 <= h->ev_rst.size();
-      if (rt) (void)hipEventRecord(h->ev_rst[h->ev_rst_used], st);
+      if (timed) h->prof_has_reset[h->prof_used] = 1;
       hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
                          h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs, share_obs);
-      if (rt) {
-        (void)hipEventRecord(h->ev_rst[h->ev_rst_used + 1], st);
-        h->ev_rst_used += 2;
-      }
       HIP_TRY(hipGetLastError());
       for (int e = 0; e < N; e++)
         if (h->host_t_rel[e] >= h->cfg.episode_steps) h->host_t_rel[e] = 0;
       recompute_steps_to_terminal(h);
     }
   }
+  if (timed) h->prof_used += 1;
   return 0;
 }
 
 int sdc_profile_enable(sdc_handle* h, int enable) {
   if (!h) return fail_msg("sdc_profile_enable: null handle");
   HIP_TRY(hipSetDevice(h->device));
-  if (enable && h->ev.empty()) {
-    h->ev.resize(3 * 4096);
-    for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
-    h->ev_rst.resize(2 * 64);
-    for (auto& e : h->ev_rst) HIP_TRY(hipEventCreate(&e));
+  if (enable > 0 && !h->prof_buf) {
+    if (dev_alloc(h, &h->prof_buf, (size_t)PROF_SLOTS * 3 * h->cfg.n_envs * 2) != 0) return -1;
+    h->prof_has_reset.assign(PROF_SLOTS, 0);
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) == hipSuccess && khz > 0)
+      h->wall_clock_khz = khz;
   }
-  h->prof = enable != 0;
+  h->prof = enable > 0 ? enable : 0;
+  h->prof_tick = 0;
   return 0;
 }
 
@@ -445,21 +443,26 @@ int sdc_profile_read(sdc_handle* h, double* out5, int reset) {
   if (!h || !out5) return fail_msg("sdc_profile_read: null argument");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
-  for (size_t i = 0; i + 3 <= h->ev_used; i += 3) {
-    float a = 0, b = 0;
-    HIP_TRY(hipEventElapsedTime(&a, h->ev[i], h->ev[i + 1]));
-    HIP_TRY(hipEventElapsedTime(&b, h->ev[i + 1], h->ev[i + 2]));
-    h->acc_ms[0] += a;
-    h->acc_ms[1] += b;
-    h->acc_ms[3] += 1;
+  const size_t N = (size_t)h->cfg.n_envs;
+  if (h->prof_used > 0) {
+    std::vector<unsigned long long> ts((size_t)h->prof_used * 3 * N * 2);
+    HIP_TRY(hipMemcpy(ts.data(), h->prof_buf, ts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int s = 0; s < h->prof_used; s++) {
+      for (int k = 0; k < 3; k++) {
+        if (k == SDC_PROF_RESET && !h->prof_has_reset[s]) continue;
+        const unsigned long long* p = ts.data() + ((size_t)s * 3 + k) * N * 2;
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        for (size_t e = 0; e < N; e++) {
+          t0 = std::min(t0, p[2 * e]);
+          t1 = std::max(t1, p[2 * e + 1]);
+        }
+        h->acc_ms[k] += (double)(t1 - t0) / h->wall_clock_khz;   // first workgroup in -> last workgroup out
+      }
+      h->acc_ms[3] += 1;
+      h->acc_ms[4] += h->prof_has_reset[s];
+    }
+    h->prof_used = 0;
   }
-  for (size_t i = 0; i + 2 <= h->ev_rst_used; i += 2) {
-    float a = 0;
-    HIP_TRY(hipEventElapsedTime(&a, h->ev_rst[i], h->ev_rst[i + 1]));
-    h->acc_ms[2] += a;
-    h->acc_ms[4] += 1;
-  }
-  h->ev_used = h->ev_rst_used = 0;
   for (int i = 0; i < 5; i++) out5[i] = h->acc_ms[i];
   if (reset)
     for (int i = 0; i < 5; i++) h->acc_ms[i] = 0;

@@ -108,7 +108,15 @@ struct SdcDev {
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
   unsigned* hdr;     // [N][SDC_HDR_DWORDS] dynamics -> reward kernel hand-off + reward-kernel state (see SdcHdr)
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
+  unsigned long long* prof_ts;  // measurement only: [3 kernels][N][2] wall-clock stamps of this launch, or nullptr
 };
+
+// per-kernel timing without host events: one lane per workgroup stamps the constant-rate wall clock at entry and
+// exit; the host takes min(entry) / max(exit) over the workgroups of a sampled launch (sdc_profile_read)
+enum { SDC_PROF_DYNAMICS = 0, SDC_PROF_REWARD = 1, SDC_PROF_RESET = 2 };
+__device__ __forceinline__ void prof_stamp(const SdcDev& S, int kernel, int env, int which) {
+  if (S.prof_ts) S.prof_ts[((size_t)kernel * S.n_envs + env) * 2 + which] = wall_clock64();
+}
 
 // record field access: every lane holds dword `lane` of the record in `r`
 __device__ __forceinline__ int rec_i32(unsigned r, int idx) { return (int)__builtin_amdgcn_readlane((int)r, idx); }

@@ -434,6 +434,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   const int lane = threadIdx.x;
   const int N = S.n_envs;
   const int TL = S.table_len;
+  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 0);
 
   // ---- level 0: state record (coalesced) + actions ---------------------------------------------------------------
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
@@ -504,6 +505,9 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   }
   if (share_obs && lane < SDC_SHARE_OBS_DIM) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = sh.pool[lane];
   if (info && lane < SDC_INFO_DIM) info[(size_t)env * SDC_INFO_DIM + lane] = sh.info[lane];
-  if (lane == 0) done[env] = (unsigned char)terminal;
+  if (lane == 0) {
+    done[env] = (unsigned char)terminal;
+    prof_stamp(S, SDC_PROF_DYNAMICS, env, 1);
+  }
   (void)N;
 }

@@ -64,6 +64,10 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
   __shared__ ResetShared sh;
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
+  if (lane == 0) {   // measurement: workgroups that return early still bracket the launch
+    prof_stamp(S, SDC_PROF_RESET, env, 0);
+    prof_stamp(S, SDC_PROF_RESET, env, 1);
+  }
   if (S.reset_mask && !S.reset_mask[env]) return;
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
   const unsigned r = recp[lane];  // the env's state record, one dword per lane
@@ -242,4 +246,5 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     if (lane < SDC_OBS_OUT - 64) obs[(size_t)env * SDC_OBS_OUT + 64 + lane] = obs_padded_at(sh.obs, 64 + lane);
   }
   if (share_obs && lane < SDC_SHARE_OBS_DIM) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = share_obs_at(sh.obs, lane);
+  if (lane == 0) prof_stamp(S, SDC_PROF_RESET, env, 1);
 }

@@ -728,13 +728,14 @@ __device__ __forceinline__ void reward_one_env(const SdcDev& S, RewardShared& sh
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(SDC_BLOCK, 5) void sdc_reward_kernel(SdcDev S, float* __restrict__ rew,
+extern "C" __global__ __launch_bounds__(SDC_BLOCK, 4) void sdc_reward_kernel(SdcDev S, float* __restrict__ rew,
                                                                            float* __restrict__ info) {
   __shared__ RewardShared sh;
   const int env = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  if (tid == 0) prof_stamp(S, SDC_PROF_REWARD, env, 0);
 
   // ---- stream the ring: every load of the workgroup is in flight before the first use -------------------------
   unsigned key[SDC_HIST_PER_THREAD];
@@ -751,4 +752,5 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK, 5) void sdc_reward_kernel(Sdc
   }
   const unsigned hd = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];
   reward_one_env(S, sh, env, key, hd, rew, info, tid, lane, wave);
+  if (tid == 0) prof_stamp(S, SDC_PROF_REWARD, env, 1);
 }

@@ -202,9 +202,9 @@ class SdcEngine:
         for n, v in sd.items():
             self.set_state(n, v)
 
-    def profile(self, enable: bool = True):
-        """Per-kernel HIP-event timing on the launch stream (measurement only)."""
-        L.check(self.lib.sdc_profile_enable(self._h, 1 if enable else 0))
+    def profile(self, every: int = 1):
+        """Per-kernel HIP-event timing on the launch stream (measurement only): every k-th step, 0 = off."""
+        L.check(self.lib.sdc_profile_enable(self._h, int(every)))
 
     def profile_read(self, reset: bool = True) -> dict:
         out = (C.c_double * 5)()

@@ -193,11 +193,12 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
 int sdc_hist_stride(const sdc_handle* h);
 int sdc_queue_stride(const sdc_handle* h);
 
-/* Per-kernel timing with HIP events recorded on the launch stream around each kernel of sdc_step
- * (measurement only; off by default).  sdc_profile_read synchronises the device and returns accumulated
- * milliseconds since the last read with reset != 0:
+/* Per-kernel timing (measurement only; off by default).  enable = k > 0 samples every k-th sdc_step, 0 switches it
+ * off.  In a sampled step one lane per workgroup of each kernel stamps the device's constant-rate wall clock at
+ * entry and exit; sdc_profile_read synchronises the device and accumulates, per sampled launch,
+ * max(exit) - min(entry) over the workgroups -- the launch's duration on the GPU, with no host-event overhead.
  *   out[0] = sdc_dynamics_kernel total ms, out[1] = sdc_reward_kernel total ms,
- *   out[2] = sdc_reset_kernel (auto-reset) total ms, out[3] = steps measured, out[4] = auto-resets measured. */
+ *   out[2] = sdc_reset_kernel (auto-reset) total ms, out[3] = steps sampled, out[4] = auto-resets sampled. */
 int sdc_profile_enable(sdc_handle* h, int enable);
 int sdc_profile_read(sdc_handle* h, double* out5, int reset);
 
