@@ -233,7 +233,7 @@ def main():
                        "envs_per_gpu": N, "episode_steps": args.episode_steps, "history_len": hlen,
                        "history_fill_steps": fill, "auto_reset": True, "actions": "uniform {0,1,2}, device-resident",
                        "parallelism": f"env-shard x{world}", "faults": faults,
-                       "order_stat_paths_last_step": {"rebuild_sweep": fallbacks[0], "bisection": fallbacks[1]}},
+                       "ring_read_envs_last_step": {"slide_or_reanchor": fallbacks[0], "bisection_rebuild": fallbacks[1]}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": "sdc_reward_kernel", "kernel_avg_us": round(k_rew * 1e6, 2),

@@ -16,6 +16,7 @@ OBS_PAD = 26
 SHARE_OBS_DIM = 29
 INFO_DIM = 44
 TABLE_LEN = 35040
+HDR_DWORDS = 128   # csrc/sdc_device.hpp SdcHdr: 512-byte per-env hand-off header
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")

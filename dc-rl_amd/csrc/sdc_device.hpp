@@ -67,8 +67,8 @@ enum SdcRec {
   SDC_REC_DWORDS = 64
 };
 
-// 256-byte per-env hand-off header (one dword per lane): written by the dynamics kernel (N .. OLDEST) and by the
-// reward kernel (RET, the two order-statistic trackers); every wavefront of the reward workgroup loads it whole.
+// 512-byte per-env hand-off header (two dwords per lane): written by the dynamics kernel (N .. OLDEST) and by the
+// reward kernel (RET, the order-statistic and tail trackers); every wavefront of the reward workgroup loads it whole.
 enum SdcHdr {
   H_N = 0,        // history length including this step's value
   H_OVERDUE,      // ls_overdue_penalty (int)
@@ -81,10 +81,13 @@ enum SdcHdr {
   H_Q1 = 16,      // order-statistic tracker of the lower quartile (SdcTrack, 13 dwords)
   H_Q3 = 32,      // ... of the upper quartile
   H_STICKY = 48,  // sticky diagnostics (bit 0: a verify-mode mismatch was seen)
-  SDC_HDR_DWORDS = 64
+  H_LO = 64,      // tail tracker at the lower clip bound (SdcTrack + T_SUM1 / T_SUM2)
+  H_HI = 96,      // ... at the upper clip bound
+  SDC_HDR_DWORDS = 128
 };
-// tracker: a window of consecutive order statistics of the history around anchor key G
-enum SdcTrack { T_G = 0, T_CLT, T_CLE, T_NP, T_NS, T_P = 5, T_S = 9, SDC_TRACK_DWORDS = 13 };
+// tracker: a window of consecutive order statistics of the history around anchor key G; the tail trackers also
+// carry the fp64 sums of v and v^2 over the keys <= G
+enum SdcTrack { T_G = 0, T_CLT, T_CLE, T_NP, T_NS, T_P = 5, T_S = 9, SDC_TRACK_DWORDS = 13, T_SUM1 = 14, T_SUM2 = 16 };
 #define SDC_QW 4   // cached neighbours on each side of the anchor
 
 struct SdcDev {
@@ -107,6 +110,9 @@ struct SdcDev {
   double* walk_tmp;  // [N][max(SDC_NORM_WINDOW, lw)] scratch of the device-side reset
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
   unsigned* hdr;     // [N][SDC_HDR_DWORDS] dynamics -> reward kernel hand-off + reward-kernel state (see SdcHdr)
+  unsigned* work_cnt;   // [2] number of envs queued for the ring path of sdc_reward_kernel, by step parity
+  unsigned* work_list;  // [N] their indices
+  int step_parity;
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
   unsigned long long* prof_ts;  // measurement only: [3 kernels][N][2] wall-clock stamps of this launch, or nullptr
 };

@@ -18,7 +18,7 @@
 // (sdc_reward.hip) through a 64-byte per-env header; the energy is appended to the history ring here.
 //
 // Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
-#include "sdc_device.hpp"
+#include "sdc_trackers.hpp"
 
 namespace {
 
@@ -68,7 +68,8 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 // the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
 __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_params& P, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
-                                              unsigned fault, const unsigned x_old, DynShared& sh) {
+                                              unsigned fault, const unsigned x_old, const unsigned hd0, const unsigned hd1,
+                                              float* __restrict__ rew, DynShared& sh) {
   const int i = rec_i32(r, R_CURSOR);
   const int rel = rec_i32(r, R_TREL);
   const int day = rec_i32(r, R_DAY);
@@ -317,6 +318,24 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     build_obs_pool(nc, nt, o, sh.pool, lane);
   }
 
+  // ---- history append (utils/reward_creator.py:7-14) --------------------------------------------------------
+  // The ring holds fp32 OFFSETS from the env's first energy value (kept in fp64): normalize_energy is
+  // shift-invariant, and offsets keep the fp32 rounding error proportional to the spread of the history
+  // instead of to the ~300 kWh magnitude (two nearly equal energies would otherwise lose the z-score).
+  // Stored as order-preserving keys for the order-statistic trackers.
+  int hl = rec_i32(r, R_HIST_LEN), hpos = rec_i32(r, R_HIST_POS);
+  const double href = hl == 0 ? energy : rec_f64(r, R_HIST_REF);
+  const double e_off = energy - href;
+  int slot;
+  if (hl < S.hist_cap) {
+    slot = hl;
+    hl += 1;
+  } else {
+    slot = hpos;
+    hpos = hpos + 1 == S.hist_cap ? 0 : hpos + 1;
+  }
+  const unsigned x_new = sdc_rw::sfl(sdc_f32_key(__float_as_uint((float)e_off)));
+
   // every lane keeps its own dword of the record; lane 0 patches the fields that changed (below)
   sh.rec[lane] = r;
   __syncthreads();
@@ -365,33 +384,8 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     inf[SDC_INFO_EP_RETURN_BAT] = 0.0f;
     inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
 
-    // ---- history append (utils/reward_creator.py:7-14) ------------------------------------------------------
-    // The ring holds fp32 OFFSETS from the env's first energy value (kept in fp64): normalize_energy is
-    // shift-invariant, and offsets keep the fp32 rounding error proportional to the spread of the history
-    // instead of to the ~300 kWh magnitude (two nearly equal energies would otherwise lose the z-score).
-    // Stored as order-preserving keys for the reward kernel.
-    int hl = rec_i32(r, R_HIST_LEN), hpos = rec_i32(r, R_HIST_POS);
-    const double href = hl == 0 ? energy : rec_f64(r, R_HIST_REF);
-    const double e_off = energy - href;
-    int slot;
-    if (hl < S.hist_cap) {
-      slot = hl;
-      hl += 1;
-    } else {
-      slot = hpos;
-      hpos = hpos + 1 == S.hist_cap ? 0 : hpos + 1;
-    }
-    const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
+    // ---- history append: the ring slot gets this step's key --------------------------------------------------
     S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
-    // ---- hand-off to the reward kernel ------------------------------------------------------------------------
-    unsigned* hw = S.hdr + (size_t)env * SDC_HDR_DWORDS;
-    hw[H_N] = (unsigned)hl;
-    hw[H_OVERDUE] = (unsigned)overdue;                               // ls_overdue_penalty
-    hw[H_XNEW] = x_new;
-    hw[H_XOLD] = x_old;
-    reinterpret_cast<double*>(hw + H_EOFF)[0] = e_off;               // bat_total_energy_with_battery_KWh - hist_ref
-    reinterpret_cast<double*>(hw + H_NORM_CI)[0] = nc[17];           // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
-    reinterpret_cast<double*>(hw + H_OLDEST)[0] = oldest_norm;       // ls_oldest_task_age
     S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
 
     // ---- new state record ------------------------------------------------------------------------------------
@@ -419,6 +413,39 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     o[R_HIST_REF] = (unsigned)__double2loint(href);
     o[R_HIST_REF + 1] = (unsigned)__double2hiint(href);
   }
+
+  // ---- rewards (utils/reward_creator.py:16-130): the trackers answer without reading the history ring, or the env
+  // is queued for sdc_reward_kernel.  Wave-uniform scalar work; the 512-byte header goes back as one coalesced store.
+  {
+    using namespace sdc_rw;
+    const int n = (int)sfl((unsigned)hl);
+    Trackers T = trackers_load(hd0, hd1);
+    double mean, sd;
+    const bool ok = reward_fast(n, x_new, x_old, T, mean, sd);
+    unsigned o0 = hd0, o1 = hd1;
+    put_u32(o0, H_N, (unsigned)n);
+    put_u32(o0, H_OVERDUE, (unsigned)overdue);                  // ls_overdue_penalty
+    put_u32(o0, H_XNEW, x_new);
+    put_u32(o0, H_XOLD, x_old);
+    put_f64(o0, H_EOFF, e_off);                                 // bat_total_energy_with_battery_KWh - hist_ref
+    put_f64(o0, H_NORM_CI, nc[17]);                             // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
+    put_f64(o0, H_OLDEST, oldest_norm);                         // ls_oldest_task_age
+    trackers_put(o0, o1, T);
+    if (ok) {
+      const double z = n < 2 ? 0.0 : (e_off - mean) / (sd > 0 ? sd : 1.0);
+      const Rewards rr = step_rewards(z, nc[17], oldest_norm, (double)overdue, hd0);
+      put_f64(o0, H_RET, rr.ret0);
+      put_f64(o0, H_RET + 2, rr.ret1);
+      put_f64(o0, H_RET + 4, rr.ret2);
+      if (lane == 0) store_rewards(rr, z, 0, env, rew, sh.info);
+    } else if (lane == 0) {
+      const unsigned w = atomicAdd(S.work_cnt + S.step_parity, 1u);
+      S.work_list[w] = (unsigned)env;
+    }
+    unsigned* hw = S.hdr + (size_t)env * SDC_HDR_DWORDS;
+    hw[lane] = o0;
+    hw[SDC_WAVE + lane] = o1;
+  }
 }
 
 }  // namespace
@@ -428,7 +455,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
                                                                                 float* __restrict__ share_obs,
                                                                                 unsigned char* __restrict__ done,
                                                                                 float* __restrict__ info,
-                                                                                float* __restrict__ final_obs) {
+                                                                                float* __restrict__ final_obs,
+                                                                                float* __restrict__ rew) {
   __shared__ DynShared sh;
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
@@ -439,6 +467,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   // ---- level 0: state record (coalesced) + actions ---------------------------------------------------------------
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
   const unsigned r = recp[lane];
+  const unsigned hd0 = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];            // reward-side state: returns + trackers
+  const unsigned hd1 = S.hdr[(size_t)env * SDC_HDR_DWORDS + SDC_WAVE + lane];
   const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
   const int i = rec_i32(r, R_CURSOR), rel = rec_i32(r, R_TREL);
   const int loc = rec_i32(r, R_LOC);
@@ -487,7 +517,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   __syncthreads();
 
   const unsigned x_old = (unsigned)__builtin_amdgcn_readlane((int)x_old_l, 63);
-  step_dynamics(S, P, env, lane, r, a_ls, a_dc, a_bat, fault, x_old, sh);
+  step_dynamics(S, P, env, lane, r, a_ls, a_dc, a_bat, fault, x_old, hd0, hd1, rew, sh);
   __syncthreads();
 
   // ---- coalesced stores: record, obs [3][26] (78 floats), share_obs [29], info --------------------------------------

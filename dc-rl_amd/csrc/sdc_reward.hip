@@ -1,265 +1,137 @@
-// sdc_reward.hip -- history-normalised rewards: one workgroup (4 wavefronts, 256 lanes) per environment.
+// sdc_reward.hip -- RING PATH of the history-normalised rewards: one workgroup (4 wavefronts) per queued env.
 //
 // utils/reward_creator.py:16-45 normalises the step's energy with the 25th / 75th percentiles, the IQR-clipped
-// mean and the clipped population std of a 10 000-entry sliding history, three times per step.  Here the
-// window is streamed ONCE per step: 40 KB per env as 10 x dwordx4 per lane (coalesced, all loads issued before
-// anything else) and held in VGPRs.
+// mean and the clipped population std of a 10 000-entry sliding history.  sdc_trackers.hpp maintains all of that
+// incrementally; the dynamics kernel answers most env-steps from the trackers alone (no history read) and queues
+// an env here only when a wanted rank or clip bound has moved past the keys its tracker lists.  This kernel then
+// streams the env's ring ONCE (40 KB as 10 x dwordx4 per lane, coalesced, all loads in flight together) into LDS
+// and re-anchors the trackers with one primitive, the REBUILD SWEEP around two anchor keys g:
+//   per key and anchor  ds = x - (g+1)  borrows <=> x <= g,   dp = (g-1) - x  borrows <=> x >= g
+// (v_sub_co_u32 + v_addc_co_u32: the borrow counts the predicate, and in wrap-around arithmetic a key on the wrong
+// side of g gets a distance above every legitimate one, so the 4 smallest ds / dp -- v_med3_u32 insertion network --
+// are the 4 nearest keys above / below g).  It serves
+//   * the quartile trackers: new anchor = the last listed key on the side the wanted rank left by;
+//   * the tail trackers: new anchors exactly at the clip bounds, plus one fp64 summation pass;
+//   * the bootstrap (first steps, injected state): anchors from an exact bisection on the key space.
+// Histories shorter than SMALL_N are computed directly.
 //
-// Order statistics.  The ring holds order-preserving uint32 keys (empty slot = 0xFFFFFFFF).  Per quartile the
-// env keeps a TRACKER: an anchor key G, the exact counts #{x < G}, #{x <= G}, and the (up to) 4 largest keys below
-// and 4 smallest keys above G -- a window of ~9 consecutive order statistics.  A step inserts one key and evicts at
-// most one (both handed over by the dynamics kernel), which updates the tracker in O(1) scalar work; the wanted
-// ranks floor((n-1)q) and +1 random-walk inside the window.  Only when they leave it (every few dozen steps) the
-// anchor SLIDES to the last listed key on that side with a one-sided sweep over the VGPR-resident keys for what
-// lies beyond it: `x - (G+1)` / `(G-1) - x` give the <= / >= predicate as a borrow (v_sub_co_u32 + v_addc_co_u32)
-// and, in wrap-around arithmetic, a distance whose 4 smallest values are the neighbours (v_med3_u32 insertion
-// network).  An exact bisection on the key space (re-reading the L2-hot ring) followed by a two-sided rebuild
-// sweep bootstraps the trackers (first steps, injected state) and serves tiny histories.
-//
-// Moments.  One pass: clip in key space (v_med3_u32), convert, accumulate sum(v-c) and sum((v-c)^2) around the
-// inter-quartile midpoint; per-lane partials (40 terms) are fp32, everything across lanes is fp64.
-//
-// Measured (tools/ablate/kbench_reward.hip, 4096 envs): streaming the rings alone takes 23 us; the previous
-// version, which swept for the order statistics every step, was VALU-bound at 35 us of compute.
-// A persistent grid with the next env's ring prefetched into a second register set was slower (54 us): at 128
-// VGPRs only 4 x 40 KB per CU are in flight and each workgroup's wait -> compute chain is serial.
-#include "sdc_device.hpp"
+// Round-1 measurements that shaped this: streaming all 4096 rings every step is HBM-bound at >= 23 us (ablation,
+// tools/ablate) and was 32 us in practice; with the trackers ~10 % of the envs need their ring on a given step.
+// Those few workgroups per CU run on a COLD instruction cache (the dynamics kernel ran in between; the cache is
+// 64 KB per CU pair): in-kernel stamps showed ~0.45 us per KB of straight-line code executed, i.e. the first
+// versions (40-way unrolled register sweeps, separate slide / rebuild code: 68 KB, later 45 KB) spent 13 us per
+// workgroup mostly fetching instructions.  Hence: keys in LDS, short rolled loops, ONE non-inlined sweep routine,
+// so that this kernel and the dynamics kernel fit the instruction cache together.
+#include "sdc_trackers.hpp"
 
 namespace {
 
-constexpr unsigned KEY_NONE = 0xFFFFFFFFu;  // empty ring slot; also "+infinity" in ascending neighbour lists
-constexpr int QW = SDC_QW;
-constexpr int SMALL_N = 32;                 // below this the bisection is used directly
+using namespace sdc_rw;
 
 struct RewardShared {
   unsigned red_u[2][4];
   unsigned red_v[2][4];
-  unsigned sweep[4][2][2 + 2 * QW];  // per wave, per quartile: count <=, count >=, QW pred distances, QW succ distances
+  unsigned sweep[4][2][2 + 2 * QW];  // per wave, per anchor: count <=, count >=, QW pred distances, QW succ distances
+  unsigned fin[2][2 + 2 * QW];       // the same, merged over the workgroup
   double red_d[4];
   double red_e[4];
+  double red_f[4][4];
 };
 
-
-__device__ __forceinline__ unsigned f32_key(float f) {
-  const unsigned b = __float_as_uint(f);
-  return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
-}
-__device__ __forceinline__ float key_f32(unsigned k) {
-  // top bit set (was >= +0): clear it; else (was negative): flip all bits
-  const unsigned m = (unsigned)((int)k >> 31);
-  return __uint_as_float(k ^ (~m | 0x80000000u));
-}
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
   unsigned r;
   asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
 
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+// ------------------------------------------------------------------------------------------------
+// Wave reductions on the DPP data path: xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror reduce within each row
+// of 16 lanes; row_bcast15 / row_bcast31 carry the rows into lane 63, which holds the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+#define SDC_DPP_STAGES(STAGE)                      \
+  STAGE(0xB1, 0xF)  /* quad_perm [1,0,3,2] */      \
+  STAGE(0x4E, 0xF)  /* quad_perm [2,3,0,1] */      \
+  STAGE(0x141, 0xF) /* row_half_mirror */          \
+  STAGE(0x140, 0xF) /* row_mirror */               \
+  STAGE(0x142, 0xA) /* row_bcast15 -> rows 1, 3 */ \
+  STAGE(0x143, 0xC) /* row_bcast31 -> rows 2, 3 */
+__device__ __forceinline__ unsigned wave_sum_to63(unsigned v) {
+#define STAGE(C, M) v += dpp_u32<C, M>(0u, v);
+  SDC_DPP_STAGES(STAGE)
+#undef STAGE
   return v;
 }
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+__device__ __forceinline__ unsigned wave_min_to63(unsigned v) {
+#define STAGE(C, M) v = min(v, dpp_u32<C, M>(KEY_NONE, v));
+  SDC_DPP_STAGES(STAGE)
+#undef STAGE
   return v;
 }
+__device__ __forceinline__ unsigned wave_max_to63(unsigned v) {
+#define STAGE(C, M) v = max(v, dpp_u32<C, M>(0u, v));
+  SDC_DPP_STAGES(STAGE)
+#undef STAGE
+  return v;
+}
+// the 4 smallest of the wave's 64 ascending 4-lists, into lane 63
+__device__ __forceinline__ void wave_merge_to63(L4& A) {
+#define STAGE(C, M)                                                                         \
+  {                                                                                         \
+    const unsigned b0 = dpp_u32<C, M>(KEY_NONE, A.e0), b1 = dpp_u32<C, M>(KEY_NONE, A.e1);  \
+    const unsigned b2 = dpp_u32<C, M>(KEY_NONE, A.e2), b3 = dpp_u32<C, M>(KEY_NONE, A.e3);  \
+    asc_insert(A, b0);                                                                      \
+    asc_insert(A, b1);                                                                      \
+    asc_insert(A, b2);                                                                      \
+    asc_insert(A, b3);                                                                      \
+  }
+  SDC_DPP_STAGES(STAGE)
+#undef STAGE
+}
+__device__ __forceinline__ void l4_sweep_insert(L4& L, const unsigned d) {
+  L.e3 = umed3(L.e2, d, L.e3);
+  L.e2 = umed3(L.e1, d, L.e2);
+  L.e1 = umed3(L.e0, d, L.e1);
+  L.e0 = min(L.e0, d);
+}
+// d = a - b, cnt += borrow
+#define SDC_SUB_COUNT(d, cnt, a, b) \
+  asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(d), "+v"(cnt) : "v"(a), "v"(b) : "vcc")
 
-// block-wide reductions over 4 wavefronts; `par` alternates the LDS slot so one barrier per call suffices
+// block-wide reductions over 4 wavefronts (lane 63 of each wave holds its partial); one barrier per call, `par`
+// alternates the LDS slot
 __device__ __forceinline__ unsigned block_sum_u32(unsigned v, unsigned (*red)[4], int par, int wave, int lane) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if (lane == 0) red[par][wave] = v;
+  v = wave_sum_to63(v);
+  if (lane == 63) red[par][wave] = v;
   __syncthreads();
   return red[par][0] + red[par][1] + red[par][2] + red[par][3];
 }
 __device__ __forceinline__ unsigned block_min_u32(unsigned v, unsigned (*red)[4], int par, int wave, int lane) {
-  v = wave_min_u32(v);
-  if (lane == 0) red[par][wave] = v;
+  v = wave_min_to63(v);
+  if (lane == 63) red[par][wave] = v;
   __syncthreads();
   return min(min(red[par][0], red[par][1]), min(red[par][2], red[par][3]));
 }
 __device__ __forceinline__ unsigned block_max_u32(unsigned v, unsigned (*red)[4], int par, int wave, int lane) {
-  v = wave_max_u32(v);
-  if (lane == 0) red[par][wave] = v;
+  v = wave_max_to63(v);
+  if (lane == 63) red[par][wave] = v;
   __syncthreads();
   return max(max(red[par][0], red[par][1]), max(red[par][2], red[par][3]));
 }
 
 // ------------------------------------------------------------------------------------------------
-// tracker: O(1) maintenance (wave-uniform scalar code)
-
-// 4-entry sorted lists kept as four named scalars (not arrays: LLVM turns unrolled select chains over an array
-// back into a dynamically indexed load, which would push the whole tracker into scratch memory).
-struct L4 {
-  unsigned e0, e1, e2, e3;
-};
-static_assert(QW == 4, "the tracker lists are written out for 4 entries");
-
-// ascending list of the 4 smallest: insert x (keeps the 4 smallest of list + x)
-__device__ __forceinline__ void asc_insert(L4& L, unsigned x) {
-  L.e3 = min(max(L.e2, x), L.e3);  // clamp x into [e2, e3] (old values)
-  L.e2 = min(max(L.e1, x), L.e2);
-  L.e1 = min(max(L.e0, x), L.e1);
-  L.e0 = min(L.e0, x);
-}
-// descending list of the 4 largest
-__device__ __forceinline__ void desc_insert(L4& L, unsigned x) {
-  L.e3 = max(min(L.e2, x), L.e3);
-  L.e2 = max(min(L.e1, x), L.e2);
-  L.e1 = max(min(L.e0, x), L.e1);
-  L.e0 = max(L.e0, x);
-}
-__device__ __forceinline__ unsigned lget(const L4& L, int j) {
-  return j == 0 ? L.e0 : (j == 1 ? L.e1 : (j == 2 ? L.e2 : L.e3));
-}
-// remove one occurrence of x from the first `cnt` entries; `fill` pads the tail.  Returns false if absent.
-__device__ __forceinline__ bool list_remove(L4& L, int& cnt, unsigned x, unsigned fill) {
-  int j = -1;
-  if (3 < cnt && L.e3 == x) j = 3;
-  if (2 < cnt && L.e2 == x) j = 2;
-  if (1 < cnt && L.e1 == x) j = 1;
-  if (0 < cnt && L.e0 == x) j = 0;
-  if (j < 0) return false;
-  if (j <= 0) L.e0 = L.e1;
-  if (j <= 1) L.e1 = L.e2;
-  if (j <= 2) L.e2 = L.e3;
-  L.e3 = fill;
-  cnt -= 1;
-  return true;
-}
-
-struct QTrack {
-  unsigned g;          // anchor key; 0 = invalid (no tracker)
-  int c_lt, c_le;      // #{x < g}, #{x <= g} over the current ring
-  int np, ns;          // valid entries of P / S
-  L4 P;                // the np largest keys below g, descending; unused entries 0
-  L4 S;                // the ns smallest keys above g, ascending; unused entries KEY_NONE
-};
-
-__device__ __forceinline__ QTrack qt_load(unsigned hd, int base) {
-  QTrack q;
-  q.g = (unsigned)rec_i32(hd, base + T_G);
-  q.c_lt = rec_i32(hd, base + T_CLT);
-  q.c_le = rec_i32(hd, base + T_CLE);
-  q.np = rec_i32(hd, base + T_NP);
-  q.ns = rec_i32(hd, base + T_NS);
-  q.P.e0 = (unsigned)rec_i32(hd, base + T_P + 0);
-  q.P.e1 = (unsigned)rec_i32(hd, base + T_P + 1);
-  q.P.e2 = (unsigned)rec_i32(hd, base + T_P + 2);
-  q.P.e3 = (unsigned)rec_i32(hd, base + T_P + 3);
-  q.S.e0 = (unsigned)rec_i32(hd, base + T_S + 0);
-  q.S.e1 = (unsigned)rec_i32(hd, base + T_S + 1);
-  q.S.e2 = (unsigned)rec_i32(hd, base + T_S + 2);
-  q.S.e3 = (unsigned)rec_i32(hd, base + T_S + 3);
-  return q;
-}
-__device__ __forceinline__ void qt_store(const QTrack& q, unsigned* w) {
-  w[T_G] = q.g;
-  w[T_CLT] = (unsigned)q.c_lt;
-  w[T_CLE] = (unsigned)q.c_le;
-  w[T_NP] = (unsigned)q.np;
-  w[T_NS] = (unsigned)q.ns;
-  w[T_P + 0] = q.P.e0;
-  w[T_P + 1] = q.P.e1;
-  w[T_P + 2] = q.P.e2;
-  w[T_P + 3] = q.P.e3;
-  w[T_S + 0] = q.S.e0;
-  w[T_S + 1] = q.S.e1;
-  w[T_S + 2] = q.S.e2;
-  w[T_S + 3] = q.S.e3;
-}
-
-// Apply this step's eviction (x_old, if has_old) and insertion (x_new) to a tracker that described the ring of
-// the previous step, which held n_prev keys.  Sets q.g = 0 if the tracker turns out to be inconsistent.
-__device__ __forceinline__ void qt_update(QTrack& q, unsigned x_new, unsigned x_old, bool has_old, int n_prev) {
-  int m = n_prev;
-  if (has_old) {
-    m -= 1;
-    if (x_old < q.g) {
-      q.c_lt -= 1;
-      q.c_le -= 1;
-      // the list holds exactly the np largest keys below g: the evicted key is in it iff it is >= the smallest listed
-      if (q.np > 0 && x_old >= lget(q.P, q.np - 1)) {
-        if (!list_remove(q.P, q.np, x_old, 0u)) q.g = 0u;
-      }
-    } else if (x_old == q.g) {
-      q.c_le -= 1;
-    } else {
-      if (q.ns > 0 && x_old <= lget(q.S, q.ns - 1)) {
-        if (!list_remove(q.S, q.ns, x_old, KEY_NONE)) q.g = 0u;
-      }
-    }
-  }
-  if (x_new < q.g) {
-    const bool complete = q.np == q.c_lt;  // every key below g is listed
-    q.c_lt += 1;
-    q.c_le += 1;
-    if (complete || (q.np > 0 && x_new > lget(q.P, q.np - 1))) {
-      desc_insert(q.P, x_new);
-      q.np = min(QW, q.np + 1);
-    }
-  } else if (x_new == q.g) {
-    q.c_le += 1;
-  } else {
-    const bool complete = q.ns == m - q.c_le;  // every key above g is listed
-    if (complete || (q.ns > 0 && x_new < lget(q.S, q.ns - 1))) {
-      asc_insert(q.S, x_new);
-      q.ns = min(QW, q.ns + 1);
-    }
-  }
-}
-
-// key at rank r, if the window covers it
-__device__ __forceinline__ bool qt_value_at(const QTrack& q, int r, unsigned& out) {
-  if (r >= q.c_lt && r < q.c_le) {
-    out = q.g;
-    return true;
-  }
-  if (r < q.c_lt) {
-    const int j = q.c_lt - 1 - r;
-    if (j >= q.np) return false;
-    out = lget(q.P, j);
-    return true;
-  }
-  const int j = r - q.c_le;
-  if (j >= q.ns) return false;
-  out = lget(q.S, j);
-  return true;
-}
-// ranks k and k+1 (the second only if it exists)
-__device__ __forceinline__ bool qt_resolve(const QTrack& q, int k, int n, unsigned& a, unsigned& b) {
-  if (q.g == 0u || q.g == KEY_NONE) return false;
-  if (!qt_value_at(q, k, a)) return false;
-  if (k + 1 > n - 1) {
-    b = a;
-    return true;
-  }
-  return qt_value_at(q, k + 1, b);
-}
-// the listed key whose rank is nearest to k: the anchor of a rebuild
-__device__ __forceinline__ unsigned qt_nearest(const QTrack& q, int k) {
-  const int lo = q.c_lt - q.np, hi = q.c_le + q.ns - 1;
-  const int r = k < lo ? lo : (k > hi ? hi : k);
-  unsigned v = q.g;
-  if (qt_value_at(q, r, v)) return v;
-  return q.g;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Exact order statistics at ranks k1, k1+1, k3, k3+1 by bisection on the key space with block-wide counts.
-// Rare (bootstrap, tiny histories, verify mode): re-reads the ring from memory (L2-hot) in rolled loops so that it
-// adds no register pressure to the main path.  Block-uniform control flow.
-__device__ __forceinline__ void quartiles_by_bisection(const unsigned* __restrict__ ring, const int k1, const int k3,
-                                                       RewardShared& sh, const int tid, const int lane, const int wave,
-                                                       unsigned& a1, unsigned& b1, unsigned& a3, unsigned& b3) {
-  const uint4* hp = reinterpret_cast<const uint4*>(ring);
+// Exact order statistics at ranks k1, k1+1, k3, k3+1 by bisection on the key space with block-wide counts
+// (bootstrap, tiny histories, verify mode).  Returns {a1, b1, a3, b3}.  Block-uniform control flow.
+__device__ __noinline__ uint4 quartiles_by_bisection(const uint4* __restrict__ lk, const int k1, const int k3,
+                                                     RewardShared* shp, const int lane, const int wave) {
+  RewardShared& sh = *shp;
   int par = 0;
   unsigned kmin = KEY_NONE, kmax = 0u;
 #pragma unroll 1
   for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) {
-    const uint4 v = hp[q * SDC_BLOCK + tid];
+    const uint4 v = lk[q * SDC_BLOCK];
     const unsigned x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -277,7 +149,7 @@ __device__ __forceinline__ void quartiles_by_bisection(const unsigned* __restric
     unsigned cnt = 0;  // packed: count(key <= m1) << 16 | count(key <= m3); each <= 10240
 #pragma unroll 1
     for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) {
-      const uint4 v = hp[q * SDC_BLOCK + tid];
+      const uint4 v = lk[q * SDC_BLOCK];
       const unsigned x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int c = 0; c < 4; c++) cnt += ((x[c] <= m1) ? 0x10000u : 0u) + ((x[c] <= m3) ? 1u : 0u);
@@ -296,7 +168,7 @@ __device__ __forceinline__ void quartiles_by_bisection(const unsigned* __restric
   unsigned cnt = 0, s1 = KEY_NONE, s3 = KEY_NONE;
 #pragma unroll 1
   for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) {
-    const uint4 v = hp[q * SDC_BLOCK + tid];
+    const uint4 v = lk[q * SDC_BLOCK];
     const unsigned x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -309,91 +181,58 @@ __device__ __forceinline__ void quartiles_by_bisection(const unsigned* __restric
   s1 = block_min_u32(s1, sh.red_v, par, wave, lane);
   par ^= 1;
   s3 = block_min_u32(s3, sh.red_u, par, wave, lane);
-  a1 = lo1;
-  a3 = lo3;
-  b1 = ((int)(cnt >> 16) >= k1 + 2 || s1 == KEY_NONE) ? a1 : s1;
-  b3 = ((int)(cnt & 0xFFFFu) >= k3 + 2 || s3 == KEY_NONE) ? a3 : s3;
+  uint4 r;
+  r.x = lo1;
+  r.z = lo3;
+  r.y = ((int)(cnt >> 16) >= k1 + 2 || s1 == KEY_NONE) ? lo1 : s1;
+  r.w = ((int)(cnt & 0xFFFFu) >= k3 + 2 || s3 == KEY_NONE) ? lo3 : s3;
   __syncthreads();
-}
-
-// merge the four wavefronts' partial results of a rebuild sweep (quartile slot t of sh.sweep) into tracker q
-__device__ __forceinline__ void rebuild_finish(const RewardShared& sh, const int t, const unsigned g, const int n, QTrack& q) {
-  unsigned c_le = 0, c_ge = 0;
-  L4 P = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE}, Sx = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-    const unsigned* v = sh.sweep[w][t];
-    c_le += v[0];
-    c_ge += v[1];
-#pragma unroll
-    for (int i = 0; i < QW; i++) {
-      asc_insert(P, v[2 + i]);
-      asc_insert(Sx, v[2 + QW + i]);
-    }
-  }
-  q.g = g;
-  // empty slots (KEY_NONE) satisfy x >= g: take them out of the >= count
-  const int n_empty = SDC_HIST_STRIDE - n;
-  q.c_le = (int)c_le;
-  q.c_lt = n - ((int)c_ge - n_empty);
-  // a legitimate predecessor distance is < g; a legitimate successor distance is < KEY_NONE - g - 1
-  const unsigned smax = KEY_NONE - g - 1u;
-  q.np = (P.e0 < g) + (P.e1 < g) + (P.e2 < g) + (P.e3 < g);
-  q.ns = (Sx.e0 < smax) + (Sx.e1 < smax) + (Sx.e2 < smax) + (Sx.e3 < smax);
-  q.P.e0 = P.e0 < g ? g - 1u - P.e0 : 0u;
-  q.P.e1 = P.e1 < g ? g - 1u - P.e1 : 0u;
-  q.P.e2 = P.e2 < g ? g - 1u - P.e2 : 0u;
-  q.P.e3 = P.e3 < g ? g - 1u - P.e3 : 0u;
-  q.S.e0 = Sx.e0 < smax ? g + 1u + Sx.e0 : KEY_NONE;
-  q.S.e1 = Sx.e1 < smax ? g + 1u + Sx.e1 : KEY_NONE;
-  q.S.e2 = Sx.e2 < smax ? g + 1u + Sx.e2 : KEY_NONE;
-  q.S.e3 = Sx.e3 < smax ? g + 1u + Sx.e3 : KEY_NONE;
+  return r;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Rebuild sweep: re-anchor both trackers (anchors g1, g3 must be valid keys in (0, KEY_NONE)).
-// Per key and quartile: ds = x - (g+1) borrows <=> x <= g;  dp = (g-1) - x borrows <=> x >= g;  a key on the wrong
-// side of g wraps to a distance above every legitimate one, so the QW smallest ds / dp are the neighbours.
-__device__ __forceinline__ void rebuild_trackers(const unsigned (&key)[SDC_HIST_PER_THREAD], const unsigned g1,
-                                                 const unsigned g3, const int n, RewardShared& sh, const int lane,
-                                                 const int wave, QTrack& q1, QTrack& q3) {
+// REBUILD SWEEP around anchors g1, g3 (any keys in (0, KEY_NONE), present in the ring or not).  Leaves, per anchor,
+// {#{x <= g}, #{x >= g} (empty slots included), 4 smallest predecessor distances, 4 smallest successor distances}
+// merged over the workgroup in sh.fin.  ONE copy of this code serves every re-anchoring (see the file header).
+__device__ __noinline__ void rebuild_sweep(const uint4* __restrict__ lk, const unsigned g1, const unsigned g3,
+                                           RewardShared* shp, const int lane, const int wave) {
+  RewardShared& sh = *shp;
   unsigned cle1 = 0u, cge1 = 0u, cle3 = 0u, cge3 = 0u;
   L4 pd1 = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE}, sd1 = pd1, pd3 = pd1, sd3 = pd1;
   const unsigned g1p = g1 + 1u, g1m = g1 - 1u, g3p = g3 + 1u, g3m = g3 - 1u;
+#pragma unroll 1
+  for (int q4 = 0; q4 < SDC_HIST_PER_THREAD / 4; q4++) {
+    const uint4 v4 = lk[q4 * SDC_BLOCK];
+    const unsigned xs[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-  for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
-    const unsigned x = key[j];
-    unsigned ds1, dp1, ds3, dp3;
-    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(ds1), "+v"(cle1) : "v"(x), "v"(g1p) : "vcc");
-    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(dp1), "+v"(cge1) : "v"(g1m), "v"(x) : "vcc");
-    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(ds3), "+v"(cle3) : "v"(x), "v"(g3p) : "vcc");
-    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(dp3), "+v"(cge3) : "v"(g3m), "v"(x) : "vcc");
-    sd1.e3 = umed3(sd1.e2, ds1, sd1.e3); sd1.e2 = umed3(sd1.e1, ds1, sd1.e2); sd1.e1 = umed3(sd1.e0, ds1, sd1.e1); sd1.e0 = min(sd1.e0, ds1);
-    pd1.e3 = umed3(pd1.e2, dp1, pd1.e3); pd1.e2 = umed3(pd1.e1, dp1, pd1.e2); pd1.e1 = umed3(pd1.e0, dp1, pd1.e1); pd1.e0 = min(pd1.e0, dp1);
-    sd3.e3 = umed3(sd3.e2, ds3, sd3.e3); sd3.e2 = umed3(sd3.e1, ds3, sd3.e2); sd3.e1 = umed3(sd3.e0, ds3, sd3.e1); sd3.e0 = min(sd3.e0, ds3);
-    pd3.e3 = umed3(pd3.e2, dp3, pd3.e3); pd3.e2 = umed3(pd3.e1, dp3, pd3.e2); pd3.e1 = umed3(pd3.e0, dp3, pd3.e1); pd3.e0 = min(pd3.e0, dp3);
-  }
-  // across lanes: butterfly merge of the sorted distance lists (insert the partner's 4 entries), counts summed
-  cle1 = (unsigned)wave_sum_i32((int)cle1);
-  cge1 = (unsigned)wave_sum_i32((int)cge1);
-  cle3 = (unsigned)wave_sum_i32((int)cle3);
-  cge3 = (unsigned)wave_sum_i32((int)cge3);
-  auto merge = [&](L4& A) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned b0 = (unsigned)__shfl_xor((int)A.e0, o), b1 = (unsigned)__shfl_xor((int)A.e1, o);
-      const unsigned b2 = (unsigned)__shfl_xor((int)A.e2, o), b3 = (unsigned)__shfl_xor((int)A.e3, o);
-      asc_insert(A, b0);
-      asc_insert(A, b1);
-      asc_insert(A, b2);
-      asc_insert(A, b3);
+    for (int c4 = 0; c4 < 4; c4++) {
+      const unsigned x = xs[c4];
+      unsigned ds1, dp1, ds3, dp3;
+      SDC_SUB_COUNT(ds1, cle1, x, g1p);
+      SDC_SUB_COUNT(dp1, cge1, g1m, x);
+      SDC_SUB_COUNT(ds3, cle3, x, g3p);
+      SDC_SUB_COUNT(dp3, cge3, g3m, x);
+      l4_sweep_insert(sd1, ds1);
+      l4_sweep_insert(pd1, dp1);
+      l4_sweep_insert(sd3, ds3);
+      l4_sweep_insert(pd3, dp3);
     }
-  };
-  merge(pd1);
-  merge(sd1);
-  merge(pd3);
-  merge(sd3);
-  if (lane == 0) {
+  }
+  // across lanes (one copy of the merge code: the four lists rotate through it)
+  cle1 = wave_sum_to63(cle1);
+  cge1 = wave_sum_to63(cge1);
+  cle3 = wave_sum_to63(cle3);
+  cge3 = wave_sum_to63(cge3);
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    wave_merge_to63(pd1);
+    const L4 t = pd1;
+    pd1 = sd1;
+    sd1 = pd3;
+    pd3 = sd3;
+    sd3 = t;
+  }
+  if (lane == 63) {
     unsigned* w = sh.sweep[wave][0];
     w[0] = cle1; w[1] = cge1;
     w[2] = pd1.e0; w[3] = pd1.e1; w[4] = pd1.e2; w[5] = pd1.e3;
@@ -404,353 +243,295 @@ __device__ __forceinline__ void rebuild_trackers(const unsigned (&key)[SDC_HIST_
     w[6] = sd3.e0; w[7] = sd3.e1; w[8] = sd3.e2; w[9] = sd3.e3;
   }
   __syncthreads();
-  rebuild_finish(sh, 0, g1, n, q1);
-  rebuild_finish(sh, 1, g3, n, q3);
+  // across the 4 wavefronts: thread t of wave 0 merges anchor t
+  if (wave == 0 && lane < 2) {
+    unsigned c_le = 0u, c_ge = 0u;
+    L4 P = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE}, Sx = P;
+#pragma unroll 1
+    for (int w = 0; w < 4; w++) {
+      const unsigned* v = sh.sweep[w][lane];
+      c_le += v[0];
+      c_ge += v[1];
+#pragma unroll
+      for (int i = 0; i < QW; i++) {
+        asc_insert(P, v[2 + i]);
+        asc_insert(Sx, v[2 + QW + i]);
+      }
+    }
+    unsigned* f = sh.fin[lane];
+    f[0] = c_le; f[1] = c_ge;
+    f[2] = P.e0; f[3] = P.e1; f[4] = P.e2; f[5] = P.e3;
+    f[6] = Sx.e0; f[7] = Sx.e1; f[8] = Sx.e2; f[9] = Sx.e3;
+  }
   __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------
-// SLIDE: when the wanted rank has walked off one end of a tracker's window, move the anchor to the last listed key
-// on that side and sweep only for what lies beyond it -- one quartile, one side: per key one v_sub_co_u32 /
-// v_addc_co_u32 pair (distance + predicate count) and the 4-entry insertion network.  Everything on the near side
-// of the new anchor is already known from the old window.
-template <bool UP>
-__device__ __forceinline__ void one_sided_sweep(const unsigned (&key)[SDC_HIST_PER_THREAD], const unsigned pivot,
-                                                RewardShared& sh, const int lane, const int wave, unsigned& count,
-                                                L4& dist) {
-  unsigned cnt = 0u;
-  L4 d4 = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-  const unsigned pp = pivot + 1u, pm = pivot - 1u;
+// tracker t of the last rebuild_sweep, anchored at g (wave-uniform scalars)
+__device__ __forceinline__ QTrack rebuild_finish(const RewardShared& sh, const int t, const unsigned g, const int n) {
+  const unsigned* f = sh.fin[t];
+  const unsigned c_le = sfl(f[0]), c_ge = sfl(f[1]);
+  const unsigned p0 = sfl(f[2]), p1 = sfl(f[3]), p2 = sfl(f[4]), p3 = sfl(f[5]);
+  const unsigned s0 = sfl(f[6]), s1 = sfl(f[7]), s2 = sfl(f[8]), s3 = sfl(f[9]);
+  QTrack q;
+  q.g = g;
+  // empty slots (KEY_NONE) satisfy x >= g: take them out of the >= count
+  const int n_empty = SDC_HIST_STRIDE - n;
+  q.c_le = (int)c_le;
+  q.c_lt = n - ((int)c_ge - n_empty);
+  // a legitimate predecessor distance is < g; a legitimate successor distance is < KEY_NONE - g - 1
+  const unsigned smax = KEY_NONE - g - 1u;
+  q.np = (p0 < g) + (p1 < g) + (p2 < g) + (p3 < g);
+  q.ns = (s0 < smax) + (s1 < smax) + (s2 < smax) + (s3 < smax);
+  q.P.e0 = p0 < g ? g - 1u - p0 : 0u;
+  q.P.e1 = p1 < g ? g - 1u - p1 : 0u;
+  q.P.e2 = p2 < g ? g - 1u - p2 : 0u;
+  q.P.e3 = p3 < g ? g - 1u - p3 : 0u;
+  q.S.e0 = s0 < smax ? g + 1u + s0 : KEY_NONE;
+  q.S.e1 = s1 < smax ? g + 1u + s1 : KEY_NONE;
+  q.S.e2 = s2 < smax ? g + 1u + s2 : KEY_NONE;
+  q.S.e3 = s3 < smax ? g + 1u + s3 : KEY_NONE;
+  return q;
+}
+
+// The key tracker q should re-anchor on so that ranks k, k+1 come inside its window: its own anchor if they already
+// are, else the last listed key on the side they left by; 0 if it cannot tell (invalid tracker, empty list).
+__device__ __forceinline__ unsigned slide_anchor(const QTrack& q, const int k, const int n) {
+  unsigned a, b;
+  if (!qt_valid(q)) return 0u;
+  if (qt_resolve(q, k, n, a, b)) return q.g;
+  const int hi_rank = (k + 1 > n - 1) ? k : k + 1;
+  if (hi_rank >= q.c_le + q.ns) return q.ns >= 1 ? lget(q.S, q.ns - 1) : 0u;
+  return q.np >= 1 ? lget(q.P, q.np - 1) : 0u;
+}
+
+// fp64 sums of v, v^2 over the keys <= gl and over the keys <= gh (gl <= gh < KEY_NONE), block-wide
+__device__ __forceinline__ void tail_sums(const uint4* __restrict__ lk, const unsigned gl, const unsigned gh,
+                                          RewardShared& sh, const int lane, const int wave, TTrack& tl, TTrack& th) {
+  double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+#pragma unroll 1
+  for (int q4 = 0; q4 < SDC_HIST_PER_THREAD / 4; q4++) {
+    const uint4 v4 = lk[q4 * SDC_BLOCK];
+    const unsigned xs[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-  for (int j = 0; j < SDC_HIST_PER_THREAD; j++) {
-    const unsigned x = key[j];
-    unsigned d;
-    if (UP)   // d = x - (pivot+1): borrows <=> x <= pivot; legitimate d = distance of a key above the pivot
-      asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(d), "+v"(cnt) : "v"(x), "v"(pp) : "vcc");
-    else      // d = (pivot-1) - x: borrows <=> x >= pivot; legitimate d = distance of a key below the pivot
-      asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(d), "+v"(cnt) : "v"(pm), "v"(x) : "vcc");
-    d4.e3 = umed3(d4.e2, d, d4.e3);
-    d4.e2 = umed3(d4.e1, d, d4.e2);
-    d4.e1 = umed3(d4.e0, d, d4.e1);
-    d4.e0 = min(d4.e0, d);
+    for (int c4 = 0; c4 < 4; c4++) {
+      const unsigned x = xs[c4];
+      if (x <= gh) {
+        const double v = key_f64(x), vv = v * v;
+        b1 += v;
+        b2 += vv;
+        if (x <= gl) {
+          a1 += v;
+          a2 += vv;
+        }
+      }
+    }
   }
-  cnt = (unsigned)wave_sum_i32((int)cnt);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned b0 = (unsigned)__shfl_xor((int)d4.e0, o), b1 = (unsigned)__shfl_xor((int)d4.e1, o);
-    const unsigned b2 = (unsigned)__shfl_xor((int)d4.e2, o), b3 = (unsigned)__shfl_xor((int)d4.e3, o);
-    asc_insert(d4, b0);
-    asc_insert(d4, b1);
-    asc_insert(d4, b2);
-    asc_insert(d4, b3);
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {   // one copy of the fp64 wave reduction: the four sums rotate through it
+    a1 = wave_sum_f64(a1);
+    const double t = a1;
+    a1 = a2;
+    a2 = b1;
+    b1 = b2;
+    b2 = t;
   }
   if (lane == 0) {
-    unsigned* w = sh.sweep[wave][0];
-    w[0] = cnt;
-    w[2] = d4.e0; w[3] = d4.e1; w[4] = d4.e2; w[5] = d4.e3;
+    sh.red_f[wave][0] = a1;
+    sh.red_f[wave][1] = a2;
+    sh.red_f[wave][2] = b1;
+    sh.red_f[wave][3] = b2;
   }
   __syncthreads();
-  count = 0u;
-  dist = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-    const unsigned* v = sh.sweep[w][0];
-    count += v[0];
-    asc_insert(dist, v[2]);
-    asc_insert(dist, v[3]);
-    asc_insert(dist, v[4]);
-    asc_insert(dist, v[5]);
-  }
+  tl.s1 = (sh.red_f[0][0] + sh.red_f[1][0]) + (sh.red_f[2][0] + sh.red_f[3][0]);
+  tl.s2 = (sh.red_f[0][1] + sh.red_f[1][1]) + (sh.red_f[2][1] + sh.red_f[3][1]);
+  th.s1 = (sh.red_f[0][2] + sh.red_f[1][2]) + (sh.red_f[2][2] + sh.red_f[3][2]);
+  th.s2 = (sh.red_f[0][3] + sh.red_f[1][3]) + (sh.red_f[2][3] + sh.red_f[3][3]);
   __syncthreads();
 }
 
-// first index of `x` in a sorted 4-list (it is present)
-__device__ __forceinline__ int first_index(const L4& L, unsigned x) {
-  return L.e0 == x ? 0 : (L.e1 == x ? 1 : (L.e2 == x ? 2 : 3));
-}
-
-// move the anchor up to the largest listed key above it (requires q.ns >= 1)
-__device__ __forceinline__ void qt_slide_up(QTrack& q, const unsigned (&key)[SDC_HIST_PER_THREAD], const int n,
-                                            RewardShared& sh, const int lane, const int wave) {
-  const unsigned g2 = lget(q.S, q.ns - 1);
-  const int e0 = first_index(q.S, g2);          // keys S[0..e0) lie strictly between the old and the new anchor
-  const int c_eq = q.c_le - q.c_lt;
-  unsigned c_le2;
-  L4 dist;
-  one_sided_sweep<true>(key, g2, sh, lane, wave, c_le2, dist);
-  // new lower list (descending): S[e0-1] .. S[0], then the old anchor c_eq times, then the old lower list
-  L4 P2 = {0u, 0u, 0u, 0u};
-  int cnt = 0;
-  auto push = [&](unsigned v) {
-    if (cnt == 0) P2.e0 = v;
-    if (cnt == 1) P2.e1 = v;
-    if (cnt == 2) P2.e2 = v;
-    if (cnt == 3) P2.e3 = v;
-    cnt += 1;
-  };
-  if (e0 >= 3) push(q.S.e2);
-  if (e0 >= 2) push(q.S.e1);
-  if (e0 >= 1) push(q.S.e0);
+// Clipped mean / population std straight from the ring, fp64, centred on `ctr`: tiny histories and the verify mode.
+// Returns {mean, sd}.
+__device__ __noinline__ double2 direct_moments(const uint4* __restrict__ lk, const int n, const double lb, const double ub,
+                                               const double ctr, RewardShared* shp, const int lane, const int wave) {
+  RewardShared& sh = *shp;
+  double s = 0.0, s2 = 0.0;
+#pragma unroll 1
+  for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) {
+    const uint4 v = lk[q * SDC_BLOCK];
+    const unsigned x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-  for (int r = 0; r < QW; r++)
-    if (r < c_eq) push(q.g);
-  if (q.np > 0) push(q.P.e0);
-  if (q.np > 1) push(q.P.e1);
-  if (q.np > 2) push(q.P.e2);
-  if (q.np > 3) push(q.P.e3);
-  const unsigned smax = KEY_NONE - g2 - 1u;
-  q.c_lt = q.c_le + e0;
-  q.c_le = (int)c_le2;
-  q.g = g2;
-  q.P = P2;
-  q.np = min(QW, cnt);
-  q.ns = (dist.e0 < smax) + (dist.e1 < smax) + (dist.e2 < smax) + (dist.e3 < smax);
-  q.S.e0 = dist.e0 < smax ? g2 + 1u + dist.e0 : KEY_NONE;
-  q.S.e1 = dist.e1 < smax ? g2 + 1u + dist.e1 : KEY_NONE;
-  q.S.e2 = dist.e2 < smax ? g2 + 1u + dist.e2 : KEY_NONE;
-  q.S.e3 = dist.e3 < smax ? g2 + 1u + dist.e3 : KEY_NONE;
-}
-
-// move the anchor down to the smallest listed key below it (requires q.np >= 1)
-__device__ __forceinline__ void qt_slide_down(QTrack& q, const unsigned (&key)[SDC_HIST_PER_THREAD], const int n,
-                                              RewardShared& sh, const int lane, const int wave) {
-  const unsigned g2 = lget(q.P, q.np - 1);
-  const int e0 = first_index(q.P, g2);          // keys P[0..e0) lie strictly between the new and the old anchor
-  const int c_eq = q.c_le - q.c_lt;
-  unsigned c_ge2;
-  L4 dist;
-  one_sided_sweep<false>(key, g2, sh, lane, wave, c_ge2, dist);
-  // new upper list (ascending): P[e0-1] .. P[0], then the old anchor c_eq times, then the old upper list
-  L4 S2 = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-  int cnt = 0;
-  auto push = [&](unsigned v) {
-    if (cnt == 0) S2.e0 = v;
-    if (cnt == 1) S2.e1 = v;
-    if (cnt == 2) S2.e2 = v;
-    if (cnt == 3) S2.e3 = v;
-    cnt += 1;
-  };
-  if (e0 >= 3) push(q.P.e2);
-  if (e0 >= 2) push(q.P.e1);
-  if (e0 >= 1) push(q.P.e0);
-#pragma unroll
-  for (int r = 0; r < QW; r++)
-    if (r < c_eq) push(q.g);
-  if (q.ns > 0) push(q.S.e0);
-  if (q.ns > 1) push(q.S.e1);
-  if (q.ns > 2) push(q.S.e2);
-  if (q.ns > 3) push(q.S.e3);
-  const int n_empty = SDC_HIST_STRIDE - n;      // empty slots (KEY_NONE) satisfy x >= pivot
-  q.c_le = q.c_lt - e0;
-  q.c_lt = n - ((int)c_ge2 - n_empty);
-  q.g = g2;
-  q.S = S2;
-  q.ns = min(QW, cnt);
-  q.np = (dist.e0 < g2) + (dist.e1 < g2) + (dist.e2 < g2) + (dist.e3 < g2);
-  q.P.e0 = dist.e0 < g2 ? g2 - 1u - dist.e0 : 0u;
-  q.P.e1 = dist.e1 < g2 ? g2 - 1u - dist.e1 : 0u;
-  q.P.e2 = dist.e2 < g2 ? g2 - 1u - dist.e2 : 0u;
-  q.P.e3 = dist.e3 < g2 ? g2 - 1u - dist.e3 : 0u;
-}
-
-// the tracker is wave-uniform: pin it to scalar registers after it was recomputed from LDS / vector values, so
-// that the 26 tracker words do not occupy vector registers next to the 40 ring keys
-__device__ __forceinline__ unsigned sfl(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ void qt_uniform(QTrack& q) {
-  q.g = sfl(q.g);
-  q.c_lt = (int)sfl((unsigned)q.c_lt);
-  q.c_le = (int)sfl((unsigned)q.c_le);
-  q.np = (int)sfl((unsigned)q.np);
-  q.ns = (int)sfl((unsigned)q.ns);
-  q.P.e0 = sfl(q.P.e0); q.P.e1 = sfl(q.P.e1); q.P.e2 = sfl(q.P.e2); q.P.e3 = sfl(q.P.e3);
-  q.S.e0 = sfl(q.S.e0); q.S.e1 = sfl(q.S.e1); q.S.e2 = sfl(q.S.e2); q.S.e3 = sfl(q.S.e3);
-}
-
-// bring ranks k, k+1 inside the window by sliding (block-uniform); false if the tracker cannot get there
-__device__ __forceinline__ bool qt_chase(QTrack& q, const int k, const int n, const unsigned (&key)[SDC_HIST_PER_THREAD],
-                                         RewardShared& sh, const int lane, const int wave, unsigned& a, unsigned& b) {
-  if (q.g == 0u || q.g == KEY_NONE) return false;
-  for (int it = 0; it < 3; it++) {
-    if (qt_resolve(q, k, n, a, b)) return true;
-    const int hi_rank = (k + 1 > n - 1) ? k : k + 1;
-    if (hi_rank >= q.c_le + q.ns) {
-      if (q.ns < 1) return false;
-      qt_slide_up(q, key, n, sh, lane, wave);
-    } else {
-      if (q.np < 1) return false;
-      qt_slide_down(q, key, n, sh, lane, wave);
-    }
-    qt_uniform(q);
-  }
-  return qt_resolve(q, k, n, a, b);
-}
-
-// ------------------------------------------------------------------------------------------------
-// one env: order statistics + clipped moments + rewards.  `key` = this lane's 40 ring slots, `hd` = this lane's
-// dword of the env's 256-byte hand-off header.
-__device__ __forceinline__ void reward_one_env(const SdcDev& S, RewardShared& sh, const int env,
-                                               const unsigned (&key)[SDC_HIST_PER_THREAD], const unsigned hd,
-                                               float* __restrict__ rew, float* __restrict__ info, const int tid,
-                                               const int lane, const int wave) {
-  const int n = rec_i32(hd, H_N);            // already includes this step's energy (appended by the dynamics kernel)
-  const double energy = rec_f64(hd, H_EOFF); // energy - hist_ref, fp64
-  const double norm_ci_next = rec_f64(hd, H_NORM_CI);
-  const double oldest_norm = rec_f64(hd, H_OLDEST);
-  const double overdue = (double)rec_i32(hd, H_OVERDUE);
-  const unsigned x_new = (unsigned)rec_i32(hd, H_XNEW), x_old = (unsigned)rec_i32(hd, H_XOLD);
-  const bool has_old = x_old != KEY_NONE;
-  const unsigned* ring = S.hist + (size_t)env * SDC_HIST_STRIDE;
-
-  // ---- normalize_energy (utils/reward_creator.py:16-45) ------------------------------------------------------------
-  double z = 0.0;
-  QTrack q1 = qt_load(hd, H_Q1), q3 = qt_load(hd, H_Q3);
-  int path = 0;  // diagnostics: 0 tracker only, 1 anchor slid (one-sided sweep), 2 bisection + rebuild
-  unsigned mismatch = 0u;
-  if (n < 2) {
-    q1.g = q3.g = 0u;
-  } else {
-    const int k1 = (n - 1) >> 2;                  // floor((n-1) * 0.25), np.percentile 'linear'
-    const double t1 = (double)((n - 1) & 3) * 0.25;
-    const int k3 = (3 * (n - 1)) >> 2;            // floor((n-1) * 0.75)
-    const double t3 = (double)((3 * (n - 1)) & 3) * 0.25;
-    unsigned a1 = 0, b1 = 0, a3 = 0, b3 = 0;
-    if (n < SMALL_N) {
-      quartiles_by_bisection(ring, k1, k3, sh, tid, lane, wave, a1, b1, a3, b3);
-      q1.g = q3.g = 0u;
-      path = 2;
-    } else {
-      const int n_prev = has_old ? n : n - 1;
-      const bool v1 = q1.g != 0u && q1.g != KEY_NONE, v3 = q3.g != 0u && q3.g != KEY_NONE;
-      if (v1) qt_update(q1, x_new, x_old, has_old, n_prev);
-      if (v3) qt_update(q3, x_new, x_old, has_old, n_prev);
-      // each tracker answers from its window, or slides its anchor (one-sided sweep) until the ranks are inside
-      const bool ok1 = qt_chase(q1, k1, n, key, sh, lane, wave, a1, b1);
-      const bool ok3 = qt_chase(q3, k3, n, key, sh, lane, wave, a3, b3);
-      if (!(v1 && v3)) path = 2;
-      else if (q1.g != (unsigned)rec_i32(hd, H_Q1 + T_G) || q3.g != (unsigned)rec_i32(hd, H_Q3 + T_G)) path = 1;
-      if (!ok1 || !ok3) {
-        // bootstrap (or a tracker that lost its window): exact bisection for the anchors, then a full rebuild sweep
-        quartiles_by_bisection(ring, k1, k3, sh, tid, lane, wave, a1, b1, a3, b3);
-        rebuild_trackers(key, sfl(a1), sfl(a3), n, sh, lane, wave, q1, q3);
-        qt_uniform(q1);
-        qt_uniform(q3);
-        path = 2;
-      }
-      if (S.debug_flags & 1) {
-        unsigned va1, vb1, va3, vb3;
-        __syncthreads();
-        quartiles_by_bisection(ring, k1, k3, sh, tid, lane, wave, va1, vb1, va3, vb3);
-        if (va1 != a1 || vb1 != b1 || va3 != a3 || vb3 != b3) mismatch = SDC_FAULT_ORDER_STAT;
+    for (int c = 0; c < 4; c++) {
+      if (x[c] != KEY_NONE) {
+        double f = key_f64(x[c]);
+        f = f < lb ? lb : (f > ub ? ub : f);  // np.clip
+        f -= ctr;
+        s += f;
+        s2 += f * f;
       }
     }
-    const double fa1 = (double)key_f32(a1), fb1 = (double)key_f32(b1);
-    const double fa3 = (double)key_f32(a3), fb3 = (double)key_f32(b3);
-    // numpy _lerp: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5
-    const double d1 = fb1 - fa1, d3 = fb3 - fa3;
-    const double qv1 = (t1 == 0.0) ? fa1 : ((t1 >= 0.5) ? fb1 - d1 * (1.0 - t1) : fa1 + d1 * t1);
-    const double qv3 = (t3 == 0.0) ? fa3 : ((t3 >= 0.5) ? fb3 - d3 * (1.0 - t3) : fa3 + d3 * t3);
-    const double iqr = qv3 - qv1;
-    const double lb = qv1 - 1.5 * iqr, ub = qv3 + 1.5 * iqr;
-    // clipped moments: clip in key space, accumulate (v - ctr) and (v - ctr)^2 around the inter-quartile midpoint;
-    // per-lane partial sums in fp32 (40 terms of magnitude <= 2 IQR), fp64 across lanes.  A register group k
-    // covers ring slots [1024 k, 1024 k + 1024): groups below the history length need no validity test
-    // (wave-uniform branch); in steady state only the last group (slots 10000..10239 are always empty) does.
-    const float lbf = (float)lb, ubf = (float)ub;
-    const float ctrf = (float)(0.5 * (qv1 + qv3));
-    const unsigned klb = f32_key(lbf), kub = f32_key(ubf);
-    float sf = 0.0f, sf2 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < SDC_HIST_PER_THREAD / 4; k++) {
-      if (n >= (k + 1) * SDC_BLOCK * 4) {
-#pragma unroll
-        for (int c4 = 0; c4 < 4; c4++) {
-          const float c = key_f32(umed3(key[4 * k + c4], klb, kub)) - ctrf;
-          sf += c;
-          sf2 = __builtin_fmaf(c, c, sf2);
-        }
-      } else {
-#pragma unroll
-        for (int c4 = 0; c4 < 4; c4++) {
-          const unsigned kk = key[4 * k + c4];
-          const float c = kk == KEY_NONE ? 0.0f : key_f32(umed3(kk, klb, kub)) - ctrf;
-          sf += c;
-          sf2 = __builtin_fmaf(c, c, sf2);
-        }
-      }
-    }
-    const double s = wave_sum_f64((double)sf);
-    const double s2 = wave_sum_f64((double)sf2);
-    if (lane == 0) {
-      sh.red_d[wave] = s;
-      sh.red_e[wave] = s2;
-    }
-    __syncthreads();
-    const double S1 = (sh.red_d[0] + sh.red_d[1]) + (sh.red_d[2] + sh.red_d[3]);
-    const double S2 = (sh.red_e[0] + sh.red_e[1]) + (sh.red_e[2] + sh.red_e[3]);
-    const double ctr = (double)ctrf;
-    const double m0 = S1 / (double)n;
-    const double mean = ctr + m0;
-    const double var = S2 / (double)n - m0 * m0;
-    const double sd = var > 0 ? sqrt(var) : 0.0;
-    z = (energy - mean) / (sd > 0 ? sd : 1.0);
   }
+  s = wave_sum_f64(s);
+  s2 = wave_sum_f64(s2);
+  if (lane == 0) {
+    sh.red_d[wave] = s;
+    sh.red_e[wave] = s2;
+  }
+  __syncthreads();
+  const double S1 = (sh.red_d[0] + sh.red_d[1]) + (sh.red_d[2] + sh.red_d[3]);
+  const double S2 = (sh.red_e[0] + sh.red_e[1]) + (sh.red_e[2] + sh.red_e[3]);
+  __syncthreads();
+  const double m0 = S1 / (double)n;
+  const double var = S2 / (double)n - m0 * m0;
+  double2 r;
+  r.x = ctr + m0;
+  r.y = var > 0 ? sqrt(var) : 0.0;
+  return r;
+}
 
-  // ---- rewards (utils/reward_creator.py:48-130), running episode return, tracker write-back -------------------------
-  if (tid == 0) {
-    const double foot = -1.0 * (norm_ci_next * z / 0.50);
-    const double overdue_pen = -0.3 * sqrt(overdue) + 0.3;
-    const double age_pen = -0.1 * oldest_norm;
-    double rls = foot + overdue_pen + age_pen;
-    rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
-    rew[env * 3 + 0] = (float)rls;
-    rew[env * 3 + 1] = (float)foot;
-    rew[env * 3 + 2] = (float)foot;
-    const double r0 = rec_f64(hd, H_RET) + rls, r1 = rec_f64(hd, H_RET + 2) + foot, r2 = rec_f64(hd, H_RET + 4) + foot;
-    unsigned* hw = S.hdr + (size_t)env * SDC_HDR_DWORDS;
-    double* hr = reinterpret_cast<double*>(hw + H_RET);
-    hr[0] = r0;
-    hr[1] = r1;
-    hr[2] = r2;
-    qt_store(q1, hw + H_Q1);
-    qt_store(q3, hw + H_Q3);
-    if (mismatch) hw[H_STICKY] = (unsigned)rec_i32(hd, H_STICKY) | 1u;
-    if (info) {
-      float* inf = info + (size_t)env * SDC_INFO_DIM;
-      inf[SDC_INFO_ENERGY_Z] = (float)z;
-      inf[SDC_INFO_RESERVED] = (float)path;   // diagnostic: 0 tracker, 1 slide, 2 bisection + rebuild
-      inf[SDC_INFO_EP_RETURN_LS] = (float)r0;
-      inf[SDC_INFO_EP_RETURN_DC] = (float)r1;
-      inf[SDC_INFO_EP_RETURN_BAT] = (float)r2;
-      if (mismatch) inf[SDC_INFO_FAULT] = (float)((unsigned)inf[SDC_INFO_FAULT] | mismatch);
-    }
-  }
+// stage one env's ring in LDS: every load of the workgroup is in flight before the first use; each lane only ever
+// reads back its own 10 x 16 bytes (no barrier needed for them)
+__device__ __forceinline__ void stage_ring(const unsigned* __restrict__ ring, uint4* __restrict__ keys, const int tid) {
+  const uint4* hp = reinterpret_cast<const uint4*>(ring);
+  uint4 v[SDC_HIST_PER_THREAD / 4];
+#pragma unroll
+  for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) v[q] = hp[q * SDC_BLOCK + tid];
+#pragma unroll
+  for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) keys[q * SDC_BLOCK + tid] = v[q];
 }
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(SDC_BLOCK, 4) void sdc_reward_kernel(SdcDev S, float* __restrict__ rew,
+// ------------------------------------------------------------------------------------------------
+// The trackers in the header are already post-update (this step's insertion / eviction applied by the dynamics
+// kernel).  Grid: min(N, 1024) workgroups, each looping over the queue; the queue length is only known on the
+// device, surplus workgroups exit at once.
+extern "C" __global__ __launch_bounds__(SDC_BLOCK, 2) void sdc_reward_kernel(SdcDev S, float* __restrict__ rew,
                                                                            float* __restrict__ info) {
   __shared__ RewardShared sh;
+  __shared__ uint4 keys[SDC_HIST_STRIDE / 4];   // 40 KB: the env's history ring
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int par = S.step_parity;
+  const unsigned env0 = S.work_list[blockIdx.x];   // speculative: issued together with the queue length
+  const int cnt = (int)sfl(S.work_cnt[par]);
+  if (blockIdx.x == 0 && tid == 0) S.work_cnt[par ^ 1] = 0u;   // the next step's queue
+  if ((int)blockIdx.x >= cnt) return;
+  if (tid == 0) prof_stamp(S, SDC_PROF_REWARD, blockIdx.x, 0);
+  const uint4* lk = keys + tid;
+
+  for (int w = blockIdx.x; w < cnt; w += gridDim.x) {
+    const int env = (int)sfl(w == (int)blockIdx.x ? env0 : S.work_list[w]);
+    unsigned* hw = S.hdr + (size_t)env * SDC_HDR_DWORDS;
+    const unsigned hd0 = hw[lane], hd1 = hw[64 + lane];
+    stage_ring(S.hist + (size_t)env * SDC_HIST_STRIDE, keys, tid);
+    const int n = rec_i32(hd0, H_N);            // includes this step's energy (appended by the dynamics kernel)
+    const double energy = rec_f64(hd0, H_EOFF); // energy - hist_ref, fp64
+    Trackers T = trackers_load(hd0, hd1);
+    int k1, k3;
+    quartile_ranks(n, k1, k3);
+    int path = 1;  // diagnostics: 1 ring read (slide / tail re-anchor), 2 bisection + rebuild
+    double mean, sd;
+    if (n < SMALL_N) {
+      // tiny history: everything directly from the ring
+      const uint4 qa = quartiles_by_bisection(lk, k1, k3, &sh, lane, wave);
+      const Bounds b = clip_bounds(n, qa.x, qa.y, qa.z, qa.w);
+      const double2 m = direct_moments(lk, n, b.lb, b.ub, b.ctr, &sh, lane, wave);
+      mean = m.x;
+      sd = m.y;
+      T.q1.g = T.q3.g = T.tl.q.g = T.th.q.g = 0u;
+      path = 2;
+    } else {
+      // quartiles: re-anchor each tracker on the last listed key towards the wanted rank (or keep its anchor)
+      unsigned a1 = 0, b1 = 0, a3 = 0, b3 = 0;
+      const unsigned g1 = slide_anchor(T.q1, k1, n), g3 = slide_anchor(T.q3, k3, n);
+      bool okq = false;
+      if (g1 != 0u && g3 != 0u) {
+        if (g1 != T.q1.g || g3 != T.q3.g) {
+          rebuild_sweep(lk, g1, g3, &sh, lane, wave);
+          T.q1 = rebuild_finish(sh, 0, g1, n);
+          T.q3 = rebuild_finish(sh, 1, g3, n);
+        }
+        okq = qt_resolve(T.q1, k1, n, a1, b1) && qt_resolve(T.q3, k3, n, a3, b3);
+      }
+      if (!okq) {
+        // bootstrap (or a tracker that lost its window): exact bisection for the anchors, then the rebuild sweep
+        const uint4 qa = quartiles_by_bisection(lk, k1, k3, &sh, lane, wave);
+        a1 = sfl(qa.x); b1 = sfl(qa.y); a3 = sfl(qa.z); b3 = sfl(qa.w);
+        rebuild_sweep(lk, a1, a3, &sh, lane, wave);
+        T.q1 = rebuild_finish(sh, 0, a1, n);
+        T.q3 = rebuild_finish(sh, 1, a3, n);
+        path = 2;
+      }
+      const Bounds b = clip_bounds(n, a1, b1, a3, b3);
+      int cl = 0, ch = 0;
+      double l1 = 0.0, l2 = 0.0, h1 = 0.0, h2 = 0.0;
+      if (!(tt_below(T.tl, b.klb, n, cl, l1, l2) && tt_below(T.th, b.kub, n, ch, h1, h2))) {
+        // a clip bound has moved past the listed keys (or bootstrap): re-anchor both tail trackers at the bounds
+        const unsigned gl = sfl(b.klb - 1u), gh = sfl(b.kub - 1u);
+        rebuild_sweep(lk, gl, gh, &sh, lane, wave);
+        T.tl.q = rebuild_finish(sh, 0, gl, n);
+        T.th.q = rebuild_finish(sh, 1, gh, n);
+        tail_sums(lk, gl, gh, sh, lane, wave, T.tl, T.th);
+        cl = T.tl.q.c_le; l1 = T.tl.s1; l2 = T.tl.s2;
+        ch = T.th.q.c_le; h1 = T.th.s1; h2 = T.th.s2;
+      }
+      clipped_moments(n, b, cl, l1, l2, ch, h1, h2, mean, sd);
+    }
+    const double z = (energy - mean) / (sd > 0 ? sd : 1.0);
+    if (wave == 0) {
+      const Rewards r = step_rewards(z, rec_f64(hd0, H_NORM_CI), rec_f64(hd0, H_OLDEST), (double)rec_i32(hd0, H_OVERDUE), hd0);
+      unsigned o0 = hd0, o1 = hd1;
+      put_f64(o0, H_RET, r.ret0);
+      put_f64(o0, H_RET + 2, r.ret1);
+      put_f64(o0, H_RET + 4, r.ret2);
+      trackers_put(o0, o1, T);
+      if (lane >= H_RET) hw[lane] = o0;
+      hw[64 + lane] = o1;
+      if (lane == 0) store_rewards(r, z, path, env, rew, info ? info + (size_t)env * SDC_INFO_DIM : nullptr);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) prof_stamp(S, SDC_PROF_REWARD, blockIdx.x, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Verify mode (debug_flags bit 0), after every step and for every env: what the stored (post-step) trackers say --
+// quartile keys, clipped mean / std, the z-score that was reported -- against an exact bisection and a direct fp64
+// pass over the ring.  A mismatch sets SDC_FAULT_ORDER_STAT in info[fault] and the sticky header bit.
+extern "C" __global__ __launch_bounds__(SDC_BLOCK, 2) void sdc_reward_verify_kernel(SdcDev S, float* __restrict__ info) {
+  __shared__ RewardShared sh;
+  __shared__ uint4 keys[SDC_HIST_STRIDE / 4];
   const int env = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  if (tid == 0) prof_stamp(S, SDC_PROF_REWARD, env, 0);
-
-  // ---- stream the ring: every load of the workgroup is in flight before the first use -------------------------
-  unsigned key[SDC_HIST_PER_THREAD];
-  {
-    const uint4* hp = reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE);
-#pragma unroll
-    for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) {
-      const uint4 v = hp[q * SDC_BLOCK + tid];
-      key[4 * q + 0] = v.x;
-      key[4 * q + 1] = v.y;
-      key[4 * q + 2] = v.z;
-      key[4 * q + 3] = v.w;
-    }
+  unsigned* hw = S.hdr + (size_t)env * SDC_HDR_DWORDS;
+  float* inf = info + (size_t)env * SDC_INFO_DIM;
+  const unsigned hd0 = hw[lane], hd1 = hw[64 + lane];
+  const int n = rec_i32(hd0, H_N);
+  if (n < SMALL_N) return;
+  stage_ring(S.hist + (size_t)env * SDC_HIST_STRIDE, keys, tid);
+  const uint4* lk = keys + tid;
+  Trackers T = trackers_load(hd0, hd1);
+  int k1, k3;
+  quartile_ranks(n, k1, k3);
+  unsigned a1 = 0, b1 = 0, a3 = 0, b3 = 0;
+  bool bad = false;
+  if (!qt_resolve(T.q1, k1, n, a1, b1) || !qt_resolve(T.q3, k3, n, a3, b3)) bad = true;
+  const uint4 qa = quartiles_by_bisection(lk, k1, k3, &sh, lane, wave);
+  if (qa.x != a1 || qa.y != b1 || qa.z != a3 || qa.w != b3) bad = true;
+  const Bounds b = clip_bounds(n, qa.x, qa.y, qa.z, qa.w);
+  int cl = 0, ch = 0;
+  double l1 = 0, l2 = 0, h1 = 0, h2 = 0, mean = 0, sd = 0;
+  if (!tt_below(T.tl, b.klb, n, cl, l1, l2) || !tt_below(T.th, b.kub, n, ch, h1, h2)) bad = true;
+  clipped_moments(n, b, cl, l1, l2, ch, h1, h2, mean, sd);
+  const double2 m = direct_moments(lk, n, b.lb, b.ub, b.ctr, &sh, lane, wave);
+  if (!(fabs(m.x - mean) <= 1e-7 * m.y + 1e-9) || !(fabs(m.y - sd) <= 1e-6 * m.y + 1e-9)) bad = true;
+  const double z = (rec_f64(hd0, H_EOFF) - m.x) / (m.y > 0 ? m.y : 1.0);
+  if (!(fabs((double)inf[SDC_INFO_ENERGY_Z] - z) <= 1e-5 * fabs(z) + 1e-6)) bad = true;
+  if (tid == 0 && bad) {
+    inf[SDC_INFO_FAULT] = (float)((unsigned)inf[SDC_INFO_FAULT] | SDC_FAULT_ORDER_STAT);
+    hw[H_STICKY] = (unsigned)rec_i32(hd0, H_STICKY) | 1u;
   }
-  const unsigned hd = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];
-  reward_one_env(S, sh, env, key, hd, rew, info, tid, lane, wave);
-  if (tid == 0) prof_stamp(S, SDC_PROF_REWARD, env, 1);
 }

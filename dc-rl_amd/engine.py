@@ -181,7 +181,7 @@ class SdcEngine:
         if name == "ep_return":
             return np.zeros((N, 3), dtype=np.float64)
         if name == "header":
-            return np.zeros((N, 64), dtype=np.uint32)
+            return np.zeros((N, L.HDR_DWORDS), dtype=np.uint32)
         raise KeyError(name)
 
     def get_state(self, name: str) -> np.ndarray:
