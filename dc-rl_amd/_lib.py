@@ -16,11 +16,12 @@ OBS_PAD = 26
 SHARE_OBS_DIM = 29
 INFO_DIM = 44
 TABLE_LEN = 35040
-HDR_DWORDS = 128   # csrc/sdc_device.hpp SdcHdr: 512-byte per-env hand-off header
+HDR_DWORDS = 64    # csrc/sdc_device.hpp SdcHdr: 256-byte per-env header
+TAIL_CAP = 512     # csrc/sdc_device.hpp SDC_TAIL_CAP: slots per env and side of the reward tail sets
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
-SOURCES = ["sdc_capi.hip", "sdc_dynamics.hip", "sdc_reward.hip", "sdc_reset.hip"]
+SOURCES = ["sdc_capi.hip", "sdc_dynamics.hip", "sdc_verify.hip", "sdc_reset.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 # info column names = the reference's info keys (sustaindc_hip.h enum sdc_info_col)

@@ -16,7 +16,6 @@
 
 extern "C" __global__ void sdc_dynamics_kernel(SdcDev S, const int32_t* actions, float* obs, float* share_obs,
                                                unsigned char* done, float* info, float* final_obs, float* rew);
-extern "C" __global__ void sdc_reward_kernel(SdcDev S, float* rew, float* info);
 extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
 extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
                                             const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
@@ -47,7 +46,7 @@ struct Field {
   size_t elem;     // ... of `elem` bytes per env,
   int rec_idx;     // or a field of a strided per-env record: first dword,
   int rec_dwords;  // width in dwords,
-  int in_hdr = 0;  // 0: the 256-byte state record, 1: the 512-byte hand-off header
+  int in_hdr = 0;  // 0: the 256-byte state record, 1: the 256-byte header
 };
 
 }  // namespace
@@ -71,7 +70,6 @@ struct sdc_handle {
   int steps_to_terminal = 0;
   bool tables_set = false, assigned = false, started = false;
   // optional per-kernel timing: the kernels stamp the device wall clock per workgroup into one slot per sampled step
-  unsigned long step_no = 0;  // parity selects the ring-path queue counter (the other one is being cleared)
   int prof = 0;       // sample every `prof`-th step (0 = off)
   long prof_tick = 0;
   unsigned long long* prof_buf = nullptr;  // [PROF_SLOTS][3][N][2]
@@ -84,7 +82,6 @@ struct sdc_handle {
 namespace {
 
 constexpr int PROF_SLOTS = 256;
-constexpr int RING_GRID = 1024;   // workgroups of the ring-path launch (4 per CU resident); each loops over the queue
 
 template <typename T>
 int dev_alloc(sdc_handle* h, T** p, size_t count, bool zero = true) {
@@ -104,7 +101,7 @@ void sync_mirror(sdc_handle* h) {
   }
 }
 
-// one field of every env's record (256-byte state record, or 512-byte hand-off header) <-> a dense host array
+// one field of every env's record (256-byte state record, or 256-byte header) <-> a dense host array
 int rec_put(sdc_handle* h, int idx, int dwords, const void* host, int in_hdr = 0) {
   unsigned* base = in_hdr ? h->d.hdr : h->d.rec;
   const size_t pitch = sizeof(unsigned) * (in_hdr ? SDC_HDR_DWORDS : SDC_REC_DWORDS);
@@ -123,8 +120,7 @@ int rec_get(sdc_handle* h, int idx, int dwords, void* host, int in_hdr = 0) {
 // the reward kernel's order-statistic trackers describe the ring contents: drop them when the ring is injected
 int invalidate_trackers(sdc_handle* h) {
   std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
-  if (rec_put(h, H_Q1 + T_G, 1, z.data(), 1) || rec_put(h, H_Q3 + T_G, 1, z.data(), 1) ||
-      rec_put(h, H_LO + T_G, 1, z.data(), 1) || rec_put(h, H_HI + T_G, 1, z.data(), 1)) return -1;
+  if (rec_put(h, H_Q1 + T_G, 1, z.data(), 1) || rec_put(h, H_Q3 + T_G, 1, z.data(), 1)) return -1;
   return 0;
 }
 
@@ -210,9 +206,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
   (void)hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE);  // every slot empty
   A(d.hdr, (size_t)N * SDC_HDR_DWORDS);
+  A(d.tails, (size_t)N * (2 * SDC_TAIL_CAP / 4));
   A(d.reset_mask, N);
-  A(d.work_cnt, 2);
-  A(d.work_list, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
 #undef A
@@ -250,6 +245,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
       {"hist_n", nullptr, 4, H_N, 1, 1}, {"ep_return", nullptr, 24, H_RET, 6, 1},
       {"order_stat_sticky", nullptr, 4, H_STICKY, 1, 1},
       {"header", (void**)&d.hdr, 4 * SDC_HDR_DWORDS, 0, 0},
+      {"tails", (void**)&d.tails, 4 * 2 * SDC_TAIL_CAP, 0, 0},
       {"t_win", (void**)&d.t_win, sizeof(double) * (size_t)d.lw, 0, 0},
       {"wb_win", (void**)&d.wb_win, sizeof(double) * (size_t)d.lw, 0, 0},
       {"qtab", (void**)&d.qtab, sizeof(uint2) * (size_t)d.qstride, 0, 0},
@@ -400,15 +396,12 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   const int N = h->cfg.n_envs;
   const bool timed = h->prof > 0 && (h->prof_tick++ % h->prof) == 0 && h->prof_used < PROF_SLOTS;
   SdcDev d = h->d;
-  d.step_parity = (int)(h->step_no++ & 1);
   if (timed) {
     d.prof_ts = h->prof_buf + (size_t)h->prof_used * 3 * N * 2;
     h->prof_has_reset[h->prof_used] = 0;
   }
   hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, actions, obs, share_obs, done, info,
                      final_obs, rew);
-  // ring path for the envs the dynamics kernel queued (count known only on the device: surplus workgroups exit)
-  hipLaunchKernelGGL(sdc_reward_kernel, dim3(N < RING_GRID ? N : RING_GRID), dim3(SDC_BLOCK), 0, st, d, rew, info);
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
   HIP_TRY(hipGetLastError());
   h->steps_to_terminal -= 1;

@@ -67,8 +67,8 @@ enum SdcRec {
   SDC_REC_DWORDS = 64
 };
 
-// 512-byte per-env hand-off header (two dwords per lane): written by the dynamics kernel (N .. OLDEST) and by the
-// reward kernel (RET, the order-statistic and tail trackers); every wavefront of the reward workgroup loads it whole.
+// 256-byte per-env header (one dword per lane): what the step hands over between its dynamics and reward parts and
+// the reward-side state (sdc_trackers.hpp); the env's wavefront loads and stores it whole, coalesced.
 enum SdcHdr {
   H_N = 0,        // history length including this step's value
   H_OVERDUE,      // ls_overdue_penalty (int)
@@ -81,13 +81,19 @@ enum SdcHdr {
   H_Q1 = 16,      // order-statistic tracker of the lower quartile (SdcTrack, 13 dwords)
   H_Q3 = 32,      // ... of the upper quartile
   H_STICKY = 48,  // sticky diagnostics (bit 0: a verify-mode mismatch was seen)
-  H_LO = 64,      // tail tracker at the lower clip bound (SdcTrack + T_SUM1 / T_SUM2)
-  H_HI = 96,      // ... at the upper clip bound
-  SDC_HDR_DWORDS = 128
+  H_KB = 49,      // last step's clip bounds in flipped key space: [0] upper (kub), [1] lower (~(klb - 1))
+  H_TAU = 51,     // tail-set thresholds in flipped key space: [0] upper, [1] lower; SDC_TAU_INVALID = no sets yet
+  H_CNT = 53,     // tail-set sizes [0] upper, [1] lower
+  H_BAND = 55,    // per side [2]: key-space distance that holds ~128 keys just inside the threshold (step of a threshold move)
+  H_A1 = 58,      // f64: sum of v over the history
+  H_A2 = 60,      // f64: sum of v^2
+  H_SLACK = 62,   // per side [2]: set keys between the threshold and last step's clip bound
+  SDC_HDR_DWORDS = 64
 };
-// tracker: a window of consecutive order statistics of the history around anchor key G; the tail trackers also
-// carry the fp64 sums of v and v^2 over the keys <= G
-enum SdcTrack { T_G = 0, T_CLT, T_CLE, T_NP, T_NS, T_P = 5, T_S = 9, SDC_TRACK_DWORDS = 13, T_SUM1 = 14, T_SUM2 = 16 };
+#define SDC_TAU_INVALID 0xFFFFFFFFu
+#define SDC_TAIL_CAP 512   // slots per env and side of the tail sets (8 per lane)
+// tracker: a window of consecutive order statistics of the history around anchor key G
+enum SdcTrack { T_G = 0, T_CLT, T_CLE, T_NP, T_NS, T_P = 5, T_S = 9, SDC_TRACK_DWORDS = 13 };
 #define SDC_QW 4   // cached neighbours on each side of the anchor
 
 struct SdcDev {
@@ -109,10 +115,8 @@ struct SdcDev {
   double* wb_win;    // [N][lw] wet bulb likewise
   double* walk_tmp;  // [N][max(SDC_NORM_WINDOW, lw)] scratch of the device-side reset
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
-  unsigned* hdr;     // [N][SDC_HDR_DWORDS] dynamics -> reward kernel hand-off + reward-kernel state (see SdcHdr)
-  unsigned* work_cnt;   // [2] number of envs queued for the ring path of sdc_reward_kernel, by step parity
-  unsigned* work_list;  // [N] their indices
-  int step_parity;
+  unsigned* hdr;     // [N][SDC_HDR_DWORDS] per-env header: step hand-off + reward-side state (see SdcHdr)
+  uint4* tails;      // [N][2][SDC_TAIL_CAP / 4] tail sets (sdc_trackers.hpp): side 0 upper, side 1 lower (complemented keys)
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
   unsigned long long* prof_ts;  // measurement only: [3 kernels][N][2] wall-clock stamps of this launch, or nullptr
 };

@@ -18,7 +18,7 @@
 // (sdc_reward.hip) through a 64-byte per-env header; the energy is appended to the history ring here.
 //
 // Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
-#include "sdc_trackers.hpp"
+#include "sdc_ringpath.hpp"
 
 namespace {
 
@@ -40,6 +40,9 @@ struct DynShared {
   float pool[32];   // observation pool (see build_obs_pool)
   float info[SDC_INFO_DIM];
   unsigned rec[SDC_REC_DWORDS];
+  unsigned long long dbg_t;
+  sdc_rw::TailLds tl;   // the env's two tail sets, parked here between the start and the end of the step
+  double sums2[2];
 };
 
 // envs/datacenter.py:356-429 calculate_chiller_power
@@ -68,8 +71,9 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 // the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
 __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_params& P, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
-                                              unsigned fault, const unsigned x_old, const unsigned hd0, const unsigned hd1,
-                                              float* __restrict__ rew, DynShared& sh) {
+                                              unsigned fault, const unsigned x_old, const unsigned hd0,
+                                              const int ahead_path, const bool sets_dirty, float* __restrict__ rew,
+                                              DynShared& sh) {
   const int i = rec_i32(r, R_CURSOR);
   const int rel = rec_i32(r, R_TREL);
   const int day = rec_i32(r, R_DAY);
@@ -414,15 +418,128 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     o[R_HIST_REF + 1] = (unsigned)__double2hiint(href);
   }
 
-  // ---- rewards (utils/reward_creator.py:16-130): the trackers answer without reading the history ring, or the env
-  // is queued for sdc_reward_kernel.  Wave-uniform scalar work; the 512-byte header goes back as one coalesced store.
+  // ---- rewards (utils/reward_creator.py:16-130).  Quartile trackers, tail sets and running sums (sdc_trackers.hpp)
+  // normally answer without reading the history ring; a miss rebuilds them from the ring right here.
   {
     using namespace sdc_rw;
+    if ((S.debug_flags & 8) && lane == 0) sh.dbg_t = wall_clock64();
     const int n = (int)sfl((unsigned)hl);
-    Trackers T = trackers_load(hd0, hd1);
-    double mean, sd;
-    const bool ok = reward_fast(n, x_new, x_old, T, mean, sd);
-    unsigned o0 = hd0, o1 = hd1;
+    const bool has_old = x_old != KEY_NONE;
+    unsigned o0 = hd0;
+    double mean = 0.0, sd = 0.0;
+    int path = ahead_path;   // diagnostics: 0 no ring read, 1 slid ahead of need, 2 tail sets re-collected, 3 rebuilt
+    const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), slot, x_new};
+    uint4* tails_g = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
+    if (n >= SMALL_N) {
+      int k1, k3;
+      quartile_ranks(n, k1, k3);
+      QTrack q1 = qt_load(hd0, H_Q1), q3 = qt_load(hd0, H_Q3);
+      unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
+      int cnt0 = rec_i32(hd0, H_CNT), cnt1 = rec_i32(hd0, H_CNT + 1);
+      unsigned band0 = (unsigned)rec_i32(hd0, H_BAND), band1 = (unsigned)rec_i32(hd0, H_BAND + 1);
+      double A1 = rec_f64(hd0, H_A1), A2 = rec_f64(hd0, H_A2);
+      TailSet ts0 = tail_from_lds(sh.tl, 0, lane), ts1 = tail_from_lds(sh.tl, 1, lane);
+      bool ok = qt_valid(q1) && qt_valid(q3) && tau0 != SDC_TAU_INVALID;
+      bool dirty0 = sets_dirty, dirty1 = sets_dirty;   // a set goes back to memory only if it changed
+      int why = ok ? 0 : 1;                            // diagnostics (debug_flags bit 1): why a rebuild was needed
+      if (ok) {
+        // O(1) updates: running sums, quartile trackers, tail sets
+        const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
+        A1 += vn - vo;
+        A2 += vn * vn - vo * vo;
+        qt_update(q1, x_new, x_old, has_old, has_old ? n : n - 1);
+        qt_update(q3, x_new, x_old, has_old, has_old ? n : n - 1);
+        if (has_old && x_old > tau0) { if (!tail_remove(ts0, x_old, lane)) { ok = false; why = 2; } cnt0 -= 1; dirty0 = true; }
+        if (has_old && ~x_old > tau1) { if (!tail_remove(ts1, ~x_old, lane)) { ok = false; why = 2; } cnt1 -= 1; dirty1 = true; }
+        if (x_new > tau0) { if (!tail_insert(ts0, x_new, lane)) { ok = false; why = 3; } cnt0 += 1; dirty0 = true; }
+        if (~x_new > tau1) { if (!tail_insert(ts1, ~x_new, lane)) { ok = false; why = 3; } cnt1 += 1; dirty1 = true; }
+      }
+      unsigned kb0 = 0u, kb1 = 0u;
+      int slack0 = 0, slack1 = 0;
+      uint4 qa_rb = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+      for (int attempt = 0; attempt < 2; attempt++) {
+        if (attempt == 1) {
+          // miss (no state yet, a window / set that did not cover, an inconsistency): rebuild everything from the ring
+          const Rebuilt rb = rebuild_state(R, lane, n, sh.tl, sh.sums2);
+          qa_rb = rb.qa;
+          q1 = rb.q1;
+          q3 = rb.q3;
+          tau0 = rb.tau[0];
+          tau1 = rb.tau[1];
+          A1 = rb.A1;
+          A2 = rb.A2;
+          cnt0 = (int)sfl(sh.tl.cnt[0]);
+          cnt1 = (int)sfl(sh.tl.cnt[1]);
+          ts0 = tail_from_lds(sh.tl, 0, lane);
+          ts1 = tail_from_lds(sh.tl, 1, lane);
+          band0 = band1 = 0u;   // re-estimated below
+          dirty0 = dirty1 = true;
+          path = 3 + ((S.debug_flags & 2) ? why : 0);
+        }
+        unsigned a1, b1, a3, b3;
+        const bool okq = (attempt == 1 || ok) && qt_resolve(q1, k1, n, a1, b1) && qt_resolve(q3, k3, n, a3, b3) &&
+                         cnt0 <= SDC_TAIL_CAP && cnt1 <= SDC_TAIL_CAP;
+        if (okq) {
+          const Bounds b = clip_bounds(n, a1, b1, a3, b3);
+          kb0 = b.kub;               // upper tail: keys >= kub
+          kb1 = ~(b.klb - 1u);       // lower tail, flipped: ~x >= ~(klb-1)  <=>  x < klb
+          if (kb0 > tau0 && kb1 > tau1) {
+            double t1 = 0.0, t2 = 0.0;
+            tail_scan(ts0, kb0, 0u, b.ub, t1, t2);
+            tail_scan(ts1, kb1, KEY_NONE, b.lb, t1, t2);
+            t1 = wave_sum_f64_dpp(t1);
+            t2 = wave_sum_f64_dpp(t2);
+            clipped_moments(n, b, A1, A2, t1, t2, mean, sd);
+            const unsigned sl = wave_sum_u32((tail_count_below(ts0, kb0) << 16) | tail_count_below(ts1, kb1));
+            slack0 = (int)(sl >> 16);
+            slack1 = (int)(sl & 0xFFFFu);
+            if (band0 == 0u) {   // after a rebuild: key distance per ~128 keys just above the threshold
+              band0 = band_estimate(kb0 - tau0, slack0);
+              band1 = band_estimate(kb1 - tau1, slack1);
+            }
+            break;
+          }
+          if (why == 0) why = kb0 > tau0 ? 7 : 6;
+        }
+        if (why == 0) why = (cnt0 > SDC_TAIL_CAP || cnt1 > SDC_TAIL_CAP) ? 5 : 4;
+        if (attempt == 1) {
+          // not even fresh state covers (more than a set's worth of keys beyond a clip bound): this step directly
+          // from the ring, and no state, so that the next step tries again
+          const Bounds b = clip_bounds(n, qa_rb.x, qa_rb.y, qa_rb.z, qa_rb.w);
+          wave_direct_moments(R, lane, n, b.lb, b.ub, b.ctr, mean, sd);
+          tau0 = tau1 = SDC_TAU_INVALID;
+        }
+      }
+      qt_put(o0, H_Q1, q1);
+      qt_put(o0, H_Q3, q3);
+      put_u32(o0, H_KB, kb0);
+      put_u32(o0, H_KB + 1, kb1);
+      put_u32(o0, H_TAU, tau0);
+      put_u32(o0, H_TAU + 1, tau1);
+      put_u32(o0, H_CNT, (unsigned)cnt0);
+      put_u32(o0, H_CNT + 1, (unsigned)cnt1);
+      put_u32(o0, H_BAND, band0);
+      put_u32(o0, H_BAND + 1, band1);
+      put_u32(o0, H_SLACK, (unsigned)slack0);
+      put_u32(o0, H_SLACK + 1, (unsigned)slack1);
+      put_f64(o0, H_A1, A1);
+      put_f64(o0, H_A2, A2);
+      if (dirty0) tail_store(tails_g, lane, ts0);
+      if (dirty1) tail_store(tails_g + SDC_TAIL_CAP / 4, lane, ts1);
+    } else {
+      if (n >= 2) {   // tiny history: everything directly from the ring
+        int k1, k3;
+        quartile_ranks(n, k1, k3);
+        const uint4 qa = wave_bisection(R, lane, k1, k3);
+        const Bounds b = clip_bounds(n, qa.x, qa.y, qa.z, qa.w);
+        wave_direct_moments(R, lane, n, b.lb, b.ub, b.ctr, mean, sd);
+        path = 3;
+      }
+      put_u32(o0, H_Q1 + T_G, 0u);
+      put_u32(o0, H_Q3 + T_G, 0u);
+      put_u32(o0, H_TAU, SDC_TAU_INVALID);
+    }
     put_u32(o0, H_N, (unsigned)n);
     put_u32(o0, H_OVERDUE, (unsigned)overdue);                  // ls_overdue_penalty
     put_u32(o0, H_XNEW, x_new);
@@ -430,21 +547,13 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     put_f64(o0, H_EOFF, e_off);                                 // bat_total_energy_with_battery_KWh - hist_ref
     put_f64(o0, H_NORM_CI, nc[17]);                             // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
     put_f64(o0, H_OLDEST, oldest_norm);                         // ls_oldest_task_age
-    trackers_put(o0, o1, T);
-    if (ok) {
-      const double z = n < 2 ? 0.0 : (e_off - mean) / (sd > 0 ? sd : 1.0);
-      const Rewards rr = step_rewards(z, nc[17], oldest_norm, (double)overdue, hd0);
-      put_f64(o0, H_RET, rr.ret0);
-      put_f64(o0, H_RET + 2, rr.ret1);
-      put_f64(o0, H_RET + 4, rr.ret2);
-      if (lane == 0) store_rewards(rr, z, 0, env, rew, sh.info);
-    } else if (lane == 0) {
-      const unsigned w = atomicAdd(S.work_cnt + S.step_parity, 1u);
-      S.work_list[w] = (unsigned)env;
-    }
-    unsigned* hw = S.hdr + (size_t)env * SDC_HDR_DWORDS;
-    hw[lane] = o0;
-    hw[SDC_WAVE + lane] = o1;
+    const double z = n < 2 ? 0.0 : (e_off - mean) / (sd > 0 ? sd : 1.0);
+    const Rewards rr = step_rewards(z, nc[17], oldest_norm, (double)overdue, hd0);
+    put_f64(o0, H_RET, rr.ret0);
+    put_f64(o0, H_RET + 2, rr.ret1);
+    put_f64(o0, H_RET + 4, rr.ret2);
+    if (lane == 0) store_rewards(rr, z, path, env, rew, sh.info);
+    S.hdr[(size_t)env * SDC_HDR_DWORDS + lane] = o0;
   }
 }
 
@@ -467,8 +576,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   // ---- level 0: state record (coalesced) + actions ---------------------------------------------------------------
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
   const unsigned r = recp[lane];
-  const unsigned hd0 = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];            // reward-side state: returns + trackers
-  const unsigned hd1 = S.hdr[(size_t)env * SDC_HDR_DWORDS + SDC_WAVE + lane];
+  unsigned hd0 = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];            // reward-side state: returns, trackers, sums
+
   const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
   const int i = rec_i32(r, R_CURSOR), rel = rec_i32(r, R_TREL);
   const int loc = rec_i32(r, R_LOC);
@@ -517,7 +626,96 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   __syncthreads();
 
   const unsigned x_old = (unsigned)__builtin_amdgcn_readlane((int)x_old_l, 63);
-  step_dynamics(S, P, env, lane, r, a_ls, a_dc, a_bat, fault, x_old, hd0, hd1, rew, sh);
+
+  // ---- reward state: maintenance AHEAD of need -------------------------------------------------------------------
+  // If, in the worst case for the key this step will add, a quartile tracker's window would no longer cover the
+  // ranks asked of it at the end of the step, slide it now; if a tail set is close to full or its threshold close
+  // to the clip bound, move the threshold now.  The sweeps over the env's 40 KB ring then overlap with the other
+  // resident wavefronts instead of extending the kernel's tail.
+  const unsigned long long dbg_a0 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
+  int ahead_path = 0;
+  bool sets_dirty = false;
+  sdc_rw::TailSet ts0, ts1;   // the env's tail sets (2 x 2 KB, coalesced)
+  if (hl0 >= sdc_rw::SMALL_N) {
+    using namespace sdc_rw;
+    const bool has_old = hl0 >= S.hist_cap;
+    const int n_next = has_old ? hl0 : hl0 + 1;
+    const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), -1, 0u};
+    int k1, k3;
+    quartile_ranks(n_next, k1, k3);
+    const int req = slide_req(quartile_slide_ahead(qt_load(hd0, H_Q1), x_old, has_old, k1, n_next),
+                              quartile_slide_ahead(qt_load(hd0, H_Q3), x_old, has_old, k3, n_next));
+    if (req != 0) {
+      hd0 = slide_trackers(hd0, R, lane, hl0, req);
+      ahead_path = 1;
+    }
+    {
+      const uint4* tails_g = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
+      ts0 = tail_load(tails_g, lane);
+      ts1 = tail_load(tails_g + SDC_TAIL_CAP / 4, lane);
+    }
+    unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
+    if (tau0 != SDC_TAU_INVALID) {
+      const unsigned kb0 = (unsigned)rec_i32(hd0, H_KB), kb1 = (unsigned)rec_i32(hd0, H_KB + 1);
+      const unsigned band0 = (unsigned)rec_i32(hd0, H_BAND), band1 = (unsigned)rec_i32(hd0, H_BAND + 1);
+      int cnt0 = rec_i32(hd0, H_CNT), cnt1 = rec_i32(hd0, H_CNT + 1);
+      const int slack0 = rec_i32(hd0, H_SLACK), slack1 = rec_i32(hd0, H_SLACK + 1);
+      // nearly full: raise the threshold a quarter of the way to the clip bound (in registers, no ring read)
+      if (cnt0 > SDC_TAIL_CAP * 7 / 8 && kb0 > tau0 && slack0 > 96) {
+        tau0 += (kb0 - tau0) / 4u;
+        cnt0 = tail_raise(ts0, tau0);
+        sets_dirty = true;
+      }
+      if (cnt1 > SDC_TAIL_CAP * 7 / 8 && kb1 > tau1 && slack1 > 96) {
+        tau1 += (kb1 - tau1) / 4u;
+        cnt1 = tail_raise(ts1, tau1);
+        sets_dirty = true;
+      }
+      // threshold close to the clip bound while keys exist below it: lower it by one band and re-collect
+      const bool low0 = slack0 < 48 && hl0 > cnt0 && tau0 > 0u, low1 = slack1 < 48 && hl0 > cnt1 && tau1 > 0u;
+      if (low0 || low1) {
+        const unsigned t0 = low0 ? (tau0 > band0 ? tau0 - band0 : 0u) : tau0;
+        const unsigned t1 = low1 ? (tau1 > band1 ? tau1 - band1 : 0u) : tau1;
+        tails_collect(R, lane, t0, t1, sh.tl, nullptr);
+        const int c0 = (int)sfl(sh.tl.cnt[0]), c1 = (int)sfl(sh.tl.cnt[1]);
+        if (c0 <= SDC_TAIL_CAP && c1 <= SDC_TAIL_CAP) {
+          // band estimate: the key distance that held ~128 keys
+          if (low0) put_u32(hd0, H_BAND, band_estimate(tau0 - t0, c0 - cnt0));
+          if (low1) put_u32(hd0, H_BAND + 1, band_estimate(tau1 - t1, c1 - cnt1));
+          tau0 = t0;
+          tau1 = t1;
+          cnt0 = c0;
+          cnt1 = c1;
+          ts0 = tail_from_lds(sh.tl, 0, lane);
+          ts1 = tail_from_lds(sh.tl, 1, lane);
+        } else {
+          tau0 = tau1 = SDC_TAU_INVALID;   // does not fit: the end-of-step rebuild picks thresholds by rank
+        }
+        ahead_path = 2;
+        sets_dirty = true;
+      }
+      put_u32(hd0, H_TAU, tau0);
+      put_u32(hd0, H_TAU + 1, tau1);
+      put_u32(hd0, H_CNT, (unsigned)cnt0);
+      put_u32(hd0, H_CNT + 1, (unsigned)cnt1);
+    }
+  }
+  if (hl0 >= sdc_rw::SMALL_N) {
+    sdc_rw::tail_to_lds(sh.tl, 0, lane, ts0);   // parked in LDS for the duration of the dynamics
+    sdc_rw::tail_to_lds(sh.tl, 1, lane, ts1);
+  }
+  const unsigned long long dbg_a1 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
+  step_dynamics(S, P, env, lane, r, a_ls, a_dc, a_bat, fault, x_old, hd0, ahead_path, sets_dirty, rew, sh);
+  if (S.debug_flags & 8) {
+    __syncthreads();
+    if (lane == 0) {
+      const unsigned long long dbg_a3 = wall_clock64();
+      sh.info[40] = (float)(dbg_a1 - dbg_a0);
+      sh.info[41] = (float)(sh.dbg_t - dbg_a1);
+      sh.info[42] = (float)(dbg_a3 - sh.dbg_t);
+      sh.info[43] = (float)(dbg_a3 - dbg_a0);
+    }
+  }
   __syncthreads();
 
   // ---- coalesced stores: record, obs [3][26] (78 floats), share_obs [29], info --------------------------------------

@@ -1,15 +1,23 @@
-// sdc_trackers.hpp -- O(1) maintenance of reward normalisation (utils/reward_creator.py:16-45) shared by the
-// dynamics kernel (fast path: no history read) and the reward kernel (ring path: slides / re-anchors).
+// sdc_trackers.hpp -- incremental reward normalisation (utils/reward_creator.py:16-45): the state kept per env so
+// that a step normally needs NO pass over the 10 000-entry energy history.
 //
-// normalize_energy needs, over a 10 000-entry sliding history, the 25th / 75th percentiles (np.percentile, linear:
-// order statistics k and k+1 each) and the mean / population std of the history clipped to
-// [q1 - 1.5 iqr, q3 + 1.5 iqr].  A step inserts one value and evicts at most one, so both are maintained
-// incrementally by four TRACKERS kept in the env's 512-byte header:
-//   * QTrack (quartiles): anchor key G present or not in the ring, exact counts #{x < G}, #{x <= G}, the (up to) 4
-//     largest keys below and 4 smallest keys above G -- a window of ~9 consecutive order statistics;
-//   * TTrack (clip bounds): a QTrack around an arbitrary anchor plus running fp64 sums of v, v^2 over {x <= G}.
-// Everything here is wave-uniform scalar work.  When a wanted rank or clip bound has moved past the listed keys
-// the env is queued for sdc_reward_kernel, which re-reads its ring.
+// normalize_energy needs the 25th / 75th percentiles of the history (np.percentile, linear: order statistics k and
+// k+1 each) and the mean / population std of the history clipped to [lb, ub] = [q1 - 1.5 iqr, q3 + 1.5 iqr].  A
+// step inserts one value and evicts at most one:
+//   * QUARTILE TRACKERS (QTrack, one per quartile, in the env's 256-byte header): an anchor key G, the exact counts
+//     #{x < G}, #{x <= G}, the (up to) 4 largest keys below and 4 smallest keys above G -- a window of ~9
+//     consecutive order statistics.  O(1) scalar update per step; the wanted rank moves by at most one per step, so
+//     the window is re-centred AHEAD of need by one sweep over the ring (sdc_ringpath.hpp);
+//   * TOTAL SUMS A1 = sum v, A2 = sum v^2 over the whole history (fp64, O(1) update);
+//   * TAIL SETS: every key above a threshold tau_hi (resp. below tau_lo), unordered, 512 slots each, in global
+//     memory; thresholds sit well inside [lb, ub], so the clipped sums are
+//        sum clip(v)   = A1 - sum_{v > ub} (v - ub)     - sum_{v < lb} (v - lb)
+//        sum clip(v)^2 = A2 - sum_{v > ub} (v^2 - ub^2) - sum_{v < lb} (v^2 - lb^2)
+//     with the two correction sums taken over the tail sets only (8 keys per lane and side, one coalesced load).
+//     The clip bounds may jump by many keys per step (they move 2.5 x the local spacing at the quartiles), which
+//     an ordered window cannot follow; a set does not care.  The lower set is stored COMPLEMENTED (~key), so both
+//     sides run the same "keys above a threshold" code.
+// Everything here is wave-uniform scalar work or one-wavefront vector work.
 #pragma once
 #include "sdc_device.hpp"
 
@@ -115,27 +123,25 @@ __device__ __forceinline__ void qt_store(const QTrack& q, unsigned* w) {
   w[T_S + 3] = q.S.e3;
 }
 
-// Apply this step's eviction (x_old, if has_old) and insertion (x_new) to a tracker that described the ring of
-// the previous step, which held n_prev keys.  Sets q.g = 0 if the tracker turns out to be inconsistent.
-__device__ __forceinline__ void qt_update(QTrack& q, unsigned x_new, unsigned x_old, bool has_old, int n_prev) {
-  int m = n_prev;
-  if (has_old) {
-    m -= 1;
-    if (x_old < q.g) {
-      q.c_lt -= 1;
-      q.c_le -= 1;
-      // the list holds exactly the np largest keys below g: the evicted key is in it iff it is >= the smallest listed
-      if (q.np > 0 && x_old >= lget(q.P, q.np - 1)) {
-        if (!list_remove(q.P, q.np, x_old, 0u)) q.g = 0u;
-      }
-    } else if (x_old == q.g) {
-      q.c_le -= 1;
-    } else {
-      if (q.ns > 0 && x_old <= lget(q.S, q.ns - 1)) {
-        if (!list_remove(q.S, q.ns, x_old, KEY_NONE)) q.g = 0u;
-      }
+// Remove one occurrence of x_old from a tracker.  Sets q.g = 0 if the tracker turns out to be inconsistent.
+__device__ __forceinline__ void qt_evict(QTrack& q, unsigned x_old) {
+  if (x_old < q.g) {
+    q.c_lt -= 1;
+    q.c_le -= 1;
+    // the list holds exactly the np largest keys below g: the evicted key is in it iff it is >= the smallest listed
+    if (q.np > 0 && x_old >= lget(q.P, q.np - 1)) {
+      if (!list_remove(q.P, q.np, x_old, 0u)) q.g = 0u;
+    }
+  } else if (x_old == q.g) {
+    q.c_le -= 1;
+  } else {
+    if (q.ns > 0 && x_old <= lget(q.S, q.ns - 1)) {
+      if (!list_remove(q.S, q.ns, x_old, KEY_NONE)) q.g = 0u;
     }
   }
+}
+// Add x_new to a tracker that describes m keys.
+__device__ __forceinline__ void qt_insert(QTrack& q, unsigned x_new, int m) {
   if (x_new < q.g) {
     const bool complete = q.np == q.c_lt;  // every key below g is listed
     q.c_lt += 1;
@@ -153,6 +159,12 @@ __device__ __forceinline__ void qt_update(QTrack& q, unsigned x_new, unsigned x_
       q.ns = min(QW, q.ns + 1);
     }
   }
+}
+// Apply this step's eviction (x_old, if has_old) and insertion (x_new) to a tracker that described the ring of
+// the previous step, which held n_prev keys.
+__device__ __forceinline__ void qt_update(QTrack& q, unsigned x_new, unsigned x_old, bool has_old, int n_prev) {
+  if (has_old) qt_evict(q, x_old);
+  qt_insert(q, x_new, has_old ? n_prev - 1 : n_prev);
 }
 
 // key at rank r, if the window covers it
@@ -182,93 +194,6 @@ __device__ __forceinline__ bool qt_resolve(const QTrack& q, int k, int n, unsign
   }
   return qt_value_at(q, k + 1, b);
 }
-// ------------------------------------------------------------------------------------------------
-// TAIL trackers.  normalize_energy clips the history to [lb, ub] = [q1 - 1.5 iqr, q3 + 1.5 iqr] and takes mean / std
-// of the clipped values.  With F(k) = (count, sum v, sum v^2) over the keys < k, the clipped sums are
-//   sum clip(v)   = F(kub).s1 - F(klb).s1 + n_lo lb   + n_hi ub,
-//   sum clip(v)^2 = F(kub).s2 - F(klb).s2 + n_lo lb^2 + n_hi ub^2,     n_lo = F(klb).c,  n_hi = n - F(kub).c,
-// where klb = smallest key whose value is >= lb and kub = smallest key whose value is > ub.  A tail tracker is a
-// QTrack around an ARBITRARY anchor key g plus running fp64 sums over {x <= g}: the step's insertion / eviction
-// update it in O(1), and F(k) for a bound k near g is read off the window (the listed keys between g and k are
-// added or removed).  Only when the bound has moved past the listed keys is the ring needed: the tracker is then
-// re-anchored exactly at the bound with one sweep + one summation pass over the VGPR-resident ring.
-struct TTrack {
-  QTrack q;
-  double s1, s2;  // sum of v, v^2 over the keys <= q.g
-};
-
-__device__ __forceinline__ TTrack tt_load(unsigned hd, int base) {
-  TTrack t;
-  t.q = qt_load(hd, base);
-  t.s1 = rec_f64(hd, base + T_SUM1);
-  t.s2 = rec_f64(hd, base + T_SUM2);
-  return t;
-}
-__device__ __forceinline__ void tt_update(TTrack& t, unsigned x_new, unsigned x_old, bool has_old, int n_prev) {
-  if (has_old && x_old <= t.q.g) {
-    const double v = key_f64(x_old);
-    t.s1 -= v;
-    t.s2 -= v * v;
-  }
-  if (x_new <= t.q.g) {
-    const double v = key_f64(x_new);
-    t.s1 += v;
-    t.s2 += v * v;
-  }
-  qt_update(t.q, x_new, x_old, has_old, n_prev);
-}
-// (count, sum, sum of squares) over the keys < kb, if the window covers the span between the anchor and kb
-__device__ __forceinline__ bool tt_below(const TTrack& t, const unsigned kb, const int n, int& c, double& s1, double& s2) {
-  const QTrack& q = t.q;
-  if (q.g == 0u || q.g == KEY_NONE) return false;
-  bool covered;
-  if (kb > q.g) {  // add the listed keys in (g, kb)
-    c = q.c_le;
-    s1 = t.s1;
-    s2 = t.s2;
-    covered = q.ns == n - q.c_le;  // every key above g is listed
-    auto add = [&](int i, unsigned e) {
-      if (i < q.ns) {
-        if (e < kb) {
-          const double v = key_f64(e);
-          c += 1;
-          s1 += v;
-          s2 += v * v;
-        } else {
-          covered = true;
-        }
-      }
-    };
-    add(0, q.S.e0);
-    add(1, q.S.e1);
-    add(2, q.S.e2);
-    add(3, q.S.e3);
-  } else {         // remove the copies of g and the listed keys in [kb, g)
-    const double vg = key_f64(q.g), ceq = (double)(q.c_le - q.c_lt);
-    c = q.c_lt;
-    s1 = t.s1 - ceq * vg;
-    s2 = t.s2 - ceq * (vg * vg);
-    covered = q.np == q.c_lt;      // every key below g is listed
-    auto sub = [&](int i, unsigned e) {
-      if (i < q.np) {
-        if (e >= kb) {
-          const double v = key_f64(e);
-          c -= 1;
-          s1 -= v;
-          s2 -= v * v;
-        } else {
-          covered = true;
-        }
-      }
-    };
-    sub(0, q.P.e0);
-    sub(1, q.P.e1);
-    sub(2, q.P.e2);
-    sub(3, q.P.e3);
-  }
-  return covered;
-}
-
 // header write-back: lane i of `o` holds dword i
 __device__ __forceinline__ void put_u32(unsigned& o, int idx, unsigned v) {
   const unsigned sv = sfl(v);
@@ -293,12 +218,6 @@ __device__ __forceinline__ void qt_put(unsigned& o, int base, const QTrack& q) {
   put_u32(o, base + T_S + 2, q.S.e2);
   put_u32(o, base + T_S + 3, q.S.e3);
 }
-__device__ __forceinline__ void tt_put(unsigned& o, int base, const TTrack& t) {
-  qt_put(o, base, t.q);
-  put_f64(o, base + T_SUM1, t.s1);
-  put_f64(o, base + T_SUM2, t.s2);
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // quartile values (numpy _lerp), clip bounds, and the bounds in key space
@@ -331,67 +250,96 @@ __device__ __forceinline__ Bounds clip_bounds(const int n, unsigned a1, unsigned
   b.kub = min(max(kub, klb), KEY_NONE - 2u);
   return b;
 }
-// clipped mean / std from F(klb) = (cl, l1, l2) and F(kub) = (ch, h1, h2)
-__device__ __forceinline__ void clipped_moments(const int n, const Bounds& b, int cl, double l1, double l2, int ch, double h1,
-                                                double h2, double& mean, double& sd) {
-  const double n_lo = (double)cl, n_hi = (double)(n - ch);
-  const double C1 = (h1 - l1) + n_lo * b.lb + n_hi * b.ub;
-  const double C2 = (h2 - l2) + n_lo * (b.lb * b.lb) + n_hi * (b.ub * b.ub);
+// clipped mean / std from the total sums and the tail corrections T1 = sum_{tails} (v - bound), T2 = sum (v^2 - bound^2)
+__device__ __forceinline__ void clipped_moments(const int n, const Bounds& b, const double A1, const double A2, const double T1,
+                                                const double T2, double& mean, double& sd) {
+  const double C1 = A1 - T1, C2 = A2 - T2;
   mean = C1 / (double)n;
   const double var = C2 / (double)n - mean * mean;
   sd = (var > 0 && b.ub > b.lb) ? sqrt(var) : 0.0;
 }
 
-// the four trackers of one env
-struct Trackers {
-  QTrack q1, q3;
-  TTrack tl, th;
-};
-__device__ __forceinline__ Trackers trackers_load(unsigned hd0, unsigned hd1) {
-  Trackers T;
-  T.q1 = qt_load(hd0, H_Q1);
-  T.q3 = qt_load(hd0, H_Q3);
-  T.tl = tt_load(hd1, H_LO - 64);
-  T.th = tt_load(hd1, H_HI - 64);
-  return T;
-}
-__device__ __forceinline__ void trackers_put(unsigned& o0, unsigned& o1, const Trackers& T) {
-  qt_put(o0, H_Q1, T.q1);
-  qt_put(o0, H_Q3, T.q3);
-  tt_put(o1, H_LO - 64, T.tl);
-  tt_put(o1, H_HI - 64, T.th);
-}
 __device__ __forceinline__ bool qt_valid(const QTrack& q) { return q.g != 0u && q.g != KEY_NONE; }
 
-// FAST PATH (dynamics kernel): apply this step's insertion / eviction to the trackers and, if every window still
-// covers what is asked of it, produce the clipped mean / std without touching the ring.  n already includes x_new.
-// Returns false when the ring is needed (the trackers are then left post-update for sdc_reward_kernel).
-__device__ __forceinline__ bool reward_fast(const int n, const unsigned x_new, const unsigned x_old, Trackers& T, double& mean,
-                                            double& sd) {
-  if (n < SMALL_N) {
-    T.q1.g = T.q3.g = T.tl.q.g = T.th.q.g = 0u;
-    mean = 0.0;
-    sd = 0.0;
-    return n < 2;   // a single value: z = 0 (no ring needed)
-  }
-  const bool has_old = x_old != KEY_NONE;
-  const int n_prev = has_old ? n : n - 1;
-  bool ok = true;
-  if (qt_valid(T.q1)) qt_update(T.q1, x_new, x_old, has_old, n_prev); else ok = false;
-  if (qt_valid(T.q3)) qt_update(T.q3, x_new, x_old, has_old, n_prev); else ok = false;
-  if (qt_valid(T.tl.q)) tt_update(T.tl, x_new, x_old, has_old, n_prev); else ok = false;
-  if (qt_valid(T.th.q)) tt_update(T.th, x_new, x_old, has_old, n_prev); else ok = false;
-  if (!ok) return false;
-  int k1, k3;
-  quartile_ranks(n, k1, k3);
-  unsigned a1, b1, a3, b3;
-  if (!qt_resolve(T.q1, k1, n, a1, b1) || !qt_resolve(T.q3, k3, n, a3, b3)) return false;
-  const Bounds b = clip_bounds(n, a1, b1, a3, b3);
-  int cl, ch;
-  double l1, l2, h1, h2;
-  if (!tt_below(T.tl, b.klb, n, cl, l1, l2) || !tt_below(T.th, b.kub, n, ch, h1, h2)) return false;
-  clipped_moments(n, b, cl, l1, l2, ch, h1, h2, mean, sd);
+// ------------------------------------------------------------------------------------------------
+// TAIL SETS.  Per env and side 512 slots (SDC_TAIL_CAP) in global memory, lane l owning slots [8 l, 8 l + 8) as
+// two uint4.  Side 0 = upper tail, keys as they are; side 1 = lower tail, keys complemented.  In this "flipped"
+// space both sides hold every key > tau; an empty slot is 0.
+struct TailSet {
+  unsigned k[8];   // this lane's 8 slots
+};
+constexpr unsigned TAIL_EMPTY = 0u;
+__device__ __forceinline__ unsigned tail_flip(int side) { return side ? KEY_NONE : 0u; }
+__device__ __forceinline__ TailSet tail_load(const uint4* __restrict__ p, const int lane) {
+  const uint4 a = p[2 * lane], b = p[2 * lane + 1];
+  TailSet s;
+  s.k[0] = a.x; s.k[1] = a.y; s.k[2] = a.z; s.k[3] = a.w;
+  s.k[4] = b.x; s.k[5] = b.y; s.k[6] = b.z; s.k[7] = b.w;
+  return s;
+}
+__device__ __forceinline__ void tail_store(uint4* __restrict__ p, const int lane, const TailSet& s) {
+  p[2 * lane] = make_uint4(s.k[0], s.k[1], s.k[2], s.k[3]);
+  p[2 * lane + 1] = make_uint4(s.k[4], s.k[5], s.k[6], s.k[7]);
+}
+
+// remove one occurrence of key x (flipped space) from the set; returns false if it is not there
+__device__ __forceinline__ bool tail_remove(TailSet& s, const unsigned x, const int lane) {
+  int c = -1;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) c = (s.k[i] == x) ? i : c;
+  const unsigned long long m = __ballot(c >= 0);
+  if (m == 0ull) return false;
+  const int owner = __ffsll((long long)m) - 1;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s.k[i] = (lane == owner && i == c) ? TAIL_EMPTY : s.k[i];
   return true;
+}
+// put key x (flipped space) into an empty slot; returns false if the set is full
+__device__ __forceinline__ bool tail_insert(TailSet& s, const unsigned x, const int lane) {
+  int c = -1;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) c = (s.k[i] == TAIL_EMPTY) ? i : c;
+  const unsigned long long m = __ballot(c >= 0);
+  if (m == 0ull) return false;
+  const int owner = __ffsll((long long)m) - 1;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s.k[i] = (lane == owner && i == c) ? x : s.k[i];
+  return true;
+}
+// this lane's share of sum (v - bound), sum (v^2 - bound^2) over the set keys >= kb (kb, keys in flipped space)
+__device__ __forceinline__ void tail_scan(const TailSet& s, const unsigned kb, const unsigned flip, const double bound,
+                                          double& t1, double& t2) {
+  const double b2 = bound * bound;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (s.k[i] >= kb) {   // kb >= 1 > TAIL_EMPTY
+      const double v = key_f64(s.k[i] ^ flip);
+      t1 += v - bound;
+      t2 += v * v - b2;
+    }
+  }
+}
+// this lane's number of set keys below kb (the slack between the threshold and the clip bound)
+__device__ __forceinline__ unsigned tail_count_below(const TailSet& s, const unsigned kb) {
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) c += (s.k[i] != TAIL_EMPTY && s.k[i] < kb) ? 1u : 0u;
+  return c;
+}
+// step of a threshold move: the key distance that holds ~128 keys, from `keys` keys found within `dist`
+__device__ __forceinline__ unsigned band_estimate(const unsigned dist, const int keys) {
+  const unsigned long long b = ((unsigned long long)dist * 128ull) / (unsigned long long)max(keys, 16);
+  return (unsigned)min(b, (unsigned long long)max(dist, 1u));
+}
+// raise the threshold to tau2 (flipped space): drop the keys <= tau2; returns the new count
+__device__ __forceinline__ int tail_raise(TailSet& s, const unsigned tau2) {
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    s.k[i] = (s.k[i] <= tau2) ? TAIL_EMPTY : s.k[i];
+    c += (s.k[i] != TAIL_EMPTY) ? 1 : 0;
+  }
+  return wave_sum_i32(c);
 }
 
 // rewards (utils/reward_creator.py:48-130) from the z-score, running episode returns
@@ -419,7 +367,7 @@ __device__ __forceinline__ void store_rewards(const Rewards& r, const double z, 
   rew[env * 3 + 2] = (float)r.foot;
   if (inf_row) {
     inf_row[SDC_INFO_ENERGY_Z] = (float)z;
-    inf_row[SDC_INFO_RESERVED] = (float)path;   // diagnostic: 0 no ring read, 1 ring read, 2 bisection + rebuild
+    inf_row[SDC_INFO_RESERVED] = (float)path;   // diagnostic: 0 no ring read, 1 slid ahead of need, 2 tail set re-thresholded, 3 rebuilt
     inf_row[SDC_INFO_EP_RETURN_LS] = (float)r.ret0;
     inf_row[SDC_INFO_EP_RETURN_DC] = (float)r.ret1;
     inf_row[SDC_INFO_EP_RETURN_BAT] = (float)r.ret2;

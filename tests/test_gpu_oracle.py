@@ -78,7 +78,7 @@ def test_order_statistic_tracker_stress():
     eng.set_state("hist_len", np.full(N, L0, np.int32))
     eng.set_state("hist_pos", np.zeros(N, np.int32))
     rig.reset_all()
-    paths = np.zeros(3, np.int64)
+    paths = np.zeros(4, np.int64)
     for ep in range(6):
         for t in range(steps):
             a = torch.randint(0, 3, (N, 3), dtype=torch.int32, device=eng.device)
@@ -88,11 +88,11 @@ def test_order_statistic_tracker_stress():
             obs, share, rew, done, info = eng.step(a)
             inf = info.cpu().numpy()
             assert (inf[:, L.INFO_IDX["fault"]] == 0).all(), (ep, t, inf[:, L.INFO_IDX["fault"]])
-            paths += np.bincount(inf[:, 39].astype(int), minlength=3)[:3]
+            paths += np.bincount(inf[:, 39].astype(int), minlength=4)[:4]
         rig.reset_all()
     assert (eng.get_state("order_stat_sticky") == 0).all()
     assert (eng.get_state("hist_len") == cap).all()
-    print("tracker paths (tracker-only, anchor slide, bisection + rebuild):", paths)
+    print("tracker paths (tracker-only, slide ahead of need, -, rebuild from the ring):", paths)
     assert paths[0] > 3 * paths[1]                         # the window usually answers without a sweep
     eng.close()
 
