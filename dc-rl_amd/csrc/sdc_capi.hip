@@ -1,8 +1,9 @@
 // sdc_capi.hip -- host side of the C-ABI declared in include/sustaindc_hip.h.
 //
-// Owns the device-resident struct-of-arrays state of N environments on one GPU and launches the two
-// kernels (sdc_dynamics_kernel + sdc_reward_kernel per step, sdc_reset_kernel) on the caller's stream.  No CPU fallback: every entry
-// point fails with an error code when HIP reports one.
+// Owns the device-resident state of N environments on one GPU and launches the kernels on the caller's stream:
+// sdc_dynamics_kernel (one launch = one env-step of all N envs, rewards included), sdc_reset_kernel at episode
+// boundaries, sdc_reward_verify_kernel only in verify mode.  No CPU fallback: every entry point fails with an
+// error code when HIP reports one.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

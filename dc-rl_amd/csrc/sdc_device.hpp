@@ -1,11 +1,10 @@
 // sdc_device.hpp -- device-side state layout and shared device functions of the SustainDC step.
 //
-// Written for gfx950 (MI355X, CDNA4) only: 64-lane wavefronts.  Two kernels per timestep:
-// sdc_dynamics_kernel -- one wavefront per environment instance integrates the coupled dynamics
-// (lanes = racks for the IT model, wave shuffles for the rack reductions) and writes obs / info;
-// sdc_reward_kernel -- one workgroup of 4 wavefronts per environment streams the env's 40 KB energy
-// history ring from HBM (16 B per lane, coalesced) and holds it in VGPRs for the order statistics
-// and the clipped mean / std of reward normalisation.
+// Written for gfx950 (MI355X, CDNA4) only: 64-lane wavefronts.  One kernel per timestep:
+// sdc_dynamics_kernel -- one wavefront per environment instance integrates the coupled dynamics (lanes = racks for
+// the IT model, wave shuffles for the rack reductions), writes obs / info, appends the step's energy to the env's
+// history ring and produces the history-normalised rewards from O(1) incremental state (sdc_trackers.hpp); the
+// ring itself (40 KB per env) is swept only every few steps, in-wave and ahead of need (sdc_ringpath.hpp).
 //
 // Arithmetic: fp64 for the dynamics, observation features and reductions (the reference is Python
 // float / NumPy float64, and its integer / decimal-rounding cliffs only reproduce in fp64);

@@ -14,8 +14,10 @@
 //   * the observation features (3 least-squares slopes, 2 x mean/std/peak/valley) run lane-parallel with segmented
 //     butterfly reductions; lane 0 assembles the info block and the new state record in LDS; all lanes store
 //     obs / share_obs / info / record coalesced.
-// The energy value and the reward terms that need the history normaliser are handed to sdc_reward_kernel
-// (sdc_reward.hip) through a 64-byte per-env header; the energy is appended to the history ring here.
+//   * rewards: the step's energy is appended to the env's history ring, and the history-normalised z-score comes
+//     from the env's reward state (quartile trackers, tail sets, running sums: sdc_trackers.hpp) in O(1) without
+//     reading the ring; the rare ring sweeps that keep that state ahead of need run in-wave (sdc_ringpath.hpp).
+// One launch of this kernel is one env-step of all N environments.
 //
 // Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
 #include "sdc_ringpath.hpp"
@@ -381,7 +383,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     inf[SDC_INFO_HOUR] = (float)((double)hourq_n * 0.25);
     const unsigned f_all = (unsigned)rec_i32(r, R_FAULT) | fault;
     inf[SDC_INFO_FAULT] = (float)f_all;
-    inf[SDC_INFO_ENERGY_Z] = 0.0f;       // the five columns below are filled by sdc_reward_kernel
+    inf[SDC_INFO_ENERGY_Z] = 0.0f;       // the five columns below are filled by the reward part of the step (below)
     inf[SDC_INFO_RESERVED] = 0.0f;
     inf[SDC_INFO_EP_RETURN_LS] = 0.0f;
     inf[SDC_INFO_EP_RETURN_DC] = 0.0f;

@@ -1,8 +1,8 @@
 """SdcEngine: N SustainDC environment instances resident on one MI355X, driven through the C-ABI.
 
 PyTorch is plumbing here: it owns the obs / action / reward / info device buffers and the HIP stream;
-the dynamics run in the hand-written kernels of csrc/ (sdc_dynamics_kernel, sdc_reward_kernel,
-sdc_reset_kernel).
+the step runs in the hand-written kernels of csrc/ (sdc_dynamics_kernel = one env-step of all N envs,
+sdc_reset_kernel at episode boundaries).
 """
 from __future__ import annotations
 

@@ -70,7 +70,9 @@ enum sdc_info_col {
   SDC_INFO_HOUR,
   SDC_INFO_FAULT,    /* bit mask, see SDC_FAULT_* (the reference raises / asserts instead) */
   SDC_INFO_ENERGY_Z, /* normalize_energy() output shared by the three rewards */
-  SDC_INFO_RESERVED,
+  SDC_INFO_RESERVED, /* diagnostic: how this step's reward normalisation was served: 0 incremental state only (no
+                        history read), 1 a quartile tracker was slid over the history ahead of need, 2 a tail set
+                        was re-collected, 3 the state was rebuilt from the history */
   /* running return of the current episode INCLUDING this step (== the episode return on the done step);
    * feeds the return statistics the runners log (harl/common/base_logger.py:75-88) without host sums */
   SDC_INFO_EP_RETURN_LS,
@@ -84,7 +86,7 @@ enum sdc_info_col {
 #define SDC_FAULT_BAT_DISCHARGE 4u /* envs/bat_env_fwd_view.py:237 asserts */
 #define SDC_FAULT_WORKLOAD 8u      /* envs/carbon_ls.py:333-336 raises */
 #define SDC_FAULT_TABLE_RANGE 16u  /* cursor would leave the year table (reference: IndexError) */
-#define SDC_FAULT_ORDER_STAT 32u   /* debug_flags bit 0: tracked order statistics disagreed with the bisection */
+#define SDC_FAULT_ORDER_STAT 32u   /* debug_flags bit 0: the incremental reward state disagreed with the exact recomputation */
 
 typedef struct sdc_handle sdc_handle;
 
@@ -102,8 +104,11 @@ typedef struct {
   double weather_noise_std;   /* 0.75 (utils/managers.py:504) ; 0 disables the noise */
   double weather_noise_weight;/* 0.02 (utils/managers.py:504) */
   int32_t max_roll_days;   /* 14: roll in [0, 14) days (utils/managers.py:601) */
-  int32_t debug_flags;     /* bit 0: verify the incrementally tracked order statistics against an exact
-                              bisection every step (slow; a mismatch sets SDC_FAULT_ORDER_STAT) */
+  int32_t debug_flags;     /* bit 0: VERIFY MODE -- after every step check the incremental reward state (quartile
+                              trackers, tail sets, running sum) and the reported z-score against an exact bisection
+                              and a direct fp64 pass over each env's history (slow; a mismatch sets
+                              SDC_FAULT_ORDER_STAT).  Bits 1, 3: diagnostics in info[reserved] / info[40..43]
+                              (why a rebuild happened; per-wavefront phase timings) -- measurement only */
 } sdc_config;
 
 /* replaces: DC_Config + Rack/CPU constants + sized HVAC values
@@ -184,7 +189,8 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
  * int32[N]:  cursor t_rel day hourq q_popped q_cum q_cumT q_head q_cum_hm1 q_cumT_hm1 last_delta consecutive
  *            scale hist_len hist_pos episode fault loc_id cfg_id day_lo day_hi hist_n
  * double[N]: stpt bat_load ci_min ci_den t_min t_den hist_ref
- * record (uint32[N][64], the raw 256-byte state records);  header (uint32[N][64], the hand-off headers);
+ * record (uint32[N][64], the raw 256-byte state records);  header (uint32[N][64], step hand-off + reward state);
+ * tails (uint32[N][2][512], the reward tail sets: upper keys, complemented lower keys, 0 = empty slot);
  * ep_return (double[N][3]);
  * hist (float[N][hist_stride], energy minus hist_ref, NaN = empty slot: every slot >= hist_len must be NaN);
  * t_win wb_win (double[N][weather_window_len]);  qtab (uint32[N][queue_stride][2]). */
@@ -197,7 +203,7 @@ int sdc_queue_stride(const sdc_handle* h);
  * off.  In a sampled step one lane per workgroup of each kernel stamps the device's constant-rate wall clock at
  * entry and exit; sdc_profile_read synchronises the device and accumulates, per sampled launch,
  * max(exit) - min(entry) over the workgroups -- the launch's duration on the GPU, with no host-event overhead.
- *   out[0] = sdc_dynamics_kernel total ms, out[1] = sdc_reward_kernel total ms,
+ *   out[0] = sdc_dynamics_kernel (the step kernel) total ms, out[1] = 0 (no separate reward kernel any more),
  *   out[2] = sdc_reset_kernel (auto-reset) total ms, out[3] = steps sampled, out[4] = auto-resets sampled. */
 int sdc_profile_enable(sdc_handle* h, int enable);
 int sdc_profile_read(sdc_handle* h, double* out5, int reset);

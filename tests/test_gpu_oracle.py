@@ -97,6 +97,41 @@ def test_order_statistic_tracker_stress():
     eng.close()
 
 
+def test_tail_sets_heavy_tails_and_threshold_moves():
+    """The tail sets of the reward normalisation (verify mode checks every step against a direct pass over the ring):
+    histories with 0.5 % .. 9 % of the keys beyond a clip bound -- the last two cannot fit a 512-slot set, so those
+    envs must fall back to the direct computation -- and a drifting level that forces thresholds to move."""
+    import torch
+    N, steps, cap = 64, 200, 10000
+    rig = P.ParityRig(N, episode_steps=steps, seed=33, hist_cap=cap, with_oracle=False)
+    eng = rig.eng
+    rng = np.random.default_rng(33)
+    hist = np.full((N, eng.hist_stride), np.nan, np.float32)
+    frac = np.array([0.005, 0.02, 0.04, 0.09])[np.arange(N) % 4]
+    base = rng.standard_normal((N, cap)) * 20
+    out = rng.random((N, cap)) < frac[:, None]
+    base = np.where(out, base + np.sign(rng.standard_normal((N, cap))) * (120 + 60 * rng.random((N, cap))), base)
+    base += np.linspace(0, 1, cap)[None, :] * (np.arange(N)[:, None] % 3 - 1) * 30     # drift: none / up / down
+    hist[:, :cap] = base.astype(np.float32)
+    eng.set_state("hist", hist)
+    eng.set_state("hist_len", np.full(N, cap, np.int32))
+    eng.set_state("hist_pos", np.zeros(N, np.int32))
+    rig.reset_all()
+    paths = np.zeros(4, np.int64)
+    for t in range(steps):
+        a = torch.randint(0, 3, (N, 3), dtype=torch.int32, device=eng.device)
+        obs, share, rew, done, info = eng.step(a)
+        inf = info.cpu().numpy()
+        assert (inf[:, L.INFO_IDX["fault"]] == 0).all(), (t, np.nonzero(inf[:, L.INFO_IDX["fault"]])[0])
+        assert np.isfinite(rew.cpu().numpy()).all()
+        paths += np.bincount(inf[:, 39].astype(int), minlength=4)[:4]
+    assert (eng.get_state("order_stat_sticky") == 0).all()
+    print("paths (no ring read, slide ahead, set re-collected, rebuilt):", paths)
+    assert paths[0] > paths[3]          # the light-tailed envs run on the incremental state
+    assert paths[3] >= steps            # the 9 % envs cannot: rebuilt / direct every step
+    eng.close()
+
+
 def test_device_reset_and_auto_reset():
     """Device-side reset (Philox draws, coherent noise, roll, clip, 30-day min/max): distributional checks and
     the reset observation recomputed by the oracle from the windows the device produced."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 PMC passes into profiles/hbm_traffic.json.
 
-Usage: python tools/pmc_summary.py <fetch_dir> <write_dir> [--kernel sdc_reward_kernel] [--last 200]
+Usage: python tools/pmc_summary.py <fetch_dir> <write_dir> [--kernel sdc_dynamics_kernel] [--last 200]
 
 Each dir holds the `*_counter_collection.csv` of one `rocprofv3 --pmc X --kernel-trace` pass (FETCH_SIZE and
 WRITE_SIZE need separate passes: TCC has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2).  Corrections follow
@@ -33,7 +33,7 @@ def per_kernel(dirname, counter, kernel, last):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    kernel = "sdc_reward_kernel"
+    kernel = "sdc_dynamics_kernel"
     last = 200
     for i, a in enumerate(sys.argv):
         if a == "--kernel":
