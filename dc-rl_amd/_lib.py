@@ -48,7 +48,35 @@ class SdcConfig(C.Structure):
         ("queue_max_len", C.c_int32), ("n_locations", C.c_int32), ("n_dc_configs", C.c_int32),
         ("auto_reset", C.c_int32), ("seed", C.c_uint64), ("weather_noise_std", C.c_double),
         ("weather_noise_weight", C.c_double), ("max_roll_days", C.c_int32), ("debug_flags", C.c_int32),
+        ("reward_method", C.c_int32 * 3), ("reserved1", C.c_int32),
     ]
+
+
+# reward-method codes (include/sustaindc_hip.h enum sdc_reward_method) by agent slot and reference name
+# (utils/reward_creator.py:322-334).  default_ls_reward is only available to agent_ls: each call appends to the
+# shared energy history (reward_creator.py:63).
+_ALT_REWARDS = {"custom_agent_reward": 2, "tou_reward": 3, "energy_efficiency_reward": 4, "energy_PUE_reward": 5,
+                "water_usage_efficiency_reward": 6}
+REWARD_CODES = {
+    "ls_reward": {"default_ls_reward": 0, "default_dc_reward": 1, "default_bat_reward": 1, **_ALT_REWARDS},
+    "dc_reward": {"default_dc_reward": 0, "default_bat_reward": 1, **_ALT_REWARDS},
+    "bat_reward": {"default_bat_reward": 0, "default_dc_reward": 1, **_ALT_REWARDS},
+}
+
+
+def reward_codes(env_args: dict):
+    """(ls, dc, bat) reward-method codes of an env_config; NotImplementedError for what the device does not run."""
+    out = []
+    for key, table in REWARD_CODES.items():
+        name = env_args.get(key, {"ls_reward": "default_ls_reward", "dc_reward": "default_dc_reward",
+                                  "bat_reward": "default_bat_reward"}[key])
+        if name not in table:
+            raise NotImplementedError(
+                f"{key}={name!r}: runs on the device: {sorted(table)} (renewable_energy_reward and "
+                "temperature_efficiency_reward need inputs the reference env never provides; default_ls_reward is "
+                "only available to agent_ls)")
+        out.append(table[name])
+    return tuple(out)
 
 
 class SdcDcParams(C.Structure):

@@ -176,6 +176,13 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   d.qstride = (cfg->episode_steps + 63) / 64 * 64;
   d.max_roll_days = cfg->max_roll_days;
   d.debug_flags = cfg->debug_flags;
+  for (int a = 0; a < 3; a++) {
+    if (cfg->reward_method[a] < 0 || cfg->reward_method[a] > SDC_REWARD_WATER) {
+      sdc_destroy(h);
+      return fail_msg("sdc_create: unknown reward_method");
+    }
+    d.reward_method[a] = cfg->reward_method[a];
+  }
   d.seed = cfg->seed;
   d.noise_std = cfg->weather_noise_std;
   d.noise_weight = cfg->weather_noise_weight;

@@ -98,6 +98,7 @@ enum SdcTrack { T_G = 0, T_CLT, T_CLE, T_NP, T_NS, T_P = 5, T_S = 9, SDC_TRACK_D
 struct SdcDev {
   int n_envs, episode_steps, hist_cap, queue_max, table_len, lw, qstride, max_roll_days;
   int debug_flags;  // bit 0: cross-check the tracked order statistics against the bisection every step
+  int reward_method[3];   // sdc_reward_method per agent slot (ls, dc, bat)
   unsigned long long seed;
   double noise_std, noise_weight;
   // shared, read-only

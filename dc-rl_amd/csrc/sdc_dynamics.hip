@@ -329,11 +329,16 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
   // shift-invariant, and offsets keep the fp32 rounding error proportional to the spread of the history
   // instead of to the ~300 kWh magnitude (two nearly equal energies would otherwise lose the z-score).
   // Stored as order-preserving keys for the order-statistic trackers.
+  // As in the reference, only default_ls_reward appends (reward_creator.py:63): with another ls reward method the
+  // history stays as it is and the other agents' footprint rewards are normalised against it.
+  const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;
   int hl = rec_i32(r, R_HIST_LEN), hpos = rec_i32(r, R_HIST_POS);
   const double href = hl == 0 ? energy : rec_f64(r, R_HIST_REF);
   const double e_off = energy - href;
   int slot;
-  if (hl < S.hist_cap) {
+  if (!append) {
+    slot = -1;
+  } else if (hl < S.hist_cap) {
     slot = hl;
     hl += 1;
   } else {
@@ -391,7 +396,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
 
     // ---- history append: the ring slot gets this step's key --------------------------------------------------
-    S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
+    if (append) S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
     S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
 
     // ---- new state record ------------------------------------------------------------------------------------
@@ -426,7 +431,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     using namespace sdc_rw;
     if ((S.debug_flags & 8) && lane == 0) sh.dbg_t = wall_clock64();
     const int n = (int)sfl((unsigned)hl);
-    const bool has_old = x_old != KEY_NONE;
+    const bool has_old = append && x_old != KEY_NONE;
     unsigned o0 = hd0;
     double mean = 0.0, sd = 0.0;
     int path = ahead_path;   // diagnostics: 0 no ring read, 1 slid ahead of need, 2 tail sets re-collected, 3 rebuilt
@@ -444,7 +449,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
       bool ok = qt_valid(q1) && qt_valid(q3) && tau0 != SDC_TAU_INVALID;
       bool dirty0 = sets_dirty, dirty1 = sets_dirty;   // a set goes back to memory only if it changed
       int why = ok ? 0 : 1;                            // diagnostics (debug_flags bit 1): why a rebuild was needed
-      if (ok) {
+      if (ok && append) {
         // O(1) updates: running sums, quartile trackers, tail sets
         const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
         A1 += vn - vo;
@@ -550,10 +555,11 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     put_f64(o0, H_NORM_CI, nc[17]);                             // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
     put_f64(o0, H_OLDEST, oldest_norm);                         // ls_oldest_task_age
     const double z = n < 2 ? 0.0 : (e_off - mean) / (sd > 0 ? sd : 1.0);
-    const Rewards rr = step_rewards(z, nc[17], oldest_norm, (double)overdue, hd0);
-    put_f64(o0, H_RET, rr.ret0);
-    put_f64(o0, H_RET + 2, rr.ret1);
-    put_f64(o0, H_RET + 4, rr.ret2);
+    const RewardIn rin = {z, nc[17], oldest_norm, (double)overdue, energy, (double)hourq_n * 0.25, p_it / 1e3, total_kw, water};
+    const Rewards rr = step_rewards(rin, S.reward_method, hd0);
+    put_f64(o0, H_RET, rr.ret[0]);
+    put_f64(o0, H_RET + 2, rr.ret[1]);
+    put_f64(o0, H_RET + 4, rr.ret[2]);
     if (lane == 0) store_rewards(rr, z, path, env, rew, sh.info);
     S.hdr[(size_t)env * SDC_HDR_DWORDS + lane] = o0;
   }
@@ -595,7 +601,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   const int hl0 = rec_i32(r, R_HIST_LEN);
   const int slot0 = hl0 < S.hist_cap ? hl0 : rec_i32(r, R_HIST_POS);
   unsigned x_old_l = 0xFFFFFFFFu;
-  if (lane == 63 && hl0 >= S.hist_cap) x_old_l = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
+  const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;   // else the history does not change this step
+  if (lane == 63 && hl0 >= S.hist_cap && append) x_old_l = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
 
   // ---- level 1: one 8-byte gather per lane -------------------------------------------------------------------------
   {
@@ -640,8 +647,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   sdc_rw::TailSet ts0, ts1;   // the env's tail sets (2 x 2 KB, coalesced)
   if (hl0 >= sdc_rw::SMALL_N) {
     using namespace sdc_rw;
-    const bool has_old = hl0 >= S.hist_cap;
-    const int n_next = has_old ? hl0 : hl0 + 1;
+    const bool has_old = append && hl0 >= S.hist_cap;
+    const int n_next = (has_old || !append) ? hl0 : hl0 + 1;
     const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), -1, 0u};
     int k1, k3;
     quartile_ranks(n_next, k1, k3);
@@ -712,10 +719,10 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     __syncthreads();
     if (lane == 0) {
       const unsigned long long dbg_a3 = wall_clock64();
-      sh.info[40] = (float)(dbg_a1 - dbg_a0);
+      sh.info[40] = (S.debug_flags & 16) ? (float)(dbg_a0 & 0xFFFFFull) : (float)(dbg_a1 - dbg_a0);
       sh.info[41] = (float)(sh.dbg_t - dbg_a1);
       sh.info[42] = (float)(dbg_a3 - sh.dbg_t);
-      sh.info[43] = (float)(dbg_a3 - dbg_a0);
+      sh.info[43] = (S.debug_flags & 16) ? (float)(dbg_a3 & 0xFFFFFull) : (float)(dbg_a3 - dbg_a0);
     }
   }
   __syncthreads();

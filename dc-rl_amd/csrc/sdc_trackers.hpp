@@ -342,35 +342,58 @@ __device__ __forceinline__ int tail_raise(TailSet& s, const unsigned tau2) {
   return wave_sum_i32(c);
 }
 
-// rewards (utils/reward_creator.py:48-130) from the z-score, running episode returns
-struct Rewards {
-  double ls, foot, ret0, ret1, ret2;
+// rewards (utils/reward_creator.py:48-334) from the z-score and the step's physical quantities; running returns
+struct RewardIn {
+  double z;             // normalize_energy(bat_total_energy_with_battery_KWh)
+  double norm_ci_next;  // norm_CI
+  double oldest_norm;   // ls_oldest_task_age
+  double overdue;       // ls_overdue_penalty
+  double energy_kwh;    // bat_total_energy_with_battery_KWh
+  double hour;          // hour of the day after the step (reward_params["hour"])
+  double ite_kw, total_kw, water;   // dc_ITE_total_power_kW, dc_total_power_kW, dc_water_usage
 };
-__device__ __forceinline__ Rewards step_rewards(const double z, const double norm_ci_next, const double oldest_norm,
-                                                const double overdue, const unsigned hd0) {
-  Rewards r;
-  r.foot = -1.0 * (norm_ci_next * z / 0.50);
-  const double overdue_pen = -0.3 * sqrt(overdue) + 0.3;
-  const double age_pen = -0.1 * oldest_norm;
-  double rls = r.foot + overdue_pen + age_pen;
-  r.ls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
-  r.ret0 = rec_f64(hd0, H_RET) + r.ls;
-  r.ret1 = rec_f64(hd0, H_RET + 2) + r.foot;
-  r.ret2 = rec_f64(hd0, H_RET + 4) + r.foot;
-  return r;
+struct Rewards {
+  double r[3], ret[3];
+};
+__device__ __forceinline__ double tou_price(const int h) {   // reward_creator.py:166-189
+  return h < 6 ? 0.25 : (h < 11 ? 0.41 : (h < 16 ? 0.30 : (h < 22 ? 0.27 : 0.25)));
+}
+__device__ __forceinline__ Rewards step_rewards(const RewardIn& in, const int (&method)[3], const unsigned hd0) {
+  const double foot = -1.0 * (in.norm_ci_next * in.z / 0.50);
+  const double overdue_pen = -0.3 * sqrt(in.overdue) + 0.3;
+  const double age_pen = -0.1 * in.oldest_norm;
+  double rls = foot + overdue_pen + age_pen;
+  rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
+  Rewards o;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    double r;
+    switch (method[a]) {   // wave-uniform
+      case SDC_REWARD_DEFAULT: r = a == 0 ? rls : foot; break;
+      case SDC_REWARD_FOOTPRINT: r = foot; break;
+      case SDC_REWARD_TOU: r = -1.0 * in.energy_kwh * tou_price((int)in.hour % 24); break;
+      case SDC_REWARD_ENERGY_EFFICIENCY: r = in.ite_kw / in.total_kw; break;
+      case SDC_REWARD_PUE: r = -fabs((in.ite_kw != 0 ? in.total_kw / in.ite_kw : (double)INFINITY) - 1); break;
+      case SDC_REWARD_WATER: r = -0.01 * in.water; break;
+      default: r = 0.0;   // SDC_REWARD_CUSTOM: custom_agent_reward returns 0
+    }
+    o.r[a] = r;
+    o.ret[a] = rec_f64(hd0, H_RET + 2 * a) + r;
+  }
+  return o;
 }
 // lane 0 writes the step's rewards and the reward-side info columns
 __device__ __forceinline__ void store_rewards(const Rewards& r, const double z, const int path, const int env,
                                               float* __restrict__ rew, float* __restrict__ inf_row) {
-  rew[env * 3 + 0] = (float)r.ls;
-  rew[env * 3 + 1] = (float)r.foot;
-  rew[env * 3 + 2] = (float)r.foot;
+  rew[env * 3 + 0] = (float)r.r[0];
+  rew[env * 3 + 1] = (float)r.r[1];
+  rew[env * 3 + 2] = (float)r.r[2];
   if (inf_row) {
     inf_row[SDC_INFO_ENERGY_Z] = (float)z;
-    inf_row[SDC_INFO_RESERVED] = (float)path;   // diagnostic: 0 no ring read, 1 slid ahead of need, 2 tail set re-thresholded, 3 rebuilt
-    inf_row[SDC_INFO_EP_RETURN_LS] = (float)r.ret0;
-    inf_row[SDC_INFO_EP_RETURN_DC] = (float)r.ret1;
-    inf_row[SDC_INFO_EP_RETURN_BAT] = (float)r.ret2;
+    inf_row[SDC_INFO_RESERVED] = (float)path;   // diagnostic: 0 no ring read, 1 slid ahead of need, 2 tail set re-collected, 3 rebuilt
+    inf_row[SDC_INFO_EP_RETURN_LS] = (float)r.ret[0];
+    inf_row[SDC_INFO_EP_RETURN_DC] = (float)r.ret[1];
+    inf_row[SDC_INFO_EP_RETURN_BAT] = (float)r.ret[2];
   }
 }
 

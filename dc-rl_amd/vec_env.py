@@ -45,7 +45,6 @@ DEFAULT_ENV_ARGS = {  # EnvConfig.DEFAULT_CONFIG (sustaindc_env.py:38-80)
     "ls_reward": "default_ls_reward", "dc_reward": "default_dc_reward", "bat_reward": "default_bat_reward",
     "evaluation": False, "actions_are_logits": False,
 }
-_SUPPORTED_REWARDS = {"ls_reward": "default_ls_reward", "dc_reward": "default_dc_reward", "bat_reward": "default_bat_reward"}
 
 
 class ShareVecEnv(ABC):
@@ -162,12 +161,13 @@ def _merge_args(env_args: Optional[dict]) -> dict:
     a = dict(DEFAULT_ENV_ARGS)
     if env_args:
         a.update(env_args)
-    for k, v in _SUPPORTED_REWARDS.items():
-        if a.get(k, v) != v:
-            raise NotImplementedError(f"{k}={a[k]!r}: only the default reward methods run on the device "
-                                      "(utils/reward_creator.py:48-130); alternates are listed as 'next' in DESIGN.md")
-    if list(a["agents"]) != AGENTS:
-        raise NotImplementedError("all three agents must be active (base do-nothing agents are not implemented)")
+    L.reward_codes(a)   # NotImplementedError for a reward method the device does not run
+    unknown = [x for x in a["agents"] if x not in AGENTS]
+    if unknown:
+        raise ValueError(f"unknown agents {unknown}; the environment has {AGENTS}")
+    if list(a["agents"]) != AGENTS and not a.get("_allow_agent_subset"):
+        raise NotImplementedError("the batched HARL surface steps all three agents; a subset of agents (the others "
+                                  "played by the reference's base do-nothing agents) is available through SustainDC")
     return a
 
 
@@ -181,6 +181,10 @@ class SustainDCVecEnv(ShareVecEnv):
         days = {a["days_per_episode"] for a in per_env}
         if len(days) != 1:
             raise ValueError("all envs of one batch must share days_per_episode")
+        rcodes = {L.reward_codes(a) for a in per_env}
+        if len(rcodes) != 1:
+            raise ValueError("all envs of one batch must share ls_reward / dc_reward / bat_reward")
+        self.reward_method = rcodes.pop()
         self.n_agents = 3
         self.agents = list(AGENTS)
         self.return_torch = return_torch
@@ -214,7 +218,8 @@ class SustainDCVecEnv(ShareVecEnv):
         self.bat_env.dcload_max = self.dc_env.power_ub_kW / 4   # sustaindc_env.py:158-160
         self.bat_env.dcload_min = self.dc_env.power_lb_kW / 4
         self.engine = SdcEngine(n_envs, episode_steps=self.episode_steps, device=device, n_locations=len(loc_keys),
-                                n_dc_configs=len(cfg_keys), auto_reset=auto_reset, seed=seed, queue_max_len=1000)
+                                n_dc_configs=len(cfg_keys), auto_reset=auto_reset, seed=seed, queue_max_len=1000,
+                                reward_method=self.reward_method)
         for i, tb in enumerate(self.tables):
             self.engine.set_tables(i, tb["W"], tb["C"], tb["T"], tb["WB"])
         for i, e in enumerate(self.dc_envs):

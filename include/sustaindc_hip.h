@@ -109,7 +109,25 @@ typedef struct {
                               and a direct fp64 pass over each env's history (slow; a mismatch sets
                               SDC_FAULT_ORDER_STAT).  Bits 1, 3: diagnostics in info[reserved] / info[40..43]
                               (why a rebuild happened; per-wavefront phase timings) -- measurement only */
+  int32_t reward_method[3]; /* reward function per agent slot (ls, dc, bat), utils/reward_creator.py:322-334:
+                               SDC_REWARD_DEFAULT the slot's own default_*_reward, SDC_REWARD_FOOTPRINT
+                               default_dc_reward = default_bat_reward, SDC_REWARD_CUSTOM custom_agent_reward (0),
+                               SDC_REWARD_TOU, SDC_REWARD_ENERGY_EFFICIENCY, SDC_REWARD_PUE, SDC_REWARD_WATER.
+                               As in the reference only default_ls_reward appends to the energy history
+                               (reward_creator.py:63): the history grows iff reward_method[0] == SDC_REWARD_DEFAULT */
+  int32_t reserved1;
 } sdc_config;
+
+enum sdc_reward_method {
+  SDC_REWARD_DEFAULT = 0,
+  SDC_REWARD_FOOTPRINT = 1,
+  SDC_REWARD_CUSTOM = 2,
+  SDC_REWARD_TOU = 3,               /* DEVIATION: the reference indexes its price table with the float hour and raises
+                                       KeyError off the full hour (reward_creator.py:191); here the hour is truncated */
+  SDC_REWARD_ENERGY_EFFICIENCY = 4,
+  SDC_REWARD_PUE = 5,
+  SDC_REWARD_WATER = 6
+};
 
 /* replaces: DC_Config + Rack/CPU constants + sized HVAC values
  * (utils/dc_config_reader.py:39-145, envs/datacenter.py:31-135, utils/make_envs_pyenv.py:139-197) */

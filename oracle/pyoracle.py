@@ -49,6 +49,7 @@ class Params(C.Structure):
         ("min_temp", C.c_double), ("max_temp", C.c_double),
         ("bat_capacity", C.c_double),
         ("queue_max_len", C.c_int),
+        ("reward_method", C.c_int * 3),
     ]
 
 
@@ -130,11 +131,15 @@ def make_params(rack_n, rack_full, rack_idle, rack_supply, rack_return, scal: di
               "max_temp", "bat_capacity"):
         setattr(p, k, float(scal[k]))
     p.queue_max_len = int(scal.get("queue_max_len", 1000))
+    for i, m in enumerate(scal.get("reward_method", (0, 0, 0))):
+        p.reward_method[i] = int(m)
     return p
 
 
 def params_from_fixture(d) -> Params:
     scal = {k[len("static_"):]: d[k] for k in d.files if k.startswith("static_") and d[k].ndim == 0}
+    if "meta_reward_method" in d.files:
+        scal["reward_method"] = [int(m) for m in d["meta_reward_method"]]
     return make_params(d["static_rack_n"], d["static_rack_full"], d["static_rack_idle"], d["static_rack_supply"],
                        d["static_rack_return"], scal)
 

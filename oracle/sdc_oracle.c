@@ -568,11 +568,13 @@ int sdco_step(sdco_env *e, const sdco_params *p, const int32_t act[3], float *ob
   if (obs53) build_obs(e, p, obs53);
 
   /* ---- rewards: sustaindc_env.py:676-737, utils/reward_creator.py:48-130 */
-  if (e->hist_len < SDCO_HIST_CAP) {
-    e->hist[e->hist_len++] = energy;
-  } else {
-    e->hist[e->hist_pos] = energy;
-    e->hist_pos = (e->hist_pos + 1) % SDCO_HIST_CAP;
+  if (p->reward_method[0] == 0) { /* only default_ls_reward appends (reward_creator.py:63) */
+    if (e->hist_len < SDCO_HIST_CAP) {
+      e->hist[e->hist_len++] = energy;
+    } else {
+      e->hist[e->hist_pos] = energy;
+      e->hist_pos = (e->hist_pos + 1) % SDCO_HIST_CAP;
+    }
   }
   /* numpy sees the deque in insertion order; order only affects the pairwise-sum tree (<=1e-16) */
   double z = normalize_energy_scratch(e->hist, e->hist_len, energy, e->scratch);
@@ -582,9 +584,31 @@ int sdco_step(sdco_env *e, const sdco_params *p, const int32_t act[3], float *ob
   double age_pen = -0.1 * e->ls_oldest_age;
   double rls = foot + overdue_pen + age_pen;
   rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
-  rew[0] = rls;
-  rew[1] = foot;
-  rew[2] = foot;
+  for (int a = 0; a < 3; a++) {
+    double r;
+    switch (p->reward_method[a]) {
+      case 0: r = a == 0 ? rls : foot; break;
+      case 1: r = foot; break;
+      case 2: r = 0.0; break; /* custom_agent_reward, reward_creator.py:133-146 */
+      case 3: { /* tou_reward, reward_creator.py:154-198.  DEVIATION: the reference indexes its price table with the
+                   float hour and raises KeyError off the full hour; here the hour is truncated. */
+        static const double tou[24] = {0.25, 0.25, 0.25, 0.25, 0.25, 0.25, 0.41, 0.41, 0.41, 0.41, 0.41, 0.30,
+                                       0.30, 0.30, 0.30, 0.30, 0.27, 0.27, 0.27, 0.27, 0.27, 0.27, 0.25, 0.25};
+        r = -1.0 * energy * tou[(int)e->hour % 24];
+        break;
+      }
+      case 4: r = info[SDCO_I_DC_ITE_KW] / info[SDCO_I_DC_TOTAL_KW]; break; /* energy_efficiency_reward :223-239 */
+      case 5: { /* energy_PUE_reward :242-265 */
+        const double it = info[SDCO_I_DC_ITE_KW];
+        const double pue = it != 0 ? info[SDCO_I_DC_TOTAL_KW] / it : INFINITY;
+        r = -fabs(pue - 1);
+        break;
+      }
+      case 6: r = -0.01 * info[SDCO_I_DC_WATER_USAGE]; break; /* water_usage_efficiency_reward :297-318 */
+      default: r = 0.0;
+    }
+    rew[a] = r;
+  }
   info[SDCO_I_NORM_CI] = norm_ci;
   info[SDCO_I_OUTSIDE_TEMP] = T[ip];
   info[SDCO_I_DAY] = e->day;

@@ -63,6 +63,12 @@ typedef struct {
   double min_temp, max_temp;          /* 15.0 / 21.6 (utils/make_envs_pyenv.py:125-126) */
   double bat_capacity;                /* MWh (sustaindc_env.py:152) */
   int queue_max_len;
+  /* reward function per agent slot (ls, dc, bat), utils/reward_creator.py:322-334 REWARD_METHOD_MAP:
+   * 0 the slot's default (default_ls_reward / default_dc_reward / default_bat_reward), 1 footprint only
+   * (default_dc_reward = default_bat_reward), 2 custom_agent_reward, 3 tou_reward, 4 energy_efficiency_reward,
+   * 5 energy_PUE_reward, 6 water_usage_efficiency_reward.  Only default_ls_reward appends to the energy history
+   * (reward_creator.py:63), i.e. the history grows iff reward_method[0] == 0. */
+  int reward_method[3];
 } sdco_params;
 
 typedef struct {

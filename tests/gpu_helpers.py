@@ -59,6 +59,8 @@ def share_from_raw(raw):
 def make_engine_for_fixture(d, n_envs=2, **kw):
     steps = int(d["meta_steps"])
     kw.setdefault("debug_flags", 1)   # cross-check the tracked order statistics against the bisection every step
+    if "meta_reward_method" in d.files:
+        kw.setdefault("reward_method", tuple(int(m) for m in d["meta_reward_method"]))
     eng = SdcEngine(n_envs, episode_steps=steps, auto_reset=False, **kw)
     W, Cc = tables_from_fixture(d, int(d["meta_episodes"]))
     z = np.zeros(TL)

@@ -27,7 +27,8 @@ def test_library_builds_and_exports_all_declared_symbols():
 def test_struct_sizes_match_header():
     # sdc_dc_params: 2 x int32 + 5 x 64 doubles + 18 doubles
     assert C.sizeof(L.SdcDcParams) == 8 + 8 * (5 * 64 + 18)
-    assert C.sizeof(L.SdcConfig) == 8 * 4 + 8 + 8 + 8 + 8
+    # sdc_config: 8 x int32, uint64, 2 doubles, 2 x int32, reward_method[3] + reserved
+    assert C.sizeof(L.SdcConfig) == 8 * 4 + 8 + 8 + 8 + 8 + 16
     assert len(L.INFO_COLS) == L.INFO_DIM
 
 

@@ -101,3 +101,31 @@ def test_vec_env_torch_outputs_stay_on_device():
     obs, share, rew, dones, infos, avail = envs.step(a)
     assert rew.is_cuda and rew.shape == (8, 3, 1) and dones.dtype == torch.bool and dones.shape == (8, 3)
     envs.close()
+
+
+def test_agent_subset_uses_base_agents_and_alt_rewards():
+    """A subset of agents: the others are played by the reference's base do-nothing agents (sustaindc_env.py:172-191,
+    623-655); alternate reward functions by name (utils/reward_creator.py:322-334)."""
+    from dc_rl_amd import SustainDC
+    env = SustainDC({"agents": ["agent_ls", "agent_bat"], "location": "ny", "month": 3, "days_per_episode": 1,
+                     "bat_reward": "water_usage_efficiency_reward"})
+    full = SustainDC({"location": "ny", "month": 3, "days_per_episode": 1,
+                      "bat_reward": "water_usage_efficiency_reward"})
+    env.seed(5)
+    full.seed(5)
+    o = env.reset()
+    of = full.reset()
+    assert set(o) == {"agent_ls", "agent_bat"} and len(env.observation_space) == 2 and len(env.action_space) == 2
+    rng = np.random.default_rng(0)
+    for t in range(96):
+        a_ls, a_bat = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        o, r, term, trunc, info = env.step({"agent_ls": a_ls, "agent_bat": a_bat})
+        of, rf, _, _, info_f = full.step({"agent_ls": a_ls, "agent_dc": 1, "agent_bat": a_bat})   # hold = BaseHVACAgent
+        assert set(r) == {"agent_ls", "agent_bat"} and set(o) == {"agent_ls", "agent_bat"}
+        assert r["agent_ls"] == rf["agent_ls"] and r["agent_bat"] == rf["agent_bat"]
+        np.testing.assert_array_equal(o["agent_ls"], of["agent_ls"])
+        water = info["__common__"]["dc_water_usage"]
+        assert abs(r["agent_bat"] - (-0.01 * water)) <= 1e-5 * max(1.0, abs(0.01 * water))
+    assert trunc["__all__"] and trunc["agent_ls"] and "agent_dc" not in trunc
+    env.close()
+    full.close()

@@ -45,10 +45,35 @@ def test_env_config_defaults_match_reference_keys():
     a = _merge_args({"location": "ca", "days_per_episode": 30, "month": 6, "partial_obs": True,
                      "nonoverlapping_shared_obs_space": True})
     assert a["location"] == "ca" and a["dc_config_file"] == "dc_config.json"
-    with pytest.raises(NotImplementedError):
-        _merge_args({"ls_reward": "tou_reward"})
-    with pytest.raises(NotImplementedError):
+    assert L.reward_codes(_merge_args({"ls_reward": "tou_reward"})) == (3, 0, 0)
+    assert L.reward_codes(_merge_args({"dc_reward": "energy_PUE_reward", "bat_reward": "default_dc_reward"})) == (0, 5, 1)
+    with pytest.raises(NotImplementedError):      # needs an external dataset the reference env never provides
+        _merge_args({"ls_reward": "renewable_energy_reward"})
+    with pytest.raises(NotImplementedError):      # every default_ls_reward call appends to the shared history
+        _merge_args({"dc_reward": "default_ls_reward"})
+    with pytest.raises(NotImplementedError):      # subsets of agents: through SustainDC only
         _merge_args({"agents": ["agent_ls", "agent_dc"]})
+    assert _merge_args({"agents": ["agent_ls", "agent_dc"], "_allow_agent_subset": True})["agents"] == ["agent_ls", "agent_dc"]
+    with pytest.raises(ValueError):
+        _merge_args({"agents": ["agent_x"]})
+
+
+def test_rule_based_agents_match_reference_semantics():
+    """utils/base_agents.py, utils/rbc_agents.py: do-nothing actions 1 / 1 / 2; RBC battery: charge iff the forecast
+    `look_ahead` steps ahead is above the current carbon intensity."""
+    import torch
+    from dc_rl_amd.agents import BaseBatteryAgent, BaseHVACAgent, BaseLoadShiftingAgent, RBCBatteryAgent
+    assert BaseLoadShiftingAgent().do_nothing_action() == 1 and BaseHVACAgent().act() == 1
+    assert BaseBatteryAgent().act("anything", x=1) == 2
+    rbc = RBCBatteryAgent(look_ahead=3, smooth_window=1)
+    assert rbc.act([0.5, 0.4, 0.3, 0.6, 0.2], 0.5) == 0 and rbc.act([0.5, 0.9, 0.9, 0.5, 0.9], 0.5) == 1
+    rng = np.random.default_rng(0)
+    for w in (1, 2, 3):
+        rbc = RBCBatteryAgent(look_ahead=3, smooth_window=w)
+        x = rng.random((64, 9))
+        got = rbc.act_batch(torch.from_numpy(x)).numpy()
+        np.testing.assert_array_equal(got, [rbc.act(row, 0.5) for row in x])
+    assert BaseBatteryAgent().act_batch(5).tolist() == [2] * 5
 
 
 def test_month_rule_of_make_train_env():
