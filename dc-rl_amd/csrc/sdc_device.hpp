@@ -139,10 +139,32 @@ __device__ __forceinline__ double rec_f64(unsigned r, int idx) {
 // ------------------------------------------------------------------------------------------------
 // wave helpers (64 lanes)
 
+// Cross-lane moves on the DPP data path (a VALU operand modifier, ~10 cycles) instead of ds_bpermute round trips
+// through the LDS crossbar (~100+ cycles each, and every reduction here is a chain of 4-6 dependent stages).
+//   quad_perm [1,0,3,2] = lane ^ 1      quad_perm [2,3,0,1] = lane ^ 2      row_ror:8 = lane ^ 8 (rows of 16)
+//   row_half_mirror / row_mirror reach the partner quad / half-row: same values as lane ^ 4 / lane ^ 8 once the
+//   quads / half-rows are uniform, i.e. after the smaller strides have been reduced;
+//   row_bcast15 / row_bcast31 carry row totals towards lane 63.
+enum { SDC_DPP_XOR1 = 0xB1, SDC_DPP_XOR2 = 0x4E, SDC_DPP_HALF_MIRROR = 0x141, SDC_DPP_MIRROR = 0x140, SDC_DPP_ROR8 = 0x128,
+       SDC_DPP_BCAST15 = 0x142, SDC_DPP_BCAST31 = 0x143, SDC_DPP_WAVE_SHL1 = 0x130 };
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64(double v) {   // unwritten lanes (row_mask, out of range) read as 0.0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// sum over the 64 lanes, wave-uniform result (tree: strides 1, 2, 4, 8 within rows, then the four rows in order)
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f64<SDC_DPP_XOR1>(v);
+  v += dpp_f64<SDC_DPP_XOR2>(v);
+  v += dpp_f64<SDC_DPP_HALF_MIRROR>(v);
+  v += dpp_f64<SDC_DPP_MIRROR>(v);
+  v += dpp_f64<SDC_DPP_BCAST15, 0xA>(v);
+  v += dpp_f64<SDC_DPP_BCAST31, 0xC>(v);
+  return readlane_f64(v, 63);
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
@@ -180,11 +202,12 @@ enum { SDC_P_COS = 0, SDC_P_SIN, SDC_P_NC, SDC_P_CI7 = 3, SDC_P_OLDEST = 10, SDC
 
 // segmented butterfly sum: lanes [0,16), [16,32) and [32,64) are three independent groups
 __device__ __forceinline__ double seg3_sum_f64(double v, int lane) {
-#pragma unroll
-  for (int o = 1; o <= 8; o <<= 1) v += __shfl_xor(v, o);
-  const double u = __shfl_xor(v, 16);
-  if (lane >= 32) v += u;
-  return v;
+  v += dpp_f64<SDC_DPP_XOR1>(v);
+  v += dpp_f64<SDC_DPP_XOR2>(v);
+  v += dpp_f64<SDC_DPP_HALF_MIRROR>(v);   // = lane ^ 4: the quads are uniform by now
+  v += dpp_f64<SDC_DPP_MIRROR>(v);        // = lane ^ 8: the half-rows are uniform by now
+  const double s = readlane_f64(v, 32) + readlane_f64(v, 48);   // third group: rows 2 + 3
+  return lane >= 32 ? s : v;
 }
 
 struct ObsScalars {
@@ -242,10 +265,10 @@ __device__ __forceinline__ void build_obs_pool(const double* nc, const double* n
   const double cur = xs[0];
   const double v = q < nv ? xs[1 + q] : 0.0;    // lanes q >= nv contribute exact zeros
   auto tree = [&](double a) {                   // NumPy pairwise order for n = 8 / 16
-    a += __shfl_xor(a, 8);
-    a += __shfl_xor(a, 1);
-    a += __shfl_xor(a, 2);
-    a += __shfl_xor(a, 4);
+    a += dpp_f64<SDC_DPP_ROR8>(a);          // lane ^ 8 within the row of 16
+    a += dpp_f64<SDC_DPP_XOR1>(a);
+    a += dpp_f64<SDC_DPP_XOR2>(a);
+    a += dpp_f64<SDC_DPP_HALF_MIRROR>(a);   // = lane ^ 4: the quads are uniform by now
     return a;
   };
   const double mean = tree(v) / (double)nv;
@@ -256,7 +279,7 @@ __device__ __forceinline__ void build_obs_pool(const double* nc, const double* n
   if (q == 0) g = xs[1] - xs[0];
   else if (q < nv) g = (xs[q + 1] - xs[q - 1]) / 2.0;
   else if (q == nv) g = xs[nv] - xs[nv - 1];
-  const double gn = __shfl_down(g, 1);
+  const double gn = dpp_f64<SDC_DPP_WAVE_SHL1>(g);   // lane i <- lane i + 1
   const bool in = q < nv;                        // pairs (g[q], g[q+1]) for q = 0 .. nv-1
   const unsigned long long pk = __ballot(in && g > 0 && gn <= 0);
   const unsigned long long vl = __ballot(in && g < 0 && gn >= 0);

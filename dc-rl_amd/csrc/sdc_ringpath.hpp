@@ -133,25 +133,25 @@ struct SlideOut {
   unsigned count;  // up: #{x <= pivot}; down: #{x >= pivot} (empty slots included)
   L4 dist;         // the 4 smallest legitimate distances beyond the pivot (then KEY_NONE-ish garbage)
 };
-__device__ __forceinline__ void slide_sweep(const RingView& R, const int lane, const unsigned pivot, const bool up,
-                                            SlideOut& o) {
-  const unsigned m = up ? 0u : KEY_NONE;
-  const unsigned pp = (pivot ^ m) + 1u;
+// (before this step's append: the ring in memory is the truth, no patch)
+template <bool UP>
+__device__ __forceinline__ void slide_sweep(const uint4* __restrict__ hp, const int lane, const unsigned pivot, SlideOut& o) {
+  const unsigned pp = (UP ? pivot : ~pivot) + 1u;
   unsigned c = 0u;
   L4 d = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-  // batches of 10 dwordx4 loads per lane, each batch fully in flight before its first use
-  constexpr int HALF = RING_VECS / 4;
+  // batches of dwordx4 loads per lane, each batch fully in flight before its first use
+  constexpr int BATCH = RING_VECS / 2;
 #pragma unroll 1
-  for (int hf = 0; hf < 4; hf++) {
-    uint4 v[HALF];
+  for (int hf = 0; hf < RING_VECS / BATCH; hf++) {
+    uint4 v[BATCH];
 #pragma unroll
-    for (int q = 0; q < HALF; q++) v[q] = ring_fetch(R, hf * HALF + q, lane);
+    for (int q = 0; q < BATCH; q++) v[q] = hp[(hf * BATCH + q) * SDC_WAVE + lane];
 #pragma unroll
-    for (int q = 0; q < HALF; q++) {
+    for (int q = 0; q < BATCH; q++) {
       const unsigned xs[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
       for (int c4 = 0; c4 < 4; c4++) {
-        const unsigned x = xs[c4] ^ m;
+        const unsigned x = UP ? xs[c4] : ~xs[c4];
         unsigned e;
         SDC_SUB_COUNT(e, c, x, pp);
         l4_sweep_insert(d, e);
@@ -265,7 +265,8 @@ __device__ __forceinline__ int slide_req(int d1, int d3) { return d1 | (d3 << 2)
 
 // SLIDE the requested quartile trackers of one env (header dwords in hd, one per lane) over its ring, which holds n
 // keys.  One copy of the sweep / surgery code: the trackers take turns through it.
-__device__ __forceinline__ unsigned slide_trackers(unsigned hd, const RingView& R, const int lane, const int n, const int req) {
+__device__ __forceinline__ unsigned slide_trackers(unsigned hd, const RingView& R, const int lane, const int n, const int req,
+                                                   unsigned long long* dbg = nullptr) {
 #pragma unroll 1
   for (int t = 0; t < 2; t++) {
     const int d = (req >> (2 * t)) & 3;
@@ -274,10 +275,19 @@ __device__ __forceinline__ unsigned slide_trackers(unsigned hd, const RingView& 
     QTrack A = qt_load(hd, base);
     const unsigned pivot = d == SLIDE_UP ? lget(A.S, A.ns - 1) : lget(A.P, A.np - 1);
     SlideOut o;
-    slide_sweep(R, lane, pivot, d == SLIDE_UP, o);
-    if (d == SLIDE_UP) qt_slide_up(A, o);
-    else qt_slide_down(A, n, o);
+    if (dbg && lane == 0) dbg[0] = wall_clock64();
+    if (d == SLIDE_UP) {
+      slide_sweep<true>(R.hp, lane, pivot, o);
+      if (dbg && lane == 0) dbg[1] = wall_clock64();
+      qt_slide_up(A, o);
+    } else {
+      slide_sweep<false>(R.hp, lane, pivot, o);
+      if (dbg && lane == 0) dbg[1] = wall_clock64();
+      qt_slide_down(A, n, o);
+    }
+    if (dbg && lane == 0) dbg[2] = wall_clock64();
     qt_put_dyn(hd, base, A);
+    if (dbg && lane == 0) dbg[3] = wall_clock64();
   }
   return hd;
 }
