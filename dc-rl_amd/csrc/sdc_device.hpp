@@ -81,7 +81,7 @@ enum SdcHdr {
   H_Q3 = 32,      // ... of the upper quartile
   H_STICKY = 48,  // sticky diagnostics (bit 0: a verify-mode mismatch was seen)
   H_KB = 49,      // last step's clip bounds in flipped key space: [0] upper (kub), [1] lower (~(klb - 1))
-  H_TAU = 51,     // tail-set thresholds in flipped key space: [0] upper, [1] lower; SDC_TAU_INVALID = no sets yet
+  H_TAU = 51,     // tail-set thresholds in flipped key space: [0] upper, [1] lower; [0] may be SDC_TAU_INVALID / _DIRECT
   H_CNT = 53,     // tail-set sizes [0] upper, [1] lower
   H_BAND = 55,    // per side [2]: key-space distance that holds ~128 keys just inside the threshold (step of a threshold move)
   H_A1 = 58,      // f64: sum of v over the history
@@ -90,6 +90,7 @@ enum SdcHdr {
   SDC_HDR_DWORDS = 64
 };
 #define SDC_TAU_INVALID 0xFFFFFFFFu
+#define SDC_TAU_DIRECT 0xFFFFFFFEu   // the tails do not fit the sets: tail corrections by a sweep over the ring every step
 #define SDC_TAIL_CAP 512   // slots per env and side of the tail sets (8 per lane)
 // tracker: a window of consecutive order statistics of the history around anchor key G
 enum SdcTrack { T_G = 0, T_CLT, T_CLE, T_NP, T_NS, T_P = 5, T_S = 9, SDC_TRACK_DWORDS = 13 };

@@ -438,7 +438,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     int path = ahead_path;   // diagnostics: 0 no ring read, 1 slid ahead of need, 2 tail sets re-collected, 3 rebuilt
     const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), slot, x_new};
     uint4* tails_g = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
-    if (n >= SMALL_N) {
+    if (n >= 2) {
       int k1, k3;
       quartile_ranks(n, k1, k3);
       QTrack q1 = qt_load(hd0, H_Q1), q3 = qt_load(hd0, H_Q3);
@@ -447,7 +447,10 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
       unsigned band0 = (unsigned)rec_i32(hd0, H_BAND), band1 = (unsigned)rec_i32(hd0, H_BAND + 1);
       double A1 = rec_f64(hd0, H_A1), A2 = rec_f64(hd0, H_A2);
       TailSet ts0 = tail_from_lds(sh.tl, 0, lane), ts1 = tail_from_lds(sh.tl, 1, lane);
-      bool ok = qt_valid(q1) && qt_valid(q3) && tau0 != SDC_TAU_INVALID;
+      // every 256th step of the episode an env in direct-tail mode tries to build its sets again
+      if (tau0 == SDC_TAU_DIRECT && (rel & 255) == 255) tau0 = SDC_TAU_INVALID;
+      const bool direct0 = tau0 == SDC_TAU_DIRECT;      // tails too heavy for the sets: swept from the ring every step
+      bool ok = n >= SMALL_N && qt_valid(q1) && qt_valid(q3) && tau0 != SDC_TAU_INVALID;
       bool dirty0 = sets_dirty, dirty1 = sets_dirty;   // a set goes back to memory only if it changed
       int why = ok ? 0 : 1;                            // diagnostics (debug_flags bit 1): why a rebuild was needed
       if (ok && append) {
@@ -457,67 +460,84 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
         A2 += vn * vn - vo * vo;
         qt_update(q1, x_new, x_old, has_old, has_old ? n : n - 1);
         qt_update(q3, x_new, x_old, has_old, has_old ? n : n - 1);
-        if (has_old && x_old > tau0) { if (!tail_remove(ts0, x_old, lane)) { ok = false; why = 2; } cnt0 -= 1; dirty0 = true; }
-        if (has_old && ~x_old > tau1) { if (!tail_remove(ts1, ~x_old, lane)) { ok = false; why = 2; } cnt1 -= 1; dirty1 = true; }
-        if (x_new > tau0) { if (!tail_insert(ts0, x_new, lane)) { ok = false; why = 3; } cnt0 += 1; dirty0 = true; }
-        if (~x_new > tau1) { if (!tail_insert(ts1, ~x_new, lane)) { ok = false; why = 3; } cnt1 += 1; dirty1 = true; }
+        if (!direct0) {
+          if (has_old && x_old > tau0) { if (!tail_remove(ts0, x_old, lane)) { ok = false; why = 2; } cnt0 -= 1; dirty0 = true; }
+          if (has_old && ~x_old > tau1) { if (!tail_remove(ts1, ~x_old, lane)) { ok = false; why = 2; } cnt1 -= 1; dirty1 = true; }
+          if (x_new > tau0) { if (!tail_insert(ts0, x_new, lane)) { ok = false; why = 3; } cnt0 += 1; dirty0 = true; }
+          if (~x_new > tau1) { if (!tail_insert(ts1, ~x_new, lane)) { ok = false; why = 3; } cnt1 += 1; dirty1 = true; }
+        }
       }
       unsigned kb0 = 0u, kb1 = 0u;
       int slack0 = 0, slack1 = 0;
-      uint4 qa_rb = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll 1
-      for (int attempt = 0; attempt < 2; attempt++) {
-        if (attempt == 1) {
-          // miss (no state yet, a window / set that did not cover, an inconsistency): rebuild everything from the ring
-          const Rebuilt rb = rebuild_state(R, lane, n, sh.tl, sh.sums2);
-          qa_rb = rb.qa;
-          q1 = rb.q1;
-          q3 = rb.q3;
-          tau0 = rb.tau[0];
-          tau1 = rb.tau[1];
-          A1 = rb.A1;
-          A2 = rb.A2;
-          cnt0 = (int)sfl(sh.tl.cnt[0]);
-          cnt1 = (int)sfl(sh.tl.cnt[1]);
-          ts0 = tail_from_lds(sh.tl, 0, lane);
-          ts1 = tail_from_lds(sh.tl, 1, lane);
-          band0 = band1 = 0u;   // re-estimated below
-          dirty0 = dirty1 = true;
-          path = 3 + ((S.debug_flags & 2) ? why : 0);
-        }
+      bool done_eval = false;
+      if (ok) {
         unsigned a1, b1, a3, b3;
-        const bool okq = (attempt == 1 || ok) && qt_resolve(q1, k1, n, a1, b1) && qt_resolve(q3, k3, n, a3, b3) &&
-                         cnt0 <= SDC_TAIL_CAP && cnt1 <= SDC_TAIL_CAP;
-        if (okq) {
+        if (qt_resolve(q1, k1, n, a1, b1) && qt_resolve(q3, k3, n, a3, b3)) {
           const Bounds b = clip_bounds(n, a1, b1, a3, b3);
           kb0 = b.kub;               // upper tail: keys >= kub
           kb1 = ~(b.klb - 1u);       // lower tail, flipped: ~x >= ~(klb-1)  <=>  x < klb
-          if (kb0 > tau0 && kb1 > tau1) {
+          if (direct0) {
+            double t1, t2;
+            int n_hi, n_lo;
+            tails_direct(R, lane, b, t1, t2, n_hi, n_lo);
+            clipped_moments(n, b, A1, A2, t1, t2, mean, sd);
+            path = max(path, 2);
+            done_eval = true;
+          } else if (kb0 > tau0 && kb1 > tau1) {
             double t1 = 0.0, t2 = 0.0;
             tail_scan(ts0, kb0, 0u, b.ub, t1, t2);
             tail_scan(ts1, kb1, KEY_NONE, b.lb, t1, t2);
-            t1 = wave_sum_f64_dpp(t1);
-            t2 = wave_sum_f64_dpp(t2);
+            t1 = wave_sum_f64(t1);
+            t2 = wave_sum_f64(t2);
             clipped_moments(n, b, A1, A2, t1, t2, mean, sd);
             const unsigned sl = wave_sum_u32((tail_count_below(ts0, kb0) << 16) | tail_count_below(ts1, kb1));
             slack0 = (int)(sl >> 16);
             slack1 = (int)(sl & 0xFFFFu);
-            if (band0 == 0u) {   // after a rebuild: key distance per ~128 keys just above the threshold
-              band0 = band_estimate(kb0 - tau0, slack0);
-              band1 = band_estimate(kb1 - tau1, slack1);
-            }
-            break;
+            done_eval = true;
+          } else {
+            why = kb0 > tau0 ? 7 : 6;
           }
-          if (why == 0) why = kb0 > tau0 ? 7 : 6;
+        } else {
+          why = 4;
         }
-        if (why == 0) why = (cnt0 > SDC_TAIL_CAP || cnt1 > SDC_TAIL_CAP) ? 5 : 4;
-        if (attempt == 1) {
-          // not even fresh state covers (more than a set's worth of keys beyond a clip bound): this step directly
-          // from the ring, and no state, so that the next step tries again
-          const Bounds b = clip_bounds(n, qa_rb.x, qa_rb.y, qa_rb.z, qa_rb.w);
-          wave_direct_moments(R, lane, n, b.lb, b.ub, b.ctr, mean, sd);
-          tau0 = tau1 = SDC_TAU_INVALID;
+      }
+      if (!done_eval) {
+        // miss (no state yet, a window / set that did not cover, an inconsistency): rebuild everything from the ring
+        const Rebuilt rb = rebuild_state(R, lane, n, sh.tl, sh.sums2);
+        if (n < SMALL_N) {   // tiny history: nothing to keep
+          mean = rb.mean;
+          sd = rb.sd;
+          q1.g = q3.g = 0u;
+          tau0 = SDC_TAU_INVALID;
+        } else {
+        q1 = rb.q1;
+        q3 = rb.q3;
+        A1 = rb.A1;
+        A2 = rb.A2;
+        kb0 = rb.b.kub;
+        kb1 = ~(rb.b.klb - 1u);
+        clipped_moments(n, rb.b, A1, A2, rb.T1, rb.T2, mean, sd);
         }
+        if (n < SMALL_N) {
+        } else if (rb.direct) {
+          tau0 = SDC_TAU_DIRECT;
+          tau1 = 0u;
+          cnt0 = cnt1 = 0;
+        } else {
+          tau0 = rb.tau[0];
+          tau1 = rb.tau[1];
+          cnt0 = (int)sfl(sh.tl.cnt[0]);
+          cnt1 = (int)sfl(sh.tl.cnt[1]);
+          ts0 = tail_from_lds(sh.tl, 0, lane);
+          ts1 = tail_from_lds(sh.tl, 1, lane);
+          const unsigned sl = wave_sum_u32((tail_count_below(ts0, kb0) << 16) | tail_count_below(ts1, kb1));
+          slack0 = (int)(sl >> 16);
+          slack1 = (int)(sl & 0xFFFFu);
+          band0 = band_estimate(kb0 - tau0, slack0);   // key distance per ~128 keys just inside the threshold
+          band1 = band_estimate(kb1 - tau1, slack1);
+          dirty0 = dirty1 = true;
+        }
+        path = 3 + ((S.debug_flags & 2) ? why : 0);
       }
       qt_put(o0, H_Q1, q1);
       qt_put(o0, H_Q3, q3);
@@ -533,17 +553,9 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
       put_u32(o0, H_SLACK + 1, (unsigned)slack1);
       put_f64(o0, H_A1, A1);
       put_f64(o0, H_A2, A2);
-      if (dirty0) tail_store(tails_g, lane, ts0);
-      if (dirty1) tail_store(tails_g + SDC_TAIL_CAP / 4, lane, ts1);
+      if (dirty0 && tau0 < SDC_TAU_DIRECT) tail_store(tails_g, lane, ts0);
+      if (dirty1 && tau0 < SDC_TAU_DIRECT) tail_store(tails_g + SDC_TAIL_CAP / 4, lane, ts1);
     } else {
-      if (n >= 2) {   // tiny history: everything directly from the ring
-        int k1, k3;
-        quartile_ranks(n, k1, k3);
-        const uint4 qa = wave_bisection(R, lane, k1, k3);
-        const Bounds b = clip_bounds(n, qa.x, qa.y, qa.z, qa.w);
-        wave_direct_moments(R, lane, n, b.lb, b.ub, b.ctr, mean, sd);
-        path = 3;
-      }
       put_u32(o0, H_Q1 + T_G, 0u);
       put_u32(o0, H_Q3 + T_G, 0u);
       put_u32(o0, H_TAU, SDC_TAU_INVALID);
@@ -668,7 +680,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
       ts1 = tail_load(tails_g + SDC_TAIL_CAP / 4, lane);
     }
     unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
-    if (tau0 != SDC_TAU_INVALID) {
+    if (tau0 < SDC_TAU_DIRECT) {   // sets exist (not SDC_TAU_INVALID / SDC_TAU_DIRECT)
       const unsigned kb0 = (unsigned)rec_i32(hd0, H_KB), kb1 = (unsigned)rec_i32(hd0, H_KB + 1);
       const unsigned band0 = (unsigned)rec_i32(hd0, H_BAND), band1 = (unsigned)rec_i32(hd0, H_BAND + 1);
       int cnt0 = rec_i32(hd0, H_CNT), cnt1 = rec_i32(hd0, H_CNT + 1);
@@ -686,7 +698,11 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
       }
       // threshold close to the clip bound while keys exist below it: lower it by one band and re-collect
       const bool low0 = slack0 < 48 && hl0 > cnt0 && tau0 > 0u, low1 = slack1 < 48 && hl0 > cnt1 && tau1 > 0u;
-      if (low0 || low1) {
+      if ((low0 && cnt0 > SDC_TAIL_CAP - 96) || (low1 && cnt1 > SDC_TAIL_CAP - 96)) {
+        // no room to take more keys in: this env's tails do not fit the sets (any more)
+        tau0 = SDC_TAU_DIRECT;
+        ahead_path = 2;
+      } else if (low0 || low1) {
         const unsigned t0 = low0 ? (tau0 > band0 ? tau0 - band0 : 0u) : tau0;
         const unsigned t1 = low1 ? (tau1 > band1 ? tau1 - band1 : 0u) : tau1;
         tails_collect(R, lane, t0, t1, sh.tl, nullptr);
@@ -702,7 +718,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
           ts0 = tail_from_lds(sh.tl, 0, lane);
           ts1 = tail_from_lds(sh.tl, 1, lane);
         } else {
-          tau0 = tau1 = SDC_TAU_INVALID;   // does not fit: the end-of-step rebuild picks thresholds by rank
+          tau0 = SDC_TAU_DIRECT;           // does not fit
         }
         ahead_path = 2;
         sets_dirty = true;

@@ -140,7 +140,7 @@ __device__ __forceinline__ void slide_sweep(const uint4* __restrict__ hp, const 
   unsigned c = 0u;
   L4 d = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
   // batches of dwordx4 loads per lane, each batch fully in flight before its first use
-  constexpr int BATCH = RING_VECS / 2;
+  constexpr int BATCH = RING_VECS / 8;   // (20 in flight was measured no faster: the sweep is VALU-bound; 5 keeps the code small)
 #pragma unroll 1
   for (int hf = 0; hf < RING_VECS / BATCH; hf++) {
     uint4 v[BATCH];
@@ -301,6 +301,8 @@ __device__ __forceinline__ unsigned slide_trackers(unsigned hd, const RingView& 
 __device__ __forceinline__ int quartile_slide_ahead(const QTrack& q0, const unsigned x_old, const bool has_old,
                                                     const int k_next, const int n_next) {
   if (!qt_valid(q0)) return SLIDE_NONE;   // nothing to slide: the end-of-step rebuild will create it
+  // common case first: at least two spare ranks on both sides survive any eviction + insertion
+  if (k_next - (q0.c_lt - q0.np) >= 3 && (q0.c_le + q0.ns - 1) - (k_next + 1) >= 3) return SLIDE_NONE;
   QTrack q = q0;
   int m = n_next - 1;                     // keys after the eviction, before the insertion
   if (has_old) qt_evict(q, x_old);
@@ -526,35 +528,86 @@ __device__ __forceinline__ void wave_direct_moments(const RingView& R, const int
   sd = var > 0 ? sqrt(var) : 0.0;
 }
 
-// Full rebuild of one env's reward state from its ring (n >= SMALL_N keys, this step's key included): fresh
-// quartile trackers, tail sets (into L; thresholds by rank, RANK_OFF keys per side) and total sums.  Returns the
-// quartile keys {a1, b1, a3, b3}.
-constexpr int TAIL_RANK_OFF = SDC_TAIL_CAP / 2;
+// Tail corrections straight from the ring (an env whose tails do not fit the sets: more than ~480 keys beyond a clip
+// bound): sum (v - bound), sum (v^2 - bound^2) over the keys >= kub and over the keys < klb, and how many there are.
+__device__ __forceinline__ void tails_direct(const RingView& R, const int lane, const Bounds& b, double& t1, double& t2,
+                                             int& n_hi, int& n_lo) {
+  double a1 = 0.0, a2 = 0.0;
+  unsigned c = 0u;   // packed: n_hi << 16 | n_lo
+  const double ub2 = b.ub * b.ub, lb2 = b.lb * b.lb;
+#pragma unroll 1
+  for (int q = 0; q < RING_VECS; q++) {
+    const uint4 v4 = ring_fetch(R, q, lane);
+    const unsigned xs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int c4 = 0; c4 < 4; c4++) {
+      const unsigned x = xs[c4];
+      if (x != KEY_NONE && (x >= b.kub || x < b.klb)) {
+        const double v = key_f64(x);
+        if (x >= b.kub) {
+          a1 += v - b.ub;
+          a2 += v * v - ub2;
+          c += 0x10000u;
+        } else {
+          a1 += v - b.lb;
+          a2 += v * v - lb2;
+          c += 1u;
+        }
+      }
+    }
+  }
+  t1 = wave_sum_f64(a1);
+  t2 = wave_sum_f64(a2);
+  c = wave_sum_u32(c);
+  n_hi = (int)(c >> 16);
+  n_lo = (int)(c & 0xFFFFu);
+}
+
+// Full rebuild of one env's reward state from its ring (n >= 2 keys, this step's key included).
+//   n < SMALL_N: only this step's clipped mean / std, directly.
+//   else: fresh quartile trackers, total sums, this step's tail corrections T1 / T2 by a direct sweep, and -- if the
+//   tails fit -- tail sets (into L) whose thresholds leave ~128 keys (at least a quarter of a set) of slack inside
+//   the clip bounds; `direct` is set when a tail has more keys than a set can hold.
 struct Rebuilt {
   QTrack q1, q3;
   unsigned tau[2];
-  double A1, A2;
-  uint4 qa;
+  double A1, A2, T1, T2;
+  double mean, sd;   // n < SMALL_N only
+  Bounds b;
+  bool direct;
 };
 __device__ __forceinline__ Rebuilt rebuild_state(const RingView& R, const int lane, const int n, TailLds& L, double* sums2) {
   Rebuilt o;
-  int k1, k3;
-  quartile_ranks(n, k1, k3);
-  uint4 qa = make_uint4(0u, 0u, 0u, 0u), ta = qa;
-  // one copy of the bisection: first the quartile ranks, then the ranks of the tail thresholds
+  const bool tiny = n < SMALL_N;
+  o.direct = false;
+  o.tau[0] = o.tau[1] = 0u;   // everything: the history still fits a set
+  o.A1 = o.A2 = o.T1 = o.T2 = o.mean = o.sd = 0.0;
+  int ra, rb;
+  quartile_ranks(n, ra, rb);
+  // one copy of the bisection: first the quartile ranks, then (if needed) the ranks of the tail thresholds
 #pragma unroll 1
   for (int ph = 0; ph < 2; ph++) {
-    const int ra = ph ? min(TAIL_RANK_OFF, n - 1) : k1, rb = ph ? max(n - 1 - TAIL_RANK_OFF, 0) : k3;
     const uint4 r = wave_bisection(R, lane, ra, rb);
-    if (ph) ta = r; else qa = r;
+    if (ph == 1) {
+      o.tau[0] = sfl(r.z);    // keys >  key at rank n-1-off_hi
+      o.tau[1] = sfl(~r.x);   // keys <  key at rank off_lo
+      break;
+    }
+    o.b = clip_bounds(n, r.x, r.y, r.z, r.w);
+    if (tiny) {
+      wave_direct_moments(R, lane, n, o.b.lb, o.b.ub, o.b.ctr, o.mean, o.sd);
+      return o;
+    }
+    wave_rebuild_pair(R, lane, sfl(r.x), sfl(r.z), n, o.q1, o.q3);
+    int n_hi, n_lo;
+    tails_direct(R, lane, o.b, o.T1, o.T2, n_hi, n_lo);
+    o.direct = n_hi > SDC_TAIL_CAP - 96 || n_lo > SDC_TAIL_CAP - 96;   // sets need >= 64 keys of slack to be stable
+    if (o.direct || n <= SDC_TAIL_CAP) break;
+    // thresholds by rank: the tail itself plus 128 keys of slack (at least half a set, at most all but 32 slots)
+    ra = min(min(max(n_lo + 128, SDC_TAIL_CAP / 2), SDC_TAIL_CAP - 32), n - 1);
+    rb = max(n - 1 - min(max(n_hi + 128, SDC_TAIL_CAP / 2), SDC_TAIL_CAP - 32), 0);
   }
-  o.qa = qa;
-  wave_rebuild_pair(R, lane, sfl(qa.x), sfl(qa.z), n, o.q1, o.q3);
-  // thresholds: everything if the history still fits a set, else the keys beyond rank TAIL_RANK_OFF from each end
-  // (but never inside the clip bounds' side of ... the bounds themselves are checked by the caller every step)
-  o.tau[0] = n <= SDC_TAIL_CAP ? 0u : sfl(ta.z);       // keys >  key at rank n-1-OFF
-  o.tau[1] = n <= SDC_TAIL_CAP ? 0u : sfl(~ta.x);      // keys <  key at rank OFF
-  tails_collect(R, lane, o.tau[0], o.tau[1], L, sums2);
+  tails_collect(R, lane, o.direct ? KEY_NONE : o.tau[0], o.direct ? KEY_NONE : o.tau[1], L, sums2);
   o.A1 = sums2[0];
   o.A2 = sums2[1];
   return o;

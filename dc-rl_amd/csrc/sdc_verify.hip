@@ -225,7 +225,7 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK, 2) void sdc_reward_verify_ker
   if (!(fabs((double)inf[SDC_INFO_ENERGY_Z] - z) <= 2e-6 * fabs(z) + 1e-6)) bad = true;
   // 3. the tail sets: sizes against the ring, membership sums (xor of keys) against the ring
   const unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
-  if (tau0 != SDC_TAU_INVALID) {
+  if (tau0 < SDC_TAU_DIRECT) {   // sets exist
     unsigned c = 0, x0 = 0, x1 = 0;   // packed counts (hi << 16 | lo), xor signatures
     for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) {
       const uint4 v = lk[q * SDC_BLOCK];

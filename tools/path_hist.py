@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
-N = 4096
+N = int(os.environ.get("SDC_N", "4096"))
 eng, tb, params = bench.build_engine(N, 672, 0, seed=1234, debug_flags=int(os.environ.get("SDC_DBG","2")))
 g = torch.Generator(device="cpu").manual_seed(1234)
 pool = torch.randint(0, 3, (64, N, 3), dtype=torch.int32, generator=g).to("cuda:0")
@@ -12,13 +12,13 @@ for i in range(10000 + 300):
     eng.step(pool[i & 63])
 h = np.zeros(1300, np.int64)
 missed = {}
-for i in range(400):
+for i in range(int(os.environ.get("SDC_STEPS", "400"))):
     o, s, r, d, info = eng.step(pool[i & 63])
     p = info[:, 39].cpu().numpy().astype(int)
     h += np.bincount(p, minlength=1300)[:1300]
     for e in np.nonzero((p >= 3) & (p < 1000))[0]:
         missed.setdefault(int(e), []).append((i, int(p[e])))
-print("path codes per step:", {k: round(v / 400, 2) for k, v in enumerate(h) if v})
+print("path codes per step:", {k: round(v / int(os.environ.get("SDC_STEPS", "400")), 3) for k, v in enumerate(h) if v})
 print("envs with misses:", len(missed), "examples:", list(missed.items())[:3])
 hist = eng.get_state("hist")
 for e in list(missed)[:3]:

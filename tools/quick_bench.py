@@ -2,7 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
-N = 4096
+N = int(os.environ.get("SDC_N", "4096"))
 dbg = int(os.environ.get("SDC_DBG", "0"))
 eng, tb, params = bench.build_engine(N, 672, 0, seed=1234, debug_flags=dbg)
 g = torch.Generator(device="cpu").manual_seed(1234)
