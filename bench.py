@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[2] at N=1; configs[4] = the same per-GPU shard o
 4096 environment instances per GPU, `dc_config.json` (20 racks), NY-profile synthetic year traces, 7-day
 episodes (672 steps) with device-side auto-reset, uniform-random {0,1,2} actions pre-generated on the
 device.  Before anything is timed every env's energy-history ring is brought to its 10 000-entry steady
-state by running real steps (`history_fill_steps`), so each timed step reads the full 40 KB window.
+state by running real steps (`history_fill_steps`), so each timed step normalises against the full window.
 
 One "step" = one sdc_step() call = one pass of the hot path over the batch: actions in -> obs, share_obs,
 rewards, dones, info out, auto-reset included (SURVEY.md section 8(d) `Metric`).
@@ -31,12 +31,6 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HIST_CAP = 10000
 ALG_BYTES_FIXED = 1540      # B(H) = 4*H + 1540 bytes per env-step
-
-
-# split of the 1540 fixed bytes between the two kernels of a step: the reward kernel
-# reads the 4*H window + 32 B hand-off + 8 B quartile keys + 24 B running returns and writes 12 B rewards,
-# 24 B returns, 8 B keys, 16 B info = 124 B; the dynamics kernel owns the remaining 1416 B.
-REWARD_FIXED = 124
 
 
 def alg_bytes_per_env_step(h):
@@ -130,7 +124,7 @@ def main():
     ap.add_argument("--mixed-racks", action="store_true", help="BASELINE configs[3]: 16/20/25-rack mix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fill", action="store_true", help="skip the history fill (debug only; invalid as a result)")
-    ap.add_argument("--profile-every", type=int, default=8, help="record per-kernel HIP events every k-th step (0 = off)")
+    ap.add_argument("--profile-every", type=int, default=8, help="stamp the kernels' wall-clock entry / exit every k-th step (0 = off)")
     args = ap.parse_args()
 
     import torch
@@ -178,7 +172,7 @@ def main():
         one_step(i)
     hlen = int(eng.get_state("hist_len").min())
 
-    eng.profile(args.profile_every)   # HIP events on the launch stream around each kernel of every k-th timed step
+    eng.profile(args.profile_every)   # in-kernel wall-clock stamps of every k-th timed step (sdc_profile_enable)
     eng.profile_read(reset=True)
     if world > 1:
         dist.barrier()

@@ -43,7 +43,6 @@ struct DynShared {
   float info[SDC_INFO_DIM];
   unsigned rec[SDC_REC_DWORDS];
   unsigned long long dbg_t;
-  unsigned long long dbg4[4];
   sdc_rw::TailLds tl;   // the env's two tail sets, parked here between the start and the end of the step
   double sums2[2];
 };
@@ -671,7 +670,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
       // this wavefront now has ~1 200 instructions more to issue than the three it shares its SIMD with, and the
       // step ends when the slowest wavefront does: let it issue first for the rest of its life
       __builtin_amdgcn_s_setprio(3);
-      hd0 = slide_trackers(hd0, R, lane, hl0, req, (S.debug_flags & 32) ? sh.dbg4 : nullptr);
+      hd0 = slide_trackers(hd0, R, lane, hl0, req);
       ahead_path = 1;
     }
     {
@@ -743,12 +742,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
       sh.info[41] = (float)(sh.dbg_t - dbg_a1);
       sh.info[42] = (float)(dbg_a3 - sh.dbg_t);
       sh.info[43] = (S.debug_flags & 16) ? (float)(dbg_a3 & 0xFFFFFull) : (float)(dbg_a3 - dbg_a0);
-      if ((S.debug_flags & 32) && ahead_path == 1) {
-        sh.info[40] = (float)(sh.dbg4[0] - dbg_a0);      // decisions + tracker load
-        sh.info[41] = (float)(sh.dbg4[1] - sh.dbg4[0]);  // sweep + wave merge
-        sh.info[42] = (float)(sh.dbg4[2] - sh.dbg4[1]);  // re-link
-        sh.info[43] = (float)(sh.dbg4[3] - sh.dbg4[2]);  // put
-      }
     }
   }
   __syncthreads();

@@ -67,17 +67,6 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 #undef STAGE
   return from63(v);
 }
-__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
-#define STAGE(C, M)                                                                  \
-  {                                                                                  \
-    const unsigned lo = dpp_u32<C, M>(0u, (unsigned)__double2loint(v));              \
-    const unsigned hi = dpp_u32<C, M>(0u, (unsigned)__double2hiint(v));              \
-    v += __hiloint2double((int)hi, (int)lo);                                         \
-  }
-  SDC_DPP_STAGES(STAGE)
-#undef STAGE
-  return __hiloint2double((int)from63((unsigned)__double2hiint(v)), (int)from63((unsigned)__double2loint(v)));
-}
 // the 4 smallest of the wave's 64 ascending 4-lists (wave-uniform result)
 __device__ __forceinline__ void wave_merge_l4(L4& A) {
 #define STAGE(C, M)                                                                         \
@@ -265,8 +254,7 @@ __device__ __forceinline__ int slide_req(int d1, int d3) { return d1 | (d3 << 2)
 
 // SLIDE the requested quartile trackers of one env (header dwords in hd, one per lane) over its ring, which holds n
 // keys.  One copy of the sweep / surgery code: the trackers take turns through it.
-__device__ __forceinline__ unsigned slide_trackers(unsigned hd, const RingView& R, const int lane, const int n, const int req,
-                                                   unsigned long long* dbg = nullptr) {
+__device__ __forceinline__ unsigned slide_trackers(unsigned hd, const RingView& R, const int lane, const int n, const int req) {
 #pragma unroll 1
   for (int t = 0; t < 2; t++) {
     const int d = (req >> (2 * t)) & 3;
@@ -275,19 +263,14 @@ __device__ __forceinline__ unsigned slide_trackers(unsigned hd, const RingView& 
     QTrack A = qt_load(hd, base);
     const unsigned pivot = d == SLIDE_UP ? lget(A.S, A.ns - 1) : lget(A.P, A.np - 1);
     SlideOut o;
-    if (dbg && lane == 0) dbg[0] = wall_clock64();
     if (d == SLIDE_UP) {
       slide_sweep<true>(R.hp, lane, pivot, o);
-      if (dbg && lane == 0) dbg[1] = wall_clock64();
       qt_slide_up(A, o);
     } else {
       slide_sweep<false>(R.hp, lane, pivot, o);
-      if (dbg && lane == 0) dbg[1] = wall_clock64();
       qt_slide_down(A, n, o);
     }
-    if (dbg && lane == 0) dbg[2] = wall_clock64();
     qt_put_dyn(hd, base, A);
-    if (dbg && lane == 0) dbg[3] = wall_clock64();
   }
   return hd;
 }

@@ -107,8 +107,9 @@ typedef struct {
   int32_t debug_flags;     /* bit 0: VERIFY MODE -- after every step check the incremental reward state (quartile
                               trackers, tail sets, running sum) and the reported z-score against an exact bisection
                               and a direct fp64 pass over each env's history (slow; a mismatch sets
-                              SDC_FAULT_ORDER_STAT).  Bits 1, 3: diagnostics in info[reserved] / info[40..43]
-                              (why a rebuild happened; per-wavefront phase timings) -- measurement only */
+                              SDC_FAULT_ORDER_STAT).  Bits 1, 3, 4: diagnostics in info[reserved] / info[40..43]
+                              (why a rebuild happened; per-wavefront phase durations; absolute wavefront start /
+                              end stamps) -- measurement only, they overwrite the episode-return columns */
   int32_t reward_method[3]; /* reward function per agent slot (ls, dc, bat), utils/reward_creator.py:322-334:
                                SDC_REWARD_DEFAULT the slot's own default_*_reward, SDC_REWARD_FOOTPRINT
                                default_dc_reward = default_bat_reward, SDC_REWARD_CUSTOM custom_agent_reward (0),
