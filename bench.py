@@ -234,7 +234,10 @@ def main():
                          "alg_bytes_per_env_step": b, "alg_bytes_per_launch": b * N,
                          "timed_launches": prof["steps"],
                          "other_kernels": {"sdc_reset_kernel_avg_us": round(k_rst * 1e6, 2), "auto_resets": prof["resets"]},
-                         "frac_without_history_term": round(ALG_BYTES_FIXED * N / k_dyn / 1e9 / HBM_PEAK_GBPS, 5)},
+                         "frac_without_history_term": round(ALG_BYTES_FIXED * N / k_dyn / 1e9 / HBM_PEAK_GBPS, 5),
+                         "note": "effective bandwidth: algorithmic bytes of the reference's per-step history pass / "
+                                 "kernel time; the kernel keeps that state incrementally (traffic = bytes really "
+                                 "moved) and is fp64-VALU / latency bound (DESIGN.md section 4)"},
             "return_stats": {"episodes": int(ret_stats[6].item()),
                              "mean_return": [round(float(x), 3) for x in (ret_stats[0:3] / max(1.0, float(ret_stats[6].item())))]},
         }
