@@ -608,7 +608,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   const int hourq_n = hourq + 1 >= 96 ? 0 : hourq + 1;
   unsigned fault = 0;
   if (i + 9 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
-  // the ring slot this step's energy will overwrite: its current key is the evicted value the reward kernel's
+  // the ring slot this step's energy will overwrite: its current key is the evicted value the reward state's
   // order-statistic trackers need (issued with the gather below; 0xFFFFFFFF while the ring is still filling)
   const int hl0 = rec_i32(r, R_HIST_LEN);
   const int slot0 = hl0 < S.hist_cap ? hl0 : rec_i32(r, R_HIST_POS);

@@ -25,7 +25,7 @@ namespace sdc_rw {
 
 constexpr unsigned KEY_NONE = 0xFFFFFFFFu;  // empty ring slot; also "+infinity" in ascending neighbour lists
 constexpr int QW = SDC_QW;
-constexpr int SMALL_N = 32;                 // below this the reward kernel computes directly from the ring
+constexpr int SMALL_N = 32;                 // below this the step computes the normalisation directly from the ring
 
 __device__ __forceinline__ unsigned f32_key(float f) {
   const unsigned b = __float_as_uint(f);

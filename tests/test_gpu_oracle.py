@@ -59,7 +59,7 @@ def test_full_history_ring_vs_oracle():
 
 
 def test_order_statistic_tracker_stress():
-    """The O(1) order-statistic trackers of the reward kernel against the exact bisection (debug_flags bit 0) on
+    """The O(1) order-statistic trackers of the reward normalisation against the exact bisection (debug_flags bit 0) on
     histories built to stress them: heavy duplicates, monotone drifts, constant runs, values straddling zero (sign
     change of the fp32 offsets), a small history capacity so evictions start early."""
     import torch
