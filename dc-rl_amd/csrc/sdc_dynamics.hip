@@ -50,8 +50,8 @@ struct DynShared {
 // envs/datacenter.py:356-429 calculate_chiller_power
 __device__ __forceinline__ double chiller_power(double max_cooling_cap, double load, double ambient_temp) {
   const double min_plr = 0.05, max_plr = 1.0, design_cond_temp = 35.0, design_evp_out_temp = 6.67;
-  const double temp_rise_coef = 2.778, rated_cop = 3.0;
-  const double delta_temp = (ambient_temp - design_cond_temp) / temp_rise_coef - (design_evp_out_temp - design_cond_temp);
+  // temp_rise_coef = 2.778, rated_cop = 3.0 (divisors below)
+  const double delta_temp = SDC_DIV_CONST(ambient_temp - design_cond_temp, 2.778) - (design_evp_out_temp - design_cond_temp);
   const double cap_rat = 0.94483600 + -0.05700880 * delta_temp + 0.00185486 * (delta_temp * delta_temp);
   const double avail = cap_rat != 0 ? max_cooling_cap * cap_rat : 0.0;
   const double fpr = 2.333 + -1.975 * cap_rat + 0.6121 * (cap_rat * cap_rat);
@@ -63,7 +63,7 @@ __device__ __forceinline__ double chiller_power(double max_cooling_cap, double l
   else
     oper = 0.0;
   const double frac = oper < min_plr ? fmin(1.0, oper / min_plr) : 1.0;
-  const double power = fflp * fpr * avail / rated_cop * frac;
+  const double power = SDC_DIV_CONST(fflp * fpr * avail, 3.0) * frac;
   return oper > 0 ? power : 0.0;
 }
 
@@ -117,19 +117,19 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     const int room = S.queue_max - (cum_prev - popped);
     add = min(shf, room);
     dropped = shf - add;
-    util = (double)(od_proc + (shf - add)) / 100;
+    util = SDC_DIV_CONST((double)(od_proc + (shf - add)), 100);
   } else if (a_ls == 2) {
     if (avail >= 1) {
       processed = min(min(shf, avail), cum_prev - popped);
       popped += processed;
-      util = (double)(shf + processed + od_proc) / 100;
+      util = SDC_DIV_CONST((double)(shf + processed + od_proc), 100);
     } else {
-      util = (double)(shf + od_proc) / 100;
+      util = SDC_DIV_CONST((double)(shf + od_proc), 100);
     }
   } else {
-    util = (double)(shf + od_proc) / 100;
+    util = SDC_DIV_CONST((double)(shf + od_proc), 100);
   }
-  util += (double)ns / 100;
+  util += SDC_DIV_CONST((double)ns, 100);
   const int cum_now = cum_prev + add;
   const unsigned cumT_now = cumT_prev + (unsigned)add * (unsigned)now;
   const int total = cum_now - popped;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     cumT_hm1 = cumT_now;
   }
   const double normq = (double)total / (double)S.queue_max;
-  const double oldest_norm = oldest / 24, avg_norm = avg / 24;
+  const double oldest_norm = SDC_DIV_CONST(oldest, 24), avg_norm = SDC_DIV_CONST(avg, 24);
 
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 ----------------------------------------
   if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
@@ -224,9 +224,9 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
   if (lane < R) {
     const double sa = fmax(3.8, fmin(P.rack_supply[lane], 5.3));  // datacenter.py:209-215
     const double inlet = sa + stpt;
-    const double ratio = ((P.m_cpu + 0.05) * inlet + P.c_cpu) + P.rs_cpu * (load_pct / 100);
+    const double ratio = ((P.m_cpu + 0.05) * inlet + P.c_cpu) + P.rs_cpu * SDC_DIV_CONST(load_pct, 100);
     const double cpu1 = fmax(P.rack_idle[lane], P.rack_full[lane] * ratio);
-    const double v = (P.m_fan * 10 * inlet + P.c_fan * 5) + P.rs_fan * (load_pct / 20);
+    const double v = (P.m_fan * 10 * inlet + P.c_fan * 5) + P.rs_fan * SDC_DIV_CONST(load_pct, 20);
     const double fan1 = P.itfan_ref_p * (v / P.itfan_ref_v_ratio);
     const double vf1 = P.it_fan_full_load_v * v;
     const double n = P.rack_n[lane];
@@ -268,17 +268,17 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     w += w * 0.01;
     water = np_round((w * 1000) / 4, 1e4);
   }
-  const double total_kw = (p_it + ct + comp) / 1e3;
+  const double total_kw = SDC_DIV_CONST(p_it + ct + comp, 1e3);
 
   // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ----------------------
   const double cap = P.bat_capacity_mwh;
-  const double dcload = total_kw / 1e3;  // MW (sustaindc_env.py:652)
+  const double dcload = SDC_DIV_CONST(total_kw, 1e3);  // MW (sustaindc_env.py:652)
   double bat_load = rec_f64(r, R_BAT);
   double energy, co2;
   if (a_bat == 0) {  // charge
     const double soc = (bat_load - 0) / (cap - 0);
     const double rate = np_round(0.5 * (1 - sigmoid(10 * (soc - 0.5))), 1e4);
-    const double tu = rate * 15 / 60;
+    const double tu = SDC_DIV_CONST(rate * 15, 60);
     const double max_charge = fmin((cap / 1) * 0.1, (1 * cap - bat_load) / ((1 * tu) - (-0.04)));
     const double charging_load = fmin(max_charge, cap) * 1 * tu;
     bat_load = np_round(bat_load + charging_load, 1e8);
@@ -287,7 +287,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
   } else if (a_bat == 1) {  // discharge
     const double soc = (bat_load - 0) / (cap - 0);
     const double rate = fmax(0.5, 4 * sigmoid(10 * (soc - 0.25)));
-    const double tu = rate * 15 / 60;
+    const double tu = SDC_DIV_CONST(rate * 15, 60);
     const double max_d = fmin(fmin((cap / 1) * 1, (bat_load - 0 * cap) / (0.01 + (1 * tu))), dcload / 4);
     bat_load = np_round(bat_load - (fmin(max_d, cap) * 1 * tu), 1e8);
     const double discharge = max_d < cap ? max_d * tu : cap * tu;
@@ -365,10 +365,10 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(util * 100);
     inf[SDC_INFO_LS_CURRENT_HOUR] = (float)hour;
     for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
-    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)(p_it / 1e3);
-    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)(ct / 1e3);
-    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)(comp / 1e3);
-    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)((ct + comp) / 1e3);
+    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(p_it, 1e3);
+    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(ct, 1e3);
+    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(comp, 1e3);
+    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(ct + comp, 1e3);
     inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
     inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
     inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
@@ -567,7 +567,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     put_f64(o0, H_NORM_CI, nc[17]);                             // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
     put_f64(o0, H_OLDEST, oldest_norm);                         // ls_oldest_task_age
     const double z = n < 2 ? 0.0 : (e_off - mean) / (sd > 0 ? sd : 1.0);
-    const RewardIn rin = {z, nc[17], oldest_norm, (double)overdue, energy, (double)hourq_n * 0.25, p_it / 1e3, total_kw, water};
+    const RewardIn rin = {z, nc[17], oldest_norm, (double)overdue, energy, (double)hourq_n * 0.25, SDC_DIV_CONST(p_it, 1e3), total_kw, water};
     const Rewards rr = step_rewards(rin, S.reward_method, hd0);
     put_f64(o0, H_RET, rr.ret[0]);
     put_f64(o0, H_RET + 2, rr.ret[1]);

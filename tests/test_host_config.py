@@ -89,3 +89,15 @@ def test_synthetic_tables_shape_and_ranges():
     assert (tb["WB"] <= tb["T"] + 1e-6).all()
     tb2 = traces.synthetic_tables("ny", seed=0)
     np.testing.assert_array_equal(tb["W"], tb2["W"])
+
+
+def test_constant_division_shortcut_is_exact(tmp_path):
+    """SDC_DIV_CONST (csrc/sdc_device.hpp): the 3-instruction division by a compile-time constant must give the IEEE
+    quotient for every constant the kernels use (3e6 samples each incl. near-all-ones / near-power-of-two significands;
+    1e8 each were run once for DESIGN.md)."""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "aux", "div_const_check.c")
+    exe = str(tmp_path / "div_const_check")
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    out = subprocess.run([exe, "3000000"], check=True, capture_output=True, text=True).stdout.strip()
+    assert out == "0"
