@@ -171,6 +171,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   d.episode_steps = cfg->episode_steps;
   d.hist_cap = cfg->hist_cap;
   d.queue_max = cfg->queue_max_len;
+  d.rc_queue_max = 1.0 / (double)cfg->queue_max_len;
+  d.rc_hist_cap = 1.0 / (double)cfg->hist_cap;
   d.table_len = SDC_TABLE_LEN;
   d.lw = cfg->episode_steps + 18;
   d.qstride = (cfg->episode_steps + 63) / 64 * 64;
@@ -195,7 +197,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
     }                                                              \
   } while (0)
   double *tabW, *tabC, *tabT, *tabWB, *hour_lut;
-  sdc_dc_params* dcp;
+  SdcDcDev* dcp;
   A(tabW, (size_t)cfg->n_locations * SDC_TABLE_LEN);
   A(tabC, (size_t)cfg->n_locations * SDC_TABLE_LEN);
   A(tabT, (size_t)cfg->n_locations * SDC_TABLE_LEN);
@@ -309,7 +311,20 @@ int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
   if (cfg_id < 0 || cfg_id >= h->cfg.n_dc_configs) return fail_msg("sdc_set_dc_params: cfg_id out of range");
   if (p->n_racks <= 0 || p->n_racks > SDC_MAX_RACKS) return fail_msg("sdc_set_dc_params: n_racks must be in [1, 64]");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemcpy(const_cast<sdc_dc_params*>(h->d.dc) + cfg_id, p, sizeof(*p), hipMemcpyHostToDevice));
+  // reciprocals for the kernels' 3-instruction divisions: exact unless a divisor's significand is all ones
+  SdcDcDev e;
+  e.p = *p;
+  const double divisors[5] = {(double)p->n_racks, p->itfan_ref_v_ratio, p->rho_air, p->ctafr, p->bat_capacity_mwh};
+  double* rcs[5] = {&e.rc_n_racks, &e.rc_itfan_ref_v_ratio, &e.rc_rho_air, &e.rc_ctafr, &e.rc_bat_capacity};
+  for (int i = 0; i < 5; i++) {
+    unsigned long long bits;
+    std::memcpy(&bits, &divisors[i], 8);
+    if (!(divisors[i] > 0) || !std::isfinite(divisors[i]) || (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull)
+      return fail_msg("sdc_set_dc_params: n_racks, itfan_ref_v_ratio, rho_air, ctafr and bat_capacity_mwh must be "
+                      "positive, finite, and not have an all-ones significand");
+    *rcs[i] = 1.0 / divisors[i];
+  }
+  HIP_TRY(hipMemcpy(const_cast<SdcDcDev*>(h->d.dc) + cfg_id, &e, sizeof(e), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -329,10 +344,10 @@ int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id,
     return -1;
   // the CRAC set-point starts at the config's initial value (make_envs_pyenv.py:124) and is never reset
   if (!h->started) {
-    std::vector<sdc_dc_params> ps(h->cfg.n_dc_configs);
-    HIP_TRY(hipMemcpy(ps.data(), h->d.dc, sizeof(sdc_dc_params) * ps.size(), hipMemcpyDeviceToHost));
+    std::vector<SdcDcDev> ps(h->cfg.n_dc_configs);
+    HIP_TRY(hipMemcpy(ps.data(), h->d.dc, sizeof(SdcDcDev) * ps.size(), hipMemcpyDeviceToHost));
     std::vector<double> st(N);
-    for (int e = 0; e < N; e++) st[e] = ps[cfg_id[e]].init_setpoint;
+    for (int e = 0; e < N; e++) st[e] = ps[cfg_id[e]].p.init_setpoint;
     if (rec_put(h, R_STPT, 2, st.data())) return -1;
   }
   h->assigned = true;

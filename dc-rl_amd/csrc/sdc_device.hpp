@@ -96,6 +96,14 @@ enum SdcHdr {
 enum SdcTrack { T_G = 0, T_CLT, T_CLE, T_NP, T_NS, T_P = 5, T_S = 9, SDC_TRACK_DWORDS = 13 };
 #define SDC_QW 4   // cached neighbours on each side of the anchor
 
+// A data-centre parameter set as the kernels see it: the caller's struct plus correctly rounded reciprocals of the
+// parameters the step divides by (computed on the host by sdc_set_dc_params), so that those divisions take the
+// 3-instruction form of sdc_div_const.
+struct SdcDcDev {
+  sdc_dc_params p;
+  double rc_n_racks, rc_itfan_ref_v_ratio, rc_rho_air, rc_ctafr, rc_bat_capacity;
+};
+
 struct SdcDev {
   int n_envs, episode_steps, hist_cap, queue_max, table_len, lw, qstride, max_roll_days;
   int debug_flags;  // bit 0: cross-check the tracked order statistics against the bisection every step
@@ -107,7 +115,8 @@ struct SdcDev {
   const double* tabC;
   const double* tabT;   // pre-noise dry bulb
   const double* tabWB;  // pre-noise wet bulb
-  const sdc_dc_params* dc;  // [n_cfg]
+  const SdcDcDev* dc;   // [n_cfg]
+  double rc_queue_max, rc_hist_cap;   // reciprocals of queue_max / hist_cap (see SdcDcDev)
   const double* hour_lut;   // [96][2] = cos, sin (utils/managers.py:66-88)
   // per-env state
   unsigned* rec;     // [N][SDC_REC_DWORDS] state records (see SdcRec)

@@ -62,7 +62,7 @@ __device__ __forceinline__ double chiller_power(double max_cooling_cap, double l
     oper = (load / avail < min_plr) ? load / avail : plr;
   else
     oper = 0.0;
-  const double frac = oper < min_plr ? fmin(1.0, oper / min_plr) : 1.0;
+  const double frac = oper < min_plr ? fmin(1.0, SDC_DIV_CONST(oper, 0.05)) : 1.0;   // / min_plr
   const double power = SDC_DIV_CONST(fflp * fpr * avail, 3.0) * frac;
   return oper > 0 ? power : 0.0;
 }
@@ -71,11 +71,12 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 
 // ------------------------------------------------------------------------------------------------
 // the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
-__device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_params& P, const int env, const int lane,
+__device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& PD, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
                                               unsigned fault, const unsigned x_old, const unsigned hd0,
                                               const int ahead_path, const bool sets_dirty, float* __restrict__ rew,
                                               DynShared& sh) {
+  const sdc_dc_params& P = PD.p;
   const int i = rec_i32(r, R_CURSOR);
   const int rel = rec_i32(r, R_TREL);
   const int day = rec_i32(r, R_DAY);
@@ -137,12 +138,13 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
   const int a24 = max(0, cum_g(G_Q24) - popped), a48 = max(0, cum_g(G_Q48) - popped);
   const int a72 = max(0, cum_g(G_Q72) - popped), a96 = max(0, cum_g(G_Q96) - popped);
   double hist[5];
+  const double den = (double)max(total, 1), rden = 1.0 / den;   // (an integer <= 1000: significand never all ones)
   {
-    const double den = (double)max(total, 1);
-    hist[0] = (double)(total - a24) / den;
-    hist[1] = (double)(a24 - a48) / den;
-    hist[2] = (double)(a48 - a72) / den;
-    hist[3] = (double)(a72 - a96) / den;
+    // four divisions by the same count: one reciprocal, then the exact 3-instruction form (sdc_div_const)
+    hist[0] = sdc_div_const((double)(total - a24), den, rden);
+    hist[1] = sdc_div_const((double)(a24 - a48), den, rden);
+    hist[2] = sdc_div_const((double)(a48 - a72), den, rden);
+    hist[3] = sdc_div_const((double)(a72 - a96), den, rden);
     hist[4] = a96 > 0 ? 1.0 : 0.0;
   }
   // oldest task: smallest step h in [head, now] with cum[h] > popped.  It only moves when tasks were popped
@@ -193,13 +195,13 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     const long long sum_t = (long long)cumT_now - (long long)cumT_hm1 - (long long)(popped - cum_hm1) * head;
     const long long sum_age_steps = (long long)total * now - sum_t;
     oldest = (double)(now - head) * 0.25;                  // hours, exact
-    avg = ((double)sum_age_steps * 0.25) / (double)total;  // sum(ages) is exact in the reference too
+    avg = sdc_div_const((double)sum_age_steps * 0.25, den, rden);  // / total (> 0 here); sum(ages) is exact in the reference too
   } else {
     head = now;
     cum_hm1 = cum_now;
     cumT_hm1 = cumT_now;
   }
-  const double normq = (double)total / (double)S.queue_max;
+  const double normq = sdc_div_const((double)total, (double)S.queue_max, S.rc_queue_max);
   const double oldest_norm = SDC_DIV_CONST(oldest, 24), avg_norm = SDC_DIV_CONST(avg, 24);
 
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 ----------------------------------------
@@ -227,7 +229,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     const double ratio = ((P.m_cpu + 0.05) * inlet + P.c_cpu) + P.rs_cpu * SDC_DIV_CONST(load_pct, 100);
     const double cpu1 = fmax(P.rack_idle[lane], P.rack_full[lane] * ratio);
     const double v = (P.m_fan * 10 * inlet + P.c_fan * 5) + P.rs_fan * SDC_DIV_CONST(load_pct, 20);
-    const double fan1 = P.itfan_ref_p * (v / P.itfan_ref_v_ratio);
+    const double fan1 = P.itfan_ref_p * sdc_div_const(v, P.itfan_ref_v_ratio, PD.rc_itfan_ref_v_ratio);
     const double vf1 = P.it_fan_full_load_v * v;
     const double n = P.rack_n[lane];
     pcpu = n * cpu1;
@@ -241,8 +243,8 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
   }
   if (__ballot(bad_delta) != 0ull) fault |= SDC_FAULT_OUTLET_DELTA;
   const double sum_cpu = wave_sum_f64(pcpu), sum_fan = wave_sum_f64(pfan);
-  const double avg_ret = wave_sum_f64(ret_plus_out) / (double)R;  // datacenter.py:531-541
-  const double mean_outlet = wave_sum_f64(outlet) / (double)R;
+  const double avg_ret = sdc_div_const(wave_sum_f64(ret_plus_out), (double)R, PD.rc_n_racks);  // datacenter.py:531-541
+  const double mean_outlet = sdc_div_const(wave_sum_f64(outlet), (double)R, PD.rc_n_racks);
   const double p_it = sum_cpu + sum_fan;
 
   // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 ------------------------------------------
@@ -255,8 +257,8 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
   } else {
     const double dlt = fmax(50 - (amb - stpt), 1);
     const double m_air = q_cool / (P.c_air * dlt);
-    const double v_air = m_air / P.rho_air;
-    const double x = fmin(v_air / P.ctafr, 1);
+    const double v_air = sdc_div_const(m_air, P.rho_air, PD.rc_rho_air);
+    const double x = fmin(sdc_div_const(v_air, P.ctafr, PD.rc_ctafr), 1);
     ct = P.ct_fan_ref_p * (x * x * x);
   }
   double water;
@@ -276,7 +278,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
   double bat_load = rec_f64(r, R_BAT);
   double energy, co2;
   if (a_bat == 0) {  // charge
-    const double soc = (bat_load - 0) / (cap - 0);
+    const double soc = sdc_div_const(bat_load - 0, cap - 0, PD.rc_bat_capacity);
     const double rate = np_round(0.5 * (1 - sigmoid(10 * (soc - 0.5))), 1e4);
     const double tu = SDC_DIV_CONST(rate * 15, 60);
     const double max_charge = fmin((cap / 1) * 0.1, (1 * cap - bat_load) / ((1 * tu) - (-0.04)));
@@ -285,7 +287,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     energy = dcload * 1e3 * 0.25 + charging_load * 1e3;
     co2 = energy * ci_i;
   } else if (a_bat == 1) {  // discharge
-    const double soc = (bat_load - 0) / (cap - 0);
+    const double soc = sdc_div_const(bat_load - 0, cap - 0, PD.rc_bat_capacity);
     const double rate = fmax(0.5, 4 * sigmoid(10 * (soc - 0.25)));
     const double tu = SDC_DIV_CONST(rate * 15, 60);
     const double max_d = fmin(fmin((cap / 1) * 1, (bat_load - 0 * cap) / (0.01 + (1 * tu))), dcload / 4);
@@ -298,7 +300,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
     energy = dcload * 1e3 * 0.25;
     co2 = energy * ci_i;
   }
-  const double soc_after = bat_load / cap;
+  const double soc_after = sdc_div_const(bat_load, cap, PD.rc_bat_capacity);
 
   // ---- time: utils/managers.py:127-147 -------------------------------------------------------------
   int hourq_n = hourq + 1, day_n = day;
@@ -479,7 +481,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
             double t1, t2;
             int n_hi, n_lo;
             tails_direct(R, lane, b, t1, t2, n_hi, n_lo);
-            clipped_moments(n, b, A1, A2, t1, t2, mean, sd);
+            clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
             path = max(path, 2);
             done_eval = true;
           } else if (kb0 > tau0 && kb1 > tau1) {
@@ -488,7 +490,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const sdc_dc_para
             tail_scan(ts1, kb1, KEY_NONE, b.lb, t1, t2);
             t1 = wave_sum_f64(t1);
             t2 = wave_sum_f64(t2);
-            clipped_moments(n, b, A1, A2, t1, t2, mean, sd);
+            clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
             const unsigned sl = wave_sum_u32((tail_count_below(ts0, kb0) << 16) | tail_count_below(ts1, kb1));
             slack0 = (int)(sl >> 16);
             slack1 = (int)(sl & 0xFFFFu);
@@ -601,7 +603,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
   const int i = rec_i32(r, R_CURSOR), rel = rec_i32(r, R_TREL);
   const int loc = rec_i32(r, R_LOC);
-  const sdc_dc_params& P = S.dc[rec_i32(r, R_CFG)];
+  const SdcDcDev& PD = S.dc[rec_i32(r, R_CFG)];
   const double ci_min = rec_f64(r, R_CI_MIN), ci_den = rec_f64(r, R_CI_DEN);
   const double t_min = rec_f64(r, R_T_MIN), t_den = rec_f64(r, R_T_DEN);
   const int hourq = rec_i32(r, R_HOURQ);
@@ -640,8 +642,9 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     else if (lane >= G_NT && lane < G_NT + 17) src = tw + 1 + (lane - G_NT);
     double v = 0.0;
     if (src) v = *src;
-    if (lane >= G_NC && lane < G_NC + 25) v = (v - ci_min) / ci_den;   // utils/managers.py:437
-    if (lane >= G_NT && lane < G_NT + 17) v = (v - t_min) / t_den;     // utils/managers.py:608
+    // NC = (C - min) / (max - min) (utils/managers.py:437), NT likewise (:608): ONE division sequence for both windows
+    const bool is_nc = lane >= G_NC && lane < G_NC + 25, is_nt = lane >= G_NT && lane < G_NT + 17;
+    if (is_nc || is_nt) v = (v - (is_nc ? ci_min : t_min)) / (is_nc ? ci_den : t_den);
     sh.g[lane] = v;
   }
   __syncthreads();
@@ -733,7 +736,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     sdc_rw::tail_to_lds(sh.tl, 1, lane, ts1);
   }
   const unsigned long long dbg_a1 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
-  step_dynamics(S, P, env, lane, r, a_ls, a_dc, a_bat, fault, x_old, hd0, ahead_path, sets_dirty, rew, sh);
+  step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old, hd0, ahead_path, sets_dirty, rew, sh);
   if (S.debug_flags & 8) {
     __syncthreads();
     if (lane == 0) {

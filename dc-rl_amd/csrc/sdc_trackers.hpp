@@ -251,11 +251,21 @@ __device__ __forceinline__ Bounds clip_bounds(const int n, unsigned a1, unsigned
   return b;
 }
 // clipped mean / std from the total sums and the tail corrections T1 = sum_{tails} (v - bound), T2 = sum (v^2 - bound^2)
+// (n_full, rc_full: the history capacity and its reciprocal -- once the ring is full, n is that constant and the two
+// divisions take the 3-instruction form)
 __device__ __forceinline__ void clipped_moments(const int n, const Bounds& b, const double A1, const double A2, const double T1,
-                                                const double T2, double& mean, double& sd) {
+                                                const double T2, double& mean, double& sd, const int n_full = 0,
+                                                const double rc_full = 0.0) {
   const double C1 = A1 - T1, C2 = A2 - T2;
-  mean = C1 / (double)n;
-  const double var = C2 / (double)n - mean * mean;
+  double m2;
+  if (n == n_full) {
+    mean = sdc_div_const(C1, (double)n, rc_full);
+    m2 = sdc_div_const(C2, (double)n, rc_full);
+  } else {
+    mean = C1 / (double)n;
+    m2 = C2 / (double)n;
+  }
+  const double var = m2 - mean * mean;
   sd = (var > 0 && b.ub > b.lb) ? sqrt(var) : 0.0;
 }
 

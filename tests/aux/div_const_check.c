@@ -12,7 +12,9 @@ static inline double mk(double x, double c, double rc) { double q = x * rc; doub
 int main(int argc, char **argv) {
   const long n = argc > 1 ? atol(argv[1]) : 1000000L;
   /* every constant divisor of sdc_dynamics.hip / sdc_device.hpp */
-  const double cs[] = {100.0, 24.0, 20.0, 1e3, 60.0, 2.778, 3.0, 1e4, 1e8, 6.0, 14.0, 17.0};
+  const double cs[] = {100.0, 24.0, 20.0, 1e3, 60.0, 2.778, 3.0, 1e4, 1e8, 6.0, 14.0, 17.0, 0.05,
+                       /* run-time divisors of the shipped configs: history / queue capacity, rack counts */
+                       1e4, 1e3, 16.0, 20.0, 25.0, 257.0};
   long bad = 0;
   for (unsigned k = 0; k < sizeof(cs) / sizeof(cs[0]); k++) {
     const double c = cs[k], rc = 1.0 / c;
