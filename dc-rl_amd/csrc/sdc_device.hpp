@@ -269,8 +269,8 @@ __device__ __forceinline__ void build_obs_pool(const double* nc, const double* n
   const int xi = lane < 32 ? j : lane - 32;
   const bool act = xi < n;
   const double xm = 0.5 * (double)(n - 1);
-  // n is 6, 14 or 17 by lane group: division by a per-group constant
-  const double nd = (double)n, rn = n == 6 ? 1.0 / 6.0 : (n == 14 ? 1.0 / 14.0 : 1.0 / 17.0);
+  // n is 6, 14 (4 without a past window) or 17 by lane group: division by a per-group constant
+  const double nd = (double)n, rn = n == 6 ? 1.0 / 6.0 : (n == 14 ? 1.0 / 14.0 : (n == 4 ? 0.25 : 1.0 / 17.0));
   const double ym = sdc_div_const(seg3_sum_f64(y, lane), nd, rn);
   const double dx = act ? (double)xi - xm : 0.0;
   const double sxy = seg3_sum_f64(act ? dx * (y - ym) : 0.0, lane);

@@ -450,8 +450,10 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
       unsigned band0 = (unsigned)rec_i32(hd0, H_BAND), band1 = (unsigned)rec_i32(hd0, H_BAND + 1);
       double A1 = rec_f64(hd0, H_A1), A2 = rec_f64(hd0, H_A2);
       TailSet ts0 = tail_from_lds(sh.tl, 0, lane), ts1 = tail_from_lds(sh.tl, 1, lane);
-      // every 256th step of the episode an env in direct-tail mode tries to build its sets again
-      if (tau0 == SDC_TAU_DIRECT && (rel & 255) == 255) tau0 = SDC_TAU_INVALID;
+      // every 256th step of the episode (or once per episode, if episodes are shorter) an env in direct-tail mode
+      // tries to build its sets again
+      if (tau0 == SDC_TAU_DIRECT && ((rel & 255) == 255 || (S.episode_steps < 256 && rel + 1 == S.episode_steps)))
+        tau0 = SDC_TAU_INVALID;
       const bool direct0 = tau0 == SDC_TAU_DIRECT;      // tails too heavy for the sets: swept from the ring every step
       bool ok = n >= SMALL_N && qt_valid(q1) && qt_valid(q3) && tau0 != SDC_TAU_INVALID;
       bool dirty0 = sets_dirty, dirty1 = sets_dirty;   // a set goes back to memory only if it changed
