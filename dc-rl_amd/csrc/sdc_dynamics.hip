@@ -598,6 +598,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   const int N = S.n_envs;
   const int TL = S.table_len;
   if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 0);
+  const unsigned long long dbg_entry = (S.debug_flags & 16) ? wall_clock64() : 0ull;
 
   // ---- level 0: state record (coalesced) + actions ---------------------------------------------------------------
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
@@ -746,7 +747,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     if (lane == 0) {
       const unsigned long long dbg_a3 = wall_clock64();
       sh.info[40] = (S.debug_flags & 16) ? (float)(dbg_a0 & 0xFFFFFull) : (float)(dbg_a1 - dbg_a0);
-      sh.info[41] = (float)(sh.dbg_t - dbg_a1);
+      sh.info[41] = (S.debug_flags & 16) ? (float)(dbg_a0 - dbg_entry) : (float)(sh.dbg_t - dbg_a1);
       sh.info[42] = (float)(dbg_a3 - sh.dbg_t);
       sh.info[43] = (S.debug_flags & 16) ? (float)(dbg_a3 & 0xFFFFFull) : (float)(dbg_a3 - dbg_a0);
     }

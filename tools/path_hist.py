@@ -7,6 +7,10 @@ N = int(os.environ.get("SDC_N", "4096"))
 eng, tb, params = bench.build_engine(N, 672, 0, seed=1234, debug_flags=int(os.environ.get("SDC_DBG","2")))
 g = torch.Generator(device="cpu").manual_seed(1234)
 pool = torch.randint(0, 3, (64, N, 3), dtype=torch.int32, generator=g).to("cuda:0")
+mode = os.environ.get("SDC_MODE", "rand")
+if mode == "ls1": pool[:, :, 0] = 1
+if mode == "bat2": pool[:, :, 2] = 2
+if mode == "idle": pool[:, :, 0] = 1; pool[:, :, 1] = 1; pool[:, :, 2] = 2
 eng.reset()
 for i in range(10000 + 300):
     eng.step(pool[i & 63])
