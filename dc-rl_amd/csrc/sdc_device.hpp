@@ -70,15 +70,16 @@ enum SdcRec {
 // the reward-side state (sdc_trackers.hpp); the env's wavefront loads and stores it whole, coalesced.
 enum SdcHdr {
   H_N = 0,        // history length including this step's value
-  H_OVERDUE,      // ls_overdue_penalty (int)
-  H_XNEW,         // key of the value appended this step
-  H_XOLD,         // key of the value it evicted (0xFFFFFFFF: ring was not full)
+  H_QS2_LO = 2,   // f64: sum of v^2 over the lower tail set's keys beyond the clip bound (see H_QC)
   H_EOFF = 4,     // f64: bat_total_energy_with_battery_KWh - hist_ref
-  H_NORM_CI = 6,  // f64: norm_CI = NC[i'+1]
-  H_OLDEST = 8,   // f64: ls_oldest_task_age
+  H_QS1 = 6,      // 2 x f64 (upper, lower): sum of v over the side's set keys at or beyond last step's clip bound
   H_RET = 10,     // 3 x f64: running return of the current episode (cleared by reset)
   H_Q1 = 16,      // order-statistic tracker of the lower quartile (SdcTrack, 13 dwords)
+  H_QC = 29,      // [2]: how many keys of the side's tail set lie at or beyond last step's clip bound (-1: unknown).
+                  // With H_QS1 / H_QS2 these running sums make the tail corrections O(1): a step only touches the
+                  // keys the bound has moved across.
   H_Q3 = 32,      // ... of the upper quartile
+  H_QS2_HI = 46,  // f64: sum of v^2, upper side
   H_STICKY = 48,  // sticky diagnostics (bit 0: a verify-mode mismatch was seen)
   H_KB = 49,      // last step's clip bounds in flipped key space: [0] upper (kub), [1] lower (~(klb - 1))
   H_TAU = 51,     // tail-set thresholds in flipped key space: [0] upper, [1] lower; [0] may be SDC_TAU_INVALID / _DIRECT

@@ -489,15 +489,45 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
             path = max(path, 2);
             done_eval = true;
           } else if (kb0 > tau0 && kb1 > tau1) {
-            double t1 = 0.0, t2 = 0.0;
-            tail_scan(ts0, kb0, 0u, b.ub, t1, t2);
-            tail_scan(ts1, kb1, KEY_NONE, b.lb, t1, t2);
-            t1 = wave_sum_f64(t1);
-            t2 = wave_sum_f64(t2);
+            // running (count, sum v, sum v^2) over each set's keys at or beyond the clip bound: first the value that
+            // came and the one that went against last step's bounds kbl (a key >= the bound is > tau, i.e. in the
+            // set), then the set keys the bounds have moved across since
+            const unsigned kbl0 = (unsigned)rec_i32(hd0, H_KB), kbl1 = (unsigned)rec_i32(hd0, H_KB + 1);
+            int qc0 = rec_i32(hd0, H_QC), qc1 = rec_i32(hd0, H_QC + 1);
+            double qs1_0 = rec_f64(hd0, H_QS1), qs1_1 = rec_f64(hd0, H_QS1 + 2);
+            double qs2_0 = rec_f64(hd0, H_QS2_HI), qs2_1 = rec_f64(hd0, H_QS2_LO);
+            if (append) {
+              const double vn = key_f64(x_new), vo = key_f64(x_old);
+              if (has_old && x_old >= kbl0) { qc0 -= 1; qs1_0 -= vo; qs2_0 -= vo * vo; }
+              if (has_old && ~x_old >= kbl1) { qc1 -= 1; qs1_1 -= vo; qs2_1 -= vo * vo; }
+              if (x_new >= kbl0) { qc0 += 1; qs1_0 += vn; qs2_0 += vn * vn; }
+              if (~x_new >= kbl1) { qc1 += 1; qs1_1 += vn; qs2_1 += vn * vn; }
+            }
+            {
+              int dc0 = 0, dc1 = 0;
+              double d1_0 = 0.0, d2_0 = 0.0, d1_1 = 0.0, d2_1 = 0.0;
+              const bool x0 = kb0 != kbl0 && tail_crossing(ts0, min(kb0, kbl0), max(kb0, kbl0), 0u, dc0, d1_0, d2_0);
+              const bool x1 = kb1 != kbl1 && tail_crossing(ts1, min(kb1, kbl1), max(kb1, kbl1), KEY_NONE, dc1, d1_1, d2_1);
+              if (x0) {
+                const double sg = kb0 > kbl0 ? -1.0 : 1.0;   // bound moved out: the keys in between leave the tail
+                qc0 += (kb0 > kbl0 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc0);
+                qs1_0 += sg * wave_sum_f64(d1_0);
+                qs2_0 += sg * wave_sum_f64(d2_0);
+              }
+              if (x1) {
+                const double sg = kb1 > kbl1 ? -1.0 : 1.0;
+                qc1 += (kb1 > kbl1 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc1);
+                qs1_1 += sg * wave_sum_f64(d1_1);
+                qs2_1 += sg * wave_sum_f64(d2_1);
+              }
+            }
+            put_running_tails(o0, qc0, qc1, qs1_0, qs1_1, qs2_0, qs2_1);
+            // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
+            const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
+            const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
             clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
-            const unsigned sl = wave_sum_u32((tail_count_below(ts0, kb0) << 16) | tail_count_below(ts1, kb1));
-            slack0 = (int)(sl >> 16);
-            slack1 = (int)(sl & 0xFFFFu);
+            slack0 = cnt0 - qc0;
+            slack1 = cnt1 - qc1;
             done_eval = true;
           } else {
             why = kb0 > tau0 ? 7 : 6;
@@ -540,6 +570,15 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
           slack1 = (int)(sl & 0xFFFFu);
           band0 = band_estimate(kb0 - tau0, slack0);   // key distance per ~128 keys just inside the threshold
           band1 = band_estimate(kb1 - tau1, slack1);
+          // running sums beyond the bounds: the set keys that are not slack
+          {
+            double c1[2] = {0.0, 0.0}, c2[2] = {0.0, 0.0};
+            tail_scan(ts0, kb0, 0u, 0.0, c1[0], c2[0]);
+            tail_scan(ts1, kb1, KEY_NONE, 0.0, c1[1], c2[1]);
+            const double s1_0 = wave_sum_f64(c1[0]), s2_0 = wave_sum_f64(c2[0]);
+            const double s1_1 = wave_sum_f64(c1[1]), s2_1 = wave_sum_f64(c2[1]);
+            put_running_tails(o0, cnt0 - slack0, cnt1 - slack1, s1_0, s1_1, s2_0, s2_1);
+          }
           dirty0 = dirty1 = true;
         }
         path = 3 + ((S.debug_flags & 2) ? why : 0);
@@ -566,12 +605,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
       put_u32(o0, H_TAU, SDC_TAU_INVALID);
     }
     put_u32(o0, H_N, (unsigned)n);
-    put_u32(o0, H_OVERDUE, (unsigned)overdue);                  // ls_overdue_penalty
-    put_u32(o0, H_XNEW, x_new);
-    put_u32(o0, H_XOLD, x_old);
     put_f64(o0, H_EOFF, e_off);                                 // bat_total_energy_with_battery_KWh - hist_ref
-    put_f64(o0, H_NORM_CI, nc[17]);                             // norm_CI = NC[i'+1]  (sustaindc_env.py:681)
-    put_f64(o0, H_OLDEST, oldest_norm);                         // ls_oldest_task_age
     const double z = n < 2 ? 0.0 : (e_off - mean) / (sd > 0 ? sd : 1.0);
     const RewardIn rin = {z, nc[17], oldest_norm, (double)overdue, energy, (double)hourq_n * 0.25, SDC_DIV_CONST(p_it, 1e3), total_kw, water};
     const Rewards rr = step_rewards(rin, S.reward_method, hd0);

@@ -329,6 +329,36 @@ __device__ __forceinline__ void tail_scan(const TailSet& s, const unsigned kb, c
     }
   }
 }
+// this lane's share of (count, sum v, sum v^2) over the set keys in [lo, hi) (flipped space): the keys a clip bound
+// crosses when it moves from one to the other.  Returns false (and leaves c / s1 / s2 alone) if no lane of the
+// wavefront has such a key -- the common case, one compare pair per slot and no fp64 work.
+__device__ __forceinline__ bool tail_crossing(const TailSet& s, const unsigned lo, const unsigned hi, const unsigned flip, int& c,
+                                              double& s1, double& s2) {
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 8; i++) any = any || (s.k[i] >= lo && s.k[i] < hi);
+  if (__ballot(any) == 0ull) return false;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (s.k[i] >= lo && s.k[i] < hi) {
+      const double v = key_f64(s.k[i] ^ flip);
+      c += 1;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  return true;
+}
+// header record of the running tail sums (H_QC / H_QS1 / H_QS2_*)
+__device__ __forceinline__ void put_running_tails(unsigned& o, const int c_hi, const int c_lo, const double s1_hi,
+                                                  const double s1_lo, const double s2_hi, const double s2_lo) {
+  put_u32(o, H_QC, (unsigned)c_hi);
+  put_u32(o, H_QC + 1, (unsigned)c_lo);
+  put_f64(o, H_QS1, s1_hi);
+  put_f64(o, H_QS1 + 2, s1_lo);
+  put_f64(o, H_QS2_HI, s2_hi);
+  put_f64(o, H_QS2_LO, s2_lo);
+}
 // this lane's number of set keys below kb (the slack between the threshold and the clip bound)
 __device__ __forceinline__ unsigned tail_count_below(const TailSet& s, const unsigned kb) {
   unsigned c = 0;

@@ -227,6 +227,8 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK, 2) void sdc_reward_verify_ker
   const unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
   if (tau0 < SDC_TAU_DIRECT) {   // sets exist
     unsigned c = 0, x0 = 0, x1 = 0;   // packed counts (hi << 16 | lo), xor signatures
+    unsigned cq = 0;                  // packed counts of the keys at or beyond the stored clip bounds
+    const unsigned kbs0 = (unsigned)rec_i32(hd0, H_KB), kbs1 = (unsigned)rec_i32(hd0, H_KB + 1);
     for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) {
       const uint4 v = lk[q * SDC_BLOCK];
       const unsigned x[4] = {v.x, v.y, v.z, v.w};
@@ -234,9 +236,15 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK, 2) void sdc_reward_verify_ker
         if (x[i] == KEY_NONE) continue;
         if (x[i] > tau0) { c += 0x10000u; x0 ^= x[i]; }
         if (~x[i] > tau1) { c += 1u; x1 ^= ~x[i]; }
+        if (x[i] >= kbs0) cq += 0x10000u;
+        if (~x[i] >= kbs1) cq += 1u;
       }
     }
     c = block_sum_u32(c, sh.red_u, 0, wave, lane);
+    cq = block_sum_u32(cq, sh.red_v, 0, wave, lane);
+    // the running tail counts (the sums that go with them are covered by the z check above)
+    if (cq != (((unsigned)rec_i32(hd0, H_QC) << 16) | ((unsigned)rec_i32(hd0, H_QC + 1) & 0xFFFFu))) bad = true;
+    __syncthreads();
     const uint4* tg = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
     unsigned sc = 0;
     if (tid < SDC_TAIL_CAP / 4) {
