@@ -18,6 +18,7 @@ INFO_DIM = 44
 TABLE_LEN = 35040
 HDR_DWORDS = 64    # csrc/sdc_device.hpp SdcHdr: 256-byte per-env header
 TAIL_CAP = 512     # csrc/sdc_device.hpp SDC_TAIL_CAP: slots per env and side of the reward tail sets
+QWIN = 64          # csrc/sdc_device.hpp SDC_WIN: keys per quartile-tracker window
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
@@ -114,8 +115,8 @@ EXPORTS = [
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "sdc_device.hpp"),
-                   os.path.join(CSRC, "..", "..", "include", "sustaindc_hip.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps.append(os.path.join(CSRC, "..", "..", "include", "sustaindc_hip.h"))
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -74,7 +74,7 @@ enum SdcHdr {
   H_EOFF = 4,     // f64: bat_total_energy_with_battery_KWh - hist_ref
   H_QS1 = 6,      // 2 x f64 (upper, lower): sum of v over the side's set keys at or beyond last step's clip bound
   H_RET = 10,     // 3 x f64: running return of the current episode (cleared by reset)
-  H_Q1 = 16,      // order-statistic tracker of the lower quartile (SdcTrack, 13 dwords)
+  H_Q1 = 16,      // order-statistic tracker of the lower quartile (SdcTrack)
   H_QC = 29,      // [2]: how many keys of the side's tail set lie at or beyond last step's clip bound (-1: unknown).
                   // With H_QS1 / H_QS2 these running sums make the tail corrections O(1): a step only touches the
                   // keys the bound has moved across.
@@ -93,9 +93,10 @@ enum SdcHdr {
 #define SDC_TAU_INVALID 0xFFFFFFFFu
 #define SDC_TAU_DIRECT 0xFFFFFFFEu   // the tails do not fit the sets: tail corrections by a sweep over the ring every step
 #define SDC_TAIL_CAP 512   // slots per env and side of the tail sets (8 per lane)
-// tracker: a window of consecutive order statistics of the history around anchor key G
-enum SdcTrack { T_G = 0, T_CLT, T_CLE, T_NP, T_NS, T_P = 5, T_S = 9, SDC_TRACK_DWORDS = 13 };
-#define SDC_QW 4   // cached neighbours on each side of the anchor
+// quartile tracker: a window of SDC_WIN consecutive order statistics of the history, the keys in SdcDev::qwin (one per
+// lane), in the header the rank of the first key and the number of valid keys (0: no tracker)
+enum SdcTrack { T_R0 = 0, T_HI = 1, SDC_TRACK_DWORDS = 2 };
+#define SDC_WIN 64
 
 // A data-centre parameter set as the kernels see it: the caller's struct plus correctly rounded reciprocals of the
 // parameters the step divides by (computed on the host by sdc_set_dc_params), so that those divisions take the
@@ -127,6 +128,7 @@ struct SdcDev {
   double* walk_tmp;  // [N][max(SDC_NORM_WINDOW, lw)] scratch of the device-side reset
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
   unsigned* hdr;     // [N][SDC_HDR_DWORDS] per-env header: step hand-off + reward-side state (see SdcHdr)
+  unsigned* qwin;    // [N][2][SDC_WIN] quartile-tracker windows (sdc_trackers.hpp): Q1's keys, then Q3's
   uint4* tails;      // [N][2][SDC_TAIL_CAP / 4] tail sets (sdc_trackers.hpp): side 0 upper, side 1 lower (complemented keys)
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
   unsigned long long* prof_ts;  // measurement only: [3 kernels][N][2] wall-clock stamps of this launch, or nullptr

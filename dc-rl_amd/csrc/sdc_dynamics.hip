@@ -44,6 +44,7 @@ struct DynShared {
   unsigned rec[SDC_REC_DWORDS];
   unsigned long long dbg_t;
   sdc_rw::TailLds tl;   // the env's two tail sets, parked here between the start and the end of the step
+  unsigned qw[2][SDC_WIN];   // ... and its two quartile-tracker windows
   double sums2[2];
 };
 
@@ -444,16 +445,13 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     if (n >= 2) {
       int k1, k3;
       quartile_ranks(n, k1, k3);
-      QTrack q1 = qt_load(hd0, H_Q1), q3 = qt_load(hd0, H_Q3);
+      QTrack q1 = qt_load(hd0, H_Q1, sh.qw[0][lane]), q3 = qt_load(hd0, H_Q3, sh.qw[1][lane]);
+      bool wd1 = false, wd3 = false;           // a window goes back to memory only if its lanes changed
       unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
       int cnt0 = rec_i32(hd0, H_CNT), cnt1 = rec_i32(hd0, H_CNT + 1);
       unsigned band0 = (unsigned)rec_i32(hd0, H_BAND), band1 = (unsigned)rec_i32(hd0, H_BAND + 1);
       double A1 = rec_f64(hd0, H_A1), A2 = rec_f64(hd0, H_A2);
       TailSet ts0 = tail_from_lds(sh.tl, 0, lane), ts1 = tail_from_lds(sh.tl, 1, lane);
-      // every 256th step of the episode (or once per episode, if episodes are shorter) an env in direct-tail mode
-      // tries to build its sets again
-      if (tau0 == SDC_TAU_DIRECT && ((rel & 255) == 255 || (S.episode_steps < 256 && rel + 1 == S.episode_steps)))
-        tau0 = SDC_TAU_INVALID;
       const bool direct0 = tau0 == SDC_TAU_DIRECT;      // tails too heavy for the sets: swept from the ring every step
       bool ok = n >= SMALL_N && qt_valid(q1) && qt_valid(q3) && tau0 != SDC_TAU_INVALID;
       bool dirty0 = sets_dirty, dirty1 = sets_dirty;   // a set goes back to memory only if it changed
@@ -463,8 +461,8 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
         const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
         A1 += vn - vo;
         A2 += vn * vn - vo * vo;
-        qt_update(q1, x_new, x_old, has_old, has_old ? n : n - 1);
-        qt_update(q3, x_new, x_old, has_old, has_old ? n : n - 1);
+        wd1 = qt_update(q1, x_new, x_old, has_old, has_old ? n : n - 1, lane) || wd1;
+        wd3 = qt_update(q3, x_new, x_old, has_old, has_old ? n : n - 1, lane) || wd3;
         if (!direct0) {
           if (has_old && x_old > tau0) { if (!tail_remove(ts0, x_old, lane)) { ok = false; why = 2; } cnt0 -= 1; dirty0 = true; }
           if (has_old && ~x_old > tau1) { if (!tail_remove(ts1, ~x_old, lane)) { ok = false; why = 2; } cnt1 -= 1; dirty1 = true; }
@@ -486,6 +484,9 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
             int n_hi, n_lo;
             tails_direct(R, lane, b, t1, t2, n_hi, n_lo);
             clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
+            // the sweep has counted the tails: once both fit a set again (with room to spare: the rebuild goes direct
+            // above SDC_TAIL_CAP - 96), the next step rebuilds the sets
+            if (max(n_hi, n_lo) <= SDC_TAIL_CAP - 160) tau0 = SDC_TAU_INVALID;
             path = max(path, 2);
             done_eval = true;
           } else if (kb0 > tau0 && kb1 > tau1) {
@@ -542,11 +543,12 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
         if (n < SMALL_N) {   // tiny history: nothing to keep
           mean = rb.mean;
           sd = rb.sd;
-          q1.g = q3.g = 0u;
+          q1.hi = q3.hi = 0;
           tau0 = SDC_TAU_INVALID;
         } else {
         q1 = rb.q1;
         q3 = rb.q3;
+        wd1 = wd3 = true;
         A1 = rb.A1;
         A2 = rb.A2;
         kb0 = rb.b.kub;
@@ -583,8 +585,6 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
         }
         path = 3 + ((S.debug_flags & 2) ? why : 0);
       }
-      qt_put(o0, H_Q1, q1);
-      qt_put(o0, H_Q3, q3);
       put_u32(o0, H_KB, kb0);
       put_u32(o0, H_KB + 1, kb1);
       put_u32(o0, H_TAU, tau0);
@@ -599,9 +599,36 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
       put_f64(o0, H_A2, A2);
       if (dirty0 && tau0 < SDC_TAU_DIRECT) tail_store(tails_g, lane, ts0);
       if (dirty1 && tau0 < SDC_TAU_DIRECT) tail_store(tails_g + SDC_TAIL_CAP / 4, lane, ts1);
+      // Quartile windows AHEAD of need: if, in the worst case for the keys the next step removes and adds, a window
+      // would no longer cover the ranks asked of it, re-centre it now -- at the end of this wavefront's life, when
+      // the memory system is quiet and the other wavefronts of its SIMD are finishing -- instead of at the start of
+      // the next launch, where the sweep's loads would queue behind every env's start-of-step traffic.
+      if (n >= SMALL_N && qt_valid(q1) && qt_valid(q3)) {
+        int k1n, k3n;
+        quartile_ranks((append && n < S.hist_cap) ? n + 1 : n, k1n, k3n);
+        const int req1 = qt_refill_ahead(q1.r0, q1.hi, k1n, n), req3 = qt_refill_ahead(q3.r0, q3.hi, k3n, n);
+        if ((req1 | req3) != 0) {
+          __builtin_amdgcn_s_setprio(3);   // the step ends when the slowest wavefront does: let this one issue first
+          // one copy of the refill code: the trackers take turns through it
+#pragma unroll 1
+          for (int t = 0; t < 2; t++) {
+            const int d = t == 0 ? req1 : req3;
+            if (d == REFILL_NONE) continue;
+            QTrack A = t == 0 ? q1 : q3;
+            qt_refill(A, d, t == 0 ? k1n : k3n, n, R, lane, sh.tl);
+            if (t == 0) { q1 = A; wd1 = true; }
+            else { q3 = A; wd3 = true; }
+          }
+          path = max(path, 1);
+        }
+      }
+      qt_put(o0, H_Q1, q1);
+      qt_put(o0, H_Q3, q3);
+      if (wd1) S.qwin[(size_t)env * (2 * SDC_WIN) + lane] = q1.w;
+      if (wd3) S.qwin[(size_t)env * (2 * SDC_WIN) + SDC_WIN + lane] = q3.w;
     } else {
-      put_u32(o0, H_Q1 + T_G, 0u);
-      put_u32(o0, H_Q3 + T_G, 0u);
+      put_u32(o0, H_Q1 + T_HI, 0u);
+      put_u32(o0, H_Q3 + T_HI, 0u);
       put_u32(o0, H_TAU, SDC_TAU_INVALID);
     }
     put_u32(o0, H_N, (unsigned)n);
@@ -619,6 +646,12 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
 
 }  // namespace
 
+#ifdef SDC_REFILL_DEBUG
+__device__ __forceinline__ void put_dyn_dbg(unsigned& o, int idx, unsigned v) {
+  const unsigned sv = sdc_rw::sfl(v);
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(o) : "s"(sv), "s"(idx) : "m0");
+}
+#endif
 extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
                                                                                 float* __restrict__ obs,
                                                                                 float* __restrict__ share_obs,
@@ -638,6 +671,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
   const unsigned r = recp[lane];
   unsigned hd0 = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];            // reward-side state: returns, trackers, sums
+  unsigned qw1 = S.qwin[(size_t)env * (2 * SDC_WIN) + lane];            // quartile-tracker windows, one key per lane
+  unsigned qw3 = S.qwin[(size_t)env * (2 * SDC_WIN) + SDC_WIN + lane];
 
   const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
   const int i = rec_i32(r, R_CURSOR), rel = rec_i32(r, R_TREL);
@@ -656,6 +691,24 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   unsigned x_old_l = 0xFFFFFFFFu;
   const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;   // else the history does not change this step
   if (lane == 63 && hl0 >= S.hist_cap && append) x_old_l = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
+  // A quartile window one step from the point where it is re-centred (sdc_ringpath.hpp qt_refill: a sweep over the
+  // env's 40 KB ring at the END of the step) makes this wavefront the likely straggler of the launch: give it issue
+  // priority from the start and pull its ring into L2 now (one dword per 128-byte line, 5 loads per lane, results
+  // unused), so that the sweep finds it there.  ~1.5 % of the envs per step.
+  if (hl0 >= sdc_rw::SMALL_N && append) {
+    int k1, k3;
+    sdc_rw::quartile_ranks(hl0 < S.hist_cap ? hl0 + 1 : hl0, k1, k3);
+    const int r1 = rec_i32(hd0, H_Q1 + T_R0), h1 = rec_i32(hd0, H_Q1 + T_HI);
+    const int r3 = rec_i32(hd0, H_Q3 + T_R0), h3 = rec_i32(hd0, H_Q3 + T_HI);
+    const bool near1 = h1 > 0 && ((k1 - r1 >= h1 - 7 && r1 + h1 < hl0) || (k1 - r1 <= 4 && r1 > 0));
+    const bool near3 = h3 > 0 && ((k3 - r3 >= h3 - 7 && r3 + h3 < hl0) || (k3 - r3 <= 4 && r3 > 0));
+    if (near1 || near3) {
+      __builtin_amdgcn_s_setprio(2);
+      const volatile unsigned* ring = S.hist + (size_t)env * SDC_HIST_STRIDE;
+#pragma unroll
+      for (int j = 0; j < SDC_HIST_STRIDE / 32 / SDC_WAVE; j++) (void)ring[(j * SDC_WAVE + lane) * 32];
+    }
+  }
 
   // ---- level 1: one 8-byte gather per lane -------------------------------------------------------------------------
   {
@@ -704,17 +757,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     const bool has_old = append && hl0 >= S.hist_cap;
     const int n_next = (has_old || !append) ? hl0 : hl0 + 1;
     const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), -1, 0u};
-    int k1, k3;
-    quartile_ranks(n_next, k1, k3);
-    const int req = slide_req(quartile_slide_ahead(qt_load(hd0, H_Q1), x_old, has_old, k1, n_next),
-                              quartile_slide_ahead(qt_load(hd0, H_Q3), x_old, has_old, k3, n_next));
-    if (req != 0) {
-      // this wavefront now has ~1 200 instructions more to issue than the three it shares its SIMD with, and the
-      // step ends when the slowest wavefront does: let it issue first for the rest of its life
-      __builtin_amdgcn_s_setprio(3);
-      hd0 = slide_trackers(hd0, R, lane, hl0, req);
-      ahead_path = 1;
-    }
     {
       const uint4* tails_g = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
       ts0 = tail_load(tails_g, lane);
@@ -774,6 +816,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     sdc_rw::tail_to_lds(sh.tl, 0, lane, ts0);   // parked in LDS for the duration of the dynamics
     sdc_rw::tail_to_lds(sh.tl, 1, lane, ts1);
   }
+  sh.qw[0][lane] = qw1;
+  sh.qw[1][lane] = qw3;
   const unsigned long long dbg_a1 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
   step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old, hd0, ahead_path, sets_dirty, rew, sh);
   if (S.debug_flags & 8) {

@@ -1,24 +1,24 @@
 // sdc_ringpath.hpp -- the rare moments when an env's history ring must be read: in-wave primitives.
 //
 // sdc_trackers.hpp answers the reward normalisation from two quartile trackers, two tail sets and running sums.
-// A tracker's window of listed keys runs out every few steps (the wanted rank random-walks through it); the env's
-// own wavefront then SLIDES the tracker: it moves the anchor to the last listed key on the side that ran out and sweeps the ring once
-// for what lies beyond it -- 10 240 keys, 160 per lane, read from L2 / HBM as coalesced dwordx4 loads:
-//   up:   d = x - (pivot+1): borrows <=> x <= pivot; a legitimate d is the distance of a key above the pivot
-//   down: d = (pivot-1) - x: borrows <=> x >= pivot -- the same formula on complemented keys (~a = -a-1)
-// One v_sub_co_u32 / v_addc_co_u32 pair per key gives the distance and counts the predicate; the 4 smallest
-// distances (v_med3_u32 insertion network per lane, DPP merge across the wave) are the new neighbours; everything
-// on the near side of the new anchor is already known from the old window.
+// A tracker's window of 64 consecutive order statistics runs out every couple of thousand steps (the wanted rank
+// random-walks through it); the env's own wavefront then REFILLS it (qt_refill): it drops the keys on the far side,
+// and sweeps the ring once -- 10 240 keys, 160 per lane, coalesced dwordx4 loads from L2 / HBM -- for the keys just
+// beyond the window's last key:
+//   d = x - (pivot+1) borrows <=> x <= pivot (counted: how many copies of the pivot lie beyond the window);
+//   d <= band  <=> x is one of the next keys: appended to a small LDS list, ranked by counting, placed.
+// The band comes from the key spacing inside the window and is widened / narrowed if it caught too few / too many.
+// Extending downwards is the same code on complemented keys with the window reversed.
 //
-// The dynamics kernel slides AHEAD of need, at its start (slide_trackers is called when a window would run out on
-// this step in the worst case), so the sweep overlaps with the other resident wavefronts instead of extending the
-// kernel's tail.  Far more rarely a tail set's threshold must move down (one sweep that re-collects both sets).  A
-// full REBUILD (bisections on the key space + a two-sided sweep + collection + fp64 sums) bootstraps everything on
-// the first steps and after state injection.
+// The dynamics kernel refills AHEAD of need, at its start (when the window could run out on this step in the worst
+// case), so the sweep overlaps with the other resident wavefronts instead of extending the kernel's tail.  Equally
+// rarely a tail set's threshold must move down (one sweep that re-collects both sets).  A full REBUILD (bisections
+// on the key space + a collecting sweep per window + tail collection + fp64 sums) bootstraps everything on the
+// first steps and after state injection, and is the fallback whenever a tracker or set turns out not to cover.
 //
 // Why in-wave and not a separate reward kernel (round-1 measurements, MI355X, 4096 envs): a kernel that streams
-// every env's ring each step is HBM-bound at >= 23 us (32 us in practice); a kernel that only serves the ~10 % of
-// envs that need their ring still took 16-22 us, because its few workgroups per CU are latency-bound single waves
+// every env's ring each step is HBM-bound at >= 23 us (32 us in practice); a kernel that only serves the envs that
+// need their ring still took 16-22 us, because its few workgroups per CU are latency-bound single waves
 // (~6 ns per instruction with nothing to overlap, cold instruction cache).  Inside the dynamics kernel the same
 // work hides behind 15 other resident wavefronts per CU.
 #pragma once
@@ -28,19 +28,9 @@ namespace sdc_rw {
 
 constexpr int RING_VECS = SDC_HIST_STRIDE / 4 / SDC_WAVE;   // dwordx4 loads per lane for one pass over the ring (40)
 
-__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
-  unsigned r;
-  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Wave reductions on the DPP data path: xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror reduce within each row
 // of 16 lanes; row_bcast15 / row_bcast31 carry the rows into lane 63, which holds the result.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
 #define SDC_DPP_STAGES(STAGE)                      \
   STAGE(0xB1, 0xF)  /* quad_perm [1,0,3,2] */      \
   STAGE(0x4E, 0xF)  /* quad_perm [2,3,0,1] */      \
@@ -67,30 +57,6 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 #undef STAGE
   return from63(v);
 }
-// the 4 smallest of the wave's 64 ascending 4-lists (wave-uniform result)
-__device__ __forceinline__ void wave_merge_l4(L4& A) {
-#define STAGE(C, M)                                                                         \
-  {                                                                                         \
-    const unsigned b0 = dpp_u32<C, M>(KEY_NONE, A.e0), b1 = dpp_u32<C, M>(KEY_NONE, A.e1);  \
-    const unsigned b2 = dpp_u32<C, M>(KEY_NONE, A.e2), b3 = dpp_u32<C, M>(KEY_NONE, A.e3);  \
-    asc_insert(A, b0);                                                                      \
-    asc_insert(A, b1);                                                                      \
-    asc_insert(A, b2);                                                                      \
-    asc_insert(A, b3);                                                                      \
-  }
-  SDC_DPP_STAGES(STAGE)
-#undef STAGE
-  A.e0 = from63(A.e0);
-  A.e1 = from63(A.e1);
-  A.e2 = from63(A.e2);
-  A.e3 = from63(A.e3);
-}
-__device__ __forceinline__ void l4_sweep_insert(L4& L, const unsigned d) {
-  L.e3 = umed3(L.e2, d, L.e3);
-  L.e2 = umed3(L.e1, d, L.e2);
-  L.e1 = umed3(L.e0, d, L.e1);
-  L.e0 = min(L.e0, d);
-}
 // d = a - b, cnt += borrow
 #define SDC_SUB_COUNT(d, cnt, a, b) \
   asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=&v"(d), "+v"(cnt) : "v"(a), "v"(b) : "vcc")
@@ -115,195 +81,191 @@ __device__ __forceinline__ uint4 ring_fetch(const RingView& R, const int q, cons
   }
   return v;
 }
-
-// ------------------------------------------------------------------------------------------------
-// one-sided sweep beyond a pivot
-struct SlideOut {
-  unsigned count;  // up: #{x <= pivot}; down: #{x >= pivot} (empty slots included)
-  L4 dist;         // the 4 smallest legitimate distances beyond the pivot (then KEY_NONE-ish garbage)
-};
-// (before this step's append: the ring in memory is the truth, no patch)
-template <bool UP>
-__device__ __forceinline__ void slide_sweep(const uint4* __restrict__ hp, const int lane, const unsigned pivot, SlideOut& o) {
-  const unsigned pp = (UP ? pivot : ~pivot) + 1u;
-  unsigned c = 0u;
-  L4 d = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-  // batches of dwordx4 loads per lane, each batch fully in flight before its first use
-  constexpr int BATCH = RING_VECS / 8;   // (20 in flight was measured no faster: the sweep is VALU-bound; 5 keeps the code small)
+// One pass over the ring: f(x0, x1, x2, x3) for every dwordx4 of this lane.
+//   ring_sweep: loads in batches of 5, each batch fully in flight before its first use (the rebuild's sweeps: they
+//   run with most of the step's state live, so registers are short);
+//   ring_sweep_pipelined: the same batches double-buffered -- while one is consumed the next is in flight (the
+//   refill, whose sweep sits on the kernel's critical path).
+template <class F>
+__device__ __forceinline__ void ring_sweep(const RingView& R, const int lane, F&& f) {
+  constexpr int BATCH = RING_VECS / 8;
 #pragma unroll 1
   for (int hf = 0; hf < RING_VECS / BATCH; hf++) {
     uint4 v[BATCH];
 #pragma unroll
-    for (int q = 0; q < BATCH; q++) v[q] = hp[(hf * BATCH + q) * SDC_WAVE + lane];
+    for (int q = 0; q < BATCH; q++) v[q] = ring_fetch(R, hf * BATCH + q, lane);
 #pragma unroll
-    for (int q = 0; q < BATCH; q++) {
-      const unsigned xs[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-      for (int c4 = 0; c4 < 4; c4++) {
-        const unsigned x = UP ? xs[c4] : ~xs[c4];
-        unsigned e;
-        SDC_SUB_COUNT(e, c, x, pp);
-        l4_sweep_insert(d, e);
-      }
-    }
+    for (int q = 0; q < BATCH; q++) f(v[q].x, v[q].y, v[q].z, v[q].w);
   }
-  o.count = wave_sum_u32(c);
-  wave_merge_l4(d);
-  o.dist = d;
 }
-
-// first / last index of `x` in a sorted 4-list of which the first `cnt` entries are valid (x is present)
-__device__ __forceinline__ int first_index(const L4& L, unsigned x) {
-  return L.e0 == x ? 0 : (L.e1 == x ? 1 : (L.e2 == x ? 2 : 3));
-}
-__device__ __forceinline__ void l4_push(L4& L, int& cnt, unsigned v) {
-  if (cnt == 0) L.e0 = v;
-  if (cnt == 1) L.e1 = v;
-  if (cnt == 2) L.e2 = v;
-  if (cnt == 3) L.e3 = v;
-  cnt += 1;
-}
-
-// Move the anchor up to the largest listed key above it (q.ns >= 1), given the sweep beyond that key.
-__device__ __forceinline__ void qt_slide_up(QTrack& q, const SlideOut& o) {
-  const unsigned g2 = lget(q.S, q.ns - 1);
-  const int e0 = first_index(q.S, g2);          // keys S[0..e0) lie strictly between the old and the new anchor
-  const int c_eq = q.c_le - q.c_lt;
-  // new lower list (descending): S[e0-1] .. S[0], then the old anchor c_eq times, then the old lower list
-  L4 P2 = {0u, 0u, 0u, 0u};
-  int cnt = 0;
-  if (e0 >= 3) l4_push(P2, cnt, q.S.e2);
-  if (e0 >= 2) l4_push(P2, cnt, q.S.e1);
-  if (e0 >= 1) l4_push(P2, cnt, q.S.e0);
+template <class F>
+__device__ __forceinline__ void ring_sweep_pipelined(const RingView& R, const int lane, F&& f) {
+  constexpr int BATCH = 5, NB = RING_VECS / BATCH;   // 8 batches, taken in pairs
+  static_assert(NB * BATCH == RING_VECS && (NB & 1) == 0, "batching assumes an even number of full batches");
+  uint4 a[BATCH], b[BATCH];
 #pragma unroll
-  for (int r = 0; r < QW; r++)
-    if (r < c_eq) l4_push(P2, cnt, q.g);
-  if (q.np > 0) l4_push(P2, cnt, q.P.e0);
-  if (q.np > 1) l4_push(P2, cnt, q.P.e1);
-  if (q.np > 2) l4_push(P2, cnt, q.P.e2);
-  if (q.np > 3) l4_push(P2, cnt, q.P.e3);
-  const unsigned smax = KEY_NONE - g2 - 1u;
-  const L4& dist = o.dist;
-  q.c_lt = q.c_le + e0;
-  q.c_le = (int)o.count;
-  q.g = g2;
-  q.P = P2;
-  q.np = min(QW, cnt);
-  q.ns = (dist.e0 < smax) + (dist.e1 < smax) + (dist.e2 < smax) + (dist.e3 < smax);
-  q.S.e0 = dist.e0 < smax ? g2 + 1u + dist.e0 : KEY_NONE;
-  q.S.e1 = dist.e1 < smax ? g2 + 1u + dist.e1 : KEY_NONE;
-  q.S.e2 = dist.e2 < smax ? g2 + 1u + dist.e2 : KEY_NONE;
-  q.S.e3 = dist.e3 < smax ? g2 + 1u + dist.e3 : KEY_NONE;
-}
-// Move the anchor down to the smallest listed key below it (q.np >= 1), given the sweep beyond that key.
-__device__ __forceinline__ void qt_slide_down(QTrack& q, const int n, const SlideOut& o) {
-  const unsigned g2 = lget(q.P, q.np - 1);
-  const int e0 = first_index(q.P, g2);          // keys P[0..e0) lie strictly between the new and the old anchor
-  const int c_eq = q.c_le - q.c_lt;
-  // new upper list (ascending): P[e0-1] .. P[0], then the old anchor c_eq times, then the old upper list
-  L4 S2 = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-  int cnt = 0;
-  if (e0 >= 3) l4_push(S2, cnt, q.P.e2);
-  if (e0 >= 2) l4_push(S2, cnt, q.P.e1);
-  if (e0 >= 1) l4_push(S2, cnt, q.P.e0);
-#pragma unroll
-  for (int r = 0; r < QW; r++)
-    if (r < c_eq) l4_push(S2, cnt, q.g);
-  if (q.ns > 0) l4_push(S2, cnt, q.S.e0);
-  if (q.ns > 1) l4_push(S2, cnt, q.S.e1);
-  if (q.ns > 2) l4_push(S2, cnt, q.S.e2);
-  if (q.ns > 3) l4_push(S2, cnt, q.S.e3);
-  const int n_empty = SDC_HIST_STRIDE - n;      // empty slots (KEY_NONE) satisfy x >= pivot
-  const L4& dist = o.dist;
-  q.c_le = q.c_lt - e0;
-  q.c_lt = n - ((int)o.count - n_empty);
-  q.g = g2;
-  q.S = S2;
-  q.ns = min(QW, cnt);
-  q.np = (dist.e0 < g2) + (dist.e1 < g2) + (dist.e2 < g2) + (dist.e3 < g2);
-  q.P.e0 = dist.e0 < g2 ? g2 - 1u - dist.e0 : 0u;
-  q.P.e1 = dist.e1 < g2 ? g2 - 1u - dist.e1 : 0u;
-  q.P.e2 = dist.e2 < g2 ? g2 - 1u - dist.e2 : 0u;
-  q.P.e3 = dist.e3 < g2 ? g2 - 1u - dist.e3 : 0u;
-}
-
-// tracker access with a run-time header offset (v_readlane / v_writelane take the lane from an SGPR / M0)
-__device__ __forceinline__ void put_dyn(unsigned& o, int idx, unsigned v) {
-  const unsigned sv = sfl(v);
-  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(o) : "s"(sv), "s"(idx) : "m0");
-}
-__device__ __forceinline__ void qt_put_dyn(unsigned& o, const int base, const QTrack& q) {
-  put_dyn(o, base + T_G, q.g);
-  put_dyn(o, base + T_CLT, (unsigned)q.c_lt);
-  put_dyn(o, base + T_CLE, (unsigned)q.c_le);
-  put_dyn(o, base + T_NP, (unsigned)q.np);
-  put_dyn(o, base + T_NS, (unsigned)q.ns);
-  put_dyn(o, base + T_P + 0, q.P.e0);
-  put_dyn(o, base + T_P + 1, q.P.e1);
-  put_dyn(o, base + T_P + 2, q.P.e2);
-  put_dyn(o, base + T_P + 3, q.P.e3);
-  put_dyn(o, base + T_S + 0, q.S.e0);
-  put_dyn(o, base + T_S + 1, q.S.e1);
-  put_dyn(o, base + T_S + 2, q.S.e2);
-  put_dyn(o, base + T_S + 3, q.S.e3);
-}
-
-// slide requests: 2 bits per quartile tracker (Q1, Q3): 0 none, 1 up, 2 down
-enum { SLIDE_NONE = 0, SLIDE_UP = 1, SLIDE_DOWN = 2 };
-__device__ __forceinline__ int slide_req(int d1, int d3) { return d1 | (d3 << 2); }
-
-// SLIDE the requested quartile trackers of one env (header dwords in hd, one per lane) over its ring, which holds n
-// keys.  One copy of the sweep / surgery code: the trackers take turns through it.
-__device__ __forceinline__ unsigned slide_trackers(unsigned hd, const RingView& R, const int lane, const int n, const int req) {
+  for (int q = 0; q < BATCH; q++) a[q] = ring_fetch(R, q, lane);
 #pragma unroll 1
-  for (int t = 0; t < 2; t++) {
-    const int d = (req >> (2 * t)) & 3;
-    if (d == SLIDE_NONE) continue;
-    const int base = t == 0 ? H_Q1 : H_Q3;
-    QTrack A = qt_load(hd, base);
-    const unsigned pivot = d == SLIDE_UP ? lget(A.S, A.ns - 1) : lget(A.P, A.np - 1);
-    SlideOut o;
-    if (d == SLIDE_UP) {
-      slide_sweep<true>(R.hp, lane, pivot, o);
-      qt_slide_up(A, o);
-    } else {
-      slide_sweep<false>(R.hp, lane, pivot, o);
-      qt_slide_down(A, n, o);
+  for (int hb = 0; hb < NB; hb += 2) {
+#pragma unroll
+    for (int q = 0; q < BATCH; q++) b[q] = ring_fetch(R, (hb + 1) * BATCH + q, lane);
+#pragma unroll
+    for (int q = 0; q < BATCH; q++) f(a[q].x, a[q].y, a[q].z, a[q].w);
+    if (hb + 2 < NB) {
+#pragma unroll
+      for (int q = 0; q < BATCH; q++) a[q] = ring_fetch(R, (hb + 2) * BATCH + q, lane);
     }
-    qt_put_dyn(hd, base, A);
+#pragma unroll
+    for (int q = 0; q < BATCH; q++) f(b[q].x, b[q].y, b[q].z, b[q].w);
   }
-  return hd;
 }
 
 // ------------------------------------------------------------------------------------------------
-// AHEAD-OF-NEED tests on the pre-step trackers (ring of n_prev keys; x_old is the key this step will evict, if any;
-// the step's new key is not known yet).
-
-// quartile tracker: would ranks k_next, k_next+1 still be inside the window after this step in the worst case?
-// (an insertion below the window shifts every covered rank up by one; one above leaves them in place)
-__device__ __forceinline__ int quartile_slide_ahead(const QTrack& q0, const unsigned x_old, const bool has_old,
-                                                    const int k_next, const int n_next) {
-  if (!qt_valid(q0)) return SLIDE_NONE;   // nothing to slide: the end-of-step rebuild will create it
-  // common case first: at least two spare ranks on both sides survive any eviction + insertion
-  if (k_next - (q0.c_lt - q0.np) >= 3 && (q0.c_le + q0.ns - 1) - (k_next + 1) >= 3) return SLIDE_NONE;
-  QTrack q = q0;
-  int m = n_next - 1;                     // keys after the eviction, before the insertion
-  if (has_old) qt_evict(q, x_old);
-  if (!qt_valid(q)) return SLIDE_NONE;
-  const int lo = q.c_lt - q.np, hi = q.c_le + q.ns - 1;   // covered ranks
-  const bool complete_lo = q.np == q.c_lt, complete_hi = q.ns == m - q.c_le;
-  const int hi_rank = (k_next + 1 > n_next - 1) ? k_next : k_next + 1;
-  if (!complete_hi && hi_rank > hi) return q0.ns >= 1 ? SLIDE_UP : SLIDE_NONE;
-  if (!complete_lo && k_next < lo + 1) return q0.np >= 1 ? SLIDE_DOWN : SLIDE_NONE;
-  return SLIDE_NONE;
-}
-// ------------------------------------------------------------------------------------------------
-// TAIL SETS: collection from the ring.  Every valid key whose flipped image exceeds the side's threshold is appended
-// (LDS atomic counter) to that side's 512-slot array in LDS; the caller then takes the arrays into registers.
+// LDS scratch of the ring paths (one wavefront = one workgroup: LDS operations of a wavefront complete in order)
 struct TailLds {
   unsigned keys[2][SDC_TAIL_CAP];
   unsigned cnt[2];
 };
+
+// ------------------------------------------------------------------------------------------------
+// QUARTILE TRACKER REFILL.
+enum { REFILL_NONE = 0, REFILL_UP = 1, REFILL_DOWN = 2 };
+
+// AHEAD-OF-NEED test on a tracker of the ring's n keys: the next step moves the wanted rank by at most one inside
+// the window and takes at most one key out of it.
+__device__ __forceinline__ int qt_refill_ahead(const int r0, const int hi, const int k_next, const int n) {
+  if (hi <= 0) return REFILL_NONE;          // nothing to extend: the end-of-step rebuild will create it
+  const int t = k_next - r0;
+  if (t > hi - 6 && r0 + hi < n) return REFILL_UP;
+  if (t < 3 && r0 > 0) return REFILL_DOWN;
+  return REFILL_NONE;
+}
+
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// Re-centre a tracker's window on rank k of the n keys in the ring: keep the part of the window that stays, fetch
+// what lies beyond its last (UP) / first (DOWN) key with ONE sweep:
+//   d = x - (pivot+1) borrows <=> x <= pivot (counted: the copies of the pivot beyond the window); otherwise d is
+//   the key's distance above the pivot, and every lane keeps the 4 smallest it sees (v_med3_u32 insertion network).
+// Below D = the smallest 4th-smallest of any lane the lanes' lists are COMPLETE (a key a lane dropped is >= that
+// lane's 4th); those ~45 keys (64 lanes x 4 slots: a birthday bound) are compacted, ranked by counting and placed.
+// A run of equal keys can stop the complete part short; then another sweep continues from that key.
+__device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k, const int n, const RingView& R, const int lane,
+                                          TailLds& L) {
+  // Work in a space where the window grows upwards: for DOWN complement the keys, reverse the window and count ranks
+  // from the top.
+  const unsigned f = dir == REFILL_DOWN ? KEY_NONE : 0u;
+  const int hi = q.hi;
+  unsigned w = q.w;
+  int r0 = q.r0, kk = k;
+  if (f) {
+    const unsigned rv = (unsigned)__shfl((int)q.w, (hi - 1 - lane) & 63);
+    w = lane < hi ? ~rv : KEY_NONE;
+    r0 = n - (q.r0 + hi);
+    kk = n - 1 - k;
+  }
+  const int n_empty = f ? SDC_HIST_STRIDE - n : 0;       // complemented empty slots (0) count as <= pivot
+  int top = r0 + hi;                                     // first rank above what the window holds so far
+  const int s = min(max(kk - WIN / 2 - r0, 0), hi - 1);  // lanes to drop at the bottom
+  const int kept = hi - s;
+  unsigned pivot = lane_key(w, hi - 1);
+  // the new window is assembled in LDS: first the kept keys
+  unsigned* win = &L.keys[1][0];
+  win[lane] = KEY_NONE;
+  __syncthreads();   // (one wavefront: orders the compiler's view of the cross-lane LDS traffic)
+  if (lane >= s && lane < hi) win[lane - s] = w;
+  int filled = kept;
+  // Rounds: normally one.  A run of equal keys that overflows some lane's list stops the complete part short of it;
+  // the next round then starts from that key (its copies are what the borrow count measures).
+#pragma unroll 1
+  for (int round = 0; round < 8 && filled < WIN && top < n; round++) {
+    const unsigned pp = pivot + 1u;
+    const unsigned smax = KEY_NONE - pp;                 // a legitimate distance is below this
+    unsigned c = 0u;
+    unsigned e0 = KEY_NONE, e1 = KEY_NONE, e2 = KEY_NONE, e3 = KEY_NONE;   // this lane's 4 smallest distances, ascending
+    ring_sweep_pipelined(R, lane, [&](unsigned x0, unsigned x1, unsigned x2, unsigned x3) {
+      const unsigned xs[4] = {x0 ^ f, x1 ^ f, x2 ^ f, x3 ^ f};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        unsigned d;
+        SDC_SUB_COUNT(d, c, xs[i], pp);
+        e3 = umed3(e2, d, e3);
+        e2 = umed3(e1, d, e2);
+        e1 = umed3(e0, d, e1);
+        e0 = min(e0, d);
+      }
+    });
+    const int extra = (int)wave_sum_u32(c) - n_empty - top;   // copies of the pivot not in the window yet
+    const unsigned D = min(wave_min_u32(e3), smax);
+    if (extra < 0) {
+      filled = -1;   // the tracker does not describe this ring
+      break;
+    }
+    // compact the complete part of the lists: slot j of every lane in turn (ballot + prefix count)
+    const unsigned mine[3] = {e0, e1, e2};                    // (e3 >= D always)
+    int idx[3];
+    int m = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const unsigned long long mk = __ballot(mine[j] < D);
+      idx[j] = mine[j] < D ? m + (int)__popcll(mk & ((1ull << lane) - 1ull)) : -1;
+      m += (int)__popcll(mk);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      if (idx[j] >= 0) L.keys[0][idx[j]] = mine[j];
+    if (lane < 4) L.keys[0][m + lane] = KEY_NONE;             // pad the list to a multiple of 4 (ranks below nothing)
+    __syncthreads();
+    // rank by counting (equal distances by list position), 4 list entries per LDS read
+    int rank[3] = {0, 0, 0};
+#pragma unroll 1
+    for (int i = 0; i < m; i += 4) {
+      const uint4 v4 = *reinterpret_cast<const uint4*>(&L.keys[0][i]);
+      const unsigned vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) rank[j] += (vs[e] < mine[j] || (vs[e] == mine[j] && i + e < idx[j])) ? 1 : 0;
+      }
+    }
+    // copies of the pivot, then the caught keys in rank order
+    if (lane < extra && filled + lane < WIN) win[filled + lane] = pivot;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int pos = filled + extra + rank[j];
+      if (idx[j] >= 0 && pos < WIN) win[pos] = pp + mine[j];
+    }
+    __syncthreads();
+    filled += extra + m;
+    top += extra + m;
+    if (D >= smax) break;           // everything above the pivot has been seen
+    if (filled - kept >= 24) break; // a usable extension: the rest can wait for the next refill
+    pivot = pp + D;                 // the key that overflowed a lane: the next round counts its copies
+  }
+  if (filled <= kept) {             // (also filled == -1)
+    q.hi = 0;
+    return;
+  }
+  const int hi2 = min(WIN, filled);
+  const int r2 = r0 + s;
+  if (f) {
+    const unsigned rv = win[(hi2 - 1 - lane) & 63];
+    q.w = lane < hi2 ? ~rv : KEY_NONE;
+    q.r0 = n - (r2 + hi2);
+  } else {
+    q.w = win[lane];
+    q.r0 = r2;
+  }
+  q.hi = hi2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TAIL SETS: collection from the ring.  Every valid key whose flipped image exceeds the side's threshold is appended
+// (LDS atomic counter) to that side's 512-slot array in LDS; the caller then takes the arrays into registers.
 __device__ __forceinline__ void tails_collect(const RingView& R, const int lane, const unsigned tau_hi, const unsigned tau_lo,
                                               TailLds& L, double* sums /* nullptr, or out: sum v, sum v^2 over the ring */) {
 #pragma unroll 1
@@ -352,136 +314,112 @@ __device__ __forceinline__ void tail_to_lds(TailLds& L, const int side, const in
 }
 
 // ------------------------------------------------------------------------------------------------
-// END-OF-STEP evaluation of the (post-update) quartile trackers.  quartile_slide_now: which way must tracker q slide
-// so that ranks k, k+1 come inside its window?  (3 = it cannot: rebuild)
-__device__ __forceinline__ int quartile_slide_now(const QTrack& q, const int k, const int n) {
-  unsigned a, b;
-  if (!qt_valid(q)) return 3;
-  if (qt_resolve(q, k, n, a, b)) return SLIDE_NONE;
-  const int hi_rank = (k + 1 > n - 1) ? k : k + 1;
-  if (hi_rank >= q.c_le + q.ns) return q.ns >= 1 ? SLIDE_UP : 3;
-  return q.np >= 1 ? SLIDE_DOWN : 3;
-}
+// REBUILD (bootstrap, injected state, a tracker or set that did not cover): everything from the ring, one wavefront.
 
-// ------------------------------------------------------------------------------------------------
-// REBUILD (bootstrap, injected state, a tracker that lost its window): everything from the ring, one wavefront.
-
-// exact order statistics at ranks k1, k1+1, k3, k3+1 by bisection on the key space: {a1, b1, a3, b3}
-__device__ __forceinline__ uint4 wave_bisection(const RingView& R, const int lane, const int k1, const int k3) {
+// exact order statistics at four ranks by bisection on the key space (robust against any number of equal keys)
+struct Keys4 {
+  unsigned v[4];
+};
+__device__ __forceinline__ Keys4 wave_bisection4(const RingView& R, const int lane, const int r0, const int r1, const int r2,
+                                                 const int r3) {
   unsigned kmin = KEY_NONE, kmax = 0u;
-#pragma unroll 1
-  for (int q = 0; q < RING_VECS; q++) {
-    const uint4 v = ring_fetch(R, q, lane);
-    const unsigned x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      kmin = min(kmin, x[c]);
-      kmax = max(kmax, x[c] == KEY_NONE ? 0u : x[c]);
-    }
-  }
+  ring_sweep(R, lane, [&](unsigned x0, unsigned x1, unsigned x2, unsigned x3) {
+    kmin = min(min(kmin, x0), min(min(x1, x2), x3));
+    kmax = max(max(kmax, x0 == KEY_NONE ? 0u : x0), max(max(x1 == KEY_NONE ? 0u : x1, x2 == KEY_NONE ? 0u : x2), x3 == KEY_NONE ? 0u : x3));
+  });
   kmin = wave_min_u32(kmin);
   kmax = wave_max_u32(kmax);
-  unsigned lo1 = kmin, hi1 = kmax, lo3 = kmin, hi3 = kmax;
-  while (lo1 < hi1 || lo3 < hi3) {
-    const unsigned m1 = lo1 + ((hi1 - lo1) >> 1);
-    const unsigned m3 = lo3 + ((hi3 - lo3) >> 1);
-    unsigned cnt = 0;  // packed: count(key <= m1) << 16 | count(key <= m3); each <= 10240
+  const int rk[4] = {r0, r1, r2, r3};
+  unsigned lo[4] = {kmin, kmin, kmin, kmin}, hi[4] = {kmax, kmax, kmax, kmax};
 #pragma unroll 1
-    for (int q = 0; q < RING_VECS; q++) {
-      const uint4 v = ring_fetch(R, q, lane);
-      const unsigned x[4] = {v.x, v.y, v.z, v.w};
+  while (lo[0] < hi[0] || lo[1] < hi[1] || lo[2] < hi[2] || lo[3] < hi[3]) {
+    unsigned mp[4], c[4] = {0u, 0u, 0u, 0u};   // count(key <= mid) = borrows of key - (mid + 1); mid < KEY_NONE - 1
 #pragma unroll
-      for (int c = 0; c < 4; c++) cnt += ((x[c] <= m1) ? 0x10000u : 0u) + ((x[c] <= m3) ? 1u : 0u);
-    }
-    cnt = wave_sum_u32(cnt);
-    const int c1 = (int)(cnt >> 16), c3 = (int)(cnt & 0xFFFFu);
-    if (lo1 < hi1) {
-      if (c1 >= k1 + 1) hi1 = m1; else lo1 = m1 + 1;
-    }
-    if (lo3 < hi3) {
-      if (c3 >= k3 + 1) hi3 = m3; else lo3 = m3 + 1;
+    for (int j = 0; j < 4; j++) mp[j] = lo[j] + ((hi[j] - lo[j]) >> 1) + 1u;
+    ring_sweep(R, lane, [&](unsigned x0, unsigned x1, unsigned x2, unsigned x3) {
+      const unsigned xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          unsigned d;
+          SDC_SUB_COUNT(d, c[j], xs[i], mp[j]);
+          (void)d;
+        }
+      }
+    });
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int cj = (int)wave_sum_u32(c[j]);
+      if (lo[j] < hi[j]) {
+        if (cj >= rk[j] + 1) hi[j] = mp[j] - 1u; else lo[j] = mp[j];
+      }
     }
   }
-  // successors: value at rank k+1 = same value if count(<= v_k) >= k+2, else min{key > v_k}
-  unsigned cnt = 0, s1 = KEY_NONE, s3 = KEY_NONE;
-#pragma unroll 1
-  for (int q = 0; q < RING_VECS; q++) {
-    const uint4 v = ring_fetch(R, q, lane);
-    const unsigned x[4] = {v.x, v.y, v.z, v.w};
+  Keys4 o;
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      cnt += ((x[c] <= lo1) ? 0x10000u : 0u) + ((x[c] <= lo3) ? 1u : 0u);
-      if (x[c] > lo1) s1 = min(s1, x[c]);
-      if (x[c] > lo3) s3 = min(s3, x[c]);
-    }
-  }
-  cnt = wave_sum_u32(cnt);
-  s1 = wave_min_u32(s1);
-  s3 = wave_min_u32(s3);
-  uint4 r;
-  r.x = lo1;
-  r.z = lo3;
-  r.y = ((int)(cnt >> 16) >= k1 + 2 || s1 == KEY_NONE) ? lo1 : s1;
-  r.w = ((int)(cnt & 0xFFFFu) >= k3 + 2 || s3 == KEY_NONE) ? lo3 : s3;
-  return r;
+  for (int j = 0; j < 4; j++) o.v[j] = sfl(lo[j]);
+  return o;
 }
 
-// two-sided sweep around anchors gA, gB (any keys in (0, KEY_NONE), present or not) -> two fresh trackers
-__device__ __forceinline__ void wave_rebuild_pair(const RingView& R, const int lane, const unsigned gA, const unsigned gB,
-                                                  const int n, QTrack& A, QTrack& B) {
-  unsigned cleA = 0u, cgeA = 0u, cleB = 0u, cgeB = 0u;
-  L4 pdA = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE}, sdA = pdA, pdB = pdA, sdB = pdA;
-  const unsigned gAp = gA + 1u, gAm = gA - 1u, gBp = gB + 1u, gBm = gB - 1u;
-#pragma unroll 1
-  for (int q = 0; q < RING_VECS; q++) {
-    const uint4 v4 = ring_fetch(R, q, lane);
-    const unsigned xs[4] = {v4.x, v4.y, v4.z, v4.w};
+// first rank / last rank of the window a tracker of rank k gets when it is built from scratch over n keys
+__device__ __forceinline__ void window_ranks(const int k, const int n, int& a, int& b) {
+  a = max(0, min(k - WIN / 2, n - WIN));
+  b = min(a + WIN - 1, n - 1);
+}
+// Both trackers' windows from the keys vA <= vB at their first and last ranks (A, B): one sweep counts the keys up to
+// vA and catches the keys strictly between vA and vB (fewer than 64) in LDS; they are ranked by counting and placed
+// between the copies of vA below and of vB above.
+__device__ __forceinline__ void windows_build(const RingView& R, const int lane, const Keys4& kv, const int A1, const int B1,
+                                              const int A3, const int B3, TailLds& L, QTrack& q1, QTrack& q3) {
+  if (lane < 2) L.cnt[lane] = 0u;
+  unsigned c1 = 0u, c3 = 0u;                                  // count(key <= vA)
+  const unsigned p1 = kv.v[0] + 1u, p3 = kv.v[2] + 1u;
+  // a key strictly between: d = x - (vA + 1) < vB - vA - 1   (empty when vB <= vA + 1; then the compare never holds)
+  const unsigned g1 = kv.v[1] - kv.v[0], g3 = kv.v[3] - kv.v[2];
+  const unsigned w1 = g1 >= 2u ? g1 - 1u : 0u, w3 = g3 >= 2u ? g3 - 1u : 0u;
+  ring_sweep(R, lane, [&](unsigned x0, unsigned x1, unsigned x2, unsigned x3) {
+    const unsigned xs[4] = {x0, x1, x2, x3};
 #pragma unroll
-    for (int c4 = 0; c4 < 4; c4++) {
-      const unsigned x = xs[c4];
-      unsigned dsA, dpA, dsB, dpB;
-      SDC_SUB_COUNT(dsA, cleA, x, gAp);   // x - (g+1) borrows <=> x <= g
-      SDC_SUB_COUNT(dpA, cgeA, gAm, x);   // (g-1) - x borrows <=> x >= g
-      SDC_SUB_COUNT(dsB, cleB, x, gBp);
-      SDC_SUB_COUNT(dpB, cgeB, gBm, x);
-      l4_sweep_insert(sdA, dsA);
-      l4_sweep_insert(pdA, dpA);
-      l4_sweep_insert(sdB, dsB);
-      l4_sweep_insert(pdB, dpB);
+    for (int i = 0; i < 4; i++) {
+      unsigned d1, d3;
+      SDC_SUB_COUNT(d1, c1, xs[i], p1);
+      SDC_SUB_COUNT(d3, c3, xs[i], p3);
+      if (d1 < w1) {
+        const unsigned pos = atomicAdd(&L.cnt[0], 1u);
+        if (pos < (unsigned)WIN) L.keys[0][pos] = xs[i];
+      }
+      if (d3 < w3) {
+        const unsigned pos = atomicAdd(&L.cnt[1], 1u);
+        if (pos < (unsigned)WIN) L.keys[1][pos] = xs[i];
+      }
     }
-  }
-  // across lanes: one copy of the merge code, the four lists rotate through it
+  });
+  __syncthreads();
+  auto finish = [&](const int side, const unsigned cle, const unsigned vA, const unsigned vB, const int A, const int B) {
+    QTrack q;
+    const int len = B - A + 1;
+    const int nA = min((int)wave_sum_u32(cle) - A, len);       // copies of vA from rank A on
+    const int mb = min((int)sfl(L.cnt[side]), WIN);            // keys strictly between
+    const unsigned mine = lane < mb ? L.keys[side][lane] : KEY_NONE;
+    int rank = 0;
 #pragma unroll 1
-  for (int r = 0; r < 4; r++) {
-    wave_merge_l4(pdA);
-    const L4 t = pdA;
-    pdA = sdA;
-    sdA = pdB;
-    pdB = sdB;
-    sdB = t;
-  }
-  auto finish = [&](unsigned g, unsigned cle, unsigned cge, const L4& pd, const L4& sd, QTrack& q) {
-    cle = wave_sum_u32(cle);
-    cge = wave_sum_u32(cge);
-    q.g = g;
-    const int n_empty = SDC_HIST_STRIDE - n;   // empty slots (KEY_NONE) satisfy x >= g
-    q.c_le = (int)cle;
-    q.c_lt = n - ((int)cge - n_empty);
-    // a legitimate predecessor distance is < g; a legitimate successor distance is < KEY_NONE - g - 1
-    const unsigned smax = KEY_NONE - g - 1u;
-    q.np = (pd.e0 < g) + (pd.e1 < g) + (pd.e2 < g) + (pd.e3 < g);
-    q.ns = (sd.e0 < smax) + (sd.e1 < smax) + (sd.e2 < smax) + (sd.e3 < smax);
-    q.P.e0 = pd.e0 < g ? g - 1u - pd.e0 : 0u;
-    q.P.e1 = pd.e1 < g ? g - 1u - pd.e1 : 0u;
-    q.P.e2 = pd.e2 < g ? g - 1u - pd.e2 : 0u;
-    q.P.e3 = pd.e3 < g ? g - 1u - pd.e3 : 0u;
-    q.S.e0 = sd.e0 < smax ? g + 1u + sd.e0 : KEY_NONE;
-    q.S.e1 = sd.e1 < smax ? g + 1u + sd.e1 : KEY_NONE;
-    q.S.e2 = sd.e2 < smax ? g + 1u + sd.e2 : KEY_NONE;
-    q.S.e3 = sd.e3 < smax ? g + 1u + sd.e3 : KEY_NONE;
+    for (int i = 0; i < mb; i++) {
+      const unsigned v = L.keys[side][i];
+      rank += (v < mine || (v == mine && i < lane)) ? 1 : 0;
+    }
+    unsigned* win = &L.keys[side][WIN];
+    win[lane] = lane < nA ? vA : (lane < len ? vB : KEY_NONE);
+    __syncthreads();   // (one wavefront: orders the compiler's view of the cross-lane LDS traffic)
+    if (lane < mb && nA + rank < len) win[nA + rank] = mine;
+    __syncthreads();
+    q.w = win[lane];
+    q.r0 = A;
+    q.hi = (nA >= 1 && nA + mb <= len) ? len : 0;             // (inconsistent counts: no tracker)
+    return q;
   };
-  finish(gA, cleA, cgeA, pdA, sdA, A);
-  finish(gB, cleB, cgeB, pdB, sdB, B);
+  q1 = finish(0, c1, kv.v[0], kv.v[1], A1, B1);
+  q3 = finish(1, c3, kv.v[2], kv.v[3], A3, B3);
 }
 
 // clipped mean / population std straight from the ring, fp64, centred on `ctr` (tiny histories)
@@ -565,30 +503,41 @@ __device__ __forceinline__ Rebuilt rebuild_state(const RingView& R, const int la
   o.direct = false;
   o.tau[0] = o.tau[1] = 0u;   // everything: the history still fits a set
   o.A1 = o.A2 = o.T1 = o.T2 = o.mean = o.sd = 0.0;
-  int ra, rb;
-  quartile_ranks(n, ra, rb);
-  // one copy of the bisection: first the quartile ranks, then (if needed) the ranks of the tail thresholds
+  o.b = Bounds{0.0, 0.0, 0.0, 2u, 2u};
+  int k1, k3, A1r, B1r, A3r, B3r;
+  quartile_ranks(n, k1, k3);
+  window_ranks(k1, n, A1r, B1r);
+  window_ranks(k3, n, A3r, B3r);
+  int ra = A1r, rb = B1r, rc = A3r, rd = B3r;
+  // one copy of the bisection: first the ends of the two windows, then (if needed) the ranks of the tail thresholds
 #pragma unroll 1
   for (int ph = 0; ph < 2; ph++) {
-    const uint4 r = wave_bisection(R, lane, ra, rb);
+    const Keys4 kv = wave_bisection4(R, lane, ra, rb, rc, rd);
     if (ph == 1) {
-      o.tau[0] = sfl(r.z);    // keys >  key at rank n-1-off_hi
-      o.tau[1] = sfl(~r.x);   // keys <  key at rank off_lo
+      o.tau[0] = kv.v[2];    // keys >  key at rank n-1-off_hi
+      o.tau[1] = ~kv.v[0];   // keys <  key at rank off_lo
       break;
     }
-    o.b = clip_bounds(n, r.x, r.y, r.z, r.w);
+    windows_build(R, lane, kv, A1r, B1r, A3r, B3r, L, o.q1, o.q3);
+    unsigned a1 = 0u, b1 = 0u, a3 = 0u, b3 = 0u;
+    if (!qt_resolve(o.q1, k1, n, a1, b1) || !qt_resolve(o.q3, k3, n, a3, b3)) {
+      // cannot happen with a consistent ring; answer "no normalisation" rather than garbage
+      o.q1.hi = o.q3.hi = 0;
+      o.direct = true;
+      break;
+    }
+    o.b = clip_bounds(n, a1, b1, a3, b3);
     if (tiny) {
       wave_direct_moments(R, lane, n, o.b.lb, o.b.ub, o.b.ctr, o.mean, o.sd);
       return o;
     }
-    wave_rebuild_pair(R, lane, sfl(r.x), sfl(r.z), n, o.q1, o.q3);
     int n_hi, n_lo;
     tails_direct(R, lane, o.b, o.T1, o.T2, n_hi, n_lo);
     o.direct = n_hi > SDC_TAIL_CAP - 96 || n_lo > SDC_TAIL_CAP - 96;   // sets need >= 64 keys of slack to be stable
     if (o.direct || n <= SDC_TAIL_CAP) break;
     // thresholds by rank: the tail itself plus 128 keys of slack (at least half a set, at most all but 32 slots)
-    ra = min(min(max(n_lo + 128, SDC_TAIL_CAP / 2), SDC_TAIL_CAP - 32), n - 1);
-    rb = max(n - 1 - min(max(n_hi + 128, SDC_TAIL_CAP / 2), SDC_TAIL_CAP - 32), 0);
+    ra = rb = min(min(max(n_lo + 128, SDC_TAIL_CAP / 2), SDC_TAIL_CAP - 32), n - 1);
+    rc = rd = max(n - 1 - min(max(n_hi + 128, SDC_TAIL_CAP / 2), SDC_TAIL_CAP - 32), 0);
   }
   tails_collect(R, lane, o.direct ? KEY_NONE : o.tau[0], o.direct ? KEY_NONE : o.tau[1], L, sums2);
   o.A1 = sums2[0];

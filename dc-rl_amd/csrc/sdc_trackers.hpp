@@ -4,10 +4,10 @@
 // normalize_energy needs the 25th / 75th percentiles of the history (np.percentile, linear: order statistics k and
 // k+1 each) and the mean / population std of the history clipped to [lb, ub] = [q1 - 1.5 iqr, q3 + 1.5 iqr].  A
 // step inserts one value and evicts at most one:
-//   * QUARTILE TRACKERS (QTrack, one per quartile, in the env's 256-byte header): an anchor key G, the exact counts
-//     #{x < G}, #{x <= G}, the (up to) 4 largest keys below and 4 smallest keys above G -- a window of ~9
-//     consecutive order statistics.  O(1) scalar update per step; the wanted rank moves by at most one per step, so
-//     the window is re-centred AHEAD of need by one sweep over the ring (sdc_ringpath.hpp);
+//   * QUARTILE TRACKERS (QTrack, one per quartile): a window of 64 consecutive order statistics around the wanted
+//     rank, one key per lane (512 bytes per env next to the header).  O(1) update per step across the lanes; the
+//     wanted rank moves by at most one per step, so the window is re-centred AHEAD of need, every ~2 000 steps,
+//     by one sweep over the ring (sdc_ringpath.hpp);
 //   * TOTAL SUMS A1 = sum v, A2 = sum v^2 over the whole history (fp64, O(1) update);
 //   * TAIL SETS: every key above a threshold tau_hi (resp. below tau_lo), unordered, 512 slots each, in global
 //     memory; thresholds sit well inside [lb, ub], so the clipped sums are
@@ -24,7 +24,6 @@
 namespace sdc_rw {
 
 constexpr unsigned KEY_NONE = 0xFFFFFFFFu;  // empty ring slot; also "+infinity" in ascending neighbour lists
-constexpr int QW = SDC_QW;
 constexpr int SMALL_N = 32;                 // below this the step computes the normalisation directly from the ring
 
 __device__ __forceinline__ unsigned f32_key(float f) {
@@ -40,159 +39,79 @@ __device__ __forceinline__ double key_f64(unsigned k) { return (double)key_f32(k
 __device__ __forceinline__ unsigned sfl(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
 // ------------------------------------------------------------------------------------------------
-// tracker: O(1) maintenance (wave-uniform scalar code)
+// DPP lane moves (one VALU instruction each; a lane without a source keeps `identity`)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned lane_key(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)sfl((unsigned)l)); }
 
-// 4-entry sorted lists kept as four named scalars (not arrays: LLVM turns unrolled select chains over an array
-// back into a dynamically indexed load, which would push the whole tracker into scratch memory).
-struct L4 {
-  unsigned e0, e1, e2, e3;
-};
-static_assert(QW == 4, "the tracker lists are written out for 4 entries");
-
-// ascending list of the 4 smallest: insert x (keeps the 4 smallest of list + x)
-__device__ __forceinline__ void asc_insert(L4& L, unsigned x) {
-  L.e3 = min(max(L.e2, x), L.e3);  // clamp x into [e2, e3] (old values)
-  L.e2 = min(max(L.e1, x), L.e2);
-  L.e1 = min(max(L.e0, x), L.e1);
-  L.e0 = min(L.e0, x);
-}
-// descending list of the 4 largest
-__device__ __forceinline__ void desc_insert(L4& L, unsigned x) {
-  L.e3 = max(min(L.e2, x), L.e3);
-  L.e2 = max(min(L.e1, x), L.e2);
-  L.e1 = max(min(L.e0, x), L.e1);
-  L.e0 = max(L.e0, x);
-}
-__device__ __forceinline__ unsigned lget(const L4& L, int j) {
-  return j == 0 ? L.e0 : (j == 1 ? L.e1 : (j == 2 ? L.e2 : L.e3));
-}
-// remove one occurrence of x from the first `cnt` entries; `fill` pads the tail.  Returns false if absent.
-__device__ __forceinline__ bool list_remove(L4& L, int& cnt, unsigned x, unsigned fill) {
-  int j = -1;
-  if (3 < cnt && L.e3 == x) j = 3;
-  if (2 < cnt && L.e2 == x) j = 2;
-  if (1 < cnt && L.e1 == x) j = 1;
-  if (0 < cnt && L.e0 == x) j = 0;
-  if (j < 0) return false;
-  if (j <= 0) L.e0 = L.e1;
-  if (j <= 1) L.e1 = L.e2;
-  if (j <= 2) L.e2 = L.e3;
-  L.e3 = fill;
-  cnt -= 1;
-  return true;
-}
-
+// ------------------------------------------------------------------------------------------------
+// QUARTILE TRACKER: a window of SDC_WIN = 64 CONSECUTIVE order statistics of the env's history, one key per lane.
+// Lane i < hi holds the key of rank r0 + i (ascending); lanes >= hi hold KEY_NONE.  hi == 0: no tracker.
+// A step removes one key from the history and adds one; each lands below the window (the ranks move: r0 -/+ 1),
+// above it (nothing changes) or inside it (one compare across the lanes, one DPP shift).  The wanted rank
+// random-walks through the window by about +-0.6 per step, so a window re-centred on it (32 ranks of room on
+// both sides) lasts ~2 000 steps before the ring has to be read again (qt_refill in sdc_ringpath.hpp).
+constexpr int WIN = SDC_WIN;
 struct QTrack {
-  unsigned g;          // anchor key; 0 = invalid (no tracker)
-  int c_lt, c_le;      // #{x < g}, #{x <= g} over the current ring
-  int np, ns;          // valid entries of P / S
-  L4 P;                // the np largest keys below g, descending; unused entries 0
-  L4 S;                // the ns smallest keys above g, ascending; unused entries KEY_NONE
+  unsigned w;   // this lane's key
+  int r0;       // rank of lane 0's key in the sorted history
+  int hi;       // valid lanes
 };
-
-__device__ __forceinline__ QTrack qt_load(unsigned hd, int base) {
+__device__ __forceinline__ bool qt_valid(const QTrack& q) { return q.hi > 0; }
+__device__ __forceinline__ QTrack qt_load(unsigned hd, int base, unsigned w) {
   QTrack q;
-  q.g = (unsigned)rec_i32(hd, base + T_G);
-  q.c_lt = rec_i32(hd, base + T_CLT);
-  q.c_le = rec_i32(hd, base + T_CLE);
-  q.np = rec_i32(hd, base + T_NP);
-  q.ns = rec_i32(hd, base + T_NS);
-  q.P.e0 = (unsigned)rec_i32(hd, base + T_P + 0);
-  q.P.e1 = (unsigned)rec_i32(hd, base + T_P + 1);
-  q.P.e2 = (unsigned)rec_i32(hd, base + T_P + 2);
-  q.P.e3 = (unsigned)rec_i32(hd, base + T_P + 3);
-  q.S.e0 = (unsigned)rec_i32(hd, base + T_S + 0);
-  q.S.e1 = (unsigned)rec_i32(hd, base + T_S + 1);
-  q.S.e2 = (unsigned)rec_i32(hd, base + T_S + 2);
-  q.S.e3 = (unsigned)rec_i32(hd, base + T_S + 3);
+  q.w = w;
+  q.r0 = rec_i32(hd, base + T_R0);
+  q.hi = rec_i32(hd, base + T_HI);
   return q;
 }
-__device__ __forceinline__ void qt_store(const QTrack& q, unsigned* w) {
-  w[T_G] = q.g;
-  w[T_CLT] = (unsigned)q.c_lt;
-  w[T_CLE] = (unsigned)q.c_le;
-  w[T_NP] = (unsigned)q.np;
-  w[T_NS] = (unsigned)q.ns;
-  w[T_P + 0] = q.P.e0;
-  w[T_P + 1] = q.P.e1;
-  w[T_P + 2] = q.P.e2;
-  w[T_P + 3] = q.P.e3;
-  w[T_S + 0] = q.S.e0;
-  w[T_S + 1] = q.S.e1;
-  w[T_S + 2] = q.S.e2;
-  w[T_S + 3] = q.S.e3;
-}
-
-// Remove one occurrence of x_old from a tracker.  Sets q.g = 0 if the tracker turns out to be inconsistent.
-__device__ __forceinline__ void qt_evict(QTrack& q, unsigned x_old) {
-  if (x_old < q.g) {
-    q.c_lt -= 1;
-    q.c_le -= 1;
-    // the list holds exactly the np largest keys below g: the evicted key is in it iff it is >= the smallest listed
-    if (q.np > 0 && x_old >= lget(q.P, q.np - 1)) {
-      if (!list_remove(q.P, q.np, x_old, 0u)) q.g = 0u;
-    }
-  } else if (x_old == q.g) {
-    q.c_le -= 1;
-  } else {
-    if (q.ns > 0 && x_old <= lget(q.S, q.ns - 1)) {
-      if (!list_remove(q.S, q.ns, x_old, KEY_NONE)) q.g = 0u;
-    }
+// Remove one occurrence of y from the history a tracker describes.  Returns true if the window's lanes changed.
+// An inconsistent tracker (y lies inside the window's span but is not in it) is dropped: hi = 0.
+__device__ __forceinline__ bool qt_evict(QTrack& q, const unsigned y, const int lane) {
+  const int m = __popcll(__ballot(q.w < y));   // valid keys below y (KEY_NONE lanes never count)
+  if (m >= q.hi) return false;                 // above the window: no rank inside it moves
+  if (lane_key(q.w, m) != y) {
+    if (m == 0) q.r0 -= 1;                     // below the window: every rank inside it moves down
+    else q.hi = 0;
+    return false;
   }
-}
-// Add x_new to a tracker that describes m keys.
-__device__ __forceinline__ void qt_insert(QTrack& q, unsigned x_new, int m) {
-  if (x_new < q.g) {
-    const bool complete = q.np == q.c_lt;  // every key below g is listed
-    q.c_lt += 1;
-    q.c_le += 1;
-    if (complete || (q.np > 0 && x_new > lget(q.P, q.np - 1))) {
-      desc_insert(q.P, x_new);
-      q.np = min(QW, q.np + 1);
-    }
-  } else if (x_new == q.g) {
-    q.c_le += 1;
-  } else {
-    const bool complete = q.ns == m - q.c_le;  // every key above g is listed
-    if (complete || (q.ns > 0 && x_new < lget(q.S, q.ns - 1))) {
-      asc_insert(q.S, x_new);
-      q.ns = min(QW, q.ns + 1);
-    }
-  }
-}
-// Apply this step's eviction (x_old, if has_old) and insertion (x_new) to a tracker that described the ring of
-// the previous step, which held n_prev keys.
-__device__ __forceinline__ void qt_update(QTrack& q, unsigned x_new, unsigned x_old, bool has_old, int n_prev) {
-  if (has_old) qt_evict(q, x_old);
-  qt_insert(q, x_new, has_old ? n_prev - 1 : n_prev);
-}
-
-// key at rank r, if the window covers it
-__device__ __forceinline__ bool qt_value_at(const QTrack& q, int r, unsigned& out) {
-  if (r >= q.c_lt && r < q.c_le) {
-    out = q.g;
-    return true;
-  }
-  if (r < q.c_lt) {
-    const int j = q.c_lt - 1 - r;
-    if (j >= q.np) return false;
-    out = lget(q.P, j);
-    return true;
-  }
-  const int j = r - q.c_le;
-  if (j >= q.ns) return false;
-  out = lget(q.S, j);
+  // inside (equal keys are interchangeable: take the first): close the gap from above
+  const unsigned down = dpp_u32<0x130, 0xF>(KEY_NONE, q.w);   // wave_shl:1 -- lane i <- lane i + 1
+  q.w = lane >= m ? down : q.w;
+  q.hi -= 1;
   return true;
 }
-// ranks k and k+1 (the second only if it exists)
-__device__ __forceinline__ bool qt_resolve(const QTrack& q, int k, int n, unsigned& a, unsigned& b) {
-  if (q.g == 0u || q.g == KEY_NONE) return false;
-  if (!qt_value_at(q, k, a)) return false;
-  if (k + 1 > n - 1) {
-    b = a;
-    return true;
+// Add x to a history of m keys that the tracker describes.  Returns true if the window's lanes changed.
+__device__ __forceinline__ bool qt_insert(QTrack& q, const unsigned x, const int m, const int lane) {
+  const int p = __popcll(__ballot(q.w <= x));  // valid keys <= x: x belongs at lane p
+  const bool room = q.hi < WIN;
+  if (p == 0 && !(q.r0 == 0 && room)) {        // below the window (unless the window starts the history and has room)
+    q.r0 += 1;
+    return false;
   }
-  return qt_value_at(q, k + 1, b);
+  if (p == q.hi && !(room && q.r0 + q.hi == m)) return false;   // above it (unless it ends the history and has room)
+  const unsigned up = dpp_u32<0x138, 0xF>(0u, q.w);             // wave_shr:1 -- lane i <- lane i - 1; lane 63's key drops out
+  q.w = lane < p ? q.w : (lane == p ? x : up);
+  q.hi = min(WIN, q.hi + 1);
+  return true;
+}
+// this step's eviction (x_old, if has_old) and insertion (x_new) on a tracker of the previous step's n_prev keys
+__device__ __forceinline__ bool qt_update(QTrack& q, unsigned x_new, unsigned x_old, bool has_old, int n_prev, int lane) {
+  bool ch = false;
+  if (has_old) ch = qt_evict(q, x_old, lane);
+  if (q.hi > 0) ch = qt_insert(q, x_new, has_old ? n_prev - 1 : n_prev, lane) || ch;
+  return ch;
+}
+// keys at ranks k and k+1 (the second only if it exists)
+__device__ __forceinline__ bool qt_resolve(const QTrack& q, int k, int n, unsigned& a, unsigned& b) {
+  const int t = k - q.r0;
+  const int tb = (k + 1 > n - 1) ? t : t + 1;
+  if (q.hi <= 0 || t < 0 || tb >= q.hi) return false;
+  a = lane_key(q.w, t);
+  b = lane_key(q.w, tb);
+  return true;
 }
 // header write-back: lane i of `o` holds dword i
 __device__ __forceinline__ void put_u32(unsigned& o, int idx, unsigned v) {
@@ -204,19 +123,8 @@ __device__ __forceinline__ void put_f64(unsigned& o, int idx, double v) {
   put_u32(o, idx + 1, (unsigned)__double2hiint(v));
 }
 __device__ __forceinline__ void qt_put(unsigned& o, int base, const QTrack& q) {
-  put_u32(o, base + T_G, q.g);
-  put_u32(o, base + T_CLT, (unsigned)q.c_lt);
-  put_u32(o, base + T_CLE, (unsigned)q.c_le);
-  put_u32(o, base + T_NP, (unsigned)q.np);
-  put_u32(o, base + T_NS, (unsigned)q.ns);
-  put_u32(o, base + T_P + 0, q.P.e0);
-  put_u32(o, base + T_P + 1, q.P.e1);
-  put_u32(o, base + T_P + 2, q.P.e2);
-  put_u32(o, base + T_P + 3, q.P.e3);
-  put_u32(o, base + T_S + 0, q.S.e0);
-  put_u32(o, base + T_S + 1, q.S.e1);
-  put_u32(o, base + T_S + 2, q.S.e2);
-  put_u32(o, base + T_S + 3, q.S.e3);
+  put_u32(o, base + T_R0, (unsigned)q.r0);
+  put_u32(o, base + T_HI, (unsigned)q.hi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -269,7 +177,6 @@ __device__ __forceinline__ void clipped_moments(const int n, const Bounds& b, co
   sd = (var > 0 && b.ub > b.lb) ? sqrt(var) : 0.0;
 }
 
-__device__ __forceinline__ bool qt_valid(const QTrack& q) { return q.g != 0u && q.g != KEY_NONE; }
 
 // ------------------------------------------------------------------------------------------------
 // TAIL SETS.  Per env and side 512 slots (SDC_TAIL_CAP) in global memory, lane l owning slots [8 l, 8 l + 8) as

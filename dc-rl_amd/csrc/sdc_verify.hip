@@ -209,15 +209,35 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK, 2) void sdc_reward_verify_ker
   if (n < SMALL_N) return;
   stage_ring(S.hist + (size_t)env * SDC_HIST_STRIDE, keys, tid);
   const uint4* lk = keys + tid;
-  const QTrack q1 = qt_load(hd0, H_Q1), q3 = qt_load(hd0, H_Q3);
+  const unsigned* qwg = S.qwin + (size_t)env * (2 * SDC_WIN);
+  const QTrack q1 = qt_load(hd0, H_Q1, qwg[lane]), q3 = qt_load(hd0, H_Q3, qwg[SDC_WIN + lane]);
   int k1, k3;
   quartile_ranks(n, k1, k3);
   unsigned a1 = 0, b1 = 0, a3 = 0, b3 = 0;
   bool bad = false;
-  // 1. the quartile trackers against an exact bisection
+  // 1. the quartile trackers against an exact bisection ...
   if (!qt_resolve(q1, k1, n, a1, b1) || !qt_resolve(q3, k3, n, a3, b3)) bad = true;
   const uint4 qa = quartiles_by_bisection(lk, k1, k3, &sh, lane, wave);
   if (qa.x != a1 || qa.y != b1 || qa.z != a3 || qa.w != b3) bad = true;
+  // ... and every key of both windows against its rank: lane i's key v must satisfy #{x < v} <= r0 + i < #{x <= v}
+  // (waves 0 / 1 take Q1 / Q3, one window key per lane, all ring keys from LDS)
+  if (wave < 2) {
+    const QTrack& q = wave == 0 ? q1 : q3;
+    if (q.hi < 0 || q.hi > SDC_WIN || q.r0 < 0 || q.r0 + q.hi > n) bad = true;
+    else if (lane < q.hi) {
+      int clt = 0, cle = 0;
+      for (int j = 0; j < SDC_HIST_STRIDE / 4; j++) {
+        const uint4 v = keys[j];
+        const unsigned x[4] = {v.x, v.y, v.z, v.w};
+        for (int i = 0; i < 4; i++) {
+          clt += x[i] < q.w ? 1 : 0;
+          cle += x[i] <= q.w ? 1 : 0;
+        }
+      }
+      if (!(clt <= q.r0 + lane && q.r0 + lane < cle)) bad = true;
+    } else if (q.w != KEY_NONE) bad = true;
+  }
+  bad = __syncthreads_or(bad ? 1 : 0) != 0;
   // 2. the reported z-score against a direct fp64 pass over the ring
   const Bounds b = clip_bounds(n, qa.x, qa.y, qa.z, qa.w);
   const double2 m = direct_moments(lk, n, b.lb, b.ub, b.ctr, &sh, lane, wave);
