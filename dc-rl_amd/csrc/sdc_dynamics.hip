@@ -72,6 +72,12 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 
 // ------------------------------------------------------------------------------------------------
 // the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
+#ifdef SDC_REFILL_DEBUG
+__device__ __forceinline__ void put_dyn_dbg(unsigned& o, int idx, unsigned v) {
+  const unsigned sv = sdc_rw::sfl(v);
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(o) : "s"(sv), "s"(idx) : "m0");
+}
+#endif
 __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& PD, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
                                               unsigned fault, const unsigned x_old, const unsigned hd0,
@@ -616,6 +622,9 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
             if (d == REFILL_NONE) continue;
             QTrack A = t == 0 ? q1 : q3;
             qt_refill(A, d, t == 0 ? k1n : k3n, n, R, lane, sh.tl);
+#ifdef SDC_REFILL_DEBUG
+            for (int j = 0; j < 8; j++) put_dyn_dbg(o0, 18 + j, sh.tl.keys[1][256 + j]);
+#endif
             if (t == 0) { q1 = A; wd1 = true; }
             else { q3 = A; wd3 = true; }
           }
@@ -646,12 +655,6 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
 
 }  // namespace
 
-#ifdef SDC_REFILL_DEBUG
-__device__ __forceinline__ void put_dyn_dbg(unsigned& o, int idx, unsigned v) {
-  const unsigned sv = sdc_rw::sfl(v);
-  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(o) : "s"(sv), "s"(idx) : "m0");
-}
-#endif
 extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
                                                                                 float* __restrict__ obs,
                                                                                 float* __restrict__ share_obs,

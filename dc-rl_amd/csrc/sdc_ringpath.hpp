@@ -179,6 +179,11 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
   __syncthreads();   // (one wavefront: orders the compiler's view of the cross-lane LDS traffic)
   if (lane >= s && lane < hi) win[lane - s] = w;
   int filled = kept;
+#ifdef SDC_REFILL_DEBUG
+  const unsigned long long dt0 = wall_clock64();
+  unsigned long long dt1 = 0, dt2 = 0;
+  int dbg_rounds = 0, dbg_m = 0;
+#endif
   // Rounds: normally one.  A run of equal keys that overflows some lane's list stops the complete part short of it;
   // the next round then starts from that key (its copies are what the borrow count measures).
 #pragma unroll 1
@@ -199,65 +204,88 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
         e0 = min(e0, d);
       }
     });
+#ifdef SDC_REFILL_DEBUG
+    if (round == 0) dt1 = wall_clock64();
+    dbg_rounds = round + 1;
+#endif
     const int extra = (int)wave_sum_u32(c) - n_empty - top;   // copies of the pivot not in the window yet
     const unsigned D = min(wave_min_u32(e3), smax);
     if (extra < 0) {
       filled = -1;   // the tracker does not describe this ring
       break;
     }
-    // compact the complete part of the lists: slot j of every lane in turn (ballot + prefix count)
-    const unsigned mine[3] = {e0, e1, e2};                    // (e3 >= D always)
-    int idx[3];
+    // compact the complete part of the lists into LDS: slot j of every lane in turn (ballot + prefix count)
+    const unsigned mine3[3] = {e0, e1, e2};                   // (e3 >= D always)
     int m = 0;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const unsigned long long mk = __ballot(mine[j] < D);
-      idx[j] = mine[j] < D ? m + (int)__popcll(mk & ((1ull << lane) - 1ull)) : -1;
+      const unsigned long long mk = __ballot(mine3[j] < D);
+      if (mine3[j] < D) L.keys[0][m + (int)__popcll(mk & ((1ull << lane) - 1ull))] = mine3[j];
       m += (int)__popcll(mk);
     }
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-      if (idx[j] >= 0) L.keys[0][idx[j]] = mine[j];
     if (lane < 4) L.keys[0][m + lane] = KEY_NONE;             // pad the list to a multiple of 4 (ranks below nothing)
-    __syncthreads();
-    // rank by counting (equal distances by list position), 4 list entries per LDS read
-    int rank[3] = {0, 0, 0};
-#pragma unroll 1
-    for (int i = 0; i < m; i += 4) {
-      const uint4 v4 = *reinterpret_cast<const uint4*>(&L.keys[0][i]);
-      const unsigned vs[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) rank[j] += (vs[e] < mine[j] || (vs[e] == mine[j] && i + e < idx[j])) ? 1 : 0;
-      }
-    }
-    // copies of the pivot, then the caught keys in rank order
+    // copies of the pivot first
     if (lane < extra && filled + lane < WIN) win[filled + lane] = pivot;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int pos = filled + extra + rank[j];
-      if (idx[j] >= 0 && pos < WIN) win[pos] = pp + mine[j];
+    __syncthreads();
+    // then the caught keys, each at the position its rank gives it: rank = how many caught distances are smaller
+    // (one borrow-count per list entry, one key per lane and pass).  Equal keys get the same rank and land on one
+    // slot; the slots they leave empty are filled from the left after the last round (the window is ascending).
+#pragma unroll 1
+    for (int c0 = 0; c0 < m; c0 += SDC_WAVE) {
+      const unsigned mine = c0 + lane < m ? L.keys[0][c0 + lane] : 0u;
+      unsigned rank = 0u;
+#pragma unroll 2
+      for (int i = 0; i < m; i += 4) {
+        const uint4 v4 = *reinterpret_cast<const uint4*>(&L.keys[0][i]);
+        unsigned t;
+        SDC_SUB_COUNT(t, rank, v4.x, mine);
+        SDC_SUB_COUNT(t, rank, v4.y, mine);
+        SDC_SUB_COUNT(t, rank, v4.z, mine);
+        SDC_SUB_COUNT(t, rank, v4.w, mine);
+        (void)t;
+      }
+      const int pos = filled + extra + (int)rank;
+      if (c0 + lane < m && pos < WIN) win[pos] = pp + mine;
     }
     __syncthreads();
+#ifdef SDC_REFILL_DEBUG
+    if (round == 0) { dt2 = wall_clock64(); dbg_m = m; }
+#endif
     filled += extra + m;
     top += extra + m;
     if (D >= smax) break;           // everything above the pivot has been seen
-    if (filled - kept >= 24) break; // a usable extension: the rest can wait for the next refill
+    if (filled - kept >= 12) break; // a usable extension: the rest can wait for the next refill
     pivot = pp + D;                 // the key that overflowed a lane: the next round counts its copies
   }
+#ifdef SDC_REFILL_DEBUG
+  if (lane == 0) {
+    unsigned* dbg = &L.keys[1][256];
+    dbg[0] = (unsigned)dbg_rounds; dbg[1] = (unsigned)dbg_m; dbg[2] = (unsigned)(dt1 - dt0); dbg[3] = (unsigned)(dt2 - dt1);
+    dbg[4] = (unsigned)(wall_clock64() - dt0); dbg[5] = (unsigned)filled; dbg[6] = (unsigned)kept; dbg[7] = (unsigned)dir;
+  }
+  __syncthreads();
+#endif
   if (filled <= kept) {             // (also filled == -1)
     q.hi = 0;
     return;
   }
   const int hi2 = min(WIN, filled);
   const int r2 = r0 + s;
+  // slots that equal keys left empty take the key to their left: an inclusive prefix maximum over the lanes (DPP scan)
+  unsigned v = win[lane];
+  v = lane < hi2 && v != KEY_NONE ? v : 0u;
+  v = max(v, dpp_u32<0x111, 0xF>(0u, v));   // row_shr:1
+  v = max(v, dpp_u32<0x112, 0xF>(0u, v));   // row_shr:2
+  v = max(v, dpp_u32<0x114, 0xF>(0u, v));   // row_shr:4
+  v = max(v, dpp_u32<0x118, 0xF>(0u, v));   // row_shr:8
+  v = max(v, dpp_u32<0x142, 0xA>(0u, v));   // row_bcast:15 -> rows 1, 3
+  v = max(v, dpp_u32<0x143, 0xC>(0u, v));   // row_bcast:31 -> rows 2, 3
   if (f) {
-    const unsigned rv = win[(hi2 - 1 - lane) & 63];
+    const unsigned rv = (unsigned)__shfl((int)v, (hi2 - 1 - lane) & 63);
     q.w = lane < hi2 ? ~rv : KEY_NONE;
     q.r0 = n - (r2 + hi2);
   } else {
-    q.w = win[lane];
+    q.w = lane < hi2 ? v : KEY_NONE;
     q.r0 = r2;
   }
   q.hi = hi2;

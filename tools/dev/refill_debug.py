@@ -16,7 +16,9 @@ for i in range(30):
         rows.append(hd[e, 18:28].astype(np.int64))
 rows = np.array(rows)
 print("refills", len(rows), "per step", len(rows) / 30)
-print("cols: tries m extra need bw hi hi2 dir s span")
-print(rows[:40])
-print("tries hist", np.bincount(rows[:, 0]))
-print("dir hist", np.bincount(rows[:, 7]), "sweep us", rows[:, 5].mean() / 100, "rank us", rows[:, 6].mean() / 100, "assemble us", rows[:, 8].mean() / 100, "m mean", rows[:, 1].mean())
+print("cols: rounds m sweep_ticks rank_ticks total_ticks filled kept dir")
+print(rows[:12, :8])
+print("rounds hist", np.bincount(rows[:, 0]))
+one = rows[rows[:, 0] == 1]
+print("single-round: sweep us %.2f  compact+rank+place us %.2f  total us %.2f  m mean %.1f  added mean %.1f" % (one[:, 2].mean() / 100, one[:, 3].mean() / 100, one[:, 4].mean() / 100, one[:, 1].mean(), (one[:, 5] - one[:, 6]).mean()))
+print("all: total us %.2f" % (rows[:, 4].mean() / 100))
