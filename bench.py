@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--mixed-racks", action="store_true", help="BASELINE configs[3]: 16/20/25-rack mix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fill", action="store_true", help="skip the history fill (debug only; invalid as a result)")
-    ap.add_argument("--profile-every", type=int, default=8, help="stamp the kernels' wall-clock entry / exit every k-th step (0 = off)")
+    ap.add_argument("--profile-every", type=int, default=7, help="stamp the kernels' wall-clock entry / exit every k-th step (0 = off)")
     args = ap.parse_args()
 
     import torch

@@ -461,7 +461,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
       const bool direct0 = tau0 == SDC_TAU_DIRECT;      // tails too heavy for the sets: swept from the ring every step
       bool ok = n >= SMALL_N && qt_valid(q1) && qt_valid(q3) && tau0 != SDC_TAU_INVALID;
       bool dirty0 = sets_dirty, dirty1 = sets_dirty;   // a set goes back to memory only if it changed
-      int why = ok ? 0 : 1;                            // diagnostics (debug_flags bit 1): why a rebuild was needed
+      int why = ok ? 0 : (tau0 == SDC_TAU_INVALID ? 1 : 8);   // diagnostics (debug_flags bit 1): why a rebuild was needed (1 no sets, 8 no tracker)
       if (ok && append) {
         // O(1) updates: running sums, quartile trackers, tail sets
         const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
@@ -490,9 +490,10 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
             int n_hi, n_lo;
             tails_direct(R, lane, b, t1, t2, n_hi, n_lo);
             clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
-            // the sweep has counted the tails: once both fit a set again (with room to spare: the rebuild goes direct
-            // above SDC_TAIL_CAP - 96), the next step rebuilds the sets
-            if (max(n_hi, n_lo) <= SDC_TAIL_CAP - 160) tau0 = SDC_TAU_INVALID;
+            // the sweep has counted the tails: once both fit a set again with plenty of room (a fresh set holds the
+            // tail plus 128 keys of slack and must stay below SDC_TAIL_CAP - 96), the next step rebuilds the sets;
+            // looked at every 64th step, which bounds what an env hovering around the limit can cost
+            if ((rel & 63) == 63 && max(n_hi, n_lo) <= SDC_TAIL_CAP / 2 - 48) tau0 = SDC_TAU_INVALID;
             path = max(path, 2);
             done_eval = true;
           } else if (kb0 > tau0 && kb1 > tau1) {
@@ -705,7 +706,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     const int r3 = rec_i32(hd0, H_Q3 + T_R0), h3 = rec_i32(hd0, H_Q3 + T_HI);
     const bool near1 = h1 > 0 && ((k1 - r1 >= h1 - 7 && r1 + h1 < hl0) || (k1 - r1 <= 4 && r1 > 0));
     const bool near3 = h3 > 0 && ((k3 - r3 >= h3 - 7 && r3 + h3 < hl0) || (k3 - r3 <= 4 && r3 > 0));
-    if (near1 || near3) {
+    // (likewise an env in direct-tail mode: it sweeps its ring every step)
+    if (near1 || near3 || (unsigned)rec_i32(hd0, H_TAU) == SDC_TAU_DIRECT) {
       __builtin_amdgcn_s_setprio(2);
       const volatile unsigned* ring = S.hist + (size_t)env * SDC_HIST_STRIDE;
 #pragma unroll
@@ -803,11 +805,16 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
           cnt1 = c1;
           ts0 = tail_from_lds(sh.tl, 0, lane);
           ts1 = tail_from_lds(sh.tl, 1, lane);
+          sets_dirty = true;
+        } else if ((low0 && c0 > SDC_TAIL_CAP && c0 - cnt0 < 256) || (low1 && c1 > SDC_TAIL_CAP && c1 - cnt1 < 256)) {
+          tau0 = SDC_TAU_DIRECT;           // even a modest step down does not fit: the tails are too heavy for the sets
         } else {
-          tau0 = SDC_TAU_DIRECT;           // does not fit
+          // the band was too wide (the sweep has counted what it holds): keep the sets as they are, try again on the
+          // next step with a band that takes in ~128 keys
+          if (low0 && c0 > SDC_TAIL_CAP) put_u32(hd0, H_BAND, band_estimate(tau0 - t0, c0 - cnt0));
+          if (low1 && c1 > SDC_TAIL_CAP) put_u32(hd0, H_BAND + 1, band_estimate(tau1 - t1, c1 - cnt1));
         }
         ahead_path = 2;
-        sets_dirty = true;
       }
       put_u32(hd0, H_TAU, tau0);
       put_u32(hd0, H_TAU + 1, tau1);

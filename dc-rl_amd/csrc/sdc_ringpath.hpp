@@ -484,10 +484,8 @@ __device__ __forceinline__ void tails_direct(const RingView& R, const int lane, 
   double a1 = 0.0, a2 = 0.0;
   unsigned c = 0u;   // packed: n_hi << 16 | n_lo
   const double ub2 = b.ub * b.ub, lb2 = b.lb * b.lb;
-#pragma unroll 1
-  for (int q = 0; q < RING_VECS; q++) {
-    const uint4 v4 = ring_fetch(R, q, lane);
-    const unsigned xs[4] = {v4.x, v4.y, v4.z, v4.w};
+  ring_sweep(R, lane, [&](unsigned x0, unsigned x1, unsigned x2, unsigned x3) {
+    const unsigned xs[4] = {x0, x1, x2, x3};
 #pragma unroll
     for (int c4 = 0; c4 < 4; c4++) {
       const unsigned x = xs[c4];
@@ -504,7 +502,7 @@ __device__ __forceinline__ void tails_direct(const RingView& R, const int lane, 
         }
       }
     }
-  }
+  });
   t1 = wave_sum_f64(a1);
   t2 = wave_sum_f64(a2);
   c = wave_sum_u32(c);
