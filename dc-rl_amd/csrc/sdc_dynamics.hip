@@ -80,7 +80,7 @@ __device__ __forceinline__ void put_dyn_dbg(unsigned& o, int idx, unsigned v) {
 #endif
 __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& PD, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
-                                              unsigned fault, const unsigned x_old, const unsigned hd0,
+                                              unsigned fault, const unsigned x_old_l, const unsigned hd0,
                                               const int ahead_path, const bool sets_dirty, float* __restrict__ rew,
                                               DynShared& sh) {
   const sdc_dc_params& P = PD.p;
@@ -442,6 +442,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     using namespace sdc_rw;
     if ((S.debug_flags & 8) && lane == 0) sh.dbg_t = wall_clock64();
     const int n = (int)sfl((unsigned)hl);
+    const unsigned x_old = (unsigned)__builtin_amdgcn_readlane((int)x_old_l, 63);   // (lane 63 loaded it at the start)
     const bool has_old = append && x_old != KEY_NONE;
     unsigned o0 = hd0;
     double mean = 0.0, sd = 0.0;
@@ -677,6 +678,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   unsigned hd0 = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];            // reward-side state: returns, trackers, sums
   unsigned qw1 = S.qwin[(size_t)env * (2 * SDC_WIN) + lane];            // quartile-tracker windows, one key per lane
   unsigned qw3 = S.qwin[(size_t)env * (2 * SDC_WIN) + SDC_WIN + lane];
+  const double stage_v = S.stage[(size_t)env * SDC_WAVE + lane];       // this step's inputs, if the last step staged them
+  sdc_rw::TailSet ts0, ts1;                                            // the env's tail sets (2 x 2 KB, coalesced)
+  {
+    const uint4* tails_g = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
+    ts0 = sdc_rw::tail_load(tails_g, lane);
+    ts1 = sdc_rw::tail_load(tails_g + SDC_TAIL_CAP / 4, lane);
+  }
 
   const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
   const int i = rec_i32(r, R_CURSOR), rel = rec_i32(r, R_TREL);
@@ -716,37 +724,49 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   }
 
   // ---- level 1: one 8-byte gather per lane -------------------------------------------------------------------------
-  {
+  // Normally the previous step has already done it (its indices are this step's minus one) and left the values in
+  // SdcDev::stage, loaded above with the record: the step then starts after one memory round trip, and gathers the
+  // NEXT step's inputs in the background.  After a reset or a host write the tags do not match and the gather runs here.
+  auto gather = [&](const int gi, const int grel, const int ghq) -> double {
     auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
     const double* tW = S.tabW + (size_t)loc * TL;
     const double* tC = S.tabC + (size_t)loc * TL;
-    const double* tw = S.t_win + (size_t)env * S.lw + rel;
-    const double* wbw = S.wb_win + (size_t)env * S.lw + rel;
+    const double* tw = S.t_win + (size_t)env * S.lw + grel;
+    const double* wbw = S.wb_win + (size_t)env * S.lw + grel;
     const uint2* qt = S.qtab + (size_t)env * S.qstride;
     const double* src = nullptr;
-    if (lane <= G_W2) src = tW + tix(i + lane);
-    else if (lane == G_C0) src = tC + tix(i);
+    if (lane <= G_W2) src = tW + tix(gi + lane);
+    else if (lane == G_C0) src = tC + tix(gi);
     else if (lane == G_T0) src = tw;
     else if (lane == G_WB0) src = wbw;
     else if (lane == G_T1) src = tw + 1;
-    else if (lane == G_LUT) src = S.hour_lut + 2 * hourq_n;
-    else if (lane == G_LUT2) src = S.hour_lut + 2 * hourq_n + 1;
+    else if (lane == G_LUT) src = S.hour_lut + 2 * ghq;
+    else if (lane == G_LUT2) src = S.hour_lut + 2 * ghq + 1;
     else if (lane >= G_Q97 && lane <= G_Q96) {
       const int back = lane == G_Q97 ? 97 : 24 * (lane - G_Q97);   // 97, 24, 48, 72, 96
-      const int t = rel - back;
+      const int t = grel - back;
       if (t >= 0) src = reinterpret_cast<const double*>(qt + t);
-    } else if (lane >= G_NC && lane < G_NC + 25) src = tC + tix(i + 1 - 16 + (lane - G_NC));
+    } else if (lane >= G_NC && lane < G_NC + 25) src = tC + tix(gi + 1 - 16 + (lane - G_NC));
     else if (lane >= G_NT && lane < G_NT + 17) src = tw + 1 + (lane - G_NT);
     double v = 0.0;
     if (src) v = *src;
     // NC = (C - min) / (max - min) (utils/managers.py:437), NT likewise (:608): ONE division sequence for both windows
     const bool is_nc = lane >= G_NC && lane < G_NC + 25, is_nt = lane >= G_NT && lane < G_NT + 17;
     if (is_nc || is_nt) v = (v - (is_nc ? ci_min : t_min)) / (is_nc ? ci_den : t_den);
+    return v;
+  };
+  {
+    const bool staged = rec_i32(r, R_STAGE_CUR) == i + 1 && rec_i32(r, R_STAGE_REL) == rel + 1;
+    double v = stage_v;
+    if (!staged) v = gather(i, rel, hourq_n);
     sh.g[lane] = v;
   }
+  // the next step's inputs: issued now, stored with this step's outputs (every index is this step's plus one; the
+  // queue-history entries it reads are at least 24 steps old)
+  const bool last_step = rel + 1 >= S.episode_steps;
+  double stage_next = 0.0;
+  if (!last_step) stage_next = gather(i + 1, rel + 1, hourq_n + 1 >= 96 ? 0 : hourq_n + 1);
   __syncthreads();
-
-  const unsigned x_old = (unsigned)__builtin_amdgcn_readlane((int)x_old_l, 63);
 
   // ---- reward state: maintenance AHEAD of need -------------------------------------------------------------------
   // If, in the worst case for the key this step will add, a quartile tracker's window would no longer cover the
@@ -756,17 +776,11 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   const unsigned long long dbg_a0 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
   int ahead_path = 0;
   bool sets_dirty = false;
-  sdc_rw::TailSet ts0, ts1;   // the env's tail sets (2 x 2 KB, coalesced)
   if (hl0 >= sdc_rw::SMALL_N) {
     using namespace sdc_rw;
     const bool has_old = append && hl0 >= S.hist_cap;
     const int n_next = (has_old || !append) ? hl0 : hl0 + 1;
     const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), -1, 0u};
-    {
-      const uint4* tails_g = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
-      ts0 = tail_load(tails_g, lane);
-      ts1 = tail_load(tails_g + SDC_TAIL_CAP / 4, lane);
-    }
     unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
     if (tau0 < SDC_TAU_DIRECT) {   // sets exist (not SDC_TAU_INVALID / SDC_TAU_DIRECT)
       const unsigned kb0 = (unsigned)rec_i32(hd0, H_KB), kb1 = (unsigned)rec_i32(hd0, H_KB + 1);
@@ -829,7 +843,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   sh.qw[0][lane] = qw1;
   sh.qw[1][lane] = qw3;
   const unsigned long long dbg_a1 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
-  step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old, hd0, ahead_path, sets_dirty, rew, sh);
+  step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old_l, hd0, ahead_path, sets_dirty, rew, sh);
   if (S.debug_flags & 8) {
     __syncthreads();
     if (lane == 0) {
@@ -843,7 +857,10 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   __syncthreads();
 
   // ---- coalesced stores: record, obs [3][26] (78 floats), share_obs [29], info --------------------------------------
+  if (lane == R_STAGE_CUR) sh.rec[lane] = last_step ? 0u : (unsigned)(i + 2);
+  if (lane == R_STAGE_REL) sh.rec[lane] = (unsigned)(rel + 2);
   recp[lane] = sh.rec[lane];
+  S.stage[(size_t)env * SDC_WAVE + lane] = stage_next;
   const int terminal = (rel + 1 >= S.episode_steps) ? 1 : 0;
   {
     const float v0 = obs_padded_at(sh.pool, lane);

@@ -74,6 +74,8 @@ class SdcEngine:
                           max_roll_days=max_roll_days, debug_flags=debug_flags,
                           reward_method=(C.c_int32 * 3)(*[int(m) for m in reward_method]))
         self._h = C.c_void_p()
+        self._pinned_stream = None
+        self._pinned_stream_obj = None
         with torch.cuda.device(self.device):
             torch.cuda.init()
             L.check(self.lib.sdc_create(C.byref(cfg), C.byref(self._h)))
@@ -114,7 +116,16 @@ class SdcEngine:
 
     # ------------------------------------------------------------------ run
     def _stream(self):
+        # launches go to torch's current stream, or to the stream pinned with use_stream() (an engine per env group,
+        # each on its own stream, lets the groups' steps overlap: tools/two_streams.py)
+        if self._pinned_stream is not None:
+            return self._pinned_stream
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def use_stream(self, stream=None):
+        """Pin this engine's launches to a torch.cuda.Stream (None: back to torch's current stream)."""
+        self._pinned_stream = None if stream is None else C.c_void_p(stream.cuda_stream)
+        self._pinned_stream_obj = stream
 
     def reset(self, mask: Optional[np.ndarray] = None, override: Optional[dict] = None):
         """SustainDC.reset for the masked envs (all if mask is None).  Returns (obs, share_obs) device tensors
