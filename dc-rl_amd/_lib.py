@@ -17,8 +17,7 @@ SHARE_OBS_DIM = 29
 INFO_DIM = 44
 TABLE_LEN = 35040
 HDR_DWORDS = 64    # csrc/sdc_device.hpp SdcHdr: 256-byte per-env header
-TAIL_CAP = 512     # csrc/sdc_device.hpp SDC_TAIL_CAP: slots per env and side of the reward tail sets
-QWIN = 64          # csrc/sdc_device.hpp SDC_WIN: keys per quartile-tracker window
+QWIN = 64          # csrc/sdc_device.hpp SDC_WIN: keys per rank window (4 windows per env: Q1, Q3, upper / lower clip bound)
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")

@@ -121,7 +121,7 @@ int rec_get(sdc_handle* h, int idx, int dwords, void* host, int in_hdr = 0) {
 // the reward state (quartile trackers, tail sets, sums) describes the ring contents: drop it when the ring is injected
 int invalidate_trackers(sdc_handle* h) {
   std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
-  if (rec_put(h, H_Q1 + T_HI, 1, z.data(), 1) || rec_put(h, H_Q3 + T_HI, 1, z.data(), 1)) return -1;
+  if (rec_put(h, H_VALID, 1, z.data(), 1)) return -1;
   return 0;
 }
 
@@ -216,9 +216,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
   (void)hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE);  // every slot empty
   A(d.hdr, (size_t)N * SDC_HDR_DWORDS);
-  A(d.qwin, (size_t)N * (2 * SDC_WIN));
+  A(d.qwin, (size_t)N * (4 * SDC_WIN));
   A(d.stage, (size_t)N * SDC_WAVE);
-  A(d.tails, (size_t)N * (2 * SDC_TAIL_CAP / 4));
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
@@ -257,8 +256,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
       {"hist_n", nullptr, 4, H_N, 1, 1}, {"ep_return", nullptr, 24, H_RET, 6, 1},
       {"order_stat_sticky", nullptr, 4, H_STICKY, 1, 1},
       {"header", (void**)&d.hdr, 4 * SDC_HDR_DWORDS, 0, 0},
-      {"qwin", (void**)&d.qwin, 4 * 2 * SDC_WIN, 0, 0},
-      {"tails", (void**)&d.tails, 4 * 2 * SDC_TAIL_CAP, 0, 0},
+      {"qwin", (void**)&d.qwin, 4 * 4 * SDC_WIN, 0, 0},
       {"t_win", (void**)&d.t_win, sizeof(double) * (size_t)d.lw, 0, 0},
       {"wb_win", (void**)&d.wb_win, sizeof(double) * (size_t)d.lw, 0, 0},
       {"qtab", (void**)&d.qtab, sizeof(uint2) * (size_t)d.qstride, 0, 0},

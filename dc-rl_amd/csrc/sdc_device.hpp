@@ -68,35 +68,30 @@ enum SdcRec {
   SDC_REC_DWORDS = 64
 };
 
-// 256-byte per-env header (one dword per lane): what the step hands over between its dynamics and reward parts and
-// the reward-side state (sdc_trackers.hpp); the env's wavefront loads and stores it whole, coalesced.
+// 256-byte per-env header (one dword per lane): the reward-side state (sdc_trackers.hpp) and the running returns; the
+// env's wavefront loads and stores it whole, coalesced.
 enum SdcHdr {
   H_N = 0,        // history length including this step's value
-  H_QS2_LO = 2,   // f64: sum of v^2 over the lower tail set's keys beyond the clip bound (see H_QC)
+  H_QS2_LO = 2,   // f64: sum of v^2 over the keys below the lower clip bound (see H_QC)
   H_EOFF = 4,     // f64: bat_total_energy_with_battery_KWh - hist_ref
-  H_QS1 = 6,      // 2 x f64 (upper, lower): sum of v over the side's set keys at or beyond last step's clip bound
+  H_QS1 = 6,      // 2 x f64 (upper, lower): sum of v over the keys at or beyond last step's clip bound
   H_RET = 10,     // 3 x f64: running return of the current episode (cleared by reset)
-  H_Q1 = 16,      // order-statistic tracker of the lower quartile (SdcTrack)
-  H_QC = 29,      // [2]: how many keys of the side's tail set lie at or beyond last step's clip bound (-1: unknown).
-                  // With H_QS1 / H_QS2 these running sums make the tail corrections O(1): a step only touches the
-                  // keys the bound has moved across.
-  H_Q3 = 32,      // ... of the upper quartile
+  H_Q1 = 16,      // rank window of the lower quartile (SdcTrack)
+  H_BU = 18,      // rank window around the upper clip bound
+  H_BL = 20,      // rank window around the lower clip bound (complemented keys)
+  H_QC = 29,      // [2]: how many keys lie at or beyond last step's clip bound.  With H_QS1 / H_QS2 these running
+                  // sums make the tail corrections O(1): a step only touches the keys the bound has moved across.
+  H_Q3 = 32,      // rank window of the upper quartile
   H_QS2_HI = 46,  // f64: sum of v^2, upper side
   H_STICKY = 48,  // sticky diagnostics (bit 0: a verify-mode mismatch was seen)
   H_KB = 49,      // last step's clip bounds in flipped key space: [0] upper (kub), [1] lower (~(klb - 1))
-  H_TAU = 51,     // tail-set thresholds in flipped key space: [0] upper, [1] lower; [0] may be SDC_TAU_INVALID / _DIRECT
-  H_CNT = 53,     // tail-set sizes [0] upper, [1] lower
-  H_BAND = 55,    // per side [2]: key-space distance that holds ~128 keys just inside the threshold (step of a threshold move)
+  H_VALID = 51,   // 1: the reward state describes the ring (0: rebuild it)
   H_A1 = 58,      // f64: sum of v over the history
   H_A2 = 60,      // f64: sum of v^2
-  H_SLACK = 62,   // per side [2]: set keys between the threshold and last step's clip bound
   SDC_HDR_DWORDS = 64
 };
-#define SDC_TAU_INVALID 0xFFFFFFFFu
-#define SDC_TAU_DIRECT 0xFFFFFFFEu   // the tails do not fit the sets: tail corrections by a sweep over the ring every step
-#define SDC_TAIL_CAP 512   // slots per env and side of the tail sets (8 per lane)
-// quartile tracker: a window of SDC_WIN consecutive order statistics of the history, the keys in SdcDev::qwin (one per
-// lane), in the header the rank of the first key and the number of valid keys (0: no tracker)
+// rank window: SDC_WIN consecutive order statistics of the history, the keys in SdcDev::qwin (one per lane), in the
+// header the rank of the first key and the number of valid keys (0: none)
 enum SdcTrack { T_R0 = 0, T_HI = 1, SDC_TRACK_DWORDS = 2 };
 #define SDC_WIN 64
 
@@ -132,8 +127,7 @@ struct SdcDev {
   unsigned* hdr;     // [N][SDC_HDR_DWORDS] per-env header: step hand-off + reward-side state (see SdcHdr)
   double* stage;     // [N][SDC_WAVE] the next step's gathered inputs (trace / weather / queue-history values), staged by
                      // the step before it so that a step starts after ONE memory round trip
-  unsigned* qwin;    // [N][2][SDC_WIN] quartile-tracker windows (sdc_trackers.hpp): Q1's keys, then Q3's
-  uint4* tails;      // [N][2][SDC_TAIL_CAP / 4] tail sets (sdc_trackers.hpp): side 0 upper, side 1 lower (complemented keys)
+  unsigned* qwin;    // [N][SDC_WIN][4] rank windows (sdc_trackers.hpp): lane l's keys of {Q1, Q3, upper bound, lower bound}
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
   unsigned long long* prof_ts;  // measurement only: [3 kernels][N][2] wall-clock stamps of this launch, or nullptr
 };

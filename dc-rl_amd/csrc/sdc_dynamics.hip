@@ -43,8 +43,8 @@ struct DynShared {
   float info[SDC_INFO_DIM];
   unsigned rec[SDC_REC_DWORDS];
   unsigned long long dbg_t;
-  sdc_rw::TailLds tl;   // the env's two tail sets, parked here between the start and the end of the step
-  unsigned qw[2][SDC_WIN];   // ... and its two quartile-tracker windows
+  sdc_rw::TailLds tl;   // scratch of the ring paths (window refill, rebuild)
+  uint4 qw[SDC_WIN];    // the env's four rank windows, parked here between the start and the end of the step
   double sums2[2];
 };
 
@@ -72,16 +72,10 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 
 // ------------------------------------------------------------------------------------------------
 // the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
-#ifdef SDC_REFILL_DEBUG
-__device__ __forceinline__ void put_dyn_dbg(unsigned& o, int idx, unsigned v) {
-  const unsigned sv = sdc_rw::sfl(v);
-  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(o) : "s"(sv), "s"(idx) : "m0");
-}
-#endif
 __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& PD, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
                                               unsigned fault, const unsigned x_old_l, const unsigned hd0,
-                                              const int ahead_path, const bool sets_dirty, float* __restrict__ rew,
+                                              float* __restrict__ rew,
                                               DynShared& sh) {
   const sdc_dc_params& P = PD.p;
   const int i = rec_i32(r, R_CURSOR);
@@ -436,8 +430,8 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     o[R_HIST_REF + 1] = (unsigned)__double2hiint(href);
   }
 
-  // ---- rewards (utils/reward_creator.py:16-130).  Quartile trackers, tail sets and running sums (sdc_trackers.hpp)
-  // normally answer without reading the history ring; a miss rebuilds them from the ring right here.
+  // ---- rewards (utils/reward_creator.py:16-130).  Four rank windows and running sums (sdc_trackers.hpp) normally
+  // answer without reading the history ring; a miss rebuilds them from the ring right here.
   {
     using namespace sdc_rw;
     if ((S.debug_flags & 8) && lane == 0) sh.dbg_t = wall_clock64();
@@ -446,39 +440,36 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     const bool has_old = append && x_old != KEY_NONE;
     unsigned o0 = hd0;
     double mean = 0.0, sd = 0.0;
-    int path = ahead_path;   // diagnostics: 0 no ring read, 1 slid ahead of need, 2 tail sets re-collected, 3 rebuilt
+    int path = 0;   // diagnostics: 0 no ring read, 1 a window re-centred ahead of need, 3 rebuilt
     const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), slot, x_new};
-    uint4* tails_g = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
     if (n >= 2) {
       int k1, k3;
       quartile_ranks(n, k1, k3);
-      QTrack q1 = qt_load(hd0, H_Q1, sh.qw[0][lane]), q3 = qt_load(hd0, H_Q3, sh.qw[1][lane]);
-      bool wd1 = false, wd3 = false;           // a window goes back to memory only if its lanes changed
-      unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
-      int cnt0 = rec_i32(hd0, H_CNT), cnt1 = rec_i32(hd0, H_CNT + 1);
-      unsigned band0 = (unsigned)rec_i32(hd0, H_BAND), band1 = (unsigned)rec_i32(hd0, H_BAND + 1);
+      // quartile windows q1 / q3; clip-bound windows bu (upper bound, keys as they are) / bl (lower bound, keys
+      // complemented, so that on both sides "beyond the bound" means "at or above it")
+      const uint4 qw = sh.qw[lane];
+      QTrack q1 = qt_load(hd0, H_Q1, qw.x), q3 = qt_load(hd0, H_Q3, qw.y);
+      QTrack bu = qt_load(hd0, H_BU, qw.z), bl = qt_load(hd0, H_BL, qw.w);
+      bool wd1 = false, wd3 = false, wdu = false, wdl = false;   // a window goes back to memory only if its lanes changed
       double A1 = rec_f64(hd0, H_A1), A2 = rec_f64(hd0, H_A2);
-      TailSet ts0 = tail_from_lds(sh.tl, 0, lane), ts1 = tail_from_lds(sh.tl, 1, lane);
-      const bool direct0 = tau0 == SDC_TAU_DIRECT;      // tails too heavy for the sets: swept from the ring every step
-      bool ok = n >= SMALL_N && qt_valid(q1) && qt_valid(q3) && tau0 != SDC_TAU_INVALID;
-      bool dirty0 = sets_dirty, dirty1 = sets_dirty;   // a set goes back to memory only if it changed
-      int why = ok ? 0 : (tau0 == SDC_TAU_INVALID ? 1 : 8);   // diagnostics (debug_flags bit 1): why a rebuild was needed (1 no sets, 8 no tracker)
+      bool ok = n >= SMALL_N && qt_valid(q1) && qt_valid(q3) && qt_valid(bu) && qt_valid(bl) && rec_i32(hd0, H_VALID) == 1;
+      int why = ok ? 0 : 1;                            // diagnostics (debug_flags bit 1): why a rebuild was needed
       if (ok && append) {
-        // O(1) updates: running sums, quartile trackers, tail sets
+        // O(1) updates: running sums, the four windows
         const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
+        const int n_prev = has_old ? n : n - 1;
         A1 += vn - vo;
         A2 += vn * vn - vo * vo;
-        wd1 = qt_update(q1, x_new, x_old, has_old, has_old ? n : n - 1, lane) || wd1;
-        wd3 = qt_update(q3, x_new, x_old, has_old, has_old ? n : n - 1, lane) || wd3;
-        if (!direct0) {
-          if (has_old && x_old > tau0) { if (!tail_remove(ts0, x_old, lane)) { ok = false; why = 2; } cnt0 -= 1; dirty0 = true; }
-          if (has_old && ~x_old > tau1) { if (!tail_remove(ts1, ~x_old, lane)) { ok = false; why = 2; } cnt1 -= 1; dirty1 = true; }
-          if (x_new > tau0) { if (!tail_insert(ts0, x_new, lane)) { ok = false; why = 3; } cnt0 += 1; dirty0 = true; }
-          if (~x_new > tau1) { if (!tail_insert(ts1, ~x_new, lane)) { ok = false; why = 3; } cnt1 += 1; dirty1 = true; }
-        }
+        wd1 = qt_update(q1, x_new, x_old, has_old, n_prev, lane);
+        wd3 = qt_update(q3, x_new, x_old, has_old, n_prev, lane);
+        wdu = qt_update(bu, x_new, x_old, has_old, n_prev, lane);
+        wdl = qt_update(bl, ~x_new, ~x_old, has_old, n_prev, lane);
+        if (!(qt_valid(q1) && qt_valid(q3) && qt_valid(bu) && qt_valid(bl))) { ok = false; why = 2; }
       }
       unsigned kb0 = 0u, kb1 = 0u;
-      int slack0 = 0, slack1 = 0;
+      // running (count, sum v, sum v^2) over the keys at or beyond each clip bound
+      int qc0 = 0, qc1 = 0;
+      double qs1_0 = 0.0, qs1_1 = 0.0, qs2_0 = 0.0, qs2_1 = 0.0;
       bool done_eval = false;
       if (ok) {
         unsigned a1, b1, a3, b3;
@@ -486,161 +477,124 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
           const Bounds b = clip_bounds(n, a1, b1, a3, b3);
           kb0 = b.kub;               // upper tail: keys >= kub
           kb1 = ~(b.klb - 1u);       // lower tail, flipped: ~x >= ~(klb-1)  <=>  x < klb
-          if (direct0) {
-            double t1, t2;
-            int n_hi, n_lo;
-            tails_direct(R, lane, b, t1, t2, n_hi, n_lo);
-            clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
-            // the sweep has counted the tails: once both fit a set again with plenty of room (a fresh set holds the
-            // tail plus 128 keys of slack and must stay below SDC_TAIL_CAP - 96), the next step rebuilds the sets;
-            // looked at every 64th step, which bounds what an env hovering around the limit can cost
-            if ((rel & 63) == 63 && max(n_hi, n_lo) <= SDC_TAIL_CAP / 2 - 48) tau0 = SDC_TAU_INVALID;
-            path = max(path, 2);
-            done_eval = true;
-          } else if (kb0 > tau0 && kb1 > tau1) {
-            // running (count, sum v, sum v^2) over each set's keys at or beyond the clip bound: first the value that
-            // came and the one that went against last step's bounds kbl (a key >= the bound is > tau, i.e. in the
-            // set), then the set keys the bounds have moved across since
-            const unsigned kbl0 = (unsigned)rec_i32(hd0, H_KB), kbl1 = (unsigned)rec_i32(hd0, H_KB + 1);
-            int qc0 = rec_i32(hd0, H_QC), qc1 = rec_i32(hd0, H_QC + 1);
-            double qs1_0 = rec_f64(hd0, H_QS1), qs1_1 = rec_f64(hd0, H_QS1 + 2);
-            double qs2_0 = rec_f64(hd0, H_QS2_HI), qs2_1 = rec_f64(hd0, H_QS2_LO);
-            if (append) {
-              const double vn = key_f64(x_new), vo = key_f64(x_old);
-              if (has_old && x_old >= kbl0) { qc0 -= 1; qs1_0 -= vo; qs2_0 -= vo * vo; }
-              if (has_old && ~x_old >= kbl1) { qc1 -= 1; qs1_1 -= vo; qs2_1 -= vo * vo; }
-              if (x_new >= kbl0) { qc0 += 1; qs1_0 += vn; qs2_0 += vn * vn; }
-              if (~x_new >= kbl1) { qc1 += 1; qs1_1 += vn; qs2_1 += vn * vn; }
+          // first the value that came and the one that went against last step's bounds kbl, then the keys the bounds
+          // have moved across since -- which a bound's window lists, as long as both the old and the new bound lie
+          // inside its span
+          const unsigned kbl0 = (unsigned)rec_i32(hd0, H_KB), kbl1 = (unsigned)rec_i32(hd0, H_KB + 1);
+          qc0 = rec_i32(hd0, H_QC);
+          qc1 = rec_i32(hd0, H_QC + 1);
+          qs1_0 = rec_f64(hd0, H_QS1);
+          qs1_1 = rec_f64(hd0, H_QS1 + 2);
+          qs2_0 = rec_f64(hd0, H_QS2_HI);
+          qs2_1 = rec_f64(hd0, H_QS2_LO);
+          if (append) {
+            const double vn = key_f64(x_new), vo = key_f64(x_old);
+            if (has_old && x_old >= kbl0) { qc0 -= 1; qs1_0 -= vo; qs2_0 -= vo * vo; }
+            if (has_old && ~x_old >= kbl1) { qc1 -= 1; qs1_1 -= vo; qs2_1 -= vo * vo; }
+            if (x_new >= kbl0) { qc0 += 1; qs1_0 += vn; qs2_0 += vn * vn; }
+            if (~x_new >= kbl1) { qc1 += 1; qs1_1 += vn; qs2_1 += vn * vn; }
+          }
+          const unsigned lo0 = min(kb0, kbl0), hi0 = max(kb0, kbl0), lo1 = min(kb1, kbl1), hi1 = max(kb1, kbl1);
+          const bool cov0 = kb0 == kbl0 || qt_spans(bu, lo0, hi0, n), cov1 = kb1 == kbl1 || qt_spans(bl, lo1, hi1, n);
+          if (cov0 && cov1) {
+            int dc0 = 0, dc1 = 0;
+            double d1_0 = 0.0, d2_0 = 0.0, d1_1 = 0.0, d2_1 = 0.0;
+            const bool x0 = kb0 != kbl0 && win_crossing(bu, lo0, hi0, 0u, dc0, d1_0, d2_0);
+            const bool x1 = kb1 != kbl1 && win_crossing(bl, lo1, hi1, KEY_NONE, dc1, d1_1, d2_1);
+            if (x0) {
+              const double sg = kb0 > kbl0 ? -1.0 : 1.0;   // bound moved out: the keys in between leave the tail
+              qc0 += (kb0 > kbl0 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc0);
+              qs1_0 += sg * wave_sum_f64(d1_0);
+              qs2_0 += sg * wave_sum_f64(d2_0);
             }
-            {
-              int dc0 = 0, dc1 = 0;
-              double d1_0 = 0.0, d2_0 = 0.0, d1_1 = 0.0, d2_1 = 0.0;
-              const bool x0 = kb0 != kbl0 && tail_crossing(ts0, min(kb0, kbl0), max(kb0, kbl0), 0u, dc0, d1_0, d2_0);
-              const bool x1 = kb1 != kbl1 && tail_crossing(ts1, min(kb1, kbl1), max(kb1, kbl1), KEY_NONE, dc1, d1_1, d2_1);
-              if (x0) {
-                const double sg = kb0 > kbl0 ? -1.0 : 1.0;   // bound moved out: the keys in between leave the tail
-                qc0 += (kb0 > kbl0 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc0);
-                qs1_0 += sg * wave_sum_f64(d1_0);
-                qs2_0 += sg * wave_sum_f64(d2_0);
-              }
-              if (x1) {
-                const double sg = kb1 > kbl1 ? -1.0 : 1.0;
-                qc1 += (kb1 > kbl1 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc1);
-                qs1_1 += sg * wave_sum_f64(d1_1);
-                qs2_1 += sg * wave_sum_f64(d2_1);
-              }
+            if (x1) {
+              const double sg = kb1 > kbl1 ? -1.0 : 1.0;
+              qc1 += (kb1 > kbl1 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc1);
+              qs1_1 += sg * wave_sum_f64(d1_1);
+              qs2_1 += sg * wave_sum_f64(d2_1);
             }
-            put_running_tails(o0, qc0, qc1, qs1_0, qs1_1, qs2_0, qs2_1);
             // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
             const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
             const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
             clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
-            slack0 = cnt0 - qc0;
-            slack1 = cnt1 - qc1;
             done_eval = true;
           } else {
-            why = kb0 > tau0 ? 7 : 6;
+            why = cov0 ? 7 : 6;
           }
         } else {
           why = 4;
         }
       }
+      bool valid = true;
       if (!done_eval) {
-        // miss (no state yet, a window / set that did not cover, an inconsistency): rebuild everything from the ring
-        const Rebuilt rb = rebuild_state(R, lane, n, sh.tl, sh.sums2);
-        if (n < SMALL_N) {   // tiny history: nothing to keep
+        // miss (no state yet, a window that did not cover, an inconsistency): rebuild everything from the ring
+        const Rebuilt rb = rebuild_state(R, lane, n, sh.tl);
+        if (n < SMALL_N || !rb.ok) {   // tiny history (nothing to keep), or a ring no window can describe
           mean = rb.mean;
           sd = rb.sd;
-          q1.hi = q3.hi = 0;
-          tau0 = SDC_TAU_INVALID;
+          q1.hi = q3.hi = bu.hi = bl.hi = 0;
+          valid = false;
         } else {
-        q1 = rb.q1;
-        q3 = rb.q3;
-        wd1 = wd3 = true;
-        A1 = rb.A1;
-        A2 = rb.A2;
-        kb0 = rb.b.kub;
-        kb1 = ~(rb.b.klb - 1u);
-        clipped_moments(n, rb.b, A1, A2, rb.T1, rb.T2, mean, sd);
-        }
-        if (n < SMALL_N) {
-        } else if (rb.direct) {
-          tau0 = SDC_TAU_DIRECT;
-          tau1 = 0u;
-          cnt0 = cnt1 = 0;
-        } else {
-          tau0 = rb.tau[0];
-          tau1 = rb.tau[1];
-          cnt0 = (int)sfl(sh.tl.cnt[0]);
-          cnt1 = (int)sfl(sh.tl.cnt[1]);
-          ts0 = tail_from_lds(sh.tl, 0, lane);
-          ts1 = tail_from_lds(sh.tl, 1, lane);
-          const unsigned sl = wave_sum_u32((tail_count_below(ts0, kb0) << 16) | tail_count_below(ts1, kb1));
-          slack0 = (int)(sl >> 16);
-          slack1 = (int)(sl & 0xFFFFu);
-          band0 = band_estimate(kb0 - tau0, slack0);   // key distance per ~128 keys just inside the threshold
-          band1 = band_estimate(kb1 - tau1, slack1);
-          // running sums beyond the bounds: the set keys that are not slack
-          {
-            double c1[2] = {0.0, 0.0}, c2[2] = {0.0, 0.0};
-            tail_scan(ts0, kb0, 0u, 0.0, c1[0], c2[0]);
-            tail_scan(ts1, kb1, KEY_NONE, 0.0, c1[1], c2[1]);
-            const double s1_0 = wave_sum_f64(c1[0]), s2_0 = wave_sum_f64(c2[0]);
-            const double s1_1 = wave_sum_f64(c1[1]), s2_1 = wave_sum_f64(c2[1]);
-            put_running_tails(o0, cnt0 - slack0, cnt1 - slack1, s1_0, s1_1, s2_0, s2_1);
-          }
-          dirty0 = dirty1 = true;
+          q1 = rb.q1;
+          q3 = rb.q3;
+          bu = rb.bu;
+          bl = rb.bl;
+          wd1 = wd3 = wdu = wdl = true;
+          A1 = rb.A1;
+          A2 = rb.A2;
+          kb0 = rb.b.kub;
+          kb1 = ~(rb.b.klb - 1u);
+          qc0 = rb.qc[0]; qc1 = rb.qc[1];
+          qs1_0 = rb.qs1[0]; qs1_1 = rb.qs1[1];
+          qs2_0 = rb.qs2[0]; qs2_1 = rb.qs2[1];
+          const double t1 = (qs1_0 - (double)qc0 * rb.b.ub) + (qs1_1 - (double)qc1 * rb.b.lb);
+          const double t2 = (qs2_0 - (double)qc0 * (rb.b.ub * rb.b.ub)) + (qs2_1 - (double)qc1 * (rb.b.lb * rb.b.lb));
+          clipped_moments(n, rb.b, A1, A2, t1, t2, mean, sd);
         }
         path = 3 + ((S.debug_flags & 2) ? why : 0);
       }
       put_u32(o0, H_KB, kb0);
       put_u32(o0, H_KB + 1, kb1);
-      put_u32(o0, H_TAU, tau0);
-      put_u32(o0, H_TAU + 1, tau1);
-      put_u32(o0, H_CNT, (unsigned)cnt0);
-      put_u32(o0, H_CNT + 1, (unsigned)cnt1);
-      put_u32(o0, H_BAND, band0);
-      put_u32(o0, H_BAND + 1, band1);
-      put_u32(o0, H_SLACK, (unsigned)slack0);
-      put_u32(o0, H_SLACK + 1, (unsigned)slack1);
+      put_u32(o0, H_VALID, valid ? 1u : 0u);
       put_f64(o0, H_A1, A1);
       put_f64(o0, H_A2, A2);
-      if (dirty0 && tau0 < SDC_TAU_DIRECT) tail_store(tails_g, lane, ts0);
-      if (dirty1 && tau0 < SDC_TAU_DIRECT) tail_store(tails_g + SDC_TAIL_CAP / 4, lane, ts1);
-      // Quartile windows AHEAD of need: if, in the worst case for the keys the next step removes and adds, a window
-      // would no longer cover the ranks asked of it, re-centre it now -- at the end of this wavefront's life, when
-      // the memory system is quiet and the other wavefronts of its SIMD are finishing -- instead of at the start of
-      // the next launch, where the sweep's loads would queue behind every env's start-of-step traffic.
-      if (n >= SMALL_N && qt_valid(q1) && qt_valid(q3)) {
+      put_running_tails(o0, qc0, qc1, qs1_0, qs1_1, qs2_0, qs2_1);
+      // Windows AHEAD of need: if, in the worst case for the keys the next step removes and adds, a window would no
+      // longer cover what is asked of it, re-centre it now -- at the end of this wavefront's life, when the memory
+      // system is quiet and the other wavefronts of its SIMD are finishing -- instead of at the start of the next
+      // launch, where the sweep's loads would queue behind every env's start-of-step traffic.
+      if (valid && n >= SMALL_N) {
         int k1n, k3n;
         quartile_ranks((append && n < S.hist_cap) ? n + 1 : n, k1n, k3n);
-        const int req1 = qt_refill_ahead(q1.r0, q1.hi, k1n, n), req3 = qt_refill_ahead(q3.r0, q3.hi, k3n, n);
-        if ((req1 | req3) != 0) {
+        // a bound's window is centred on the rank of the first key beyond the bound
+        const int req = qt_refill_ahead(q1, k1n, n, 3, 6) | (qt_refill_ahead(q3, k3n, n, 3, 6) << 2) |
+                        (qt_refill_ahead(bu, n - qc0, n, 10, 10) << 4) | (qt_refill_ahead(bl, n - qc1, n, 10, 10) << 6);
+        if (req != 0) {
           __builtin_amdgcn_s_setprio(3);   // the step ends when the slowest wavefront does: let this one issue first
-          // one copy of the refill code: the trackers take turns through it
+          // one copy of the refill code: the windows take turns through it
 #pragma unroll 1
-          for (int t = 0; t < 2; t++) {
-            const int d = t == 0 ? req1 : req3;
+          for (int t = 0; t < 4; t++) {
+            const int d = (req >> (2 * t)) & 3;
             if (d == REFILL_NONE) continue;
-            QTrack A = t == 0 ? q1 : q3;
-            qt_refill(A, d, t == 0 ? k1n : k3n, n, R, lane, sh.tl);
-#ifdef SDC_REFILL_DEBUG
-            for (int j = 0; j < 8; j++) put_dyn_dbg(o0, 18 + j, sh.tl.keys[1][256 + j]);
-#endif
+            QTrack A = t == 0 ? q1 : (t == 1 ? q3 : (t == 2 ? bu : bl));
+            const int kt = t == 0 ? k1n : (t == 1 ? k3n : (t == 2 ? n - qc0 : n - qc1));
+            qt_refill(A, d, kt, n, R, lane, sh.tl, t == 3 ? KEY_NONE : 0u);
             if (t == 0) { q1 = A; wd1 = true; }
-            else { q3 = A; wd3 = true; }
+            if (t == 1) { q3 = A; wd3 = true; }
+            if (t == 2) { bu = A; wdu = true; }
+            if (t == 3) { bl = A; wdl = true; }
           }
           path = max(path, 1);
         }
       }
       qt_put(o0, H_Q1, q1);
       qt_put(o0, H_Q3, q3);
-      if (wd1) S.qwin[(size_t)env * (2 * SDC_WIN) + lane] = q1.w;
-      if (wd3) S.qwin[(size_t)env * (2 * SDC_WIN) + SDC_WIN + lane] = q3.w;
+      qt_put(o0, H_BU, bu);
+      qt_put(o0, H_BL, bl);
+      if (wd1 || wd3 || wdu || wdl)
+        reinterpret_cast<uint4*>(S.qwin)[(size_t)env * SDC_WIN + lane] = make_uint4(q1.w, q3.w, bu.w, bl.w);
     } else {
-      put_u32(o0, H_Q1 + T_HI, 0u);
-      put_u32(o0, H_Q3 + T_HI, 0u);
-      put_u32(o0, H_TAU, SDC_TAU_INVALID);
+      put_u32(o0, H_VALID, 0u);
     }
     put_u32(o0, H_N, (unsigned)n);
     put_f64(o0, H_EOFF, e_off);                                 // bat_total_energy_with_battery_KWh - hist_ref
@@ -676,15 +630,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
   const unsigned r = recp[lane];
   unsigned hd0 = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];            // reward-side state: returns, trackers, sums
-  unsigned qw1 = S.qwin[(size_t)env * (2 * SDC_WIN) + lane];            // quartile-tracker windows, one key per lane
-  unsigned qw3 = S.qwin[(size_t)env * (2 * SDC_WIN) + SDC_WIN + lane];
+  const uint4 qw0 = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env * SDC_WIN + lane];   // the four rank windows, one key each per lane
   const double stage_v = S.stage[(size_t)env * SDC_WAVE + lane];       // this step's inputs, if the last step staged them
-  sdc_rw::TailSet ts0, ts1;                                            // the env's tail sets (2 x 2 KB, coalesced)
-  {
-    const uint4* tails_g = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
-    ts0 = sdc_rw::tail_load(tails_g, lane);
-    ts1 = sdc_rw::tail_load(tails_g + SDC_TAIL_CAP / 4, lane);
-  }
 
   const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
   const int i = rec_i32(r, R_CURSOR), rel = rec_i32(r, R_TREL);
@@ -714,8 +661,12 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     const int r3 = rec_i32(hd0, H_Q3 + T_R0), h3 = rec_i32(hd0, H_Q3 + T_HI);
     const bool near1 = h1 > 0 && ((k1 - r1 >= h1 - 7 && r1 + h1 < hl0) || (k1 - r1 <= 4 && r1 > 0));
     const bool near3 = h3 > 0 && ((k3 - r3 >= h3 - 7 && r3 + h3 < hl0) || (k3 - r3 <= 4 && r3 > 0));
-    // (likewise an env in direct-tail mode: it sweeps its ring every step)
-    if (near1 || near3 || (unsigned)rec_i32(hd0, H_TAU) == SDC_TAU_DIRECT) {
+    // (likewise a clip-bound window whose bound sits within a dozen ranks of its edge)
+    const int ru = rec_i32(hd0, H_BU + T_R0), hu = rec_i32(hd0, H_BU + T_HI), tu = hl0 - rec_i32(hd0, H_QC) - ru;
+    const int rl = rec_i32(hd0, H_BL + T_R0), hl_ = rec_i32(hd0, H_BL + T_HI), tl = hl0 - rec_i32(hd0, H_QC + 1) - rl;
+    const bool nearu = hu > 0 && ((tu >= hu - 12 && ru + hu < hl0) || (tu <= 12 && ru > 0));
+    const bool nearl = hl_ > 0 && ((tl >= hl_ - 12 && rl + hl_ < hl0) || (tl <= 12 && rl > 0));
+    if (near1 || near3 || nearu || nearl) {
       __builtin_amdgcn_s_setprio(2);
       const volatile unsigned* ring = S.hist + (size_t)env * SDC_HIST_STRIDE;
 #pragma unroll
@@ -768,82 +719,10 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   if (!last_step) stage_next = gather(i + 1, rel + 1, hourq_n + 1 >= 96 ? 0 : hourq_n + 1);
   __syncthreads();
 
-  // ---- reward state: maintenance AHEAD of need -------------------------------------------------------------------
-  // If, in the worst case for the key this step will add, a quartile tracker's window would no longer cover the
-  // ranks asked of it at the end of the step, slide it now; if a tail set is close to full or its threshold close
-  // to the clip bound, move the threshold now.  The sweeps over the env's 40 KB ring then overlap with the other
-  // resident wavefronts instead of extending the kernel's tail.
   const unsigned long long dbg_a0 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
-  int ahead_path = 0;
-  bool sets_dirty = false;
-  if (hl0 >= sdc_rw::SMALL_N) {
-    using namespace sdc_rw;
-    const bool has_old = append && hl0 >= S.hist_cap;
-    const int n_next = (has_old || !append) ? hl0 : hl0 + 1;
-    const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), -1, 0u};
-    unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
-    if (tau0 < SDC_TAU_DIRECT) {   // sets exist (not SDC_TAU_INVALID / SDC_TAU_DIRECT)
-      const unsigned kb0 = (unsigned)rec_i32(hd0, H_KB), kb1 = (unsigned)rec_i32(hd0, H_KB + 1);
-      const unsigned band0 = (unsigned)rec_i32(hd0, H_BAND), band1 = (unsigned)rec_i32(hd0, H_BAND + 1);
-      int cnt0 = rec_i32(hd0, H_CNT), cnt1 = rec_i32(hd0, H_CNT + 1);
-      const int slack0 = rec_i32(hd0, H_SLACK), slack1 = rec_i32(hd0, H_SLACK + 1);
-      // nearly full: raise the threshold a quarter of the way to the clip bound (in registers, no ring read)
-      if (cnt0 > SDC_TAIL_CAP * 7 / 8 && kb0 > tau0 && slack0 > 96) {
-        tau0 += (kb0 - tau0) / 4u;
-        cnt0 = tail_raise(ts0, tau0);
-        sets_dirty = true;
-      }
-      if (cnt1 > SDC_TAIL_CAP * 7 / 8 && kb1 > tau1 && slack1 > 96) {
-        tau1 += (kb1 - tau1) / 4u;
-        cnt1 = tail_raise(ts1, tau1);
-        sets_dirty = true;
-      }
-      // threshold close to the clip bound while keys exist below it: lower it by one band and re-collect
-      const bool low0 = slack0 < 48 && hl0 > cnt0 && tau0 > 0u, low1 = slack1 < 48 && hl0 > cnt1 && tau1 > 0u;
-      if ((low0 && cnt0 > SDC_TAIL_CAP - 96) || (low1 && cnt1 > SDC_TAIL_CAP - 96)) {
-        // no room to take more keys in: this env's tails do not fit the sets (any more)
-        tau0 = SDC_TAU_DIRECT;
-        ahead_path = 2;
-      } else if (low0 || low1) {
-        const unsigned t0 = low0 ? (tau0 > band0 ? tau0 - band0 : 0u) : tau0;
-        const unsigned t1 = low1 ? (tau1 > band1 ? tau1 - band1 : 0u) : tau1;
-        tails_collect(R, lane, t0, t1, sh.tl, nullptr);
-        const int c0 = (int)sfl(sh.tl.cnt[0]), c1 = (int)sfl(sh.tl.cnt[1]);
-        if (c0 <= SDC_TAIL_CAP && c1 <= SDC_TAIL_CAP) {
-          // band estimate: the key distance that held ~128 keys
-          if (low0) put_u32(hd0, H_BAND, band_estimate(tau0 - t0, c0 - cnt0));
-          if (low1) put_u32(hd0, H_BAND + 1, band_estimate(tau1 - t1, c1 - cnt1));
-          tau0 = t0;
-          tau1 = t1;
-          cnt0 = c0;
-          cnt1 = c1;
-          ts0 = tail_from_lds(sh.tl, 0, lane);
-          ts1 = tail_from_lds(sh.tl, 1, lane);
-          sets_dirty = true;
-        } else if ((low0 && c0 > SDC_TAIL_CAP && c0 - cnt0 < 256) || (low1 && c1 > SDC_TAIL_CAP && c1 - cnt1 < 256)) {
-          tau0 = SDC_TAU_DIRECT;           // even a modest step down does not fit: the tails are too heavy for the sets
-        } else {
-          // the band was too wide (the sweep has counted what it holds): keep the sets as they are, try again on the
-          // next step with a band that takes in ~128 keys
-          if (low0 && c0 > SDC_TAIL_CAP) put_u32(hd0, H_BAND, band_estimate(tau0 - t0, c0 - cnt0));
-          if (low1 && c1 > SDC_TAIL_CAP) put_u32(hd0, H_BAND + 1, band_estimate(tau1 - t1, c1 - cnt1));
-        }
-        ahead_path = 2;
-      }
-      put_u32(hd0, H_TAU, tau0);
-      put_u32(hd0, H_TAU + 1, tau1);
-      put_u32(hd0, H_CNT, (unsigned)cnt0);
-      put_u32(hd0, H_CNT + 1, (unsigned)cnt1);
-    }
-  }
-  if (hl0 >= sdc_rw::SMALL_N) {
-    sdc_rw::tail_to_lds(sh.tl, 0, lane, ts0);   // parked in LDS for the duration of the dynamics
-    sdc_rw::tail_to_lds(sh.tl, 1, lane, ts1);
-  }
-  sh.qw[0][lane] = qw1;
-  sh.qw[1][lane] = qw3;
+  sh.qw[lane] = qw0;   // parked in LDS for the duration of the dynamics
   const unsigned long long dbg_a1 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
-  step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old_l, hd0, ahead_path, sets_dirty, rew, sh);
+  step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old_l, hd0, rew, sh);
   if (S.debug_flags & 8) {
     __syncthreads();
     if (lane == 0) {

@@ -123,7 +123,7 @@ __device__ __forceinline__ void ring_sweep_pipelined(const RingView& R, const in
 // ------------------------------------------------------------------------------------------------
 // LDS scratch of the ring paths (one wavefront = one workgroup: LDS operations of a wavefront complete in order)
 struct TailLds {
-  unsigned keys[2][SDC_TAIL_CAP];
+  unsigned keys[2][256];
   unsigned cnt[2];
 };
 
@@ -133,11 +133,12 @@ enum { REFILL_NONE = 0, REFILL_UP = 1, REFILL_DOWN = 2 };
 
 // AHEAD-OF-NEED test on a tracker of the ring's n keys: the next step moves the wanted rank by at most one inside
 // the window and takes at most one key out of it.
-__device__ __forceinline__ int qt_refill_ahead(const int r0, const int hi, const int k_next, const int n) {
-  if (hi <= 0) return REFILL_NONE;          // nothing to extend: the end-of-step rebuild will create it
-  const int t = k_next - r0;
-  if (t > hi - 6 && r0 + hi < n) return REFILL_UP;
-  if (t < 3 && r0 > 0) return REFILL_DOWN;
+// (quartile windows: margins 3 / 6; a clip bound may cross a few keys in one step: margins 10 / 10)
+__device__ __forceinline__ int qt_refill_ahead(const QTrack& q, const int k_next, const int n, const int m_lo, const int m_hi) {
+  if (q.hi <= 0) return REFILL_NONE;        // nothing to extend: the end-of-step rebuild will create it
+  const int t = k_next - q.r0;
+  if (t > q.hi - m_hi && q.r0 + q.hi < n) return REFILL_UP;
+  if (t < m_lo && q.r0 > 0) return REFILL_DOWN;
   return REFILL_NONE;
 }
 
@@ -154,15 +155,17 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
 // Below D = the smallest 4th-smallest of any lane the lanes' lists are COMPLETE (a key a lane dropped is >= that
 // lane's 4th); those ~45 keys (64 lanes x 4 slots: a birthday bound) are compacted, ranked by counting and placed.
 // A run of equal keys can stop the complete part short; then another sweep continues from that key.
+// `side` = KEY_NONE for a window over complemented keys (the lower clip bound's), else 0.
 __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k, const int n, const RingView& R, const int lane,
-                                          TailLds& L) {
+                                          TailLds& L, const unsigned side) {
   // Work in a space where the window grows upwards: for DOWN complement the keys, reverse the window and count ranks
   // from the top.
-  const unsigned f = dir == REFILL_DOWN ? KEY_NONE : 0u;
+  const unsigned fd = dir == REFILL_DOWN ? KEY_NONE : 0u;
+  const unsigned f = fd ^ side;               // what turns a ring key into a key of that space
   const int hi = q.hi;
   unsigned w = q.w;
   int r0 = q.r0, kk = k;
-  if (f) {
+  if (fd) {
     const unsigned rv = (unsigned)__shfl((int)q.w, (hi - 1 - lane) & 63);
     w = lane < hi ? ~rv : KEY_NONE;
     r0 = n - (q.r0 + hi);
@@ -179,11 +182,6 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
   __syncthreads();   // (one wavefront: orders the compiler's view of the cross-lane LDS traffic)
   if (lane >= s && lane < hi) win[lane - s] = w;
   int filled = kept;
-#ifdef SDC_REFILL_DEBUG
-  const unsigned long long dt0 = wall_clock64();
-  unsigned long long dt1 = 0, dt2 = 0;
-  int dbg_rounds = 0, dbg_m = 0;
-#endif
   // Rounds: normally one.  A run of equal keys that overflows some lane's list stops the complete part short of it;
   // the next round then starts from that key (its copies are what the borrow count measures).
 #pragma unroll 1
@@ -204,10 +202,6 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
         e0 = min(e0, d);
       }
     });
-#ifdef SDC_REFILL_DEBUG
-    if (round == 0) dt1 = wall_clock64();
-    dbg_rounds = round + 1;
-#endif
     const int extra = (int)wave_sum_u32(c) - n_empty - top;   // copies of the pivot not in the window yet
     const unsigned D = min(wave_min_u32(e3), smax);
     if (extra < 0) {
@@ -248,23 +242,12 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
       if (c0 + lane < m && pos < WIN) win[pos] = pp + mine;
     }
     __syncthreads();
-#ifdef SDC_REFILL_DEBUG
-    if (round == 0) { dt2 = wall_clock64(); dbg_m = m; }
-#endif
     filled += extra + m;
     top += extra + m;
     if (D >= smax) break;           // everything above the pivot has been seen
     if (filled - kept >= 12) break; // a usable extension: the rest can wait for the next refill
     pivot = pp + D;                 // the key that overflowed a lane: the next round counts its copies
   }
-#ifdef SDC_REFILL_DEBUG
-  if (lane == 0) {
-    unsigned* dbg = &L.keys[1][256];
-    dbg[0] = (unsigned)dbg_rounds; dbg[1] = (unsigned)dbg_m; dbg[2] = (unsigned)(dt1 - dt0); dbg[3] = (unsigned)(dt2 - dt1);
-    dbg[4] = (unsigned)(wall_clock64() - dt0); dbg[5] = (unsigned)filled; dbg[6] = (unsigned)kept; dbg[7] = (unsigned)dir;
-  }
-  __syncthreads();
-#endif
   if (filled <= kept) {             // (also filled == -1)
     q.hi = 0;
     return;
@@ -280,7 +263,7 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
   v = max(v, dpp_u32<0x118, 0xF>(0u, v));   // row_shr:8
   v = max(v, dpp_u32<0x142, 0xA>(0u, v));   // row_bcast:15 -> rows 1, 3
   v = max(v, dpp_u32<0x143, 0xC>(0u, v));   // row_bcast:31 -> rows 2, 3
-  if (f) {
+  if (fd) {
     const unsigned rv = (unsigned)__shfl((int)v, (hi2 - 1 - lane) & 63);
     q.w = lane < hi2 ? ~rv : KEY_NONE;
     q.r0 = n - (r2 + hi2);
@@ -289,56 +272,6 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
     q.r0 = r2;
   }
   q.hi = hi2;
-}
-
-// ------------------------------------------------------------------------------------------------
-// TAIL SETS: collection from the ring.  Every valid key whose flipped image exceeds the side's threshold is appended
-// (LDS atomic counter) to that side's 512-slot array in LDS; the caller then takes the arrays into registers.
-__device__ __forceinline__ void tails_collect(const RingView& R, const int lane, const unsigned tau_hi, const unsigned tau_lo,
-                                              TailLds& L, double* sums /* nullptr, or out: sum v, sum v^2 over the ring */) {
-#pragma unroll 1
-  for (int i = lane; i < 2 * SDC_TAIL_CAP; i += SDC_WAVE) (&L.keys[0][0])[i] = TAIL_EMPTY;
-  if (lane < 2) L.cnt[lane] = 0u;
-  double a1 = 0.0, a2 = 0.0;
-#pragma unroll 1
-  for (int q = 0; q < RING_VECS; q++) {
-    const uint4 v4 = ring_fetch(R, q, lane);
-    const unsigned xs[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-    for (int c4 = 0; c4 < 4; c4++) {
-      const unsigned x = xs[c4];
-      if (x != KEY_NONE) {
-        if (x > tau_hi) {
-          const unsigned pos = atomicAdd(&L.cnt[0], 1u);
-          if (pos < SDC_TAIL_CAP) L.keys[0][pos] = x;
-        }
-        if (~x > tau_lo) {
-          const unsigned pos = atomicAdd(&L.cnt[1], 1u);
-          if (pos < SDC_TAIL_CAP) L.keys[1][pos] = ~x;
-        }
-        if (sums) {
-          const double v = key_f64(x);
-          a1 += v;
-          a2 += v * v;
-        }
-      }
-    }
-  }
-  if (sums) {
-    sums[0] = wave_sum_f64(a1);
-    sums[1] = wave_sum_f64(a2);
-  }
-}
-// LDS slot i * 64 + lane <-> register slot i of lane (bank-conflict free; which key sits in which slot is immaterial)
-__device__ __forceinline__ TailSet tail_from_lds(const TailLds& L, const int side, const int lane) {
-  TailSet s;
-#pragma unroll
-  for (int i = 0; i < 8; i++) s.k[i] = L.keys[side][i * SDC_WAVE + lane];
-  return s;
-}
-__device__ __forceinline__ void tail_to_lds(TailLds& L, const int side, const int lane, const TailSet& s) {
-#pragma unroll
-  for (int i = 0; i < 8; i++) L.keys[side][i * SDC_WAVE + lane] = s.k[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -477,97 +410,108 @@ __device__ __forceinline__ void wave_direct_moments(const RingView& R, const int
   sd = var > 0 ? sqrt(var) : 0.0;
 }
 
-// Tail corrections straight from the ring (an env whose tails do not fit the sets: more than ~480 keys beyond a clip
-// bound): sum (v - bound), sum (v^2 - bound^2) over the keys >= kub and over the keys < klb, and how many there are.
-__device__ __forceinline__ void tails_direct(const RingView& R, const int lane, const Bounds& b, double& t1, double& t2,
-                                             int& n_hi, int& n_lo) {
-  double a1 = 0.0, a2 = 0.0;
+// Totals and tail sums straight from the ring: A1 / A2 = sum v, sum v^2 over all keys; per side (count, sum v,
+// sum v^2) over the keys >= kub (side 0) and over the keys < klb (side 1).
+struct RingSums {
+  double A1, A2;
+  int qc[2];
+  double qs1[2], qs2[2];
+};
+__device__ __forceinline__ RingSums ring_sums(const RingView& R, const int lane, const Bounds& b) {
+  double a1 = 0.0, a2 = 0.0, h1 = 0.0, h2 = 0.0, l1 = 0.0, l2 = 0.0;
   unsigned c = 0u;   // packed: n_hi << 16 | n_lo
-  const double ub2 = b.ub * b.ub, lb2 = b.lb * b.lb;
   ring_sweep(R, lane, [&](unsigned x0, unsigned x1, unsigned x2, unsigned x3) {
     const unsigned xs[4] = {x0, x1, x2, x3};
 #pragma unroll
     for (int c4 = 0; c4 < 4; c4++) {
       const unsigned x = xs[c4];
-      if (x != KEY_NONE && (x >= b.kub || x < b.klb)) {
-        const double v = key_f64(x);
-        if (x >= b.kub) {
-          a1 += v - b.ub;
-          a2 += v * v - ub2;
-          c += 0x10000u;
-        } else {
-          a1 += v - b.lb;
-          a2 += v * v - lb2;
-          c += 1u;
-        }
+      if (x != KEY_NONE) {
+        const double v = key_f64(x), v2 = v * v;
+        const bool hi = x >= b.kub, lo = x < b.klb;
+        a1 += v;
+        a2 += v2;
+        h1 += hi ? v : 0.0;
+        h2 += hi ? v2 : 0.0;
+        l1 += lo ? v : 0.0;
+        l2 += lo ? v2 : 0.0;
+        c += (hi ? 0x10000u : 0u) + (lo ? 1u : 0u);
       }
     }
   });
-  t1 = wave_sum_f64(a1);
-  t2 = wave_sum_f64(a2);
+  RingSums o;
+  o.A1 = wave_sum_f64(a1);
+  o.A2 = wave_sum_f64(a2);
+  o.qs1[0] = wave_sum_f64(h1);
+  o.qs2[0] = wave_sum_f64(h2);
+  o.qs1[1] = wave_sum_f64(l1);
+  o.qs2[1] = wave_sum_f64(l2);
   c = wave_sum_u32(c);
-  n_hi = (int)(c >> 16);
-  n_lo = (int)(c & 0xFFFFu);
+  o.qc[0] = (int)(c >> 16);
+  o.qc[1] = (int)(c & 0xFFFFu);
+  return o;
 }
 
 // Full rebuild of one env's reward state from its ring (n >= 2 keys, this step's key included).
 //   n < SMALL_N: only this step's clipped mean / std, directly.
-//   else: fresh quartile trackers, total sums, this step's tail corrections T1 / T2 by a direct sweep, and -- if the
-//   tails fit -- tail sets (into L) whose thresholds leave ~128 keys (at least a quarter of a set) of slack inside
-//   the clip bounds; `direct` is set when a tail has more keys than a set can hold.
+//   else: the four rank windows, the total sums and the running tail sums.
 struct Rebuilt {
-  QTrack q1, q3;
-  unsigned tau[2];
-  double A1, A2, T1, T2;
+  QTrack q1, q3, bu, bl;
+  double A1, A2;
+  int qc[2];
+  double qs1[2], qs2[2];
   double mean, sd;   // n < SMALL_N only
   Bounds b;
-  bool direct;
+  bool ok;
 };
-__device__ __forceinline__ Rebuilt rebuild_state(const RingView& R, const int lane, const int n, TailLds& L, double* sums2) {
+__device__ __forceinline__ Rebuilt rebuild_state(const RingView& R, const int lane, const int n, TailLds& L) {
   Rebuilt o;
   const bool tiny = n < SMALL_N;
-  o.direct = false;
-  o.tau[0] = o.tau[1] = 0u;   // everything: the history still fits a set
-  o.A1 = o.A2 = o.T1 = o.T2 = o.mean = o.sd = 0.0;
+  o.ok = false;
+  o.A1 = o.A2 = o.mean = o.sd = 0.0;
+  o.qc[0] = o.qc[1] = 0;
+  o.qs1[0] = o.qs1[1] = o.qs2[0] = o.qs2[1] = 0.0;
   o.b = Bounds{0.0, 0.0, 0.0, 2u, 2u};
-  int k1, k3, A1r, B1r, A3r, B3r;
+  o.q1.hi = o.q3.hi = o.bu.hi = o.bl.hi = 0;
+  int k1, k3, ra, rb, rc, rd;
   quartile_ranks(n, k1, k3);
-  window_ranks(k1, n, A1r, B1r);
-  window_ranks(k3, n, A3r, B3r);
-  int ra = A1r, rb = B1r, rc = A3r, rd = B3r;
-  // one copy of the bisection: first the ends of the two windows, then (if needed) the ranks of the tail thresholds
+  window_ranks(k1, n, ra, rb);
+  window_ranks(k3, n, rc, rd);
+  // one copy of the bisection and of the window builder: first the quartile windows, then the clip-bound windows
 #pragma unroll 1
   for (int ph = 0; ph < 2; ph++) {
     const Keys4 kv = wave_bisection4(R, lane, ra, rb, rc, rd);
+    QTrack wa, wb;
+    windows_build(R, lane, kv, ra, rb, rc, rd, L, wa, wb);
+    if (!qt_valid(wa) || !qt_valid(wb)) return o;   // cannot happen with a consistent ring
     if (ph == 1) {
-      o.tau[0] = kv.v[2];    // keys >  key at rank n-1-off_hi
-      o.tau[1] = ~kv.v[0];   // keys <  key at rank off_lo
+      o.bu = wa;
+      // the lower bound's window lives on complemented keys: reverse it, count ranks from the top
+      const unsigned rv = (unsigned)__shfl((int)wb.w, (wb.hi - 1 - lane) & 63);
+      o.bl.w = lane < wb.hi ? ~rv : KEY_NONE;
+      o.bl.r0 = n - (wb.r0 + wb.hi);
+      o.bl.hi = wb.hi;
+      o.ok = true;
       break;
     }
-    windows_build(R, lane, kv, A1r, B1r, A3r, B3r, L, o.q1, o.q3);
+    o.q1 = wa;
+    o.q3 = wb;
     unsigned a1 = 0u, b1 = 0u, a3 = 0u, b3 = 0u;
-    if (!qt_resolve(o.q1, k1, n, a1, b1) || !qt_resolve(o.q3, k3, n, a3, b3)) {
-      // cannot happen with a consistent ring; answer "no normalisation" rather than garbage
-      o.q1.hi = o.q3.hi = 0;
-      o.direct = true;
-      break;
-    }
+    if (!qt_resolve(o.q1, k1, n, a1, b1) || !qt_resolve(o.q3, k3, n, a3, b3)) return o;
     o.b = clip_bounds(n, a1, b1, a3, b3);
     if (tiny) {
       wave_direct_moments(R, lane, n, o.b.lb, o.b.ub, o.b.ctr, o.mean, o.sd);
       return o;
     }
-    int n_hi, n_lo;
-    tails_direct(R, lane, o.b, o.T1, o.T2, n_hi, n_lo);
-    o.direct = n_hi > SDC_TAIL_CAP - 96 || n_lo > SDC_TAIL_CAP - 96;   // sets need >= 64 keys of slack to be stable
-    if (o.direct || n <= SDC_TAIL_CAP) break;
-    // thresholds by rank: the tail itself plus 128 keys of slack (at least half a set, at most all but 32 slots)
-    ra = rb = min(min(max(n_lo + 128, SDC_TAIL_CAP / 2), SDC_TAIL_CAP - 32), n - 1);
-    rc = rd = max(n - 1 - min(max(n_hi + 128, SDC_TAIL_CAP / 2), SDC_TAIL_CAP - 32), 0);
+    const RingSums rs = ring_sums(R, lane, o.b);
+    o.A1 = rs.A1;
+    o.A2 = rs.A2;
+    o.qc[0] = rs.qc[0]; o.qc[1] = rs.qc[1];
+    o.qs1[0] = rs.qs1[0]; o.qs1[1] = rs.qs1[1];
+    o.qs2[0] = rs.qs2[0]; o.qs2[1] = rs.qs2[1];
+    // the first key at or above the upper bound has rank n - n_hi; the first key not below the lower bound rank n_lo
+    window_ranks(n - rs.qc[0], n, ra, rb);
+    window_ranks(rs.qc[1], n, rc, rd);
   }
-  tails_collect(R, lane, o.direct ? KEY_NONE : o.tau[0], o.direct ? KEY_NONE : o.tau[1], L, sums2);
-  o.A1 = sums2[0];
-  o.A2 = sums2[1];
   return o;
 }
 

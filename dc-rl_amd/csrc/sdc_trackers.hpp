@@ -9,14 +9,12 @@
 //     wanted rank moves by at most one per step, so the window is re-centred AHEAD of need, every ~2 000 steps,
 //     by one sweep over the ring (sdc_ringpath.hpp);
 //   * TOTAL SUMS A1 = sum v, A2 = sum v^2 over the whole history (fp64, O(1) update);
-//   * TAIL SETS: every key above a threshold tau_hi (resp. below tau_lo), unordered, 512 slots each, in global
-//     memory; thresholds sit well inside [lb, ub], so the clipped sums are
+//   * RUNNING TAIL SUMS: per side (count, sum v, sum v^2) over the keys beyond the clip bound, so that
 //        sum clip(v)   = A1 - sum_{v > ub} (v - ub)     - sum_{v < lb} (v - lb)
 //        sum clip(v)^2 = A2 - sum_{v > ub} (v^2 - ub^2) - sum_{v < lb} (v^2 - lb^2)
-//     with the two correction sums taken over the tail sets only (8 keys per lane and side, one coalesced load).
-//     The clip bounds may jump by many keys per step (they move 2.5 x the local spacing at the quartiles), which
-//     an ordered window cannot follow; a set does not care.  The lower set is stored COMPLEMENTED (~key), so both
-//     sides run the same "keys above a threshold" code.
+//     cost a few multiply-adds; and two more rank windows, one around each clip bound, which list the keys a bound
+//     moves across from one step to the next (the bounds move with the quartiles, a fraction of a key per step out
+//     in the tails).  However heavy a tail is, it is only ever a count and two sums.
 // Everything here is wave-uniform scalar work or one-wavefront vector work.
 #pragma once
 #include "sdc_device.hpp"
@@ -84,14 +82,23 @@ __device__ __forceinline__ bool qt_evict(QTrack& q, const unsigned y, const int 
   return true;
 }
 // Add x to a history of m keys that the tracker describes.  Returns true if the window's lanes changed.
+// A window that starts (ends) the history keeps doing so: a key below (above) all of it still enters, and the key at
+// the far end drops out if the window is full.
 __device__ __forceinline__ bool qt_insert(QTrack& q, const unsigned x, const int m, const int lane) {
   const int p = __popcll(__ballot(q.w <= x));  // valid keys <= x: x belongs at lane p
-  const bool room = q.hi < WIN;
-  if (p == 0 && !(q.r0 == 0 && room)) {        // below the window (unless the window starts the history and has room)
+  if (p == 0 && q.r0 != 0) {                   // below the window: every rank inside it moves up
     q.r0 += 1;
     return false;
   }
-  if (p == q.hi && !(room && q.r0 + q.hi == m)) return false;   // above it (unless it ends the history and has room)
+  const bool ends = q.r0 + q.hi == m;          // the window lists the history's last key
+  if (p == q.hi && !ends) return false;        // above the window and of keys it does not list: no rank inside it moves
+  if (q.hi == WIN && ends) {
+    // full, and it must go on ending the history: x enters at lane p - 1, the keys below it move down, the first drops out
+    const unsigned down = dpp_u32<0x130, 0xF>(KEY_NONE, q.w);   // wave_shl:1 -- lane i <- lane i + 1
+    q.w = lane < p - 1 ? down : (lane == p - 1 ? x : q.w);
+    q.r0 += 1;
+    return true;
+  }
   const unsigned up = dpp_u32<0x138, 0xF>(0u, q.w);             // wave_shr:1 -- lane i <- lane i - 1; lane 63's key drops out
   q.w = lane < p ? q.w : (lane == p ? x : up);
   q.hi = min(WIN, q.hi + 1);
@@ -179,80 +186,33 @@ __device__ __forceinline__ void clipped_moments(const int n, const Bounds& b, co
 
 
 // ------------------------------------------------------------------------------------------------
-// TAIL SETS.  Per env and side 512 slots (SDC_TAIL_CAP) in global memory, lane l owning slots [8 l, 8 l + 8) as
-// two uint4.  Side 0 = upper tail, keys as they are; side 1 = lower tail, keys complemented.  In this "flipped"
-// space both sides hold every key > tau; an empty slot is 0.
-struct TailSet {
-  unsigned k[8];   // this lane's 8 slots
-};
-constexpr unsigned TAIL_EMPTY = 0u;
-__device__ __forceinline__ unsigned tail_flip(int side) { return side ? KEY_NONE : 0u; }
-__device__ __forceinline__ TailSet tail_load(const uint4* __restrict__ p, const int lane) {
-  const uint4 a = p[2 * lane], b = p[2 * lane + 1];
-  TailSet s;
-  s.k[0] = a.x; s.k[1] = a.y; s.k[2] = a.z; s.k[3] = a.w;
-  s.k[4] = b.x; s.k[5] = b.y; s.k[6] = b.z; s.k[7] = b.w;
-  return s;
-}
-__device__ __forceinline__ void tail_store(uint4* __restrict__ p, const int lane, const TailSet& s) {
-  p[2 * lane] = make_uint4(s.k[0], s.k[1], s.k[2], s.k[3]);
-  p[2 * lane + 1] = make_uint4(s.k[4], s.k[5], s.k[6], s.k[7]);
-}
+// CLIP-BOUND WINDOWS and the running tail sums.  The clipped sums need, per side, (count, sum v, sum v^2) over the
+// keys at or beyond the clip bound; they are kept as running values (header H_QC / H_QS1 / H_QS2_*).  A step adjusts
+// them for the value appended and the one evicted, and then for the keys the bound has moved across -- which the
+// side's rank window (a QTrack centred on the rank of the first key beyond the bound) lists, as long as both the
+// old and the new bound lie inside its span.  The lower side works on complemented keys, so both sides run the same
+// "keys at or above a bound" code.
 
-// remove one occurrence of key x (flipped space) from the set; returns false if it is not there
-__device__ __forceinline__ bool tail_remove(TailSet& s, const unsigned x, const int lane) {
-  int c = -1;
-#pragma unroll
-  for (int i = 7; i >= 0; i--) c = (s.k[i] == x) ? i : c;
-  const unsigned long long m = __ballot(c >= 0);
-  if (m == 0ull) return false;
-  const int owner = __ffsll((long long)m) - 1;
-#pragma unroll
-  for (int i = 0; i < 8; i++) s.k[i] = (lane == owner && i == c) ? TAIL_EMPTY : s.k[i];
-  return true;
+// does the window list EVERY history key in [lo, hi)?  (it does if lo lies above its first key -- or the window starts
+// the history -- and hi does not lie above its last key -- or the window ends the history)
+__device__ __forceinline__ bool qt_spans(const QTrack& q, const unsigned lo, const unsigned hi, const int n) {
+  if (q.hi <= 0) return false;
+  const bool lo_ok = q.r0 == 0 || lane_key(q.w, 0) < lo;
+  const bool hi_ok = q.r0 + q.hi >= n || hi <= lane_key(q.w, q.hi - 1);
+  return lo_ok && hi_ok;
 }
-// put key x (flipped space) into an empty slot; returns false if the set is full
-__device__ __forceinline__ bool tail_insert(TailSet& s, const unsigned x, const int lane) {
-  int c = -1;
-#pragma unroll
-  for (int i = 7; i >= 0; i--) c = (s.k[i] == TAIL_EMPTY) ? i : c;
-  const unsigned long long m = __ballot(c >= 0);
-  if (m == 0ull) return false;
-  const int owner = __ffsll((long long)m) - 1;
-#pragma unroll
-  for (int i = 0; i < 8; i++) s.k[i] = (lane == owner && i == c) ? x : s.k[i];
-  return true;
-}
-// this lane's share of sum (v - bound), sum (v^2 - bound^2) over the set keys >= kb (kb, keys in flipped space)
-__device__ __forceinline__ void tail_scan(const TailSet& s, const unsigned kb, const unsigned flip, const double bound,
-                                          double& t1, double& t2) {
-  const double b2 = bound * bound;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    if (s.k[i] >= kb) {   // kb >= 1 > TAIL_EMPTY
-      const double v = key_f64(s.k[i] ^ flip);
-      t1 += v - bound;
-      t2 += v * v - b2;
-    }
-  }
-}
-// this lane's share of (count, sum v, sum v^2) over the set keys in [lo, hi) (flipped space): the keys a clip bound
+// this lane's share of (count, sum v, sum v^2) over the window keys in [lo, hi) (flipped space): the keys a clip bound
 // crosses when it moves from one to the other.  Returns false (and leaves c / s1 / s2 alone) if no lane of the
-// wavefront has such a key -- the common case, one compare pair per slot and no fp64 work.
-__device__ __forceinline__ bool tail_crossing(const TailSet& s, const unsigned lo, const unsigned hi, const unsigned flip, int& c,
-                                              double& s1, double& s2) {
-  bool any = false;
-#pragma unroll
-  for (int i = 0; i < 8; i++) any = any || (s.k[i] >= lo && s.k[i] < hi);
-  if (__ballot(any) == 0ull) return false;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    if (s.k[i] >= lo && s.k[i] < hi) {
-      const double v = key_f64(s.k[i] ^ flip);
-      c += 1;
-      s1 += v;
-      s2 += v * v;
-    }
+// wavefront has such a key -- the common case: two compares, a ballot and no fp64 work.
+__device__ __forceinline__ bool win_crossing(const QTrack& q, const unsigned lo, const unsigned hi, const unsigned flip, int& c,
+                                             double& s1, double& s2) {
+  const bool in = q.w >= lo && q.w < hi;   // (KEY_NONE lanes: hi <= KEY_NONE)
+  if (__ballot(in) == 0ull) return false;
+  if (in) {
+    const double v = key_f64(q.w ^ flip);
+    c = 1;
+    s1 = v;
+    s2 = v * v;
   }
   return true;
 }
@@ -266,30 +226,9 @@ __device__ __forceinline__ void put_running_tails(unsigned& o, const int c_hi, c
   put_f64(o, H_QS2_HI, s2_hi);
   put_f64(o, H_QS2_LO, s2_lo);
 }
-// this lane's number of set keys below kb (the slack between the threshold and the clip bound)
-__device__ __forceinline__ unsigned tail_count_below(const TailSet& s, const unsigned kb) {
-  unsigned c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) c += (s.k[i] != TAIL_EMPTY && s.k[i] < kb) ? 1u : 0u;
-  return c;
-}
-// step of a threshold move: the key distance that holds ~128 keys, from `keys` keys found within `dist`
-__device__ __forceinline__ unsigned band_estimate(const unsigned dist, const int keys) {
-  const unsigned long long b = ((unsigned long long)dist * 128ull) / (unsigned long long)max(keys, 16);
-  return (unsigned)min(b, (unsigned long long)max(dist, 1u));
-}
-// raise the threshold to tau2 (flipped space): drop the keys <= tau2; returns the new count
-__device__ __forceinline__ int tail_raise(TailSet& s, const unsigned tau2) {
-  int c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    s.k[i] = (s.k[i] <= tau2) ? TAIL_EMPTY : s.k[i];
-    c += (s.k[i] != TAIL_EMPTY) ? 1 : 0;
-  }
-  return wave_sum_i32(c);
-}
 
-// rewards (utils/reward_creator.py:48-334) from the z-score and the step's physical quantities; running returns
+// ------------------------------------------------------------------------------------------------
+// per-agent rewards
 struct RewardIn {
   double z;             // normalize_energy(bat_total_energy_with_battery_KWh)
   double norm_ci_next;  // norm_CI

@@ -209,29 +209,33 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK, 2) void sdc_reward_verify_ker
   if (n < SMALL_N) return;
   stage_ring(S.hist + (size_t)env * SDC_HIST_STRIDE, keys, tid);
   const uint4* lk = keys + tid;
-  const unsigned* qwg = S.qwin + (size_t)env * (2 * SDC_WIN);
-  const QTrack q1 = qt_load(hd0, H_Q1, qwg[lane]), q3 = qt_load(hd0, H_Q3, qwg[SDC_WIN + lane]);
+  const uint4 qw = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env * SDC_WIN + lane];
+  const QTrack q1 = qt_load(hd0, H_Q1, qw.x), q3 = qt_load(hd0, H_Q3, qw.y);
+  const QTrack bu = qt_load(hd0, H_BU, qw.z), bl = qt_load(hd0, H_BL, qw.w);
   int k1, k3;
   quartile_ranks(n, k1, k3);
   unsigned a1 = 0, b1 = 0, a3 = 0, b3 = 0;
-  bool bad = false;
-  // 1. the quartile trackers against an exact bisection ...
+  bool bad = rec_i32(hd0, H_VALID) != 1;
+  // 1. the quartile windows against an exact bisection ...
   if (!qt_resolve(q1, k1, n, a1, b1) || !qt_resolve(q3, k3, n, a3, b3)) bad = true;
   const uint4 qa = quartiles_by_bisection(lk, k1, k3, &sh, lane, wave);
   if (qa.x != a1 || qa.y != b1 || qa.z != a3 || qa.w != b3) bad = true;
-  // ... and every key of both windows against its rank: lane i's key v must satisfy #{x < v} <= r0 + i < #{x <= v}
-  // (waves 0 / 1 take Q1 / Q3, one window key per lane, all ring keys from LDS)
-  if (wave < 2) {
-    const QTrack& q = wave == 0 ? q1 : q3;
-    if (q.hi < 0 || q.hi > SDC_WIN || q.r0 < 0 || q.r0 + q.hi > n) bad = true;
+  // ... and every key of all four windows against its rank: lane i's key v must satisfy #{x < v} <= r0 + i < #{x <= v}
+  // (one window per wavefront, one window key per lane, all ring keys from LDS; the lower clip bound's window lives on
+  // complemented keys)
+  {
+    const QTrack& q = wave == 0 ? q1 : (wave == 1 ? q3 : (wave == 2 ? bu : bl));
+    const unsigned flip = wave == 3 ? KEY_NONE : 0u;
+    if (q.hi <= 0 || q.hi > SDC_WIN || q.r0 < 0 || q.r0 + q.hi > n) bad = true;
     else if (lane < q.hi) {
       int clt = 0, cle = 0;
       for (int j = 0; j < SDC_HIST_STRIDE / 4; j++) {
         const uint4 v = keys[j];
         const unsigned x[4] = {v.x, v.y, v.z, v.w};
         for (int i = 0; i < 4; i++) {
-          clt += x[i] < q.w ? 1 : 0;
-          cle += x[i] <= q.w ? 1 : 0;
+          if (x[i] == KEY_NONE) continue;   // empty slot
+          clt += (x[i] ^ flip) < q.w ? 1 : 0;
+          cle += (x[i] ^ flip) <= q.w ? 1 : 0;
         }
       }
       if (!(clt <= q.r0 + lane && q.r0 + lane < cle)) bad = true;
@@ -243,61 +247,24 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK, 2) void sdc_reward_verify_ker
   const double2 m = direct_moments(lk, n, b.lb, b.ub, b.ctr, &sh, lane, wave);
   const double z = (rec_f64(hd0, H_EOFF) - m.x) / (m.y > 0 ? m.y : 1.0);
   if (!(fabs((double)inf[SDC_INFO_ENERGY_Z] - z) <= 2e-6 * fabs(z) + 1e-6)) bad = true;
-  // 3. the tail sets: sizes against the ring, membership sums (xor of keys) against the ring
-  const unsigned tau0 = (unsigned)rec_i32(hd0, H_TAU), tau1 = (unsigned)rec_i32(hd0, H_TAU + 1);
-  if (tau0 < SDC_TAU_DIRECT) {   // sets exist
-    unsigned c = 0, x0 = 0, x1 = 0;   // packed counts (hi << 16 | lo), xor signatures
-    unsigned cq = 0;                  // packed counts of the keys at or beyond the stored clip bounds
+  // 3. the running tail counts against the ring (the sums that go with them are covered by the z check above), and
+  //    the running total against the direct one
+  {
+    unsigned cq = 0;                  // packed counts (hi << 16 | lo) of the keys at or beyond the stored clip bounds
     const unsigned kbs0 = (unsigned)rec_i32(hd0, H_KB), kbs1 = (unsigned)rec_i32(hd0, H_KB + 1);
+    double s1 = 0.0;
     for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) {
       const uint4 v = lk[q * SDC_BLOCK];
       const unsigned x[4] = {v.x, v.y, v.z, v.w};
       for (int i = 0; i < 4; i++) {
         if (x[i] == KEY_NONE) continue;
-        if (x[i] > tau0) { c += 0x10000u; x0 ^= x[i]; }
-        if (~x[i] > tau1) { c += 1u; x1 ^= ~x[i]; }
         if (x[i] >= kbs0) cq += 0x10000u;
         if (~x[i] >= kbs1) cq += 1u;
+        s1 += key_f64(x[i]);
       }
     }
-    c = block_sum_u32(c, sh.red_u, 0, wave, lane);
     cq = block_sum_u32(cq, sh.red_v, 0, wave, lane);
-    // the running tail counts (the sums that go with them are covered by the z check above)
     if (cq != (((unsigned)rec_i32(hd0, H_QC) << 16) | ((unsigned)rec_i32(hd0, H_QC + 1) & 0xFFFFu))) bad = true;
-    __syncthreads();
-    const uint4* tg = S.tails + (size_t)env * (2 * SDC_TAIL_CAP / 4);
-    unsigned sc = 0;
-    if (tid < SDC_TAIL_CAP / 4) {
-      const uint4 a = tg[tid], bb = tg[SDC_TAIL_CAP / 4 + tid];
-      const unsigned ka[4] = {a.x, a.y, a.z, a.w}, kb[4] = {bb.x, bb.y, bb.z, bb.w};
-      for (int i = 0; i < 4; i++) {
-        if (ka[i] != TAIL_EMPTY) { sc += 0x10000u; x0 ^= ka[i]; }
-        if (kb[i] != TAIL_EMPTY) { sc += 1u; x1 ^= kb[i]; }
-      }
-    }
-    sc = block_sum_u32(sc, sh.red_v, 0, wave, lane);
-    // xor over ring members and set members together must cancel
-    unsigned xa = x0, xb = x1;
-    for (int o = 32; o > 0; o >>= 1) {
-      xa ^= (unsigned)__shfl_xor((int)xa, o);
-      xb ^= (unsigned)__shfl_xor((int)xb, o);
-    }
-    if (lane == 0) {
-      sh.red_u[1][wave] = xa;
-      sh.red_v[1][wave] = xb;
-    }
-    __syncthreads();
-    xa = sh.red_u[1][0] ^ sh.red_u[1][1] ^ sh.red_u[1][2] ^ sh.red_u[1][3];
-    xb = sh.red_v[1][0] ^ sh.red_v[1][1] ^ sh.red_v[1][2] ^ sh.red_v[1][3];
-    const unsigned want = ((unsigned)rec_i32(hd0, H_CNT) << 16) | ((unsigned)rec_i32(hd0, H_CNT + 1) & 0xFFFFu);
-    if (c != sc || c != want || xa != 0u || xb != 0u) bad = true;
-    // running sum against the direct one
-    double s1 = 0.0;
-    for (int q = 0; q < SDC_HIST_PER_THREAD / 4; q++) {
-      const uint4 v = lk[q * SDC_BLOCK];
-      const unsigned x[4] = {v.x, v.y, v.z, v.w};
-      for (int i = 0; i < 4; i++) s1 += x[i] == KEY_NONE ? 0.0 : key_f64(x[i]);
-    }
     s1 = wave_sum_f64(s1);
     __syncthreads();
     if (lane == 0) sh.red_d[wave] = s1;

@@ -26,7 +26,7 @@ _STATE_DTYPES = {
 }
 # a full checkpoint: the raw records + every array the kernels own
 # "hist" first: injecting the ring drops the order-statistic trackers, which "header" then restores
-_CHECKPOINT = ["hist", "record", "header", "qwin", "tails", "t_win", "wb_win", "qtab"]
+_CHECKPOINT = ["hist", "record", "header", "qwin", "t_win", "wb_win", "qtab"]
 
 
 def dc_params_struct(p: dict) -> L.SdcDcParams:
@@ -194,10 +194,8 @@ class SdcEngine:
             return np.zeros((N, 3), dtype=np.float64)
         if name == "header":
             return np.zeros((N, L.HDR_DWORDS), dtype=np.uint32)
-        if name == "tails":
-            return np.zeros((N, 2, L.TAIL_CAP), dtype=np.uint32)
         if name == "qwin":
-            return np.zeros((N, 2, L.QWIN), dtype=np.uint32)
+            return np.zeros((N, L.QWIN, 4), dtype=np.uint32)
         raise KeyError(name)
 
     def get_state(self, name: str) -> np.ndarray:

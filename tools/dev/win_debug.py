@@ -34,11 +34,12 @@ for t in range(steps):
         ref = eng.get_state("hist_ref")[e] if False else 0.0
         keys = np.sort(f32_key(v))
         n = len(keys)
-        for side, base in ((0, 16), (1, 32)):
+        for side, base in ((0, 16), (1, 32), (2, 18), (3, 20)):
             r0, hi = int(hd[e, base].view(np.int32) if hasattr(hd[e, base], "view") else hd[e, base]), int(hd[e, base + 1])
             r0 = int(np.int32(np.uint32(hd[e, base])))
-            w = qw[e, side].astype(np.uint64)
-            want = keys[r0:r0 + hi] if r0 >= 0 else None
+            w = qw[e, :, side].astype(np.uint64)
+            ks = keys if side < 3 else np.sort((~keys) & 0xFFFFFFFF)
+            want = ks[r0:r0 + hi] if r0 >= 0 else None
             ok = hi > 0 and r0 >= 0 and r0 + hi <= n and np.array_equal(w[:hi], want) and (w[hi:] == 0xFFFFFFFF).all()
             if not ok:
                 nbad += 1
