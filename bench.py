@@ -233,7 +233,7 @@ def main():
                        "envs_per_gpu": N, "episode_steps": args.episode_steps, "history_len": hlen,
                        "history_fill_steps": fill, "auto_reset": True, "actions": "uniform {0,1,2}, device-resident",
                        "parallelism": f"env-shard x{world}", "faults": faults,
-                       "ring_read_envs_last_step": {"slide_ahead_of_need": fallbacks[0], "rebuild": fallbacks[1]}},
+                       "ring_read_envs_last_step": {"window_recentred_ahead_of_need": fallbacks[0], "rebuild": fallbacks[1]}},
             # the one kernel of a step.  `achieved` prices the reference algorithm's bytes (the whole
             # history window is read every step); the trackers make most steps skip that read, so the HBM bytes
             # actually moved (`traffic`, PMC) are far below it and `frac` is an effective, not a physical, bandwidth.

@@ -217,7 +217,6 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   (void)hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE);  // every slot empty
   A(d.hdr, (size_t)N * SDC_HDR_DWORDS);
   A(d.qwin, (size_t)N * (4 * SDC_WIN));
-  A(d.stage, (size_t)N * SDC_WAVE);
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
@@ -543,11 +542,6 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
     HIP_TRY(hipMemcpy(*f->ptr, k.data(), need, hipMemcpyHostToDevice));
   } else {
     HIP_TRY(hipMemcpy(*f->ptr, host_buf, need, hipMemcpyHostToDevice));
-  }
-  {
-    // whatever was written, the inputs staged for the next step may no longer match it
-    std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
-    if (rec_put(h, R_STAGE_CUR, 1, z.data())) return -1;
   }
   if (std::strcmp(field, "t_rel") == 0 || std::strcmp(field, "record") == 0) {
     std::vector<int> tr(h->cfg.n_envs);

@@ -62,9 +62,7 @@ enum SdcRec {
   R_T_MIN = 32,
   R_T_DEN = 34,
   R_HIST_REF = 36,
-  R_STAGE_CUR = 38,   // cursor + 1 / episode step + 1 the env's staged step inputs (SdcDev::stage) were gathered for;
-  R_STAGE_REL = 39,   // 0 = none (after a reset or any host write to the env's state)
-  R_END = 40,
+  R_END = 38,
   SDC_REC_DWORDS = 64
 };
 
@@ -125,8 +123,6 @@ struct SdcDev {
   double* walk_tmp;  // [N][max(SDC_NORM_WINDOW, lw)] scratch of the device-side reset
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
   unsigned* hdr;     // [N][SDC_HDR_DWORDS] per-env header: step hand-off + reward-side state (see SdcHdr)
-  double* stage;     // [N][SDC_WAVE] the next step's gathered inputs (trace / weather / queue-history values), staged by
-                     // the step before it so that a step starts after ONE memory round trip
   unsigned* qwin;    // [N][SDC_WIN][4] rank windows (sdc_trackers.hpp): lane l's keys of {Q1, Q3, upper bound, lower bound}
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
   unsigned long long* prof_ts;  // measurement only: [3 kernels][N][2] wall-clock stamps of this launch, or nullptr

@@ -44,7 +44,6 @@ struct DynShared {
   unsigned rec[SDC_REC_DWORDS];
   unsigned long long dbg_t;
   sdc_rw::TailLds tl;   // scratch of the ring paths (window refill, rebuild)
-  uint4 qw[SDC_WIN];    // the env's four rank windows, parked here between the start and the end of the step
   double sums2[2];
 };
 
@@ -74,7 +73,7 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 // the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
 __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& PD, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
-                                              unsigned fault, const unsigned x_old_l, const unsigned hd0,
+                                              unsigned fault, const unsigned x_old_l, const unsigned hd0, const uint4 qw,
                                               float* __restrict__ rew,
                                               DynShared& sh) {
   const sdc_dc_params& P = PD.p;
@@ -447,7 +446,6 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
       quartile_ranks(n, k1, k3);
       // quartile windows q1 / q3; clip-bound windows bu (upper bound, keys as they are) / bl (lower bound, keys
       // complemented, so that on both sides "beyond the bound" means "at or above it")
-      const uint4 qw = sh.qw[lane];
       QTrack q1 = qt_load(hd0, H_Q1, qw.x), q3 = qt_load(hd0, H_Q3, qw.y);
       QTrack bu = qt_load(hd0, H_BU, qw.z), bl = qt_load(hd0, H_BL, qw.w);
       bool wd1 = false, wd3 = false, wdu = false, wdl = false;   // a window goes back to memory only if its lanes changed
@@ -630,8 +628,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
   const unsigned r = recp[lane];
   unsigned hd0 = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];            // reward-side state: returns, trackers, sums
-  const uint4 qw0 = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env * SDC_WIN + lane];   // the four rank windows, one key each per lane
-  const double stage_v = S.stage[(size_t)env * SDC_WAVE + lane];       // this step's inputs, if the last step staged them
 
   const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
   const int i = rec_i32(r, R_CURSOR), rel = rec_i32(r, R_TREL);
@@ -675,9 +671,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   }
 
   // ---- level 1: one 8-byte gather per lane -------------------------------------------------------------------------
-  // Normally the previous step has already done it (its indices are this step's minus one) and left the values in
-  // SdcDev::stage, loaded above with the record: the step then starts after one memory round trip, and gathers the
-  // NEXT step's inputs in the background.  After a reset or a host write the tags do not match and the gather runs here.
+  // (Staging these values one step ahead -- the previous step gathers them and the record load brings them in -- was
+  // measured and is 1 % SLOWER: the start of a launch is bound by how much every env loads, not by round trips.)
   auto gather = [&](const int gi, const int grel, const int ghq) -> double {
     auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
     const double* tW = S.tabW + (size_t)loc * TL;
@@ -706,23 +701,15 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     if (is_nc || is_nt) v = (v - (is_nc ? ci_min : t_min)) / (is_nc ? ci_den : t_den);
     return v;
   };
-  {
-    const bool staged = rec_i32(r, R_STAGE_CUR) == i + 1 && rec_i32(r, R_STAGE_REL) == rel + 1;
-    double v = stage_v;
-    if (!staged) v = gather(i, rel, hourq_n);
-    sh.g[lane] = v;
-  }
-  // the next step's inputs: issued now, stored with this step's outputs (every index is this step's plus one; the
-  // queue-history entries it reads are at least 24 steps old)
-  const bool last_step = rel + 1 >= S.episode_steps;
-  double stage_next = 0.0;
-  if (!last_step) stage_next = gather(i + 1, rel + 1, hourq_n + 1 >= 96 ? 0 : hourq_n + 1);
+  sh.g[lane] = gather(i, rel, hourq_n);
   __syncthreads();
 
   const unsigned long long dbg_a0 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
-  sh.qw[lane] = qw0;   // parked in LDS for the duration of the dynamics
+  // the four rank windows, one key each per lane: wanted at the end of the step, so the load is issued here -- after
+  // the start-of-launch burst of every env's record / header / gather loads -- and rides along in 4 registers
+  const uint4 qw0 = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env * SDC_WIN + lane];
   const unsigned long long dbg_a1 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
-  step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old_l, hd0, rew, sh);
+  step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old_l, hd0, qw0, rew, sh);
   if (S.debug_flags & 8) {
     __syncthreads();
     if (lane == 0) {
@@ -736,10 +723,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   __syncthreads();
 
   // ---- coalesced stores: record, obs [3][26] (78 floats), share_obs [29], info --------------------------------------
-  if (lane == R_STAGE_CUR) sh.rec[lane] = last_step ? 0u : (unsigned)(i + 2);
-  if (lane == R_STAGE_REL) sh.rec[lane] = (unsigned)(rel + 2);
   recp[lane] = sh.rec[lane];
-  S.stage[(size_t)env * SDC_WAVE + lane] = stage_next;
   const int terminal = (rel + 1 >= S.episode_steps) ? 1 : 0;
   {
     const float v0 = obs_padded_at(sh.pool, lane);

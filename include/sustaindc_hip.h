@@ -71,8 +71,8 @@ enum sdc_info_col {
   SDC_INFO_FAULT,    /* bit mask, see SDC_FAULT_* (the reference raises / asserts instead) */
   SDC_INFO_ENERGY_Z, /* normalize_energy() output shared by the three rewards */
   SDC_INFO_RESERVED, /* diagnostic: how this step's reward normalisation was served: 0 incremental state only (no
-                        history read), 1 a quartile tracker was slid over the history ahead of need, 2 a tail set
-                        was re-collected, 3 the state was rebuilt from the history */
+                        history read), 1 a rank window was re-centred over the history ahead of need, 3 the state
+                        was rebuilt from the history */
   /* running return of the current episode INCLUDING this step (== the episode return on the done step);
    * feeds the return statistics the runners log (harl/common/base_logger.py:75-88) without host sums */
   SDC_INFO_EP_RETURN_LS,
@@ -104,8 +104,8 @@ typedef struct {
   double weather_noise_std;   /* 0.75 (utils/managers.py:504) ; 0 disables the noise */
   double weather_noise_weight;/* 0.02 (utils/managers.py:504) */
   int32_t max_roll_days;   /* 14: roll in [0, 14) days (utils/managers.py:601) */
-  int32_t debug_flags;     /* bit 0: VERIFY MODE -- after every step check the incremental reward state (quartile
-                              trackers, tail sets, running sum) and the reported z-score against an exact bisection
+  int32_t debug_flags;     /* bit 0: VERIFY MODE -- after every step check the incremental reward state (the four rank
+                              windows, running sums) and the reported z-score against an exact bisection
                               and a direct fp64 pass over each env's history (slow; a mismatch sets
                               SDC_FAULT_ORDER_STAT).  Bits 1, 3, 4: diagnostics in info[reserved] / info[40..43]
                               (why a rebuild happened; per-wavefront phase durations; absolute wavefront start /
@@ -209,7 +209,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
  *            scale hist_len hist_pos episode fault loc_id cfg_id day_lo day_hi hist_n
  * double[N]: stpt bat_load ci_min ci_den t_min t_den hist_ref
  * record (uint32[N][64], the raw 256-byte state records);  header (uint32[N][64], step hand-off + reward state);
- * tails (uint32[N][2][512], the reward tail sets: upper keys, complemented lower keys, 0 = empty slot);
+ * qwin (uint32[N][64][4], the reward state's rank windows: per lane the keys of {Q1, Q3, upper bound, lower bound});
  * ep_return (double[N][3]);
  * hist (float[N][hist_stride], energy minus hist_ref, NaN = empty slot: every slot >= hist_len must be NaN);
  * t_win wb_win (double[N][weather_window_len]);  qtab (uint32[N][queue_stride][2]). */

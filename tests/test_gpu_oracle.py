@@ -92,7 +92,7 @@ def test_order_statistic_tracker_stress():
         rig.reset_all()
     assert (eng.get_state("order_stat_sticky") == 0).all()
     assert (eng.get_state("hist_len") == cap).all()
-    print("tracker paths (tracker-only, slide ahead of need, -, rebuild from the ring):", paths)
+    print("paths (windows only, a window re-centred ahead of need, -, rebuild from the ring):", paths)
     assert paths[0] > 3 * paths[1]                         # the window usually answers without a sweep
     eng.close()
 
