@@ -118,7 +118,7 @@ int rec_get(sdc_handle* h, int idx, int dwords, void* host, int in_hdr = 0) {
   return 0;
 }
 
-// the reward state (quartile trackers, tail sets, sums) describes the ring contents: drop it when the ring is injected
+// the reward state (rank windows, running sums) describes the ring contents: drop it when the ring is injected
 int invalidate_trackers(sdc_handle* h) {
   std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
   if (rec_put(h, H_VALID, 1, z.data(), 1)) return -1;

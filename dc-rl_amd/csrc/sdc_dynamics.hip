@@ -15,7 +15,7 @@
 //     butterfly reductions; lane 0 assembles the info block and the new state record in LDS; all lanes store
 //     obs / share_obs / info / record coalesced.
 //   * rewards: the step's energy is appended to the env's history ring, and the history-normalised z-score comes
-//     from the env's reward state (quartile trackers, tail sets, running sums: sdc_trackers.hpp) in O(1) without
+//     from the env's reward state (four 64-key rank windows, running sums: sdc_trackers.hpp) in O(1) without
 //     reading the ring; the rare ring sweeps that keep that state ahead of need run in-wave (sdc_ringpath.hpp).
 // One launch of this kernel is one env-step of all N environments.
 //

@@ -1,20 +1,19 @@
 // sdc_ringpath.hpp -- the rare moments when an env's history ring must be read: in-wave primitives.
 //
-// sdc_trackers.hpp answers the reward normalisation from two quartile trackers, two tail sets and running sums.
-// A tracker's window of 64 consecutive order statistics runs out every couple of thousand steps (the wanted rank
-// random-walks through it); the env's own wavefront then REFILLS it (qt_refill): it drops the keys on the far side,
-// and sweeps the ring once -- 10 240 keys, 160 per lane, coalesced dwordx4 loads from L2 / HBM -- for the keys just
-// beyond the window's last key:
+// sdc_trackers.hpp answers the reward normalisation from four 64-key rank windows and running sums.  The rank a
+// window is centred on random-walks through it and gets near an edge every ~600 steps; the env's own wavefront then
+// REFILLS the window (qt_refill): it drops the keys on the far side and sweeps the ring once -- 10 240 keys, 160
+// per lane, coalesced dwordx4 loads -- for the keys just beyond the window's last key:
 //   d = x - (pivot+1) borrows <=> x <= pivot (counted: how many copies of the pivot lie beyond the window);
-//   d <= band  <=> x is one of the next keys: appended to a small LDS list, ranked by counting, placed.
-// The band comes from the key spacing inside the window and is widened / narrowed if it caught too few / too many.
+//   otherwise d is the key's distance above the pivot; every lane keeps the 4 smallest it sees, and below the
+//   smallest 4th-smallest of any lane those lists are complete: compacted, ranked by counting, placed.
 // Extending downwards is the same code on complemented keys with the window reversed.
 //
-// The dynamics kernel refills AHEAD of need, at its start (when the window could run out on this step in the worst
-// case), so the sweep overlaps with the other resident wavefronts instead of extending the kernel's tail.  Equally
-// rarely a tail set's threshold must move down (one sweep that re-collects both sets).  A full REBUILD (bisections
-// on the key space + a collecting sweep per window + tail collection + fp64 sums) bootstraps everything on the
-// first steps and after state injection, and is the fallback whenever a tracker or set turns out not to cover.
+// The dynamics kernel refills AHEAD of need and at the END of a step (when a window could run out on the next step
+// in the worst case): the memory system is quiet then, and a wavefront that is one step away from a refill has had
+// issue priority and an L2 prefetch of its ring since the start of the launch.  A full REBUILD (4-rank bisections on
+// the key space + a collecting sweep per window pair + one fp64 sweep for the sums) bootstraps everything on the
+// first steps and after state injection, and is the fallback whenever a window turns out not to cover.
 //
 // Why in-wave and not a separate reward kernel (round-1 measurements, MI355X, 4096 envs): a kernel that streams
 // every env's ring each step is HBM-bound at >= 23 us (32 us in practice); a kernel that only serves the envs that

@@ -4,10 +4,10 @@
 // normalize_energy needs the 25th / 75th percentiles of the history (np.percentile, linear: order statistics k and
 // k+1 each) and the mean / population std of the history clipped to [lb, ub] = [q1 - 1.5 iqr, q3 + 1.5 iqr].  A
 // step inserts one value and evicts at most one:
-//   * QUARTILE TRACKERS (QTrack, one per quartile): a window of 64 consecutive order statistics around the wanted
-//     rank, one key per lane (512 bytes per env next to the header).  O(1) update per step across the lanes; the
-//     wanted rank moves by at most one per step, so the window is re-centred AHEAD of need, every ~2 000 steps,
-//     by one sweep over the ring (sdc_ringpath.hpp);
+//   * RANK WINDOWS (QTrack): 64 consecutive order statistics around a wanted rank, one key per lane (four windows =
+//     1 KB per env next to the header).  O(1) update per step across the lanes; the wanted rank moves by at most
+//     one per step, so a window is re-centred AHEAD of need, every ~600 steps, by one sweep over the ring
+//     (sdc_ringpath.hpp).  Two of them sit on the quartile ranks;
 //   * TOTAL SUMS A1 = sum v, A2 = sum v^2 over the whole history (fp64, O(1) update);
 //   * RUNNING TAIL SUMS: per side (count, sum v, sum v^2) over the keys beyond the clip bound, so that
 //        sum clip(v)   = A1 - sum_{v > ub} (v - ub)     - sum_{v < lb} (v - lb)
@@ -45,12 +45,13 @@ __device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
 __device__ __forceinline__ unsigned lane_key(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)sfl((unsigned)l)); }
 
 // ------------------------------------------------------------------------------------------------
-// QUARTILE TRACKER: a window of SDC_WIN = 64 CONSECUTIVE order statistics of the env's history, one key per lane.
-// Lane i < hi holds the key of rank r0 + i (ascending); lanes >= hi hold KEY_NONE.  hi == 0: no tracker.
+// RANK WINDOW: SDC_WIN = 64 CONSECUTIVE order statistics of the env's history, one key per lane.
+// Lane i < hi holds the key of rank r0 + i (ascending); lanes >= hi hold KEY_NONE.  hi == 0: no window.
 // A step removes one key from the history and adds one; each lands below the window (the ranks move: r0 -/+ 1),
 // above it (nothing changes) or inside it (one compare across the lanes, one DPP shift).  The wanted rank
-// random-walks through the window by about +-0.6 per step, so a window re-centred on it (32 ranks of room on
-// both sides) lasts ~2 000 steps before the ring has to be read again (qt_refill in sdc_ringpath.hpp).
+// random-walks through the window by about +-0.6 per step (more under autocorrelated energies), so a window
+// re-centred on it (32 ranks of room on both sides) lasts ~600 steps before the ring has to be read again
+// (qt_refill in sdc_ringpath.hpp).
 constexpr int WIN = SDC_WIN;
 struct QTrack {
   unsigned w;   // this lane's key
@@ -276,7 +277,7 @@ __device__ __forceinline__ void store_rewards(const Rewards& r, const double z, 
   rew[env * 3 + 2] = (float)r.r[2];
   if (inf_row) {
     inf_row[SDC_INFO_ENERGY_Z] = (float)z;
-    inf_row[SDC_INFO_RESERVED] = (float)path;   // diagnostic: 0 no ring read, 1 slid ahead of need, 2 tail set re-collected, 3 rebuilt
+    inf_row[SDC_INFO_RESERVED] = (float)path;   // diagnostic: 0 no ring read, 1 a window re-centred ahead of need, 3 rebuilt
     inf_row[SDC_INFO_EP_RETURN_LS] = (float)r.ret[0];
     inf_row[SDC_INFO_EP_RETURN_DC] = (float)r.ret[1];
     inf_row[SDC_INFO_EP_RETURN_BAT] = (float)r.ret[2];

@@ -1,7 +1,7 @@
 // sdc_verify.hip -- verify mode of the reward normalisation (sdc_config.debug_flags bit 0; every GPU parity test
 // runs with it): after each step, one workgroup per env recomputes the order statistics by exact bisection on the
 // key space and the clipped mean / std by a direct fp64 pass over the env's history ring (staged in LDS), and
-// compares them with the env's quartile trackers, tail sets and running sum (sdc_trackers.hpp) and with the
+// compares them with the env's rank windows and running sums (sdc_trackers.hpp) and with the
 // z-score that was reported.
 // Measurement / test infrastructure only: never launched when debug_flags is 0.
 #include "sdc_trackers.hpp"
