@@ -65,3 +65,37 @@ def test_reward_state_soak(hist_cap, steps_total):
     assert paths[0] > 0 and paths[1] > 0 and paths[3] > 0   # every way of serving a step was exercised
     assert paths[3] < paths[1]                              # ... and rebuilds stay the exception
     eng.close()
+
+
+@pytest.mark.parametrize("hist_cap", [33, 64, 65, 100, 200])
+def test_rank_windows_small_histories(hist_cap):
+    """Histories about as long as a 64-key window, from empty: the windows list the whole history while it is shorter
+    than a window, stay anchored at its ends when it is not much longer, and every eviction hits a window.  Random and
+    constant policies (the latter: runs of equal keys).  Verify mode checks every window key against its rank."""
+    import torch
+    N, ep = 128, 96
+    rig = P.ParityRig(N, episode_steps=ep, seed=91 + hist_cap, hist_cap=hist_cap, with_oracle=False)
+    eng = rig.eng
+    rig.reset_all()
+    paths = np.zeros(4, np.int64)
+    steps = 3 * hist_cap + 2 * ep
+    for t in range(steps):
+        a = torch.randint(0, 3, (N, 3), dtype=torch.int32, device=eng.device)
+        if (t // 48) % 3 == 1:
+            a[:, 0] = 1
+            a[:, 1] = 1
+            a[:, 2] = 2
+        obs, share, rew, done, info = eng.step(a)
+        inf = info.cpu().numpy()
+        bad = np.nonzero(inf[:, L.INFO_IDX["fault"]])[0]
+        assert bad.size == 0, (t, bad[:8], inf[bad[:8], L.INFO_IDX["fault"]])
+        assert np.isfinite(rew.cpu().numpy()).all()
+        if t >= 3 * hist_cap:
+            paths += np.bincount(inf[:, 39].astype(int), minlength=4)[:4]
+        if (t + 1) % ep == 0:
+            rig.reset_all()
+    assert (eng.get_state("order_stat_sticky") == 0).all()
+    assert (eng.get_state("hist_len") == hist_cap).all()
+    print("hist_cap", hist_cap, "paths once the ring is full (windows only, re-centred, -, rebuilt):", paths)
+    assert paths[3] * 20 < paths[0]      # a full ring is served by the windows, not by rebuilds
+    eng.close()
