@@ -423,7 +423,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
     d.prof_ts = h->prof_buf + (size_t)h->prof_used * 3 * N * 2;
     h->prof_has_reset[h->prof_used] = 0;
   }
-  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, actions, obs, share_obs, done, info,
+  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, actions, obs, share_obs, done, info,
                      final_obs, rew);
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
   HIP_TRY(hipGetLastError());

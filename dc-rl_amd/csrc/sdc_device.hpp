@@ -21,6 +21,10 @@
 
 #define SDC_BLOCK 256
 #define SDC_WAVE 64
+#ifndef SDC_WPB
+#define SDC_WPB 4   // wavefronts (= envs) per workgroup of the step kernel: the dispatcher starts workgroups, not wavefronts,
+                    // at a fixed rate, and the wavefronts of a workgroup share nothing (no s_barrier anywhere)
+#endif
 #define SDC_HIST_PER_THREAD 40  // 10 x float4 per thread -> 10240 ring slots per env
 #define SDC_HIST_STRIDE (SDC_BLOCK * SDC_HIST_PER_THREAD)
 #define SDC_NORM_WINDOW 2880    // 30 days x 96 (utils/managers.py:435, :606)
@@ -92,6 +96,14 @@ enum SdcHdr {
 // header the rank of the first key and the number of valid keys (0: none)
 enum SdcTrack { T_R0 = 0, T_HI = 1, SDC_TRACK_DWORDS = 2 };
 #define SDC_WIN 64
+
+// One wavefront = one env: LDS traffic between the lanes of ONE wavefront needs no s_barrier (a wavefront's LDS
+// operations complete in order), only the compiler's view of it ordered.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // A data-centre parameter set as the kernels see it: the caller's struct plus correctly rounded reciprocals of the
 // parameters the step divides by (computed on the host by sdc_set_dc_params), so that those divisions take the

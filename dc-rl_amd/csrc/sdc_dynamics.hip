@@ -353,7 +353,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
 
   // every lane keeps its own dword of the record; lane 0 patches the fields that changed (below)
   sh.rec[lane] = r;
-  __syncthreads();
+  wave_sync();
   if (lane == 0) {
     // ---- info block --------------------------------------------------------------------------------
     float* inf = sh.info;
@@ -609,17 +609,20 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
                                                                                 float* __restrict__ obs,
                                                                                 float* __restrict__ share_obs,
                                                                                 unsigned char* __restrict__ done,
                                                                                 float* __restrict__ info,
                                                                                 float* __restrict__ final_obs,
                                                                                 float* __restrict__ rew) {
-  __shared__ DynShared sh;
-  const int env = blockIdx.x;
-  const int lane = threadIdx.x;
+  __shared__ DynShared shs[SDC_WPB];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
+  DynShared& sh = shs[wave];
+  const int env = blockIdx.x * SDC_WPB + wave;
+  const int lane = threadIdx.x % SDC_WAVE;
   const int N = S.n_envs;
+  if (env >= N) return;
   const int TL = S.table_len;
   if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 0);
   const unsigned long long dbg_entry = (S.debug_flags & 16) ? wall_clock64() : 0ull;
@@ -702,7 +705,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
     return v;
   };
   sh.g[lane] = gather(i, rel, hourq_n);
-  __syncthreads();
+  wave_sync();
 
   const unsigned long long dbg_a0 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
   // the four rank windows, one key each per lane: wanted at the end of the step, so the load is issued here -- after
@@ -711,7 +714,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
   const unsigned long long dbg_a1 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
   step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old_l, hd0, qw0, rew, sh);
   if (S.debug_flags & 8) {
-    __syncthreads();
+    wave_sync();
     if (lane == 0) {
       const unsigned long long dbg_a3 = wall_clock64();
       sh.info[40] = (S.debug_flags & 16) ? (float)(dbg_a0 & 0xFFFFFull) : (float)(dbg_a1 - dbg_a0);
@@ -720,7 +723,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE, 4) void sdc_dynamics_kernel(Sd
       sh.info[43] = (S.debug_flags & 16) ? (float)(dbg_a3 & 0xFFFFFull) : (float)(dbg_a3 - dbg_a0);
     }
   }
-  __syncthreads();
+  wave_sync();
 
   // ---- coalesced stores: record, obs [3][26] (78 floats), share_obs [29], info --------------------------------------
   recp[lane] = sh.rec[lane];

@@ -178,7 +178,7 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
   // the new window is assembled in LDS: first the kept keys
   unsigned* win = &L.keys[1][0];
   win[lane] = KEY_NONE;
-  __syncthreads();   // (one wavefront: orders the compiler's view of the cross-lane LDS traffic)
+  wave_sync();   // (one wavefront: orders the compiler's view of the cross-lane LDS traffic)
   if (lane >= s && lane < hi) win[lane - s] = w;
   int filled = kept;
   // Rounds: normally one.  A run of equal keys that overflows some lane's list stops the complete part short of it;
@@ -219,7 +219,7 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
     if (lane < 4) L.keys[0][m + lane] = KEY_NONE;             // pad the list to a multiple of 4 (ranks below nothing)
     // copies of the pivot first
     if (lane < extra && filled + lane < WIN) win[filled + lane] = pivot;
-    __syncthreads();
+    wave_sync();
     // then the caught keys, each at the position its rank gives it: rank = how many caught distances are smaller
     // (one borrow-count per list entry, one key per lane and pass).  Equal keys get the same rank and land on one
     // slot; the slots they leave empty are filled from the left after the last round (the window is ascending).
@@ -240,7 +240,7 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
       const int pos = filled + extra + (int)rank;
       if (c0 + lane < m && pos < WIN) win[pos] = pp + mine;
     }
-    __syncthreads();
+    wave_sync();
     filled += extra + m;
     top += extra + m;
     if (D >= smax) break;           // everything above the pivot has been seen
@@ -355,7 +355,7 @@ __device__ __forceinline__ void windows_build(const RingView& R, const int lane,
       }
     }
   });
-  __syncthreads();
+  wave_sync();
   auto finish = [&](const int side, const unsigned cle, const unsigned vA, const unsigned vB, const int A, const int B) {
     QTrack q;
     const int len = B - A + 1;
@@ -370,9 +370,9 @@ __device__ __forceinline__ void windows_build(const RingView& R, const int lane,
     }
     unsigned* win = &L.keys[side][WIN];
     win[lane] = lane < nA ? vA : (lane < len ? vB : KEY_NONE);
-    __syncthreads();   // (one wavefront: orders the compiler's view of the cross-lane LDS traffic)
+    wave_sync();   // (one wavefront: orders the compiler's view of the cross-lane LDS traffic)
     if (lane < mb && nA + rank < len) win[nA + rank] = mine;
-    __syncthreads();
+    wave_sync();
     q.w = win[lane];
     q.r0 = A;
     q.hi = (nA >= 1 && nA + mb <= len) ? len : 0;             // (inconsistent counts: no tracker)
