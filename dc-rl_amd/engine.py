@@ -76,6 +76,7 @@ class SdcEngine:
         self._h = C.c_void_p()
         self._pinned_stream = None
         self._pinned_stream_obj = None
+        self._out_ptrs = None
         with torch.cuda.device(self.device):
             torch.cuda.init()
             L.check(self.lib.sdc_create(C.byref(cfg), C.byref(self._h)))
@@ -168,12 +169,19 @@ class SdcEngine:
         if not (isinstance(actions, t.Tensor) and actions.dtype == t.int32 and actions.is_cuda and
                 actions.is_contiguous() and tuple(actions.shape) == (self.n_envs, 3)):
             raise ValueError("actions must be a contiguous int32 CUDA tensor of shape (n_envs, 3)")
-        with t.cuda.device(self.device):
-            L.check(self.lib.sdc_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
-                                      C.c_void_p(self.share_obs.data_ptr()), C.c_void_p(self.rew.data_ptr()),
-                                      C.c_void_p(self.done.data_ptr()),
-                                      C.c_void_p(self.info.data_ptr()) if want_info else None,
-                                      C.c_void_p(self.final_obs.data_ptr()), self._stream()))
+        p = self._out_ptrs
+        if p is None:   # the output tensors live as long as the engine: take their addresses once
+            p = self._out_ptrs = tuple(C.c_void_p(x.data_ptr()) for x in
+                                       (self.obs, self.share_obs, self.rew, self.done, self.info, self.final_obs))
+        args = (self._h, C.c_void_p(actions.data_ptr()), p[0], p[1], p[2], p[3], p[4] if want_info else None, p[5],
+                self._stream())
+        if t.cuda.current_device() == self.device_index:   # the usual case (one process per GPU): no device switch
+            rc = self.lib.sdc_step(*args)
+        else:
+            with t.cuda.device(self.device):
+                rc = self.lib.sdc_step(*args)
+        if rc != 0:
+            L.check(rc)
         return self.obs, self.share_obs, self.rew, self.done, self.info
 
     # ------------------------------------------------------------------ state access (parity injection / checkpoint)
