@@ -251,6 +251,8 @@ class SustainDCVecEnv(ShareVecEnv):
         self._avail_np = np.ones((n_envs, 3, 3), dtype=np.float32)
         self._actions = None
         self._need_reset = True
+        self._host = None       # pinned host output buffers (NumPy outputs only)
+        self._host_flip = 0
 
     # ------------------------------------------------------------------ helpers
     def _out(self, t):
@@ -282,7 +284,16 @@ class SustainDCVecEnv(ShareVecEnv):
         a = self._actions
         self._actions = None
         obs, share, rew, done, info = self.engine.step(a)
-        done_h = done.cpu().numpy().astype(bool)
+        if self.return_torch:
+            done_h = done.cpu().numpy().astype(bool)
+        else:
+            # NumPy outputs: four asynchronous copies into pinned host buffers, ONE synchronisation (two buffer sets
+            # alternate, so the arrays of a step stay valid until the step after next)
+            hb = self._host_buffers()
+            for k, src in (("obs", obs), ("share", share), ("rew", rew), ("done", done)):
+                hb[k].copy_(src, non_blocking=True)
+            self._torch.cuda.current_stream(self.engine.device).synchronize()
+            done_h = hb["done"].numpy().astype(bool)
         extra = {}
         if done_h.any():
             fo = self.engine.final_obs.cpu().numpy()
@@ -292,11 +303,22 @@ class SustainDCVecEnv(ShareVecEnv):
                                       "original_state": np.repeat(raw[None, :], 3, axis=0),
                                       "original_avail_actions": np.ones((3, 3), dtype=np.float32)}
         infos = LazyInfos(info, a, done_h, self._const, extra)
-        dones3 = done.bool().unsqueeze(1).expand(-1, 3)
         if self.return_torch:
+            dones3 = done.bool().unsqueeze(1).expand(-1, 3)
             return obs, self._share3(share), rew.unsqueeze(-1), dones3, infos, self._avail
-        return (obs.cpu().numpy(), self._share3(share).cpu().numpy(), rew.cpu().numpy()[..., None],
-                np.repeat(done_h[:, None], 3, axis=1), infos, self._avail_np)
+        share3 = np.broadcast_to(hb["share"].numpy()[:, None, :], (self.num_envs, 3, hb["share"].shape[1]))
+        return (hb["obs"].numpy(), share3, hb["rew"].numpy()[..., None], np.repeat(done_h[:, None], 3, axis=1), infos,
+                self._avail_np)
+
+    def _host_buffers(self):
+        t = self._torch
+        if self._host is None:
+            e = self.engine
+            self._host = [{k: t.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                           for k, v in (("obs", e.obs), ("share", e.share_obs), ("rew", e.rew), ("done", e.done))}
+                          for _ in range(2)]
+        self._host_flip ^= 1
+        return self._host[self._host_flip]
 
     def info_sums(self, keys: Sequence[str] = LOGGER_KEYS):
         """Sum over envs of the given info columns for the last step, computed on the device."""
