@@ -44,7 +44,6 @@ struct DynShared {
   unsigned rec[SDC_REC_DWORDS];
   unsigned long long dbg_t;
   sdc_rw::TailLds tl;   // scratch of the ring paths (window refill, rebuild)
-  double sums2[2];
 };
 
 // envs/datacenter.py:356-429 calculate_chiller_power
