@@ -129,3 +129,42 @@ def test_agent_subset_uses_base_agents_and_alt_rewards():
     assert trunc["__all__"] and trunc["agent_ls"] and "agent_dc" not in trunc
     env.close()
     full.close()
+
+
+def test_env_groups_on_separate_streams_match_sequential_stepping():
+    """Two engines (env groups) pinned to their own streams with use_stream(), stepped interleaved without any
+    synchronisation between the groups, give exactly what the same two engines give when stepped one after the other
+    on the default stream: a group's launches stay ordered on its stream, and groups share no state."""
+    import torch
+    import bench
+
+    def run(pinned):
+        engs = [bench.build_engine(256, 96, 0, seed=500 + g)[0] for g in range(2)]
+        streams = [torch.cuda.Stream() for _ in engs]
+        if pinned:
+            for e, s in zip(engs, streams):
+                e.use_stream(s)
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        acts = [torch.randint(0, 3, (40, 256, 3), dtype=torch.int32, generator=gen).to("cuda:0") for _ in engs]
+        torch.cuda.synchronize()
+        for e in engs:
+            e.reset()
+        out = [[], []]
+        for t in range(250):          # crosses two auto-resets (96-step episodes)
+            for g, e in enumerate(engs):
+                obs, share, rew, done, info = e.step(acts[g][t % 40])
+                if t % 50 == 49:
+                    if pinned:
+                        streams[g].synchronize()
+                    out[g].append((obs.clone(), rew.clone(), done.clone()))
+        torch.cuda.synchronize()
+        res = [[tuple(x.cpu().numpy() for x in snap) for snap in o] for o in out]
+        for e in engs:
+            e.close()
+        return res
+
+    a, b = run(True), run(False)
+    for g in range(2):
+        for sa, sb in zip(a[g], b[g]):
+            for xa, xb in zip(sa, sb):
+                np.testing.assert_array_equal(xa, xb)
