@@ -18,6 +18,7 @@
 extern "C" __global__ void sdc_dynamics_kernel(SdcDev S, const int32_t* actions, float* obs, float* share_obs,
                                                unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
+extern "C" __global__ void sdc_features_kernel(SdcDev S);
 extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
                                             const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
                                             const double* ovr_t_max, int only_done, float* obs, float* share_obs);
@@ -103,6 +104,15 @@ void sync_mirror(sdc_handle* h) {
 }
 
 // one field of every env's record (256-byte state record, or 256-byte header) <-> a dense host array
+// the episode's observation feature rows of the envs a reset kernel has just reset (sdc_features.hip); episodes too long
+// for the kernel's LDS windows go without (the step then computes the features itself)
+void launch_features(sdc_handle* h, const SdcDev& d, hipStream_t st) {
+  if (!d.feat) return;
+  const size_t lds = sizeof(double) * (size_t)(d.episode_steps + 25 + d.lw);
+  hipLaunchKernelGGL(sdc_features_kernel, dim3(d.n_envs), dim3(SDC_WAVE), lds, st, d);
+  (void)h;
+}
+
 int rec_put(sdc_handle* h, int idx, int dwords, const void* host, int in_hdr = 0) {
   unsigned* base = in_hdr ? h->d.hdr : h->d.rec;
   const size_t pitch = sizeof(unsigned) * (in_hdr ? SDC_HDR_DWORDS : SDC_REC_DWORDS);
@@ -116,6 +126,12 @@ int rec_get(sdc_handle* h, int idx, int dwords, void* host, int in_hdr = 0) {
   HIP_TRY(hipMemcpy2D(host, sizeof(unsigned) * dwords, base + idx, pitch, sizeof(unsigned) * dwords,
                       (size_t)h->cfg.n_envs, hipMemcpyDeviceToHost));
   return 0;
+}
+
+// the episode's precomputed observation rows follow the traces, the env's location and its weather windows
+int invalidate_features(sdc_handle* h) {
+  std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
+  return rec_put(h, R_FEAT_OK, 1, z.data());
 }
 
 // the reward state (rank windows, running sums) describes the ring contents: drop it when the ring is injected
@@ -217,6 +233,9 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   (void)hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE);  // every slot empty
   A(d.hdr, (size_t)N * SDC_HDR_DWORDS);
   A(d.qwin, (size_t)N * (4 * SDC_WIN));
+  d.feat = nullptr;
+  if (sizeof(double) * (size_t)(cfg->episode_steps + 25 + d.lw) <= 60 * 1024)   // the features kernel's LDS windows
+    A(d.feat, (size_t)N * (size_t)(cfg->episode_steps + 1) * SDC_FEAT_ROW);
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
@@ -302,6 +321,7 @@ int sdc_set_tables(sdc_handle* h, int loc_id, const double* W, const double* C, 
   HIP_TRY(hipMemcpy(const_cast<double*>(h->d.tabC) + off, C, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(const_cast<double*>(h->d.tabT) + off, T, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(const_cast<double*>(h->d.tabWB) + off, WB, bytes, hipMemcpyHostToDevice));
+  if (invalidate_features(h)) return -1;
   h->tables_set = true;
   return 0;
 }
@@ -340,7 +360,7 @@ int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id,
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   if (rec_put(h, R_LOC, 1, loc_id) || rec_put(h, R_CFG, 1, cfg_id) || rec_put(h, R_DAY_LO, 1, day_lo) ||
-      rec_put(h, R_DAY_HI, 1, day_hi))
+      rec_put(h, R_DAY_HI, 1, day_hi) || invalidate_features(h))
     return -1;
   // the CRAC set-point starts at the config's initial value (make_envs_pyenv.py:124) and is never reset
   if (!h->started) {
@@ -398,6 +418,7 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
   }
   hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, ovr ? 1 : 0, h->ovr_day, h->ovr_hour,
                      h->ovr_ci_min, h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 0, obs, share_obs);
+  launch_features(h, d, st);
   HIP_TRY(hipGetLastError());
   if (mask_host) HIP_TRY(hipStreamSynchronize(st));  // mask staging buffer is reused by the next call
   sync_mirror(h);
@@ -439,6 +460,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
       if (timed) h->prof_has_reset[h->prof_used] = 1;
       hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
                          h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs, share_obs);
+      launch_features(h, d, st);
       HIP_TRY(hipGetLastError());
       for (int e = 0; e < N; e++)
         if (h->host_t_rel[e] >= h->cfg.episode_steps) h->host_t_rel[e] = 0;
@@ -543,6 +565,7 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
   } else {
     HIP_TRY(hipMemcpy(*f->ptr, host_buf, need, hipMemcpyHostToDevice));
   }
+  if (invalidate_features(h)) return -1;   // whatever was written, the precomputed observation rows may no longer match it
   if (std::strcmp(field, "t_rel") == 0 || std::strcmp(field, "record") == 0) {
     std::vector<int> tr(h->cfg.n_envs);
     if (rec_get(h, R_TREL, 1, tr.data())) return -1;

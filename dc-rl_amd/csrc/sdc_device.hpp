@@ -66,7 +66,9 @@ enum SdcRec {
   R_T_MIN = 32,
   R_T_DEN = 34,
   R_HIST_REF = 36,
-  R_END = 38,
+  R_FEAT_OK = 38,    // 1: the episode's observation feature rows (SdcDev::feat) are valid (sdc_features.hip); cleared by
+                     // a reset (whose features kernel sets it again) and by any host write to the env's state
+  R_END = 39,
   SDC_REC_DWORDS = 64
 };
 
@@ -135,6 +137,8 @@ struct SdcDev {
   double* walk_tmp;  // [N][max(SDC_NORM_WINDOW, lw)] scratch of the device-side reset
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
   unsigned* hdr;     // [N][SDC_HDR_DWORDS] per-env header: step hand-off + reward-side state (see SdcHdr)
+  float* feat;       // [N][episode_steps + 1][SDC_FEAT_ROW] the trace-only observation entries of every step of the
+                     // episode, in observation-pool layout (SDC_P_*), + NC[i'+1] as a double at SDC_FEAT_NCNEXT
   unsigned* qwin;    // [N][SDC_WIN][4] rank windows (sdc_trackers.hpp): lane l's keys of {Q1, Q3, upper bound, lower bound}
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
   unsigned long long* prof_ts;  // measurement only: [3 kernels][N][2] wall-clock stamps of this launch, or nullptr
@@ -229,6 +233,9 @@ __device__ __forceinline__ double sdc_div_const(double x, double c, double rc) {
 //   ls (26): cos_h sin_h NC | 7 CI features | oldest_age avg_age queue | W NT | t_slope 5 temp features | 5 age bins
 enum { SDC_P_COS = 0, SDC_P_SIN, SDC_P_NC, SDC_P_CI7 = 3, SDC_P_OLDEST = 10, SDC_P_AVG, SDC_P_NORMQ, SDC_P_W, SDC_P_NT,
        SDC_P_TSLOPE = 15, SDC_P_T5 = 16, SDC_P_HIST = 21, SDC_P_WNEXT = 26, SDC_P_NTNEXT, SDC_P_SOC, SDC_POOL_DIM };
+
+#define SDC_FEAT_ROW 32      // floats per feature row (128 bytes)
+#define SDC_FEAT_NCNEXT 30   // ... the last two hold one double
 
 // segmented butterfly sum: lanes [0,16), [16,32) and [32,64) are three independent groups
 __device__ __forceinline__ double seg3_sum_f64(double v, int lane) {

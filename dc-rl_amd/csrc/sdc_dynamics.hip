@@ -72,7 +72,7 @@ __device__ __forceinline__ double sigmoid(double x) { return 1 / (1 + exp(-x)); 
 // the coupled dynamics at cursor i and the observation at i' = i + 1; one wavefront, lane in [0, 64)
 __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& PD, const int env, const int lane,
                                               const unsigned r, const int a_ls, const int a_dc, const int a_bat,
-                                              unsigned fault, const unsigned x_old_l, const unsigned hd0, const uint4 qw,
+                                              unsigned fault, const unsigned x_old_l, const unsigned hd0, const uint4 qw, const bool feat_ok, const float frow,
                                               float* __restrict__ rew,
                                               DynShared& sh) {
   const sdc_dc_params& P = PD.p;
@@ -86,6 +86,11 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
   const double amb = sh.g[G_T0], wet_bulb = sh.g[G_WB0], amb_next = sh.g[G_T1];
   const double* nc = sh.g + G_NC;
   const double* nt = sh.g + G_NT;
+  // norm_CI = NC[i'+1] (sustaindc_env.py:681): from the episode's feature row (a double in its last two floats), or
+  // from the window gathered by this step
+  const double norm_ci = feat_ok ? __hiloint2double(__builtin_amdgcn_readlane(__float_as_int(frow), SDC_FEAT_NCNEXT + 1),
+                                                    __builtin_amdgcn_readlane(__float_as_int(frow), SDC_FEAT_NCNEXT))
+                                 : nc[17];
 
   // ---- load shifting: envs/carbon_ls.py:172-324 ------------------------------------------------
   // The reference keeps a deque of per-task enqueue timestamps and only ever removes a FIFO prefix
@@ -324,7 +329,22 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     o.avg = avg_norm;
     for (int b = 0; b < 5; b++) o.hist[b] = hist[b];
     o.have_past = ip >= 16;
-    build_obs_pool(nc, nt, o, sh.pool, lane);
+    if (feat_ok) {
+      // the trace-only entries come from the episode's feature row (sdc_features.hip), one float per lane; lane 1
+      // adds the nine entries that depend on the step
+      constexpr unsigned TRACE_ONLY = 0x7u | (0x7Fu << SDC_P_CI7) | (1u << SDC_P_W) | (1u << SDC_P_NT) | (1u << SDC_P_TSLOPE) |
+                                      (0x1Fu << SDC_P_T5) | (1u << SDC_P_WNEXT) | (1u << SDC_P_NTNEXT);
+      if (lane < SDC_POOL_DIM && ((TRACE_ONLY >> lane) & 1u)) sh.pool[lane] = frow;
+      if (lane == 1) {
+        sh.pool[SDC_P_OLDEST] = (float)o.oldest;
+        sh.pool[SDC_P_AVG] = (float)o.avg;
+        sh.pool[SDC_P_NORMQ] = (float)o.normq;
+        for (int b = 0; b < 5; b++) sh.pool[SDC_P_HIST + b] = (float)o.hist[b];
+        sh.pool[SDC_P_SOC] = (float)o.soc;
+      }
+    } else {
+      build_obs_pool(nc, nt, o, sh.pool, lane);
+    }
   }
 
   // ---- history append (utils/reward_creator.py:7-14) --------------------------------------------------------
@@ -385,7 +405,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     inf[SDC_INFO_BAT_AVG_CI] = (float)ci_i;
     inf[SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH] = (float)(dcload * 1e3 * 0.25);
     inf[SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH] = (float)energy;
-    inf[SDC_INFO_NORM_CI] = (float)nc[17];
+    inf[SDC_INFO_NORM_CI] = (float)norm_ci;
     inf[SDC_INFO_OUTSIDE_TEMP] = (float)amb_next;
     inf[SDC_INFO_DAY] = (float)day_n;
     inf[SDC_INFO_HOUR] = (float)((double)hourq_n * 0.25);
@@ -596,7 +616,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     put_u32(o0, H_N, (unsigned)n);
     put_f64(o0, H_EOFF, e_off);                                 // bat_total_energy_with_battery_KWh - hist_ref
     const double z = n < 2 ? 0.0 : (e_off - mean) / (sd > 0 ? sd : 1.0);
-    const RewardIn rin = {z, nc[17], oldest_norm, (double)overdue, energy, (double)hourq_n * 0.25, SDC_DIV_CONST(p_it, 1e3), total_kw, water};
+    const RewardIn rin = {z, norm_ci, oldest_norm, (double)overdue, energy, (double)hourq_n * 0.25, SDC_DIV_CONST(p_it, 1e3), total_kw, water};
     const Rewards rr = step_rewards(rin, S.reward_method, hd0);
     put_f64(o0, H_RET, rr.ret[0]);
     put_f64(o0, H_RET + 2, rr.ret[1]);
@@ -675,6 +695,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics
   // ---- level 1: one 8-byte gather per lane -------------------------------------------------------------------------
   // (Staging these values one step ahead -- the previous step gathers them and the record load brings them in -- was
   // measured and is 1 % SLOWER: the start of a launch is bound by how much every env loads, not by round trips.)
+  // The trace-only observation entries of this step come precomputed (sdc_features.hip), unless the episode has no
+  // feature rows (a host write since the reset, an episode too long for that kernel): then the CI / temperature
+  // windows are gathered and the features computed here.
+  const bool feat_ok = S.feat != nullptr && rec_i32(r, R_FEAT_OK) == 1;
+  float frow = 0.0f;
+  if (feat_ok && lane < SDC_FEAT_ROW)
+    frow = S.feat[((size_t)env * (S.episode_steps + 1) + (rel + 1)) * SDC_FEAT_ROW + lane];
   auto gather = [&](const int gi, const int grel, const int ghq) -> double {
     auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
     const double* tW = S.tabW + (size_t)loc * TL;
@@ -694,13 +721,15 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics
       const int back = lane == G_Q97 ? 97 : 24 * (lane - G_Q97);   // 97, 24, 48, 72, 96
       const int t = grel - back;
       if (t >= 0) src = reinterpret_cast<const double*>(qt + t);
-    } else if (lane >= G_NC && lane < G_NC + 25) src = tC + tix(gi + 1 - 16 + (lane - G_NC));
-    else if (lane >= G_NT && lane < G_NT + 17) src = tw + 1 + (lane - G_NT);
+    } else if (!feat_ok && lane >= G_NC && lane < G_NC + 25) src = tC + tix(gi + 1 - 16 + (lane - G_NC));
+    else if (!feat_ok && lane >= G_NT && lane < G_NT + 17) src = tw + 1 + (lane - G_NT);
     double v = 0.0;
     if (src) v = *src;
-    // NC = (C - min) / (max - min) (utils/managers.py:437), NT likewise (:608): ONE division sequence for both windows
-    const bool is_nc = lane >= G_NC && lane < G_NC + 25, is_nt = lane >= G_NT && lane < G_NT + 17;
-    if (is_nc || is_nt) v = (v - (is_nc ? ci_min : t_min)) / (is_nc ? ci_den : t_den);
+    if (!feat_ok) {
+      // NC = (C - min) / (max - min) (utils/managers.py:437), NT likewise (:608): ONE division sequence for both windows
+      const bool is_nc = lane >= G_NC && lane < G_NC + 25, is_nt = lane >= G_NT && lane < G_NT + 17;
+      if (is_nc || is_nt) v = (v - (is_nc ? ci_min : t_min)) / (is_nc ? ci_den : t_den);
+    }
     return v;
   };
   sh.g[lane] = gather(i, rel, hourq_n);
@@ -711,7 +740,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics
   // the start-of-launch burst of every env's record / header / gather loads -- and rides along in 4 registers
   const uint4 qw0 = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env * SDC_WIN + lane];
   const unsigned long long dbg_a1 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
-  step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old_l, hd0, qw0, rew, sh);
+  step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old_l, hd0, qw0, feat_ok, frow, rew, sh);
   if (S.debug_flags & 8) {
     wave_sync();
     if (lane == 0) {

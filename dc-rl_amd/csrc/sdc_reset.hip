@@ -223,6 +223,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     put64(R_BAT, 0.0);                 // battery_model.py:90-91
     o[R_CURSOR] = (unsigned)c0;
     o[R_TREL] = 0u;
+    o[R_FEAT_OK] = 0u;                 // the features kernel that follows fills the episode's rows
     o[R_DAY] = (unsigned)day;
     o[R_HOURQ] = (unsigned)(hour * 4);
     o[R_QPOPPED] = 0u;                 // carbon_ls.py:85

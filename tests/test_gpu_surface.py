@@ -168,3 +168,31 @@ def test_env_groups_on_separate_streams_match_sequential_stepping():
         for sa, sb in zip(a[g], b[g]):
             for xa, xb in zip(sa, sb):
                 np.testing.assert_array_equal(xa, xb)
+
+
+def test_precomputed_observation_rows_match_per_step_features():
+    """The trace-only observation entries come from rows computed once per episode (sdc_features.hip, one lane per
+    step); after a host write to the env's state the step computes them itself (all lanes of the wavefront on one
+    step).  Both follow the reference's arithmetic: same observations, to the bit, over episodes that include the
+    start-of-year cursor edge (no past CI window) and device-side auto-resets."""
+    import torch
+    import bench
+
+    def run(fallback):
+        eng = bench.build_engine(192, 96, 0, seed=321)[0]
+        gen = torch.Generator(device="cpu").manual_seed(11)
+        acts = torch.randint(0, 3, (64, 192, 3), dtype=torch.int32, generator=gen).to("cuda:0")
+        eng.reset()
+        snaps = []
+        for t in range(300):
+            if fallback and t % 96 == 0:
+                eng.set_state("episode", eng.get_state("episode"))   # a host write: the rows count as stale
+            obs, share, rew, done, info = eng.step(acts[t % 64])
+            snaps.append((obs.cpu().numpy().copy(), share.cpu().numpy().copy(), rew.cpu().numpy().copy()))
+        eng.close()
+        return snaps
+
+    a, b = run(False), run(True)
+    for t, (sa, sb) in enumerate(zip(a, b)):
+        for xa, xb in zip(sa, sb):
+            assert np.array_equal(xa, xb), (t, np.abs(xa - xb).max())
