@@ -710,13 +710,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics
     const double* wbw = S.wb_win + (size_t)env * S.lw + grel;
     const uint2* qt = S.qtab + (size_t)env * S.qstride;
     const double* src = nullptr;
-    if (lane <= G_W2) src = tW + tix(gi + lane);
+    if (lane <= (feat_ok ? G_W0 : G_W2)) src = tW + tix(gi + lane);   // (W[i+1], W[i+2], the hour LUT: observations only)
     else if (lane == G_C0) src = tC + tix(gi);
     else if (lane == G_T0) src = tw;
     else if (lane == G_WB0) src = wbw;
     else if (lane == G_T1) src = tw + 1;
-    else if (lane == G_LUT) src = S.hour_lut + 2 * ghq;
-    else if (lane == G_LUT2) src = S.hour_lut + 2 * ghq + 1;
+    else if (!feat_ok && lane == G_LUT) src = S.hour_lut + 2 * ghq;
+    else if (!feat_ok && lane == G_LUT2) src = S.hour_lut + 2 * ghq + 1;
     else if (lane >= G_Q97 && lane <= G_Q96) {
       const int back = lane == G_Q97 ? 97 : 24 * (lane - G_Q97);   // 97, 24, 48, 72, 96
       const int t = grel - back;
