@@ -344,6 +344,7 @@ int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
                       "positive, finite, and not have an all-ones significand");
     *rcs[i] = 1.0 / divisors[i];
   }
+  e.k_outlet = 1.918 / (p->c_air * p->rho_air * 0.526);
   HIP_TRY(hipMemcpy(const_cast<SdcDcDev*>(h->d.dc) + cfg_id, &e, sizeof(e), hipMemcpyHostToDevice));
   return 0;
 }

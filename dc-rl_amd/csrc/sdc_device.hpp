@@ -113,6 +113,7 @@ __device__ __forceinline__ void wave_sync() {
 struct SdcDcDev {
   sdc_dc_params p;
   double rc_n_racks, rc_itfan_ref_v_ratio, rc_rho_air, rc_ctafr, rc_bat_capacity;
+  double k_outlet;   // 1.918 / (c_air rho_air 0.526): the constant factor of the rack outlet-temperature rise
 };
 
 struct SdcDev {

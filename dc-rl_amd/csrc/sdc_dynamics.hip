@@ -241,9 +241,9 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     const double vtot = n * vf1;
     // x^y as exp2(y log2 x): <= 3e-15 relative against the correctly rounded power (the reference's libm pow is
     // <= 1.3e-16), nine orders below the fp32 outputs' resolution, at less than half the instructions of pow()
-    const double power_term = exp2(1.096 * log2(pcpu + pfan));
-    const double airflow_term = P.c_air * P.rho_air * exp2(0.824 * log2(vtot)) * 0.526;
-    outlet = inlet + 1.918 * power_term / airflow_term + -14.01;
+    // ... and power^1.096 / airflow^0.824 as ONE exp2 of the difference of the two scaled logarithms
+    const double rise = exp2(1.096 * log2(pcpu + pfan) - 0.824 * log2(vtot));
+    outlet = inlet + PD.k_outlet * rise + -14.01;   // 1.918 power^1.096 / (c_air rho_air airflow^0.824 0.526) - 14.01
     if (outlet - inlet < 2) bad_delta = 1;
     ret_plus_out = P.rack_return[lane] + outlet;
   }
