@@ -106,7 +106,8 @@ class SdcResetOverride(C.Structure):
 
 EXPORTS = [
     "sdc_last_error", "sdc_version", "sdc_create", "sdc_destroy", "sdc_set_seed", "sdc_weather_window_len", "sdc_set_tables",
-    "sdc_set_dc_params", "sdc_assign_envs", "sdc_reset", "sdc_step", "sdc_get_state", "sdc_set_state",
+    "sdc_set_dc_params", "sdc_assign_envs", "sdc_reset", "sdc_step", "sdc_rollout", "sdc_steps_to_episode_end",
+    "sdc_get_state", "sdc_set_state",
     "sdc_hist_stride", "sdc_queue_stride", "sdc_profile_enable", "sdc_profile_read",
 ]
 
@@ -154,6 +155,8 @@ def load():
     L.sdc_assign_envs.argtypes = [vp, ip, ip, ip, ip]
     L.sdc_reset.argtypes = [vp, u8p, C.POINTER(SdcResetOverride), fp, fp, vp]
     L.sdc_step.argtypes = [vp, vp, fp, fp, fp, vp, fp, fp, vp]
+    L.sdc_rollout.argtypes = [vp, C.c_int, vp, fp, fp, fp, vp, fp, fp, vp]
+    L.sdc_steps_to_episode_end.argtypes = [vp]
     L.sdc_get_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_set_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_profile_enable.argtypes = [vp, C.c_int]

@@ -19,6 +19,8 @@ extern "C" __global__ void sdc_dynamics_kernel(SdcDev S, const int32_t* actions,
                                                unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
 extern "C" __global__ void sdc_features_kernel(SdcDev S);
+extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, const int32_t* actions, float* obs, float* share_obs,
+                                              unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
                                             const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
                                             const double* ovr_t_max, int only_done, float* obs, float* share_obs);
@@ -471,6 +473,46 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   if (timed) h->prof_used += 1;
   return 0;
 }
+
+int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, float* share_obs, float* rew,
+                uint8_t* done, float* info, float* final_obs, void* stream) {
+  if (!h || !actions || !obs || !rew || !done) return fail_msg("sdc_rollout: null argument");
+  if (!h->started) return fail_msg("sdc_rollout: sdc_reset must be called first");
+  if (n_steps <= 0) return fail_msg("sdc_rollout: n_steps must be positive");
+  if (n_steps > h->steps_to_terminal)
+    return fail_msg("sdc_rollout: the rollout would run past the end of an episode (" +
+                    std::to_string(h->steps_to_terminal) + " steps left); split it there");
+  if (h->cfg.debug_flags & 1) return fail_msg("sdc_rollout: verify mode checks single steps; use sdc_step");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int N = h->cfg.n_envs;
+  SdcDev d = h->d;
+  hipLaunchKernelGGL(sdc_rollout_kernel, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, n_steps,
+                     actions, obs, share_obs, done, info, final_obs, rew);
+  HIP_TRY(hipGetLastError());
+  h->steps_to_terminal -= n_steps;
+  h->pending += n_steps;
+  if (h->steps_to_terminal == 0) {
+    sync_mirror(h);
+    if (h->cfg.auto_reset) {
+      // as in sdc_step: the finished envs are reset inside the call; the LAST step's obs / share_obs slices receive
+      // the reset observation, final_obs the pre-reset one
+      d.reset_mask = nullptr;
+      const size_t last = (size_t)(n_steps - 1) * N;
+      hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
+                         h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs + last * SDC_OBS_OUT,
+                         share_obs ? share_obs + last * SDC_SHARE_OBS_DIM : nullptr);
+      launch_features(h, d, st);
+      HIP_TRY(hipGetLastError());
+      for (int e = 0; e < N; e++)
+        if (h->host_t_rel[e] >= h->cfg.episode_steps) h->host_t_rel[e] = 0;
+      recompute_steps_to_terminal(h);
+    }
+  }
+  return 0;
+}
+
+int sdc_steps_to_episode_end(const sdc_handle* h) { return h ? h->steps_to_terminal : -1; }
 
 int sdc_profile_enable(sdc_handle* h, int enable) {
   if (!h) return fail_msg("sdc_profile_enable: null handle");

@@ -626,24 +626,15 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
   }
 }
 
-}  // namespace
 
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
-                                                                                float* __restrict__ obs,
-                                                                                float* __restrict__ share_obs,
-                                                                                unsigned char* __restrict__ done,
-                                                                                float* __restrict__ info,
-                                                                                float* __restrict__ final_obs,
-                                                                                float* __restrict__ rew) {
-  __shared__ DynShared shs[SDC_WPB];
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
-  DynShared& sh = shs[wave];
-  const int env = blockIdx.x * SDC_WPB + wave;
-  const int lane = threadIdx.x % SDC_WAVE;
-  const int N = S.n_envs;
-  if (env >= N) return;
+// One env-step of env `env` by its wavefront (lane in [0, 64), LDS block sh): loads the env's state, runs the dynamics,
+// the rewards and the reward-state upkeep, stores the new state and the outputs.
+__device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const int env, const int lane,
+                                         const int32_t* __restrict__ actions, float* __restrict__ obs,
+                                         float* __restrict__ share_obs, unsigned char* __restrict__ done,
+                                         float* __restrict__ info, float* __restrict__ final_obs,
+                                         float* __restrict__ rew) {
   const int TL = S.table_len;
-  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 0);
   const unsigned long long dbg_entry = (S.debug_flags & 16) ? wall_clock64() : 0ull;
 
   // ---- level 0: state record (coalesced) + actions ---------------------------------------------------------------
@@ -768,9 +759,63 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics
   }
   if (share_obs && lane < SDC_SHARE_OBS_DIM) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = sh.pool[lane];
   if (info && lane < SDC_INFO_DIM) info[(size_t)env * SDC_INFO_DIM + lane] = sh.info[lane];
-  if (lane == 0) {
-    done[env] = (unsigned char)terminal;
-    prof_stamp(S, SDC_PROF_DYNAMICS, env, 1);
+  if (lane == 0) done[env] = (unsigned char)terminal;
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
+                                                                                float* __restrict__ obs,
+                                                                                float* __restrict__ share_obs,
+                                                                                unsigned char* __restrict__ done,
+                                                                                float* __restrict__ info,
+                                                                                float* __restrict__ final_obs,
+                                                                                float* __restrict__ rew) {
+  __shared__ DynShared shs[SDC_WPB];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
+  const int env = blockIdx.x * SDC_WPB + wave;
+  const int lane = threadIdx.x % SDC_WAVE;
+  if (env >= S.n_envs) return;
+  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 0);
+  env_step(S, shs[wave], env, lane, actions, obs, share_obs, done, info, final_obs, rew);
+  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 1);
+}
+
+// K env-steps per launch for action sequences that are known up front (scripted / rule-based policies, open-loop
+// evaluation): every wavefront advances its own env K times -- envs do not interact, so there is nothing to wait for
+// between steps; the dispatch ramp, the launch gap and the tail of a launch are paid once per K steps.  actions
+// [K][N][3]; obs [K][N][3][26], share_obs [K][N][29] (or null), rew [K][N][3], done [K][N], info [K][N][44] (or null)
+// hold every step's outputs.  The host keeps K within the episode (sdc_rollout).
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_rollout_kernel(SdcDev S, const int K,
+                                                                               const int32_t* __restrict__ actions,
+                                                                               float* __restrict__ obs,
+                                                                               float* __restrict__ share_obs,
+                                                                               unsigned char* __restrict__ done,
+                                                                               float* __restrict__ info,
+                                                                               float* __restrict__ final_obs,
+                                                                               float* __restrict__ rew) {
+  __shared__ DynShared shs[SDC_WPB];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
+  const int env = blockIdx.x * SDC_WPB + wave;
+  const int lane = threadIdx.x % SDC_WAVE;
+  const size_t N = (size_t)S.n_envs;
+  if (env >= S.n_envs) return;
+  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 0);
+#pragma unroll 1
+  for (int k = 0; k < K; k++) {
+    __builtin_amdgcn_s_setprio(0);
+    // (opaque copies: otherwise every per-env / per-lane address of the step is hoisted out of the loop and held in
+    // registers across it -- 50 VGPRs the step itself needs)
+    int env_k = env, lane_k = lane;
+    asm volatile("" : "+s"(env_k), "+v"(lane_k));
+    env_step(S, shs[wave], env_k, lane_k, actions + (size_t)k * N * 3, obs + (size_t)k * N * SDC_OBS_OUT,
+             share_obs ? share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM : nullptr, done + (size_t)k * N,
+             info ? info + (size_t)k * N * SDC_INFO_DIM : nullptr, k == K - 1 ? final_obs : nullptr, rew + (size_t)k * N * 3);
+    // this wavefront's stores of step k are the loads of its step k + 1: complete them and drop stale lines of the
+    // CU's vector L1 (workgroup scope: the L2 behind it is the same for both)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_sync();
   }
-  (void)N;
+  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 1);
 }

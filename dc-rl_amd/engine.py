@@ -184,6 +184,36 @@ class SdcEngine:
             L.check(rc)
         return self.obs, self.share_obs, self.rew, self.done, self.info
 
+    def steps_to_episode_end(self) -> int:
+        return int(self.lib.sdc_steps_to_episode_end(self._h))
+
+    def rollout(self, actions, want_info: bool = True):
+        """K env-steps in one launch for an action sequence known up front (scripted / rule-based policies, open-loop
+        evaluation).  actions: int32 device tensor [K, N, 3]; K must not run past the end of an episode
+        (steps_to_episode_end()).  Returns fresh device tensors holding every step's outputs:
+        obs [K,N,3,26], share_obs [K,N,29], rew [K,N,3], done [K,N] (uint8), info [K,N,44] (or None).
+        Same results as K calls of step()."""
+        t = self.torch
+        if not (isinstance(actions, t.Tensor) and actions.dtype == t.int32 and actions.is_cuda and
+                actions.is_contiguous() and actions.dim() == 3 and tuple(actions.shape[1:]) == (self.n_envs, 3)):
+            raise ValueError("actions must be a contiguous int32 CUDA tensor of shape (K, n_envs, 3)")
+        K, N = int(actions.shape[0]), self.n_envs
+        kw = dict(device=self.device)
+        obs = t.empty((K, N, L.N_AGENTS, L.OBS_PAD), dtype=t.float32, **kw)
+        share = t.empty((K, N, L.SHARE_OBS_DIM), dtype=t.float32, **kw)
+        rew = t.empty((K, N, L.N_AGENTS), dtype=t.float32, **kw)
+        done = t.empty((K, N), dtype=t.uint8, **kw)
+        info = t.empty((K, N, L.INFO_DIM), dtype=t.float32, **kw) if want_info else None
+        p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        with t.cuda.device(self.device):
+            L.check(self.lib.sdc_rollout(self._h, K, p(actions), p(obs), p(share), p(rew), p(done), p(info),
+                                         p(self.final_obs), self._stream()))
+        # the engine's single-step views follow the last step
+        self.obs.copy_(obs[-1]); self.share_obs.copy_(share[-1]); self.rew.copy_(rew[-1]); self.done.copy_(done[-1])
+        if info is not None:
+            self.info.copy_(info[-1])
+        return obs, share, rew, done, info
+
     # ------------------------------------------------------------------ state access (parity injection / checkpoint)
     def _state_array(self, name):
         N = self.n_envs

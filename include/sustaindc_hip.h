@@ -204,6 +204,18 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
 int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs, float* rew, uint8_t* done,
              float* info, float* final_obs, void* stream);
 
+/* n_steps env-steps in ONE launch for action sequences known up front (scripted / rule-based policies -- the
+ * reference's utils/rbc_agents.py, utils/base_agents.py --, open-loop evaluation): every env advances n_steps times
+ * without waiting for the others.  actions [n_steps][N][3]; obs [n_steps][N][3][26], share_obs [n_steps][N][29],
+ * rew [n_steps][N][3], done [n_steps][N], info [n_steps][N][SDC_INFO_DIM] receive every step's outputs (share_obs /
+ * info / final_obs may be NULL).  n_steps must not exceed sdc_steps_to_episode_end(); if it reaches the episode's
+ * end and auto_reset is on, the finished envs are reset as in sdc_step (the last step's obs slice holds the reset
+ * observation, final_obs [N][3][26] the pre-reset one).  Same results as n_steps calls of sdc_step. */
+int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, float* share_obs, float* rew,
+                uint8_t* done, float* info, float* final_obs, void* stream);
+/* steps until the first env finishes its episode (0: a reset is due) */
+int sdc_steps_to_episode_end(const sdc_handle* h);
+
 /* parity injection + env checkpoint: copy one named state field to / from HOST memory, dense per env.
  * int32[N]:  cursor t_rel day hourq q_popped q_cum q_cumT q_head q_cum_hm1 q_cumT_hm1 last_delta consecutive
  *            scale hist_len hist_pos episode fault loc_id cfg_id day_lo day_hi hist_n

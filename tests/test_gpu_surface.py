@@ -196,3 +196,38 @@ def test_precomputed_observation_rows_match_per_step_features():
     for t, (sa, sb) in enumerate(zip(a, b)):
         for xa, xb in zip(sa, sb):
             assert np.array_equal(xa, xb), (t, np.abs(xa - xb).max())
+
+
+def test_rollout_matches_single_steps():
+    """sdc_rollout (K env-steps per launch, every wavefront advancing its own env K times) gives what K calls of
+    sdc_step give, to the bit -- across window re-centrings, an auto-reset at the end of a rollout, and the
+    episode-boundary guard."""
+    import torch
+    import bench
+    from dc_rl_amd._lib import SdcError
+
+    N, EP = 256, 96
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    acts = torch.randint(0, 3, (3 * EP, N, 3), dtype=torch.int32, generator=gen).to("cuda:0")
+    a = bench.build_engine(N, EP, 0, seed=77)[0]
+    b = bench.build_engine(N, EP, 0, seed=77)[0]
+    a.reset()
+    b.reset()
+    t = 0
+    for K in (1, 7, 40, 48, 30, 66, 96):          # 48 ends the first episode, 66 the second, 96 is a whole one
+        assert b.steps_to_episode_end() >= K
+        obs, share, rew, done, info = b.rollout(acts[t:t + K])
+        for k in range(K):
+            o1, s1, r1, d1, i1 = a.step(acts[t + k])
+            np.testing.assert_array_equal(o1.cpu().numpy(), obs[k].cpu().numpy())
+            np.testing.assert_array_equal(s1.cpu().numpy(), share[k].cpu().numpy())
+            np.testing.assert_array_equal(r1.cpu().numpy(), rew[k].cpu().numpy())
+            np.testing.assert_array_equal(d1.cpu().numpy(), done[k].cpu().numpy())
+            np.testing.assert_array_equal(i1.cpu().numpy(), info[k].cpu().numpy())
+        np.testing.assert_array_equal(a.final_obs.cpu().numpy(), b.final_obs.cpu().numpy())
+        t += K
+    assert b.steps_to_episode_end() == EP
+    with pytest.raises(SdcError):
+        b.rollout(acts[:EP + 1])                   # would run past the end of the episode
+    a.close()
+    b.close()
