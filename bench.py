@@ -251,6 +251,24 @@ def main():
             "return_stats": {"episodes": int(ret_stats[6].item()),
                              "mean_return": [round(float(x), 3) for x in (ret_stats[0:3] / max(1.0, float(ret_stats[6].item())))]},
         }
+        if world == 1:
+            # next to the headline (one launch per step): sdc_rollout, 48 env-steps per launch for action sequences
+            # known up front (scripted policies); same work per step, every step's outputs written
+            try:
+                K, done_steps = 48, 0
+                seq = pool[:K].contiguous()
+                torch.cuda.synchronize()
+                tr = time.perf_counter()
+                while done_steps < 960:
+                    k = min(K, eng.steps_to_episode_end())
+                    eng.rollout(seq[:k])
+                    done_steps += k
+                torch.cuda.synchronize()
+                tr = time.perf_counter() - tr
+                out["rollout"] = {"steps_per_launch": K, "value": round(N * done_steps / tr, 1), "unit": "env-steps/s",
+                                  "ms_per_step": round(tr / done_steps * 1e3, 5)}
+            except Exception as e:
+                out["rollout"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(tb, params, args.episode_steps)
