@@ -110,7 +110,7 @@ void sync_mirror(sdc_handle* h) {
 // for the kernel's LDS windows go without (the step then computes the features itself)
 void launch_features(sdc_handle* h, const SdcDev& d, hipStream_t st) {
   if (!d.feat) return;
-  const size_t lds = sizeof(double) * (size_t)(d.episode_steps + 25 + d.lw);
+  const size_t lds = sizeof(double) * (size_t)(d.episode_steps + 25 + d.lw) + sizeof(float) * SDC_WAVE * (SDC_FEAT_ROW + 1);
   hipLaunchKernelGGL(sdc_features_kernel, dim3(d.n_envs), dim3(SDC_WAVE), lds, st, d);
   (void)h;
 }
@@ -236,7 +236,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   A(d.hdr, (size_t)N * SDC_HDR_DWORDS);
   A(d.qwin, (size_t)N * (4 * SDC_WIN));
   d.feat = nullptr;
-  if (sizeof(double) * (size_t)(cfg->episode_steps + 25 + d.lw) <= 60 * 1024)   // the features kernel's LDS windows
+  if (sizeof(double) * (size_t)(cfg->episode_steps + 25 + d.lw) <= 50 * 1024)   // the features kernel's LDS windows (+ 8.4 KB tile)
     A(d.feat, (size_t)N * (size_t)(cfg->episode_steps + 1) * SDC_FEAT_ROW);
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);

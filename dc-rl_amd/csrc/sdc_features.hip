@@ -90,6 +90,10 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDe
   const double t_min = rec_f64(r, R_T_MIN), t_den = rec_f64(r, R_T_DEN);
   double* ncw = lds;                  // ncw[j] = NC[c0 - 16 + j], j in [0, steps + 25)
   double* ntw = lds + (steps + 25);   // ntw[k] = NT[c0 + k],      k in [0, lw)
+  // a pass's 64 rows are assembled in LDS (row stride 33 floats: conflict-free for one lane per row) and go out as
+  // whole 128-byte rows, two per store instruction
+  float* tile = reinterpret_cast<float*>(ntw + S.lw);
+  constexpr int TS = SDC_FEAT_ROW + 1;
   const double* tC = S.tabC + (size_t)loc * TL;
   const double* tW = S.tabW + (size_t)loc * TL;
   const double* tw = S.t_win + (size_t)env * S.lw;
@@ -98,11 +102,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDe
   for (int k = lane; k < S.lw; k += SDC_WAVE) ntw[k] = (tw[k] - t_min) / t_den;                           // managers.py:608
   __syncthreads();
   float* rows = S.feat + (size_t)env * (steps + 1) * SDC_FEAT_ROW;
-  for (int s = lane; s <= steps; s += SDC_WAVE) {   // row s: the observation at i' = c0 + s
+  for (int s0 = 0; s0 <= steps; s0 += SDC_WAVE) {
+   const int s = s0 + lane;                         // row s: the observation at i' = c0 + s
+   if (s <= steps) {
     const int ip = c0 + s;
     const double* nc = ncw + s;   // nc[0..24] = NC[i'-16 .. i'+8]
     const double* nt = ntw + s;   // nt[0..16] = NT[i' .. i'+16]  (the last rows of an episode read up to ntw[lw - 1])
-    float* o = rows + (size_t)s * SDC_FEAT_ROW;
+    float* o = tile + lane * TS;
     const int hq = (hq0 + s) % 96;
     o[SDC_P_COS] = (float)S.hour_lut[2 * hq];
     o[SDC_P_SIN] = (float)S.hour_lut[2 * hq + 1];
@@ -143,7 +149,18 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDe
       extract_features(nt[0], v, o + SDC_P_T5);
     }
     // norm_CI = NC[i'+1] of the reward (sustaindc_env.py:681), fp64, in the row's last two floats
-    *reinterpret_cast<double*>(o + SDC_FEAT_NCNEXT) = nc[17];
+    const double ncn = nc[17];
+    o[SDC_FEAT_NCNEXT] = __int_as_float(__double2loint(ncn));
+    o[SDC_FEAT_NCNEXT + 1] = __int_as_float(__double2hiint(ncn));
+   }
+   __syncthreads();
+   const int n_rows = min(SDC_WAVE, steps + 1 - s0);
+#pragma unroll 4
+   for (int j = 0; j < SDC_WAVE / 2; j++) {
+     const int rr = 2 * j + (lane >> 5), k = lane & 31;
+     if (rr < n_rows) rows[(size_t)(s0 + rr) * SDC_FEAT_ROW + k] = tile[rr * TS + k];
+   }
+   __syncthreads();
   }
   if (lane == R_FEAT_OK) recp[lane] = 1u;
 }
