@@ -15,11 +15,11 @@
 
 #include "sdc_device.hpp"
 
-extern "C" __global__ void sdc_dynamics_kernel(SdcDev S, const int32_t* actions, float* obs, float* share_obs,
+extern "C" __global__ void sdc_dynamics_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                                unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
 extern "C" __global__ void sdc_features_kernel(SdcDev S);
-extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, const int32_t* actions, float* obs, float* share_obs,
+extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                               unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
                                             const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
@@ -58,6 +58,7 @@ struct Field {
 struct sdc_handle {
   sdc_config cfg;
   SdcDev d;
+  int rel_hint = -1;   // the episode step all envs are at, if they are in lock-step (else -1)
   int device;
   std::vector<void*> allocs;
   std::vector<Field> fields;
@@ -151,6 +152,10 @@ void recompute_steps_to_terminal(sdc_handle* h) {
     if (left < m) m = left;
   }
   h->steps_to_terminal = m;
+  // envs in lock-step: the kernels are told the episode step up front (see env_step)
+  h->rel_hint = h->host_t_rel.empty() ? -1 : h->host_t_rel[0];
+  for (int e = 1; e < h->cfg.n_envs && h->rel_hint >= 0; e++)
+    if (h->host_t_rel[e] != h->rel_hint) h->rel_hint = -1;
 }
 
 }  // namespace
@@ -447,12 +452,13 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
     d.prof_ts = h->prof_buf + (size_t)h->prof_used * 3 * N * 2;
     h->prof_has_reset[h->prof_used] = 0;
   }
-  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, actions, obs, share_obs, done, info,
+  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, h->rel_hint, actions, obs, share_obs, done, info,
                      final_obs, rew);
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
   HIP_TRY(hipGetLastError());
   h->steps_to_terminal -= 1;
   h->pending += 1;
+  if (h->rel_hint >= 0) h->rel_hint += 1;
   if (h->steps_to_terminal == 0) {
     // At least one env just finished.  Episodes have a fixed length and every env advances one step per
     // launch, so the host knows this from its mirror of the step counters -- no device read-back.
@@ -488,10 +494,11 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
   const int N = h->cfg.n_envs;
   SdcDev d = h->d;
   hipLaunchKernelGGL(sdc_rollout_kernel, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, n_steps,
-                     actions, obs, share_obs, done, info, final_obs, rew);
+                     h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
   HIP_TRY(hipGetLastError());
   h->steps_to_terminal -= n_steps;
   h->pending += n_steps;
+  if (h->rel_hint >= 0) h->rel_hint += n_steps;
   if (h->steps_to_terminal == 0) {
     sync_mirror(h);
     if (h->cfg.auto_reset) {

@@ -237,6 +237,13 @@ enum { SDC_P_COS = 0, SDC_P_SIN, SDC_P_NC, SDC_P_CI7 = 3, SDC_P_OLDEST = 10, SDC
 
 #define SDC_FEAT_ROW 32      // floats per feature row (128 bytes)
 #define SDC_FEAT_NCNEXT 30   // ... the last two hold one double
+// ... and the slots of the step-dependent observation entries hold the inputs of the step that LEADS to the row's
+// observation (row r: the step from episode step r - 1): W[i], C[i], T[i], WB[i] as doubles, T[i+1] as a float
+#define SDC_FEAT_W 10
+#define SDC_FEAT_T1 12
+#define SDC_FEAT_C 22
+#define SDC_FEAT_T 24
+#define SDC_FEAT_WB 28
 
 // segmented butterfly sum: lanes [0,16), [16,32) and [32,64) are three independent groups
 __device__ __forceinline__ double seg3_sum_f64(double v, int lane) {

@@ -629,12 +629,26 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
 
 // One env-step of env `env` by its wavefront (lane in [0, 64), LDS block sh): loads the env's state, runs the dynamics,
 // the rewards and the reward-state upkeep, stores the new state and the outputs.
-__device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const int env, const int lane,
+__device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const int env, const int lane, const int rel_hint,
                                          const int32_t* __restrict__ actions, float* __restrict__ obs,
                                          float* __restrict__ share_obs, unsigned char* __restrict__ done,
                                          float* __restrict__ info, float* __restrict__ final_obs,
                                          float* __restrict__ rew) {
   const int TL = S.table_len;
+  // When the host knows the episode step every env is at (envs in lock-step: rel_hint >= 0), the step's feature row
+  // -- which also holds its trace inputs -- and its queue-history probes are requested together with the state
+  // record: ONE memory round trip before the dynamics start instead of two (record, then what it points to).
+  const bool pre = rel_hint >= 0 && S.feat != nullptr;
+  float frow_pre = 0.0f;
+  double q_pre = 0.0;
+  if (pre) {
+    if (lane < SDC_FEAT_ROW) frow_pre = S.feat[((size_t)env * (S.episode_steps + 1) + (rel_hint + 1)) * SDC_FEAT_ROW + lane];
+    if (lane >= G_Q97 && lane <= G_Q96) {
+      const int back = lane == G_Q97 ? 97 : 24 * (lane - G_Q97);   // 97, 24, 48, 72, 96
+      const int t = rel_hint - back;
+      if (t >= 0) q_pre = *reinterpret_cast<const double*>(S.qtab + (size_t)env * S.qstride + t);
+    }
+  }
   const unsigned long long dbg_entry = (S.debug_flags & 16) ? wall_clock64() : 0ull;
 
   // ---- level 0: state record (coalesced) + actions ---------------------------------------------------------------
@@ -690,8 +704,9 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
   // feature rows (a host write since the reset, an episode too long for that kernel): then the CI / temperature
   // windows are gathered and the features computed here.
   const bool feat_ok = S.feat != nullptr && rec_i32(r, R_FEAT_OK) == 1;
-  float frow = 0.0f;
-  if (feat_ok && lane < SDC_FEAT_ROW)
+  const bool fast = pre && feat_ok && rel == rel_hint;   // what was requested up front is what this step needs
+  float frow = frow_pre;
+  if (feat_ok && !fast && lane < SDC_FEAT_ROW)
     frow = S.feat[((size_t)env * (S.episode_steps + 1) + (rel + 1)) * SDC_FEAT_ROW + lane];
   auto gather = [&](const int gi, const int grel, const int ghq) -> double {
     auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
@@ -723,7 +738,19 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
     }
     return v;
   };
-  sh.g[lane] = gather(i, rel, hourq_n);
+  if (fast) {
+    // the row's input slots and the probes go to the places the gather would have put them
+    unsigned* g32 = reinterpret_cast<unsigned*>(sh.g);
+    const unsigned fb = (unsigned)__float_as_int(frow);
+    if (lane == SDC_FEAT_W || lane == SDC_FEAT_W + 1) g32[2 * G_W0 + (lane - SDC_FEAT_W)] = fb;
+    if (lane == SDC_FEAT_C || lane == SDC_FEAT_C + 1) g32[2 * G_C0 + (lane - SDC_FEAT_C)] = fb;
+    if (lane == SDC_FEAT_T || lane == SDC_FEAT_T + 1) g32[2 * G_T0 + (lane - SDC_FEAT_T)] = fb;
+    if (lane == SDC_FEAT_WB || lane == SDC_FEAT_WB + 1) g32[2 * G_WB0 + (lane - SDC_FEAT_WB)] = fb;
+    if (lane == SDC_FEAT_T1) sh.g[G_T1] = (double)frow;
+    if (lane >= G_Q97 && lane <= G_Q96) sh.g[lane] = q_pre;
+  } else {
+    sh.g[lane] = gather(i, rel, hourq_n);
+  }
   wave_sync();
 
   const unsigned long long dbg_a0 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
@@ -764,7 +791,7 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics_kernel(SdcDev S, const int32_t* __restrict__ actions,
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics_kernel(SdcDev S, const int rel_hint, const int32_t* __restrict__ actions,
                                                                                 float* __restrict__ obs,
                                                                                 float* __restrict__ share_obs,
                                                                                 unsigned char* __restrict__ done,
@@ -777,7 +804,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics
   const int lane = threadIdx.x % SDC_WAVE;
   if (env >= S.n_envs) return;
   if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 0);
-  env_step(S, shs[wave], env, lane, actions, obs, share_obs, done, info, final_obs, rew);
+  env_step(S, shs[wave], env, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
   if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 1);
 }
 
@@ -786,7 +813,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics
 // between steps; the dispatch ramp, the launch gap and the tail of a launch are paid once per K steps.  actions
 // [K][N][3]; obs [K][N][3][26], share_obs [K][N][29] (or null), rew [K][N][3], done [K][N], info [K][N][44] (or null)
 // hold every step's outputs.  The host keeps K within the episode (sdc_rollout).
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_rollout_kernel(SdcDev S, const int K,
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_rollout_kernel(SdcDev S, const int K, const int rel_hint,
                                                                                const int32_t* __restrict__ actions,
                                                                                float* __restrict__ obs,
                                                                                float* __restrict__ share_obs,
@@ -808,7 +835,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_rollout_
     // registers across it -- 50 VGPRs the step itself needs)
     int env_k = env, lane_k = lane;
     asm volatile("" : "+s"(env_k), "+v"(lane_k));
-    env_step(S, shs[wave], env_k, lane_k, actions + (size_t)k * N * 3, obs + (size_t)k * N * SDC_OBS_OUT,
+    env_step(S, shs[wave], env_k, lane_k, rel_hint >= 0 ? rel_hint + k : -1, actions + (size_t)k * N * 3, obs + (size_t)k * N * SDC_OBS_OUT,
              share_obs ? share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM : nullptr, done + (size_t)k * N,
              info ? info + (size_t)k * N * SDC_INFO_DIM : nullptr, k == K - 1 ? final_obs : nullptr, rew + (size_t)k * N * 3);
     // this wavefront's stores of step k are the loads of its step k + 1: complete them and drop stale lines of the

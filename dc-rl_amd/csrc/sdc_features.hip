@@ -149,9 +149,18 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDe
       extract_features(nt[0], v, o + SDC_P_T5);
     }
     // norm_CI = NC[i'+1] of the reward (sustaindc_env.py:681), fp64, in the row's last two floats
-    const double ncn = nc[17];
-    o[SDC_FEAT_NCNEXT] = __int_as_float(__double2loint(ncn));
-    o[SDC_FEAT_NCNEXT + 1] = __int_as_float(__double2hiint(ncn));
+    auto put_f64 = [&](const int slot, const double v) {
+      o[slot] = __int_as_float(__double2loint(v));
+      o[slot + 1] = __int_as_float(__double2hiint(v));
+    };
+    put_f64(SDC_FEAT_NCNEXT, nc[17]);
+    // the inputs of the step that leads here (from episode step s - 1, table cursor i = i' - 1)
+    const int sp = s > 0 ? s - 1 : 0;
+    put_f64(SDC_FEAT_W, tW[tix(c0 + sp)]);
+    put_f64(SDC_FEAT_C, tC[tix(c0 + sp)]);
+    put_f64(SDC_FEAT_T, tw[sp]);
+    put_f64(SDC_FEAT_WB, S.wb_win[(size_t)env * S.lw + sp]);
+    o[SDC_FEAT_T1] = (float)tw[sp + 1];
    }
    __syncthreads();
    const int n_rows = min(SDC_WAVE, steps + 1 - s0);
