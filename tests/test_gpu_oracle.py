@@ -264,3 +264,11 @@ def test_full_size_properties_4096():
         assert torch.equal(u, v)
     for e in (a, b, small, c):
         e.close()
+
+
+def test_long_episode_without_feature_rows_vs_oracle():
+    """Episodes too long for the per-episode feature rows (the features kernel keeps an episode's windows in LDS): the
+    step computes the trace-only observation entries itself, and the result still matches the oracle."""
+    w = P.run_engine_vs_oracle(n_envs=16, n_steps=150, episode_steps=4000, seed=17)
+    print("long episode", w)
+    assert w["obs"] <= TOL and w["rew"] <= TOL and w["info"] <= 2e-6
