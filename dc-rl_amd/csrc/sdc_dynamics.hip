@@ -622,7 +622,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     put_f64(o0, H_RET + 2, rr.ret[1]);
     put_f64(o0, H_RET + 4, rr.ret[2]);
     if (lane == 0) store_rewards(rr, z, path, env, rew, sh.info);
-    S.hdr[(size_t)env * SDC_HDR_DWORDS + lane] = o0;
+    __builtin_nontemporal_store(o0, &S.hdr[(size_t)env * SDC_HDR_DWORDS + lane]);
   }
 }
 
@@ -771,21 +771,24 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
   }
   wave_sync();
 
+  // (non-temporal: nothing in this launch reads them again, and whole lines that have already left the L2 shorten the
+  // write-back at the end of the launch; partial-line stores -- rew, done, the ring slot -- must NOT be: they turn
+  // into read-modify-writes at the memory and add 10 us)
   // ---- coalesced stores: record, obs [3][26] (78 floats), share_obs [29], info --------------------------------------
-  recp[lane] = sh.rec[lane];
+  __builtin_nontemporal_store(sh.rec[lane], &recp[lane]);
   const int terminal = (rel + 1 >= S.episode_steps) ? 1 : 0;
   {
     const float v0 = obs_padded_at(sh.pool, lane);
-    obs[(size_t)env * SDC_OBS_OUT + lane] = v0;
+    __builtin_nontemporal_store(v0, &obs[(size_t)env * SDC_OBS_OUT + lane]);
     if (terminal && final_obs) final_obs[(size_t)env * SDC_OBS_OUT + lane] = v0;
     if (lane < SDC_OBS_OUT - SDC_WAVE) {
       const float v1 = obs_padded_at(sh.pool, SDC_WAVE + lane);
-      obs[(size_t)env * SDC_OBS_OUT + SDC_WAVE + lane] = v1;
+      __builtin_nontemporal_store(v1, &obs[(size_t)env * SDC_OBS_OUT + SDC_WAVE + lane]);
       if (terminal && final_obs) final_obs[(size_t)env * SDC_OBS_OUT + SDC_WAVE + lane] = v1;
     }
   }
-  if (share_obs && lane < SDC_SHARE_OBS_DIM) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = sh.pool[lane];
-  if (info && lane < SDC_INFO_DIM) info[(size_t)env * SDC_INFO_DIM + lane] = sh.info[lane];
+  if (share_obs && lane < SDC_SHARE_OBS_DIM) __builtin_nontemporal_store(sh.pool[lane], &share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane]);
+  if (info && lane < SDC_INFO_DIM) __builtin_nontemporal_store(sh.info[lane], &info[(size_t)env * SDC_INFO_DIM + lane]);
   if (lane == 0) done[env] = (unsigned char)terminal;
 }
 
