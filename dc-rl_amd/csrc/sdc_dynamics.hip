@@ -803,7 +803,12 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics
                                                                                 float* __restrict__ rew) {
   __shared__ DynShared shs[SDC_WPB];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
-  const int env = blockIdx.x * SDC_WPB + wave;
+  // Workgroup b runs on XCD b % 8 (the dispatcher deals workgroups round-robin to the 8 XCDs, each with its own L2):
+  // give every XCD a CONTIGUOUS range of envs, so that output lines shared by neighbouring envs (rew, done, the
+  // unaligned obs rows) are assembled in one L2 instead of being written back in pieces from several.
+  const int nb = (int)gridDim.x;
+  const int vb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int env = vb * SDC_WPB + wave;
   const int lane = threadIdx.x % SDC_WAVE;
   if (env >= S.n_envs) return;
   if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env, 0);
@@ -826,7 +831,9 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_rollout_
                                                                                float* __restrict__ rew) {
   __shared__ DynShared shs[SDC_WPB];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
-  const int env = blockIdx.x * SDC_WPB + wave;
+  const int nb = (int)gridDim.x;   // (each XCD a contiguous range of envs: see sdc_dynamics_kernel)
+  const int vb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int env = vb * SDC_WPB + wave;
   const int lane = threadIdx.x % SDC_WAVE;
   const size_t N = (size_t)S.n_envs;
   if (env >= S.n_envs) return;
