@@ -329,7 +329,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     o.avg = avg_norm;
     for (int b = 0; b < 5; b++) o.hist[b] = hist[b];
     o.have_past = ip >= 16;
-    if (feat_ok) {
+    if (__builtin_expect(feat_ok, 1)) {
       // the trace-only entries come from the episode's feature row (sdc_features.hip), one float per lane; lane 1
       // adds the nine entries that depend on the step
       constexpr unsigned TRACE_ONLY = 0x7u | (0x7Fu << SDC_P_CI7) | (1u << SDC_P_W) | (1u << SDC_P_NT) | (1u << SDC_P_TSLOPE) |
@@ -452,7 +452,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
   // answer without reading the history ring; a miss rebuilds them from the ring right here.
   {
     using namespace sdc_rw;
-    if ((S.debug_flags & 8) && lane == 0) sh.dbg_t = wall_clock64();
+    if (__builtin_expect((S.debug_flags & 8) != 0, 0) && lane == 0) sh.dbg_t = wall_clock64();
     const int n = (int)sfl((unsigned)hl);
     const unsigned x_old = (unsigned)__builtin_amdgcn_readlane((int)x_old_l, 63);   // (lane 63 loaded it at the start)
     const bool has_old = append && x_old != KEY_NONE;
@@ -460,7 +460,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
     double mean = 0.0, sd = 0.0;
     int path = 0;   // diagnostics: 0 no ring read, 1 a window re-centred ahead of need, 3 rebuilt
     const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), slot, x_new};
-    if (n >= 2) {
+    if (__builtin_expect(n >= 2, 1)) {
       int k1, k3;
       quartile_ranks(n, k1, k3);
       // quartile windows q1 / q3; clip-bound windows bu (upper bound, keys as they are) / bl (lower bound, keys
@@ -471,7 +471,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
       double A1 = rec_f64(hd0, H_A1), A2 = rec_f64(hd0, H_A2);
       bool ok = n >= SMALL_N && qt_valid(q1) && qt_valid(q3) && qt_valid(bu) && qt_valid(bl) && rec_i32(hd0, H_VALID) == 1;
       int why = ok ? 0 : 1;                            // diagnostics (debug_flags bit 1): why a rebuild was needed
-      if (ok && append) {
+      if (__builtin_expect(ok && append, 1)) {
         // O(1) updates: running sums, the four windows
         const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
         const int n_prev = has_old ? n : n - 1;
@@ -488,9 +488,9 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
       int qc0 = 0, qc1 = 0;
       double qs1_0 = 0.0, qs1_1 = 0.0, qs2_0 = 0.0, qs2_1 = 0.0;
       bool done_eval = false;
-      if (ok) {
+      if (__builtin_expect(ok, 1)) {
         unsigned a1, b1, a3, b3;
-        if (qt_resolve(q1, k1, n, a1, b1) && qt_resolve(q3, k3, n, a3, b3)) {
+        if (__builtin_expect(qt_resolve(q1, k1, n, a1, b1) && qt_resolve(q3, k3, n, a3, b3), 1)) {
           const Bounds b = clip_bounds(n, a1, b1, a3, b3);
           kb0 = b.kub;               // upper tail: keys >= kub
           kb1 = ~(b.klb - 1u);       // lower tail, flipped: ~x >= ~(klb-1)  <=>  x < klb
@@ -513,18 +513,18 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
           }
           const unsigned lo0 = min(kb0, kbl0), hi0 = max(kb0, kbl0), lo1 = min(kb1, kbl1), hi1 = max(kb1, kbl1);
           const bool cov0 = kb0 == kbl0 || qt_spans(bu, lo0, hi0, n), cov1 = kb1 == kbl1 || qt_spans(bl, lo1, hi1, n);
-          if (cov0 && cov1) {
+          if (__builtin_expect(cov0 && cov1, 1)) {
             int dc0 = 0, dc1 = 0;
             double d1_0 = 0.0, d2_0 = 0.0, d1_1 = 0.0, d2_1 = 0.0;
             const bool x0 = kb0 != kbl0 && win_crossing(bu, lo0, hi0, 0u, dc0, d1_0, d2_0);
             const bool x1 = kb1 != kbl1 && win_crossing(bl, lo1, hi1, KEY_NONE, dc1, d1_1, d2_1);
-            if (x0) {
+            if (__builtin_expect(x0, 0)) {
               const double sg = kb0 > kbl0 ? -1.0 : 1.0;   // bound moved out: the keys in between leave the tail
               qc0 += (kb0 > kbl0 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc0);
               qs1_0 += sg * wave_sum_f64(d1_0);
               qs2_0 += sg * wave_sum_f64(d2_0);
             }
-            if (x1) {
+            if (__builtin_expect(x1, 0)) {
               const double sg = kb1 > kbl1 ? -1.0 : 1.0;
               qc1 += (kb1 > kbl1 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc1);
               qs1_1 += sg * wave_sum_f64(d1_1);
@@ -543,7 +543,7 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
         }
       }
       bool valid = true;
-      if (!done_eval) {
+      if (__builtin_expect(!done_eval, 0)) {
         // miss (no state yet, a window that did not cover, an inconsistency): rebuild everything from the ring
         const Rebuilt rb = rebuild_state(R, lane, n, sh.tl);
         if (n < SMALL_N || !rb.ok) {   // tiny history (nothing to keep), or a ring no window can describe
@@ -580,13 +580,13 @@ __device__ __forceinline__ void step_dynamics(const SdcDev& S, const SdcDcDev& P
       // longer cover what is asked of it, re-centre it now -- at the end of this wavefront's life, when the memory
       // system is quiet and the other wavefronts of its SIMD are finishing -- instead of at the start of the next
       // launch, where the sweep's loads would queue behind every env's start-of-step traffic.
-      if (valid && n >= SMALL_N) {
+      if (__builtin_expect(valid && n >= SMALL_N, 1)) {
         int k1n, k3n;
         quartile_ranks((append && n < S.hist_cap) ? n + 1 : n, k1n, k3n);
         // a bound's window is centred on the rank of the first key beyond the bound
         const int req = qt_refill_ahead(q1, k1n, n, 3, 6) | (qt_refill_ahead(q3, k3n, n, 3, 6) << 2) |
                         (qt_refill_ahead(bu, n - qc0, n, 10, 10) << 4) | (qt_refill_ahead(bl, n - qc1, n, 10, 10) << 6);
-        if (req != 0) {
+        if (__builtin_expect(req != 0, 0)) {
           __builtin_amdgcn_s_setprio(3);   // the step ends when the slowest wavefront does: let this one issue first
           // one copy of the refill code: the windows take turns through it
 #pragma unroll 1
@@ -689,7 +689,7 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
     const int rl = rec_i32(hd0, H_BL + T_R0), hl_ = rec_i32(hd0, H_BL + T_HI), tl = hl0 - rec_i32(hd0, H_QC + 1) - rl;
     const bool nearu = hu > 0 && ((tu >= hu - 12 && ru + hu < hl0) || (tu <= 12 && ru > 0));
     const bool nearl = hl_ > 0 && ((tl >= hl_ - 12 && rl + hl_ < hl0) || (tl <= 12 && rl > 0));
-    if (near1 || near3 || nearu || nearl) {
+    if (__builtin_expect(near1 || near3 || nearu || nearl, 0)) {
       __builtin_amdgcn_s_setprio(2);
       const volatile unsigned* ring = S.hist + (size_t)env * SDC_HIST_STRIDE;
 #pragma unroll
@@ -738,7 +738,7 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
     }
     return v;
   };
-  if (fast) {
+  if (__builtin_expect(fast, 1)) {
     // the row's input slots and the probes go to the places the gather would have put them
     unsigned* g32 = reinterpret_cast<unsigned*>(sh.g);
     const unsigned fb = (unsigned)__float_as_int(frow);
@@ -759,7 +759,7 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
   const uint4 qw0 = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env * SDC_WIN + lane];
   const unsigned long long dbg_a1 = (S.debug_flags & 8) ? wall_clock64() : 0ull;
   step_dynamics(S, PD, env, lane, r, a_ls, a_dc, a_bat, fault, x_old_l, hd0, qw0, feat_ok, frow, rew, sh);
-  if (S.debug_flags & 8) {
+  if (__builtin_expect((S.debug_flags & 8) != 0, 0)) {
     wave_sync();
     if (lane == 0) {
       const unsigned long long dbg_a3 = wall_clock64();

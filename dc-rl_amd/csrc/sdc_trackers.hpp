@@ -71,7 +71,7 @@ __device__ __forceinline__ QTrack qt_load(unsigned hd, int base, unsigned w) {
 __device__ __forceinline__ bool qt_evict(QTrack& q, const unsigned y, const int lane) {
   const int m = __popcll(__ballot(q.w < y));   // valid keys below y (KEY_NONE lanes never count)
   if (m >= q.hi) return false;                 // above the window: no rank inside it moves
-  if (lane_key(q.w, m) != y) {
+  if (__builtin_expect(lane_key(q.w, m) != y, 1)) {
     if (m == 0) q.r0 -= 1;                     // below the window: every rank inside it moves down
     else q.hi = 0;
     return false;
@@ -208,7 +208,7 @@ __device__ __forceinline__ bool qt_spans(const QTrack& q, const unsigned lo, con
 __device__ __forceinline__ bool win_crossing(const QTrack& q, const unsigned lo, const unsigned hi, const unsigned flip, int& c,
                                              double& s1, double& s2) {
   const bool in = q.w >= lo && q.w < hi;   // (KEY_NONE lanes: hi <= KEY_NONE)
-  if (__ballot(in) == 0ull) return false;
+  if (__builtin_expect(__ballot(in) == 0ull, 1)) return false;
   if (in) {
     const double v = key_f64(q.w ^ flip);
     c = 1;
