@@ -1,9 +1,34 @@
-"""Import shim: the package directory is named `dc-rl_amd` (not a valid Python identifier), so
-`import dc_rl_amd` resolves here and forwards to it."""
-import os as _os
+"""dc_rl_amd (also reachable as the directory name `dc-rl_amd`, a symlink): MI355X-native vectorised SustainDC step behind the reference's own surface.
 
-_real = _os.path.abspath(_os.path.join(_os.path.dirname(__file__), "..", "dc-rl_amd"))
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f
+Public surface (mirrors the reference's names for this path):
+  * `SustainDC`, `EnvConfig`                      -- sustaindc_env.py:34, :90
+  * `make_ls_env`, `make_dc_pyeplus_env`, `make_bat_fwd_env` -- utils/make_envs_pyenv.py:19, :75, :45
+  * `SustainDCVecEnv` (a `ShareVecEnv`), `make_train_env`, `make_eval_env`
+                                                   -- harl/envs/env_wrappers.py:53, harl/utils/envs_tools.py:49
+  * `SdcEngine`                                    -- thin ctypes wrapper over the C-ABI (include/sustaindc_hip.h)
+
+The compute path is the HIP extension `csrc/libsustaindc_hip.so` (hand-written gfx950 kernels).  There is
+no CPU fallback: constructing an engine without the extension or without an MI355X raises.
+"""
+__version__ = "0.1.0"
+
+_LAZY = {
+    "SdcEngine": ("engine", "SdcEngine"),
+    "SustainDC": ("sustaindc_env", "SustainDC"),
+    "EnvConfig": ("sustaindc_env", "EnvConfig"),
+    "SustainDCVecEnv": ("vec_env", "SustainDCVecEnv"),
+    "ShareVecEnv": ("vec_env", "ShareVecEnv"),
+    "make_train_env": ("envs_tools", "make_train_env"),
+    "make_eval_env": ("envs_tools", "make_eval_env"),
+    "make_ls_env": ("make_envs_pyenv", "make_ls_env"),
+    "make_dc_pyeplus_env": ("make_envs_pyenv", "make_dc_pyeplus_env"),
+    "make_bat_fwd_env": ("make_envs_pyenv", "make_bat_fwd_env"),
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        mod, attr = _LAZY[name]
+        return getattr(importlib.import_module("dc_rl_amd." + mod), attr)
+    raise AttributeError(name)

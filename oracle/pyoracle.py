@@ -1,7 +1,7 @@
 """ctypes binding of the CPU oracle (oracle/libsdc_oracle.so).
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg.  The product package (dc-rl_amd/) must never import this module.
+cpu_baseline leg.  The product package (dc_rl_amd/) must never import this module.
 """
 from __future__ import annotations
 

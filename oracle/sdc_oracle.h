@@ -2,7 +2,7 @@
  * sdc_oracle.h -- CPU restatement (plain C99, fp64, scalar, one env at a time) of the
  * reference's coupled SustainDC step.
  *
- * TEST INFRASTRUCTURE ONLY.  Nothing in the product (dc-rl_amd/, include/) may include,
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (dc_rl_amd/, include/) may include,
  * link or call this.  Allowed users: tests/, __graft_entry__.smoke() and bench.py's
  * `cpu_baseline` leg -- and there only as the checker / the timed CPU baseline.
  *

@@ -241,7 +241,7 @@ def run_fixture(spec):
     return out
 
 
-VARIANT_DIR = os.path.join(REPO, "dc-rl_amd", "configs")
+VARIANT_DIR = os.path.join(REPO, "dc_rl_amd", "configs")
 
 # reward-method codes of include/sustaindc_hip.h (sdc_config.reward_method), per agent slot
 _ALT = {"custom_agent_reward": 2, "tou_reward": 3, "energy_efficiency_reward": 4, "energy_PUE_reward": 5,
