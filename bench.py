@@ -10,15 +10,38 @@ state by running real steps (`history_fill_steps`), so each timed step normalise
 One "step" = one sdc_step() call = one pass of the hot path over the batch: actions in -> obs, share_obs,
 rewards, dones, info out, auto-reset included (SURVEY.md section 8(d) `Metric`).
 
+Timing: the timed region is R back-to-back blocks of K = --steps steps, bracketed by barrier +
+torch.cuda.synchronize() on both sides; R is chosen so that the region lasts >= 200 ms (R = 1 once K alone does),
+so a short `--steps 20` run measures the same steady state as a long one instead of the first launches after
+an idle GPU.  `value` = envs x K x R / wall time of the region (MAX over ranks); HIP events at the block
+boundaries give the per-block times (`block_ms_median` etc.) without extra synchronisation.
+
+Roofline: the step is ONE kernel and it is NOT HBM bound -- it keeps the reward normalisation's order statistics
+incrementally instead of streaming the 40 KB history, so it is bound by VALU issue and dependent-instruction
+latency of wave-uniform fp64 physics.  `roofline.frac` is therefore the measured VALU-busy fraction (PMC
+SQ_ACTIVE_INST_VALU against the SIMD-cycles of the launch), `hbm_frac` = PMC bytes / kernel time / 8 TB/s, both
+physical and <= 1.  The bytes the REFERENCE algorithm would move (4*H + 1540 per env-step) over
+the kernel time is reported separately as `effective_hbm_frac` and may exceed 1.  The PMC counters are collected
+in this very run (rank 0, N = 1) by short `rocprofv3 --pmc ... --kernel-trace` passes over `bench.py --pmc-inner`;
+if rocprofv3 is not usable the numbers fall back to profiles/pmc_latest.json, which carries the hash of the
+kernel sources it was measured at (`pmc_source`, `pmc_current`).
+
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run, one
-rank per GPU; prints ONE JSON line on rank 0.
+rank per GPU; prints ONE JSON line on rank 0.  SDC_DIST_BACKEND=gloo runs the N > 1 path without RCCL (ranks may
+then share a device: LOCAL_RANK is taken modulo the visible device count) -- used by the 2-ranks-on-1-GPU test.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -29,8 +52,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
+MAX_CLOCK_GHZ = 2.4
 HIST_CAP = 10000
 ALG_BYTES_FIXED = 1540      # B(H) = 4*H + 1540 bytes per env-step
+STEP_KERNEL = "sdc_dynamics_kernel"
+MIN_REGION_S = 0.2
 
 
 def alg_bytes_per_env_step(h):
@@ -49,17 +76,26 @@ def host_cores():
     return n
 
 
-def build_engine(n_envs, episode_steps, device, seed, dc_files=("dc_config.json",), debug_flags=0):
+def csrc_hash():
+    """Hash of the kernel sources: PMC numbers are only valid for the binary they were measured on."""
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dc_rl_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def build_engine(n_envs, episode_steps, device, seed, dc_files=("dc_config.json",), debug_flags=0, env_index_base=0):
     from dc_rl_amd import dc_config, traces
     from dc_rl_amd.engine import SdcEngine
     tb = traces.synthetic_tables("ny", seed=0)
     eng = SdcEngine(n_envs, episode_steps=episode_steps, device=device, auto_reset=True, seed=seed,
-                    n_dc_configs=len(dc_files), debug_flags=debug_flags)
+                    n_dc_configs=len(dc_files), debug_flags=debug_flags, env_index_base=env_index_base)
     eng.set_tables(0, tb["W"], tb["C"], tb["T"], tb["WB"])
     params = [dc_config.size_datacenter(f, 1, traces.max_ambient_for_sizing("NY")) for f in dc_files]
     for i, p in enumerate(params):
         eng.set_dc_params(i, p)
-    e = np.arange(n_envs)
+    e = env_index_base + np.arange(n_envs)                               # GLOBAL env index (sharded jobs)
     init_day = np.array([traces.get_init_day(int(m)) for m in e % 12])   # harl/utils/envs_tools.py:58-59
     eng.assign(0, e % len(dc_files), np.maximum(0, init_day - 7), np.minimum(364, init_day + 7))
     return eng, tb, params
@@ -76,7 +112,7 @@ def cpu_baseline(tb, params, episode_steps, budget_s=12.0):
     cores = host_cores()
     p = G.oracle_params_from_dict(params[0])
     rng = np.random.default_rng(99)
-    envs, keep = [], []
+    envs = []
     for c in range(cores):
         dr = host_reset_draw(rng, tb, 174, 188, episode_steps)
         c0 = dr["c0"]
@@ -111,7 +147,86 @@ def cpu_baseline(tb, params, episode_steps, budget_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": round(cores * n / dt, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
             "per_core": round(n / dt, 1),
-            "sample": f"{n} steps x {cores} envs (one per host thread), history ring full (10000), fp64 C oracle"}
+            "sample": f"{n} steps x {cores} envs (one per host thread), history ring full (10000), fp64 C oracle "
+                      "(one normalize_energy per step where the reference's Python runs three)",
+            "reference_python_steps_per_s_per_core": 227}   # SURVEY.md section 6 (quoted, not measured here)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PMC passes: rocprofv3 over a short inner run of this script
+
+PMC_PASSES = (
+    ("fetch", ["FETCH_SIZE"]),
+    ("write", ["WRITE_SIZE"]),
+    ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES",
+            "SQ_INSTS_LDS"]),
+    ("grbm", ["GRBM_GUI_ACTIVE"]),
+)
+
+
+def _pmc_parse(dirname, last):
+    out = {}
+    for fn in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        vals = {}
+        with open(fn, newline="") as f:
+            for row in csv.DictReader(f):
+                if STEP_KERNEL in row.get("Kernel_Name", ""):
+                    vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        for k, v in vals.items():
+            tail = v[-last:]
+            out[k] = sum(tail) / len(tail)
+            out["_launches_" + k] = len(v)
+    return out
+
+
+def pmc_collect(args, timeout_s=240):
+    """Counters of the step kernel from separate rocprofv3 passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE
+    cannot share a pass; --pmc with --kernel-trace only).  Returns (dict, error string or None)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    res, errs = {}, []
+    work = tempfile.mkdtemp(prefix="sdc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for name, ctrs in PMC_PASSES:
+            d = os.path.join(work, name)
+            cmd = [exe, "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-inner", "--steps", "48", "--warmup", "16",
+                   "--envs-per-gpu", str(args.envs_per_gpu), "--episode-steps", str(args.episode_steps)]
+            if args.mixed_racks:
+                cmd.append("--mixed-racks")
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                   timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                errs.append(f"rocprofv3 pass '{name}' timed out")
+                continue
+            got = _pmc_parse(d, last=32)
+            if not any(c in got for c in ctrs):
+                errs.append(f"rocprofv3 pass '{name}' gave no counters (rc {p.returncode}): " +
+                            p.stdout.decode(errors="replace")[-200:])
+                continue
+            res.update(got)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return (res or None), ("; ".join(errs) or None)
+
+
+def pmc_summary(c):
+    """Raw counters -> per-launch figures (gfx950 corrections of MI355X_MICROARCH.md section HBM)."""
+    out = {"raw": {k: v for k, v in c.items() if not k.startswith("_")}}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fetch = c["FETCH_SIZE"] * 1024 * 2      # KiB; gfx950 tallies 128-B read requests at 64 B
+        write = c["WRITE_SIZE"] * 1024          # KiB; uncalibrated, as reported
+        out.update(fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write)
+    w = c.get("SQ_WAVES", 0.0)
+    if w:
+        out["per_wave"] = {k[len("SQ_INSTS_"):].lower(): round(c[k] / w, 1) for k in c if k.startswith("SQ_INSTS_")}
+        out["waves_per_launch"] = w
+    if "SQ_ACTIVE_INST_VALU" in c:
+        out["valu_active_simd_cycles_per_launch"] = 4.0 * c["SQ_ACTIVE_INST_VALU"]   # SQ_ACTIVE_INST_* count quad-cycles
+    return out
 
 
 def main():
@@ -123,8 +238,12 @@ def main():
     ap.add_argument("--episode-steps", type=int, default=672)
     ap.add_argument("--mixed-racks", action="store_true", help="BASELINE configs[3]: 16/20/25-rack mix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (use profiles/pmc_latest.json)")
+    ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--no-fill", action="store_true", help="skip the history fill (debug only; invalid as a result)")
+    ap.add_argument("--repeats", type=int, default=0, help="blocks of --steps in the timed region (0 = until >= 200 ms)")
     ap.add_argument("--profile-every", type=int, default=7, help="stamp the kernels' wall-clock entry / exit every k-th step (0 = off)")
+    ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps
     args = ap.parse_args()
 
     import torch
@@ -132,37 +251,72 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SDC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev = local_rank if backend == "nccl" else local_rank % max(1, ndev)
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    else:
+        dev = 0
+        torch.cuda.set_device(dev)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    dev = local_rank if world > 1 else 0
-    torch.cuda.set_device(dev)
+    cdev = torch.device("cuda", dev)
+
+    def all_reduce(t, op=None):
+        """RCCL on device tensors; with gloo the (tiny) tensor takes the host round trip."""
+        if world == 1:
+            return t
+        op = op or dist.ReduceOp.SUM
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+        return t
+
+    ranks_seen = 1
+    if world > 1:
+        ranks_seen = int(all_reduce(torch.ones(1, dtype=torch.float64, device=cdev)).item())
+
     N = args.envs_per_gpu
     dc_files = ("dc_config.json", "dc_config_r16.json", "dc_config_r25.json") if args.mixed_racks else ("dc_config.json",)
-    eng, tb, params = build_engine(N, args.episode_steps, dev, seed=1234 + rank, dc_files=dc_files)
+    # one job seed; the reset RNG is keyed on the GLOBAL env index, so the job is the same set of environments
+    # whatever the number of GPUs it is sharded over
+    eng, tb, params = build_engine(N, args.episode_steps, dev, seed=1234, dc_files=dc_files, env_index_base=rank * N)
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)   # SURVEY 8(d): seed 1234
-    pool = torch.randint(0, 3, (64, N, 3), dtype=torch.int32, generator=g).to(f"cuda:{dev}")
+    # actions: i.i.d. uniform per env and step.  A pool of 1024 pre-generated steps indexed by a GLOBAL step counter --
+    # a short cycle (say one block of --steps 20 repeated) gives every env a periodic action sequence, which narrows
+    # its energy history and measurably changes the workload (more window re-centrings): 24 vs 21 us per step
+    POOL = 1024
+    pool = torch.randint(0, 3, (POOL, N, 3), dtype=torch.int32, generator=g).to(cdev)
+    step_no = 0
     eng.reset()
 
-    ret_stats = torch.zeros(7, dtype=torch.float64, device=f"cuda:{dev}")  # sum r[3], sum r^2[3], episodes
+    ret_stats = torch.zeros(7, dtype=torch.float64, device=cdev)  # sum r[3], sum r^2[3], episodes
     steps_in_episode = 0
     EP_COLS = slice(40, 43)
+    n_collectives = 0
 
-    def one_step(i):
-        nonlocal steps_in_episode
-        obs, share, rew, done, info = eng.step(pool[i & 63])
+    def one_step(_i=None):
+        nonlocal steps_in_episode, n_collectives, step_no
+        obs, share, rew, done, info = eng.step(pool[step_no % POOL])
+        step_no += 1
         steps_in_episode += 1
         if steps_in_episode == args.episode_steps:   # every env finished: fixed-length episodes in lock-step
             steps_in_episode = 0
             r = info[:, EP_COLS].double()
             st = torch.cat([r.sum(0), (r * r).sum(0), torch.tensor([float(N)], dtype=torch.float64, device=r.device)])
-            if world > 1:
-                dist.all_reduce(st)                  # RCCL: the only collective
+            all_reduce(st)                           # RCCL: the only collective (SURVEY 8(e))
+            n_collectives += 1
             ret_stats.add_(st)
 
     fill = 0 if args.no_fill else HIST_CAP
@@ -172,112 +326,195 @@ def main():
         one_step(i)
     hlen = int(eng.get_state("hist_len").min())
 
+    if args.pmc_inner:        # the short run the counter passes wrap: steady-state launches only, nothing printed
+        for i in range(args.steps):
+            one_step(i)
+        torch.cuda.synchronize()
+        eng.close()
+        return
+
+    # ---- calibrate the number of blocks: the timed region should last >= MIN_REGION_S ---------------------------------
+    K = args.steps
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(64):
+        one_step(i)
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / 64
+    R = args.repeats if args.repeats > 0 else max(1, int(np.ceil(MIN_REGION_S / max(1e-9, est * K))))
+    if world > 1:   # every rank times the same number of blocks
+        R = int(all_reduce(torch.tensor([float(R)], dtype=torch.float64, device=cdev), dist.ReduceOp.MAX).item())
+    R = min(R, 4096)
+
     eng.profile(args.profile_every)   # in-kernel wall-clock stamps of every k-th timed step (sdc_profile_enable)
     eng.profile_read(reset=True)
+    coll0 = n_collectives
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # HIP events on the launch stream (the engine launches on torch's current stream) bracket the timed launches
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # HIP events on the launch stream (the engine launches on torch's current stream) at the block boundaries
+    # (an event record is a system-scope release on this runtime -- the launch after it starts with cold caches, ~70 us
+    # -- so events are at least EV_STEPS steps apart: a group of blocks per event when K is small)
+    EV_STEPS = 1000
+    bpe = max(1, -(-EV_STEPS // K))            # blocks per event interval
+    evs = [torch.cuda.Event(enable_timing=True)]
     t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        one_step(i)
-    ev1.record()
+    evs[0].record()
+    for b in range(R):
+        for i in range(K):
+            one_step(i)
+        if (b + 1) % bpe == 0 or b == R - 1:
+            evs.append(torch.cuda.Event(enable_timing=True))
+            evs[-1].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    nb = [min(bpe, R - j * bpe) for j in range(len(evs) - 1)]            # blocks in each event interval
+    block_ms = np.array([evs[j].elapsed_time(evs[j + 1]) / nb[j] for j in range(len(evs) - 1)])   # per block of K steps
+    ev_ms = float(sum(evs[j].elapsed_time(evs[j + 1]) for j in range(len(evs) - 1)))
     prof = eng.profile_read(reset=True)
     if prof["steps"] == 0:     # profiling was off in the timed region: sample the kernels in a short extra pass
         eng.profile(1)
         for i in range(64):
             one_step(i)
         prof = eng.profile_read(reset=True)
-        eng.profile(0)
+    eng.profile(0)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = float(all_reduce(torch.tensor([dt], dtype=torch.float64, device=cdev), dist.ReduceOp.MAX).item())
     faults = int((eng.info[:, 37] != 0).sum().item())
     fallbacks = [int((eng.info[:, 39] == v).sum().item()) for v in (1, 3)]
+    timed_steps = K * R
+
+    # the amortised cost of the episode boundary (device-side reset + the episode's feature rows), measured on its own:
+    # it is inside `value` (auto-resets happen in the timed region) but not inside the step kernel's duration
+    reset_us = None
+    if world == 1:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            eng.reset()
+        e1.record()
+        torch.cuda.synchronize()
+        reset_us = e0.elapsed_time(e1) / 3 * 1e3
+        steps_in_episode = 0
 
     if rank == 0:
         total_envs = N * world
-        value = total_envs * args.steps / dt
+        value = total_envs * timed_steps / dt
         b = alg_bytes_per_env_step(hlen)
         nst = max(1, prof["steps"])
-        k_dyn = prof["dynamics_ms"] / nst * 1e-3     # average launch duration, in-kernel wall-clock stamps
+        k_dyn = prof["dynamics_ms"] / nst * 1e-3     # first wavefront's entry -> last one's exit, in-kernel stamps
         k_rst = prof["reset_ms"] / max(1, prof["resets"]) * 1e-3
-        # the step is ONE kernel: its average launch duration = HIP-event time over the timed launches / launches
-        # (dispatch gaps between back-to-back launches included, so this is the conservative figure; the span from
-        # the first wavefront's entry to the last one's exit, from in-kernel clock stamps, is reported next to it)
-        k_evt = ev_ms * 1e-3 / args.steps
-        achieved = b * N / k_evt / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # the step is ONE kernel: HIP-event time over the timed launches / launches = its average launch duration
+        # with the dispatch gaps between back-to-back launches (and the ~1/672 auto-resets) included
+        k_evt = ev_ms * 1e-3 / timed_steps
         out = {
             "metric": "coupled env-steps/s", "value": round(value, 1), "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(dt / timed_steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 dynamics / f32 history ring + outputs", "data": "synthetic",
+            "repeats": R, "timed_steps": timed_steps, "ranks_seen": ranks_seen,
+            "dist_backend": (backend if world > 1 else None),
+            "block_ms_median": round(float(np.median(block_ms)), 5), "block_ms_min": round(float(block_ms.min()), 5),
+            "block_ms_max": round(float(block_ms.max()), 5),
             "config": {"workload": ("4096 envs x mixed 16/20/25-rack dc configs" if args.mixed_racks else
                                     "BASELINE configs[2]: 4096 parallel envs, dc_config.json (20 racks), 1xMI355X")
-                       if world == 1 else f"BASELINE configs[4]: {total_envs} envs sharded {world}xMI355X (4096/GPU)",
+                       if world == 1 else f"BASELINE configs[4]: {total_envs} envs sharded {world}xMI355X ({N}/GPU)",
                        "envs_per_gpu": N, "episode_steps": args.episode_steps, "history_len": hlen,
-                       "history_fill_steps": fill, "auto_reset": True, "actions": "uniform {0,1,2}, device-resident",
+                       "history_fill_steps": fill, "auto_reset": True, "actions": "i.i.d. uniform {0,1,2}, device-resident pool of 1024 steps",
                        "parallelism": f"env-shard x{world}", "faults": faults,
+                       "return_stats_all_reduces_in_timed_region": n_collectives - coll0,
                        "ring_read_envs_last_step": {"window_recentred_ahead_of_need": fallbacks[0], "rebuild": fallbacks[1]}},
-            # the one kernel of a step.  `achieved` prices the reference algorithm's bytes (the whole
-            # history window is read every step); the trackers make most steps skip that read, so the HBM bytes
-            # actually moved (`traffic`, PMC) are far below it and `frac` is an effective, not a physical, bandwidth.
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "sdc_dynamics_kernel", "kernel_avg_us": round(k_evt * 1e6, 2),
-                         "kernel_first_entry_to_last_exit_us": round(k_dyn * 1e6, 2),
-                         "alg_bytes_per_env_step": b, "alg_bytes_per_launch": b * N,
-                         "timed_launches": prof["steps"],
-                         "other_kernels": {"sdc_reset_kernel_avg_us": round(k_rst * 1e6, 2), "auto_resets": prof["resets"]},
-                         "frac_without_history_term": round(ALG_BYTES_FIXED * N / k_evt / 1e9 / HBM_PEAK_GBPS, 5),
-                         "note": "effective bandwidth: algorithmic bytes of the reference's per-step history pass / "
-                                 "kernel time; the kernel keeps that state incrementally (traffic = bytes really "
-                                 "moved) and is fp64-VALU / latency bound (DESIGN.md section 4)"},
             "return_stats": {"episodes": int(ret_stats[6].item()),
                              "mean_return": [round(float(x), 3) for x in (ret_stats[0:3] / max(1.0, float(ret_stats[6].item())))]},
         }
-        if world == 1:
+        if reset_us is not None:
+            out["episode_boundary"] = {"reset_plus_features_us": round(reset_us, 1),
+                                       "amortised_us_per_step": round(reset_us / args.episode_steps, 3),
+                                       "note": "sdc_reset_kernel + sdc_features_kernel, once per episode; inside `value`"}
+
+        # ---- roofline of the step kernel ---------------------------------------------------------------------------------
+        pmc, pmc_err, pmc_src = None, None, None
+        here = csrc_hash()
+        latest = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if world == 1 and not args.no_pmc:
+            c, pmc_err = pmc_collect(args)
+            if c is not None:
+                pmc, pmc_src = pmc_summary(c), "this run (rocprofv3 --pmc passes over bench.py --pmc-inner)"
+                pmc["csrc_sha"] = here
+        if pmc is None and os.path.exists(latest):
+            try:
+                pmc = json.load(open(latest))
+                pmc_src = f"profiles/pmc_latest.json (measured at csrc_sha {pmc.get('csrc_sha')})"
+            except Exception as e:
+                pmc_err = (pmc_err or "") + f"; pmc_latest.json unreadable: {e!r}"
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        valu_cyc = pmc.get("valu_active_simd_cycles_per_launch") if pmc else None
+        simd_cycles = N_SIMD * k_evt * MAX_CLOCK_GHZ * 1e9            # SIMD-cycles the launch occupies at max clock
+        valu_busy = (valu_cyc / simd_cycles) if valu_cyc else None
+        eff = b * N / k_evt / 1e9
+        roof = {
+            "bound": "valu", "kernel": STEP_KERNEL,
+            # achieved / peak in SIMD-cycles with a VALU instruction executing per launch (PMC SQ_ACTIVE_INST_VALU x 4)
+            # against the SIMD-cycles of the launch: 1024 SIMDs x kernel_avg_us x 2.4 GHz
+            "achieved": round(valu_cyc / 1e6, 3) if valu_cyc else None, "peak": round(simd_cycles / 1e6, 3),
+            "unit": "M SIMD-cycles per launch (VALU active / available)",
+            "frac": round(valu_busy, 4) if valu_busy else None,
+            "traffic": traffic,
+            "hbm_frac": round(traffic / k_evt / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+            "hbm_achieved_GBps": round(traffic / k_evt / 1e9, 1) if traffic else None, "hbm_peak_GBps": HBM_PEAK_GBPS,
+            "kernel_avg_us": round(k_evt * 1e6, 2),
+            "kernel_first_entry_to_last_exit_us": round(k_dyn * 1e6, 2),
+            "timed_launches": timed_steps,
+            "instructions_per_wavefront": pmc.get("per_wave") if pmc else None,
+            "wavefronts_per_launch": pmc.get("waves_per_launch") if pmc else None,
+            "alg_bytes_per_env_step": b, "alg_bytes_per_launch": b * N,
+            "effective_hbm_GBps": round(eff, 1), "effective_hbm_frac": round(eff / HBM_PEAK_GBPS, 4),
+            "effective_hbm_frac_without_history_term": round(ALG_BYTES_FIXED * N / k_evt / 1e9 / HBM_PEAK_GBPS, 5),
+            "pmc_source": pmc_src, "pmc_current": bool(pmc and pmc.get("csrc_sha") == here), "csrc_sha": here,
+            "other_kernels": {"sdc_reset_kernel_avg_us": round(k_rst * 1e6, 2), "auto_resets_sampled": prof["resets"]},
+            "note": "frac = VALU-busy fraction (physical, <= 1); hbm_frac = PMC bytes / kernel time / 8 TB/s (physical); "
+                    "effective_hbm_* price the REFERENCE algorithm's bytes (whole history window read every step), "
+                    "which this kernel does not move -- not a physical bandwidth (DESIGN.md section 4)",
+        }
+        if pmc_err:
+            roof["pmc_error"] = pmc_err[:400]
+        out["roofline"] = roof
+        if pmc and pmc_src and pmc_src.startswith("this run") and os.environ.get("SDC_WRITE_PMC"):
+            json.dump(pmc, open(latest, "w"), indent=1)
+
+        if world == 1 and not args.no_rollout:
             # next to the headline (one launch per step): sdc_rollout, 48 env-steps per launch for action sequences
             # known up front (scripted policies); same work per step, every step's outputs written
             try:
-                K, done_steps = 48, 0
-                seq = pool[:K].contiguous()
+                eng.reset()
+                for i in range(16):
+                    eng.step(pool[i])
+                Kr, done_steps = 48, 0
                 torch.cuda.synchronize()
                 tr = time.perf_counter()
-                while done_steps < 960:
-                    k = min(K, eng.steps_to_episode_end())
-                    eng.rollout(seq[:k])
+                while done_steps < 1920:
+                    k = min(Kr, eng.steps_to_episode_end())
+                    o = (16 + done_steps) % (POOL - Kr)
+                    eng.rollout(pool[o:o + k])
                     done_steps += k
                 torch.cuda.synchronize()
                 tr = time.perf_counter() - tr
-                out["rollout"] = {"steps_per_launch": K, "value": round(N * done_steps / tr, 1), "unit": "env-steps/s",
+                out["rollout"] = {"steps_per_launch": Kr, "value": round(N * done_steps / tr, 1), "unit": "env-steps/s",
                                   "ms_per_step": round(tr / done_steps * 1e3, 5)}
             except Exception as e:
                 out["rollout"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(tb, params, args.episode_steps)
-                out["cpu_baseline"]["reference_python_steps_per_s_per_core"] = 227
             except Exception as e:  # the oracle is only the timed baseline here; never hide the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

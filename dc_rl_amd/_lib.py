@@ -48,7 +48,7 @@ class SdcConfig(C.Structure):
         ("queue_max_len", C.c_int32), ("n_locations", C.c_int32), ("n_dc_configs", C.c_int32),
         ("auto_reset", C.c_int32), ("seed", C.c_uint64), ("weather_noise_std", C.c_double),
         ("weather_noise_weight", C.c_double), ("max_roll_days", C.c_int32), ("debug_flags", C.c_int32),
-        ("reward_method", C.c_int32 * 3), ("reserved1", C.c_int32),
+        ("reward_method", C.c_int32 * 3), ("env_index_base", C.c_int32),
     ]
 
 

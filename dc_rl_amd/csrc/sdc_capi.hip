@@ -172,6 +172,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   if (cfg->hist_cap < 2 || cfg->hist_cap > SDC_HIST_STRIDE)
     return fail_msg("sdc_create: hist_cap must be in [2, 10240]");
   if (cfg->n_locations <= 0 || cfg->n_dc_configs <= 0) return fail_msg("sdc_create: need >= 1 location and dc config");
+  if (cfg->env_index_base < 0) return fail_msg("sdc_create: env_index_base must be >= 0");
   if (cfg->queue_max_len <= 0 || cfg->queue_max_len > 65535) return fail_msg("sdc_create: bad queue_max_len");
   if ((long long)cfg->episode_steps * 20 > 0x7FFFFFFFLL / cfg->episode_steps)
     return fail_msg("sdc_create: episode too long for the 32-bit queue prefix sums");
@@ -201,6 +202,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   d.qstride = (cfg->episode_steps + 63) / 64 * 64;
   d.max_roll_days = cfg->max_roll_days;
   d.debug_flags = cfg->debug_flags;
+  d.env_base = cfg->env_index_base;
   for (int a = 0; a < 3; a++) {
     if (cfg->reward_method[a] < 0 || cfg->reward_method[a] > SDC_REWARD_WATER) {
       sdc_destroy(h);
@@ -237,7 +239,10 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
     A(d.walk_tmp, (size_t)N * w);
   }
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
-  (void)hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE);  // every slot empty
+  if (hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE) != hipSuccess) {  // every slot empty
+    sdc_destroy(h);
+    return fail_msg("sdc_create: clearing the history rings failed");
+  }
   A(d.hdr, (size_t)N * SDC_HDR_DWORDS);
   A(d.qwin, (size_t)N * (4 * SDC_WIN));
   d.feat = nullptr;

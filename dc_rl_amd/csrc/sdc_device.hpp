@@ -118,6 +118,7 @@ struct SdcDcDev {
 
 struct SdcDev {
   int n_envs, episode_steps, hist_cap, queue_max, table_len, lw, qstride, max_roll_days;
+  int env_base;     // global index of env 0 (sdc_config.env_index_base): keys the reset RNG
   int debug_flags;  // bit 0: cross-check the tracked order statistics against the bisection every step
   int reward_method[3];   // sdc_reward_method per agent slot (ls, dc, bat)
   unsigned long long seed;
@@ -380,7 +381,11 @@ __device__ __forceinline__ float obs_padded_at(const float* pool, int idx) {
     default: return 0.0f;
   }
 }
-__device__ __forceinline__ float share_obs_at(const float* pool, int idx) { return pool[idx]; }
+// HARL shared observation (harlsustaindc_env.py:78-80): ls state [0..25], states[1][11] = next workload, states[1][13]
+// = next outside temperature, states[2][-1].  The states are the PADDED 26-vectors (ss.pad_observations_v0 runs before
+// _create_shared_observation, harlsustaindc_env.py:25-26), so states[2][-1] is agent_bat's zero padding, not the SoC
+// the reference's comment names: slot 28 is always 0.0 there, and here.
+__device__ __forceinline__ float share_obs_at(const float* pool, int idx) { return idx == SDC_P_SOC ? 0.0f : pool[idx]; }
 
 // stage the obs windows for table cursor ip (= i') into LDS.  tsrc points at T[i'] of the env's weather
 // window (global memory, or LDS right after a device-side reset).  Called with tid = 0..63.

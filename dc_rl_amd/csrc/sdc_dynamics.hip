@@ -656,7 +656,15 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
   const unsigned r = recp[lane];
   unsigned hd0 = S.hdr[(size_t)env * SDC_HDR_DWORDS + lane];            // reward-side state: returns, trackers, sums
 
-  const int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
+  int a_ls = actions[env * 3 + 0], a_dc = actions[env * 3 + 1], a_bat = actions[env * 3 + 2];
+  // actions outside {0,1,2}: the reference's dict lookups raise (envs/dc_gym.py:160, bat_env_fwd_view.py:99); here
+  // the step flags SDC_FAULT_ACTION and treats the action as "do nothing" / "no change" / "idle"
+  const bool bad_action = (unsigned)a_ls > 2u || (unsigned)a_dc > 2u || (unsigned)a_bat > 2u;
+  if (__builtin_expect(bad_action, 0)) {
+    if ((unsigned)a_ls > 2u) a_ls = 1;
+    if ((unsigned)a_dc > 2u) a_dc = 1;
+    if ((unsigned)a_bat > 2u) a_bat = 2;
+  }
   const int i = rec_i32(r, R_CURSOR), rel = rec_i32(r, R_TREL);
   const int loc = rec_i32(r, R_LOC);
   const SdcDcDev& PD = S.dc[rec_i32(r, R_CFG)];
@@ -666,6 +674,7 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
   const int hourq_n = hourq + 1 >= 96 ? 0 : hourq + 1;
   unsigned fault = 0;
   if (i + 9 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
+  if (__builtin_expect(bad_action, 0)) fault |= SDC_FAULT_ACTION;
   // the ring slot this step's energy will overwrite: its current key is the evicted value the reward state's
   // order-statistic trackers need (issued with the gather below; 0xFFFFFFFF while the ring is still filling)
   const int hl0 = rec_i32(r, R_HIST_LEN);
@@ -787,7 +796,7 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
       if (terminal && final_obs) final_obs[(size_t)env * SDC_OBS_OUT + SDC_WAVE + lane] = v1;
     }
   }
-  if (share_obs && lane < SDC_SHARE_OBS_DIM) __builtin_nontemporal_store(sh.pool[lane], &share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane]);
+  if (share_obs && lane < SDC_SHARE_OBS_DIM) __builtin_nontemporal_store(share_obs_at(sh.pool, lane), &share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane]);
   if (info && lane < SDC_INFO_DIM) __builtin_nontemporal_store(sh.info[lane], &info[(size_t)env * SDC_INFO_DIM + lane]);
   if (lane == 0) done[env] = (unsigned char)terminal;
 }

@@ -37,7 +37,7 @@ __device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
 // four standard normals per Philox4x32-10 block: two Box-Muller pairs in fp32 (hardware log2 / sin / cos); the
 // random walk itself is accumulated in fp64.  Block c of (env, episode) yields the normals of samples 4c .. 4c+3.
 __device__ __forceinline__ void normals4(const SdcDev& S, int env, int episode, int c, float (&nz)[4]) {
-  const Philox4 r = philox4x32_10((unsigned)c, (unsigned)env, (unsigned)episode, 0x7E47u, (unsigned)S.seed,
+  const Philox4 r = philox4x32_10((unsigned)c, (unsigned)(S.env_base + env), (unsigned)episode, 0x7E47u, (unsigned)S.seed,
                                   (unsigned)(S.seed >> 32));
   const float k24 = 1.0f / 16777216.0f;
   const float u1 = ((float)(r.x >> 8) + 0.5f) * k24, u2 = ((float)(r.y >> 8) + 0.5f) * k24;   // (0, 1)
@@ -90,7 +90,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     if (day * 96 + hour * 4 + S.episode_steps + 17 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
   } else {
     // ---- draws: sustaindc_env.py:454-455 (day in [lo, hi], hour in [0, 23]); managers.py:601 (roll) ----
-    const Philox4 px = philox4x32_10(0u, (unsigned)env, (unsigned)episode, 0xD4A7u, (unsigned)S.seed,
+    const Philox4 px = philox4x32_10(0u, (unsigned)(S.env_base + env), (unsigned)episode, 0xD4A7u, (unsigned)S.seed,
                                      (unsigned)(S.seed >> 32));
     const int lo = rec_i32(r, R_DAY_LO), hi = rec_i32(r, R_DAY_HI);
     day = lo + (int)(((unsigned long long)px.x * (unsigned)(hi - lo + 1)) >> 32);

@@ -74,8 +74,10 @@ class ReturnStats:
 
 
 def make_sharded_train_env(env_name, seed, n_total_envs, env_args, return_torch=True):
-    """This rank's shard of an `n_total_envs`-env job: months / seeds follow the GLOBAL env index, so the job
-    is the same set of environments whatever the GPU count."""
+    """This rank's shard of an `n_total_envs`-env job: months follow the GLOBAL env index and the reset RNG is keyed
+    on (job seed, global env index, episode) -- `env_index_base` of the shard's engine -- so the job is the same set
+    of environments, drawing the same start days / hours / weather noise, whatever the GPU count
+    (tests/test_gpu_distributed.py checks a shard against the same envs of the unsharded batch)."""
     from .envs_tools import make_train_env
     rank, local_rank, world = init_process_group()
     lo, hi = shard_range(n_total_envs, rank, world)

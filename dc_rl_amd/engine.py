@@ -56,7 +56,7 @@ class SdcEngine:
     def __init__(self, n_envs: int, episode_steps: int = 672, device: int = 0, n_locations: int = 1,
                  n_dc_configs: int = 1, auto_reset: bool = True, seed: int = 0, hist_cap: int = 10000,
                  queue_max_len: int = 1000, weather_noise_std: float = 0.75, weather_noise_weight: float = 0.02,
-                 max_roll_days: int = 14, debug_flags: int = 0, reward_method=(0, 0, 0)):
+                 max_roll_days: int = 14, debug_flags: int = 0, reward_method=(0, 0, 0), env_index_base: int = 0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("SdcEngine needs an MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is False); "
@@ -72,7 +72,8 @@ class SdcEngine:
                           n_dc_configs=n_dc_configs, auto_reset=1 if auto_reset else 0, seed=seed,
                           weather_noise_std=weather_noise_std, weather_noise_weight=weather_noise_weight,
                           max_roll_days=max_roll_days, debug_flags=debug_flags,
-                          reward_method=(C.c_int32 * 3)(*[int(m) for m in reward_method]))
+                          reward_method=(C.c_int32 * 3)(*[int(m) for m in reward_method]),
+                          env_index_base=int(env_index_base))
         self._h = C.c_void_p()
         self._pinned_stream = None
         self._pinned_stream_obj = None

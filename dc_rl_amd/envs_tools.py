@@ -1,7 +1,10 @@
 """`make_train_env` / `make_eval_env`: the one function of the HARL stack that is re-targeted
 (harl/utils/envs_tools.py:49-103): `n_threads` environments become one device batch instead of
-`n_threads` worker processes.  Same month assignment and seeding rule as the reference:
-month = rank % 12 for rank < 12 else rank % 3 + 5 unless `month` is given; seed + rank * 1000.
+`n_threads` worker processes.  Same month assignment as the reference (month = rank % 12 for rank < 12 else
+rank % 3 + 5 unless `month` is given).  Seeding: the reference gives env `rank` the seed `seed + rank * 1000`
+(envs_tools.py:63); here the batch has ONE seed and the counter-based reset RNG is keyed on (seed, global env index,
+episode) -- distinct, reproducible streams per env, and the same streams for global env i whatever the number of GPUs
+the job is sharded over (`rank_offset`).
 """
 from __future__ import annotations
 
@@ -30,9 +33,9 @@ def make_train_env(env_name, seed, n_threads, env_args, device: int = 0, return_
     if env_name != "sustaindc":
         print("Can not support the " + env_name + "environment.")
         raise NotImplementedError
-    return SustainDCVecEnv(env_args, n_envs=n_threads, seed=seed + rank_offset * 1000,
+    return SustainDCVecEnv(env_args, n_envs=n_threads, seed=seed,
                            months=months_for_ranks(n_threads, env_args, rank_offset), device=device,
-                           return_torch=return_torch)
+                           return_torch=return_torch, env_index_base=rank_offset)
 
 
 def make_eval_env(env_name, seed, n_threads, env_args, device: int = 0, return_torch: bool = False,
@@ -41,9 +44,9 @@ def make_eval_env(env_name, seed, n_threads, env_args, device: int = 0, return_t
     if env_name != "sustaindc":
         print("Can not support the " + env_name + "environment.")
         raise NotImplementedError
-    return SustainDCVecEnv(env_args, n_envs=n_threads, seed=seed * 50000 + rank_offset * 10000,
+    return SustainDCVecEnv(env_args, n_envs=n_threads, seed=seed * 50000,
                            months=months_for_ranks(n_threads, env_args, rank_offset), device=device,
-                           return_torch=return_torch)
+                           return_torch=return_torch, env_index_base=rank_offset)
 
 
 def get_num_agents(env, env_args, envs):

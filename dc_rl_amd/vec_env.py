@@ -174,7 +174,7 @@ def _merge_args(env_args: Optional[dict]) -> dict:
 class SustainDCVecEnv(ShareVecEnv):
     def __init__(self, env_args: Union[dict, List[dict], None] = None, n_envs: int = 1, seed: int = 0,
                  months: Optional[Sequence[int]] = None, device: int = 0, return_torch: bool = False,
-                 auto_reset: bool = True, data_root: Optional[str] = None):
+                 auto_reset: bool = True, data_root: Optional[str] = None, env_index_base: int = 0):
         per_env = [_merge_args(a) for a in env_args] if isinstance(env_args, (list, tuple)) else [_merge_args(env_args)] * n_envs
         if len(per_env) != n_envs:
             raise ValueError("env_args list must have n_envs entries")
@@ -219,7 +219,7 @@ class SustainDCVecEnv(ShareVecEnv):
         self.bat_env.dcload_min = self.dc_env.power_lb_kW / 4
         self.engine = SdcEngine(n_envs, episode_steps=self.episode_steps, device=device, n_locations=len(loc_keys),
                                 n_dc_configs=len(cfg_keys), auto_reset=auto_reset, seed=seed, queue_max_len=1000,
-                                reward_method=self.reward_method)
+                                reward_method=self.reward_method, env_index_base=env_index_base)
         for i, tb in enumerate(self.tables):
             self.engine.set_tables(i, tb["W"], tb["C"], tb["T"], tb["WB"])
         for i, e in enumerate(self.dc_envs):
@@ -298,7 +298,8 @@ class SustainDCVecEnv(ShareVecEnv):
         if done_h.any():
             fo = self.engine.final_obs.cpu().numpy()
             for i in np.nonzero(done_h)[0]:
-                raw = np.concatenate([fo[i, 0, :26], fo[i, 1, 11:12], fo[i, 1, 13:14], fo[i, 2, 12:13]])
+                # states[2][-1] of the PADDED obs: agent_bat's zero padding (harlsustaindc_env.py:25-26, :80)
+                raw = np.concatenate([fo[i, 0, :26], fo[i, 1, 11:12], fo[i, 1, 13:14], fo[i, 2, 25:26]])
                 extra[(int(i), 0)] = {"original_obs": fo[i].copy(),
                                       "original_state": np.repeat(raw[None, :], 3, axis=0),
                                       "original_avail_actions": np.ones((3, 3), dtype=np.float32)}

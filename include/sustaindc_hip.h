@@ -86,6 +86,10 @@ enum sdc_info_col {
 #define SDC_FAULT_BAT_DISCHARGE 4u /* envs/bat_env_fwd_view.py:237 asserts */
 #define SDC_FAULT_WORKLOAD 8u      /* envs/carbon_ls.py:333-336 raises */
 #define SDC_FAULT_TABLE_RANGE 16u  /* cursor would leave the year table (reference: IndexError) */
+#define SDC_FAULT_ACTION 64u       /* agent_dc / agent_bat action outside {0,1,2} (the reference's action_mapping /
+                                      _action_to_direction lookups raise KeyError: envs/dc_gym.py:160, bat_env_fwd_view.py:99);
+                                      the step treats it as "no change" / "idle".  agent_ls: any other value is "do
+                                      nothing" in the reference too (envs/carbon_ls.py:266), flagged all the same */
 #define SDC_FAULT_ORDER_STAT 32u   /* debug_flags bit 0: the incremental reward state disagreed with the exact recomputation */
 
 typedef struct sdc_handle sdc_handle;
@@ -116,7 +120,11 @@ typedef struct {
                                SDC_REWARD_TOU, SDC_REWARD_ENERGY_EFFICIENCY, SDC_REWARD_PUE, SDC_REWARD_WATER.
                                As in the reference only default_ls_reward appends to the energy history
                                (reward_creator.py:63): the history grows iff reward_method[0] == SDC_REWARD_DEFAULT */
-  int32_t reserved1;
+  int32_t env_index_base;  /* global index of this batch's env 0 when the batch is one shard of a multi-GPU job: the
+                              counter-based RNG of device-side resets is keyed on (seed, env_index_base + env, episode),
+                              so a job draws the same start day / hour / roll / weather noise for global env i whatever
+                              the number of GPUs it is sharded over (harl/utils/envs_tools.py:56-65 keys months and
+                              seeds on the global rank the same way) */
 } sdc_config;
 
 enum sdc_reward_method {

@@ -53,7 +53,10 @@ def raw_obs(obs_padded):
 
 
 def share_from_raw(raw):
-    return np.concatenate([raw[..., :26], raw[..., 26 + 11:26 + 12], raw[..., 26 + 13:26 + 14], raw[..., 40 + 12:40 + 13]], axis=-1)
+    """harlsustaindc_env.py:78-80 on the padded states: ls state, states[1][11], states[1][13], states[2][-1] (= agent_bat's
+    zero padding; pinned against the reference's own HARL layer by tests/golden/harl_ny_n4.npz)."""
+    return np.concatenate([raw[..., :26], raw[..., 26 + 11:26 + 12], raw[..., 26 + 13:26 + 14],
+                           np.zeros_like(raw[..., :1])], axis=-1)
 
 
 def make_engine_for_fixture(d, n_envs=2, **kw):

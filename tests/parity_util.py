@@ -97,6 +97,32 @@ class ParityRig:
         obs, _ = self.eng.reset(override=ov)
         return G.raw_obs(obs.cpu().numpy()), oobs
 
+    def reset_some(self, mask):
+        """Inject a fresh episode into the masked envs only (sdc_reset with a mask): the others keep stepping where
+        they are, so the batch is no longer in lock-step.  Returns (engine raw obs [N,53], oracle raw obs {env: [53]})
+        -- rows of unmasked envs are whatever the engine's obs buffer held."""
+        N, lw = self.N, self.eng.lw
+        mask = np.asarray(mask, dtype=bool)
+        ov = dict(day=np.zeros(N, np.int32), hour=np.zeros(N, np.int32), ci_min=np.zeros(N), ci_max=np.ones(N),
+                  t_min=np.zeros(N), t_max=np.ones(N), t_win=np.zeros((N, lw)), wb_win=np.zeros((N, lw)))
+        oobs = {}
+        for i in np.nonzero(mask)[0]:
+            tb = self.tables[self.loc_id[i]]
+            dr = host_reset_draw(self.rng, tb, self.day_lo[i], self.day_hi[i], self.steps)
+            c0 = dr["c0"]
+            for k in ("day", "hour", "ci_min", "ci_max", "t_min", "t_max"):
+                ov[k][i] = dr[k]
+            ov["t_win"][i] = dr["T"][c0:c0 + lw]
+            ov["wb_win"][i] = dr["WB"][c0:c0 + lw]
+            if i in self.oracles:
+                lo, hi = max(0, c0 - 16), c0 + self.steps + 18
+                NC = (tb["C"][lo:hi] - dr["ci_min"]) / (dr["ci_max"] - dr["ci_min"])
+                NT = (dr["T"][lo:hi] - dr["t_min"]) / (dr["t_max"] - dr["t_min"])
+                oobs[int(i)] = self.oracles[i].begin(tb["W"][lo:hi], tb["C"][lo:hi], NC, dr["T"][lo:hi], dr["WB"][lo:hi],
+                                                     NT, lo, dr["day"], dr["hour"], self.steps)
+        obs, _ = self.eng.reset(mask=mask.astype(np.uint8), override=ov)
+        return G.raw_obs(obs.cpu().numpy()), oobs
+
     def step(self, actions_np):
         import torch
         a = torch.from_numpy(np.ascontiguousarray(actions_np, dtype=np.int32)).to(self.eng.device)
@@ -110,6 +136,7 @@ INFO_CMP = [k for k in po.INFO_COLS[:37] if not k.startswith("reserved")]
 
 def compare_step(rig, acts, worst, check_every_env=True):
     eo, es, er, ed, ei = rig.step(acts)
+    np.testing.assert_array_equal(es, G.share_from_raw(eo))   # share_obs is a re-arrangement of the same step's obs
     for i, orc in rig.oracles.items():
         oo, orew, odone, oinfo = orc.step(acts[i])
         worst["obs"] = max(worst["obs"], float(G.rel_err(eo[i], oo).max()))

@@ -1,0 +1,96 @@
+"""The N > 1 path on hardware inside a one-GPU lease: two torch.distributed ranks of bench.py share
+the one MI355X (gloo for the 7-double return-statistics all-reduce and the MAX timing reduction -- RCCL needs one
+device per rank), and a shard of a job is the same set of environments as the same index range of the unsharded job."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bench(world, extra_env=None):
+    common = ["--steps", "40", "--warmup", "8", "--envs-per-gpu", "256", "--episode-steps", "96", "--repeats", "6",
+              "--no-cpu-baseline", "--no-pmc", "--no-rollout"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+               "--gpus", str(world)] + common
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines          # ONE JSON line, printed by rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    one = _bench(1)
+    two = _bench(2, {"SDC_DIST_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["dist_backend"] == "gloo"
+    assert two["scaling"] == "weak" and two["config"]["envs_per_gpu"] == 256
+    assert two["config"]["parallelism"] == "env-shard x2"
+    # same number of steps on every rank: the all-reduced episode count doubles, and so does the number of envs behind `value`
+    assert one["timed_steps"] == two["timed_steps"] == 240
+    assert two["return_stats"]["episodes"] == 2 * one["return_stats"]["episodes"] > 0
+    assert two["config"]["return_stats_all_reduces_in_timed_region"] == one["config"]["return_stats_all_reduces_in_timed_region"] >= 2
+    assert two["value"] > 0 and two["ms_per_step"] > 0 and two["config"]["faults"] == 0
+    # rank 0 of the 2-rank job steps the same envs (global indices 0..255, same job seed) with the same actions as the
+    # 1-rank job: its share of the mean return is the same, the other rank's differs but is of the same size
+    m1, m2 = np.array(one["return_stats"]["mean_return"]), np.array(two["return_stats"]["mean_return"])
+    assert np.all(np.abs(m2 - m1) < 0.25 * np.abs(m1) + 1.0)
+
+
+def test_shard_is_the_same_environments_as_the_unsharded_job():
+    """Months follow the global env index (harl/utils/envs_tools.py:56-62) and the reset RNG is keyed on
+    (seed, env_index_base + env, episode): shard [lo, hi) of a job draws what envs lo..hi-1 of the whole job draw."""
+    import torch
+    from dc_rl_amd import dc_config, traces
+    from dc_rl_amd.engine import SdcEngine
+    from dc_rl_amd.envs_tools import months_for_ranks
+    from dc_rl_amd.distributed import shard_range
+    n_total, steps, seed = 96, 48, 77
+    tb = traces.synthetic_tables("ny", 0)
+    p = dc_config.size_datacenter("dc_config.json", 1, 30.0)
+
+    def mk(lo, hi):
+        e = SdcEngine(hi - lo, episode_steps=steps, auto_reset=True, seed=seed, env_index_base=lo)
+        e.set_tables(0, tb["W"], tb["C"], tb["T"], tb["WB"])
+        e.set_dc_params(0, p)
+        d0 = np.array([traces.get_init_day(m) for m in months_for_ranks(hi - lo, {}, rank_offset=lo)])
+        e.assign(0, 0, np.maximum(0, d0 - 7), np.minimum(364, d0 + 7))
+        return e
+
+    whole = mk(0, n_total)
+    lo, hi = shard_range(n_total, 1, 2)
+    shard = mk(lo, hi)
+    ow, _ = whole.reset()
+    os_, _ = shard.reset()
+    assert torch.equal(ow[lo:hi], os_)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    acts = torch.randint(0, 3, (60, n_total, 3), dtype=torch.int32, generator=g).cuda()
+    for t in range(60):     # crosses an auto-reset (episode 2 draws)
+        xw = whole.step(acts[t])
+        xs = shard.step(acts[t, lo:hi].contiguous())
+        for u, v in zip(xw, xs):
+            assert torch.equal(u[lo:hi], v), t
+    for name in ("day", "hourq", "cursor", "t_min", "t_den", "episode"):
+        np.testing.assert_array_equal(whole.get_state(name)[lo:hi], shard.get_state(name))
+    np.testing.assert_array_equal(whole.get_state("t_win")[lo:hi], shard.get_state("t_win"))
+    assert (whole.get_state("episode") == 2).all()
+    whole.close()
+    shard.close()

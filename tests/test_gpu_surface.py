@@ -59,7 +59,7 @@ def test_vec_env_shapes_and_auto_reset():
     np.testing.assert_array_equal(share[:, 0, :26], obs[:, 0])
     np.testing.assert_array_equal(share[:, 0, 26], obs[:, 1, 11])
     np.testing.assert_array_equal(share[:, 0, 27], obs[:, 1, 13])
-    np.testing.assert_array_equal(share[:, 0, 28], obs[:, 2, 12])
+    np.testing.assert_array_equal(share[:, 0, 28], obs[:, 2, 25])   # the padded bat state's last entry: 0
     day = envs.engine.get_state("day")
     from dc_rl_amd import traces
     for i, m in enumerate(envs.months):
