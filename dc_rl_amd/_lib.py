@@ -101,6 +101,7 @@ class SdcResetOverride(C.Structure):
         ("ci_min", C.POINTER(C.c_double)), ("ci_max", C.POINTER(C.c_double)),
         ("t_min", C.POINTER(C.c_double)), ("t_max", C.POINTER(C.c_double)),
         ("t_win", C.POINTER(C.c_double)), ("wb_win", C.POINTER(C.c_double)),
+        ("noise", C.POINTER(C.c_double)), ("roll_days", C.POINTER(C.c_int32)),
     ]
 
 

@@ -23,7 +23,8 @@ extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, int rel_hint, con
                                               unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
                                             const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
-                                            const double* ovr_t_max, int only_done, float* obs, float* share_obs);
+                                            const double* ovr_t_max, int only_done, float* obs, float* share_obs,
+                                            const double* inj_noise, const int* inj_roll);
 
 namespace {
 
@@ -400,7 +401,33 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
   } else {
     d.reset_mask = nullptr;
   }
-  if (ovr) {
+  double* inj_noise = nullptr;
+  int* inj_roll = nullptr;
+  const bool inject_noise = ovr && ovr->noise;
+  if (inject_noise) {
+    // the reference's own draws, the arithmetic on the device: day / hour / roll + the year's noise array per env
+    if (!ovr->day || !ovr->hour || !ovr->roll_days) return fail_msg("sdc_reset: noise injection needs day, hour and roll_days");
+    for (int e = 0; e < N; e++) {
+      if (mask_host && !mask_host[e]) continue;
+      if (ovr->day[e] < 0 || ovr->day[e] > 364 || ovr->hour[e] < 0 || ovr->hour[e] > 23 || ovr->roll_days[e] < 0 ||
+          ovr->roll_days[e] > 364)
+        return fail_msg("sdc_reset: injected day / hour / roll_days out of range");
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&inj_noise), sizeof(double) * (size_t)N * SDC_TABLE_LEN));
+    if (hipMalloc(reinterpret_cast<void**>(&inj_roll), sizeof(int) * (size_t)N) != hipSuccess) {
+      (void)hipFree(inj_noise);
+      return fail_msg("sdc_reset: allocation for the injected roll failed");
+    }
+    hipError_t e1 = hipMemcpy(inj_noise, ovr->noise, sizeof(double) * (size_t)N * SDC_TABLE_LEN, hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemcpy(inj_roll, ovr->roll_days, sizeof(int) * (size_t)N, hipMemcpyHostToDevice);
+    hipError_t e3 = hipMemcpy(h->ovr_day, ovr->day, sizeof(int) * (size_t)N, hipMemcpyHostToDevice);
+    hipError_t e4 = hipMemcpy(h->ovr_hour, ovr->hour, sizeof(int) * (size_t)N, hipMemcpyHostToDevice);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+      (void)hipFree(inj_noise);
+      (void)hipFree(inj_roll);
+      return fail_msg("sdc_reset: upload of the injected noise failed");
+    }
+  } else if (ovr) {
     if (!ovr->day || !ovr->hour || !ovr->ci_min || !ovr->ci_max || !ovr->t_min || !ovr->t_max || !ovr->t_win ||
         !ovr->wb_win)
       return fail_msg("sdc_reset: incomplete override");
@@ -429,9 +456,16 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
     // the host buffers may be pageable: the copies above must have consumed them before we return
     HIP_TRY(hipStreamSynchronize(st));
   }
-  hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, ovr ? 1 : 0, h->ovr_day, h->ovr_hour,
-                     h->ovr_ci_min, h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 0, obs, share_obs);
+  hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, inject_noise ? 2 : (ovr ? 1 : 0), h->ovr_day,
+                     h->ovr_hour, h->ovr_ci_min, h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 0, obs, share_obs, inj_noise,
+                     inj_roll);
   launch_features(h, d, st);
+  if (inject_noise) {
+    const hipError_t es = hipStreamSynchronize(st);
+    (void)hipFree(inj_noise);
+    (void)hipFree(inj_roll);
+    if (es != hipSuccess) return fail("sdc_reset: injected reset", es);
+  }
   HIP_TRY(hipGetLastError());
   if (mask_host) HIP_TRY(hipStreamSynchronize(st));  // mask staging buffer is reused by the next call
   sync_mirror(h);
@@ -473,7 +507,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
       d.reset_mask = nullptr;
       if (timed) h->prof_has_reset[h->prof_used] = 1;
       hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
-                         h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs, share_obs);
+                         h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs, share_obs, nullptr, nullptr);
       launch_features(h, d, st);
       HIP_TRY(hipGetLastError());
       for (int e = 0; e < N; e++)
@@ -513,7 +547,7 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
       const size_t last = (size_t)(n_steps - 1) * N;
       hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
                          h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs + last * SDC_OBS_OUT,
-                         share_obs ? share_obs + last * SDC_SHARE_OBS_DIM : nullptr);
+                         share_obs ? share_obs + last * SDC_SHARE_OBS_DIM : nullptr, nullptr, nullptr);
       launch_features(h, d, st);
       HIP_TRY(hipGetLastError());
       for (int e = 0; e < N; e++)

@@ -60,7 +60,9 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
                                                                           const double* __restrict__ ovr_t_min,
                                                                           const double* __restrict__ ovr_t_max,
                                                                           int only_done, float* __restrict__ obs,
-                                                                          float* __restrict__ share_obs) {
+                                                                          float* __restrict__ share_obs,
+                                                                          const double* __restrict__ inj_noise,
+                                                                          const int* __restrict__ inj_roll) {
   __shared__ ResetShared sh;
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
@@ -79,7 +81,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
   int day, hour;
   double ci_min, ci_den, t_min, t_den;
   const double* tsrc;
-  if (use_override) {
+  if (use_override == 1) {
     day = ovr_day[env];
     hour = ovr_hour[env];
     ci_min = ovr_ci_min[env];
@@ -90,12 +92,17 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     if (day * 96 + hour * 4 + S.episode_steps + 17 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
   } else {
     // ---- draws: sustaindc_env.py:454-455 (day in [lo, hi], hour in [0, 23]); managers.py:601 (roll) ----
+    // (use_override == 2: day, hour, roll and the year's noise array come from the caller -- what the reference's
+    // reset drew -- and only the arithmetic below runs here: add, roll, clip, 30-day min / max)
+    const bool injected = use_override == 2;
     const Philox4 px = philox4x32_10(0u, (unsigned)(S.env_base + env), (unsigned)episode, 0xD4A7u, (unsigned)S.seed,
                                      (unsigned)(S.seed >> 32));
     const int lo = rec_i32(r, R_DAY_LO), hi = rec_i32(r, R_DAY_HI);
-    day = lo + (int)(((unsigned long long)px.x * (unsigned)(hi - lo + 1)) >> 32);
-    hour = (int)(((unsigned long long)px.y * 24u) >> 32);
-    const int roll_days = S.max_roll_days > 0 ? (int)(((unsigned long long)px.z * (unsigned)S.max_roll_days) >> 32) : 0;
+    day = injected ? ovr_day[env] : lo + (int)(((unsigned long long)px.x * (unsigned)(hi - lo + 1)) >> 32);
+    hour = injected ? ovr_hour[env] : (int)(((unsigned long long)px.y * 24u) >> 32);
+    const int roll_days = injected ? inj_roll[env]
+                                   : (S.max_roll_days > 0 ? (int)(((unsigned long long)px.z * (unsigned)S.max_roll_days) >> 32) : 0);
+    const double* inj = injected ? inj_noise + (size_t)env * TL : nullptr;
     // year-end fence: the reference reads table[cursor + 1 .. + 17] and raises IndexError at the end of the
     // year; keep the whole episode inside the table instead
     {
@@ -111,7 +118,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     const int wlen = min(max(SDC_NORM_WINDOW, S.lw), TL - c0 + 0);  // samples of the rolled table we may touch
     double* walk = S.walk_tmp + (size_t)env * max(SDC_NORM_WINDOW, S.lw);
     double walk_std = 0.0;
-    if (S.noise_std > 0.0) {
+    if (S.noise_std > 0.0 && !injected) {
       // pass 1: CoherentNoise.generate (managers.py:35-48): random walk, its population std.
       // 256 samples per iteration: 4 per lane (one Philox block), lane-local prefix + wave scan of the lane totals.
       double carry = 0.0, sum = 0.0, sumsq = 0.0;
@@ -162,7 +169,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
     for (int rel = lane; rel < wlen; rel += SDC_WAVE) {
       int j = c0 + rel - shift;
       if (j < 0) j += TL;
-      const double nz = walk_std > 0.0 ? (walk[rel] / walk_std) * S.noise_std : 0.0;  // managers.py:47
+      const double nz = injected ? inj[j] : (walk_std > 0.0 ? (walk[rel] / walk_std) * S.noise_std : 0.0);  // managers.py:47
       const double t = fmin(fmax(tT[j] + nz, 0.0), 45.0);
       if (rel < SDC_NORM_WINDOW) {
         tmin = fmin(tmin, t);

@@ -141,7 +141,21 @@ class SdcEngine:
             mptr = m.ctypes.data_as(C.POINTER(C.c_uint8))
         optr = None
         keep = None
-        if override is not None:
+        if override is not None and "noise" in override:
+            # the reference's own draws (day, hour, roll, the year's coherent-noise array): the device does the rest
+            dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+            day = np.ascontiguousarray(override["day"], dtype=np.int32)
+            hour = np.ascontiguousarray(override["hour"], dtype=np.int32)
+            roll = np.ascontiguousarray(override["roll_days"], dtype=np.int32)
+            noise = np.ascontiguousarray(override["noise"], dtype=np.float64)
+            if noise.shape != (N, L.TABLE_LEN) or any(a.shape != (N,) for a in (day, hour, roll)):
+                raise ValueError(f"noise injection: noise ({N}, {L.TABLE_LEN}), day / hour / roll_days ({N},)")
+            nul = C.POINTER(C.c_double)()
+            o = L.SdcResetOverride(day.ctypes.data_as(ip), hour.ctypes.data_as(ip), nul, nul, nul, nul, nul, nul,
+                                   noise.ctypes.data_as(dp), roll.ctypes.data_as(ip))
+            keep = (day, hour, roll, noise, o)
+            optr = C.byref(o)
+        elif override is not None:
             dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
             day = np.ascontiguousarray(override["day"], dtype=np.int32)
             hour = np.ascontiguousarray(override["hour"], dtype=np.int32)
@@ -154,7 +168,8 @@ class SdcEngine:
             if tw.shape != (N, self.lw) or wb.shape != (N, self.lw):
                 raise ValueError(f"override weather windows must have shape ({N}, {self.lw})")
             o = L.SdcResetOverride(day.ctypes.data_as(ip), hour.ctypes.data_as(ip), *[a.ctypes.data_as(dp) for a in sc],
-                                   tw.ctypes.data_as(dp), wb.ctypes.data_as(dp))
+                                   tw.ctypes.data_as(dp), wb.ctypes.data_as(dp), C.POINTER(C.c_double)(),
+                                   C.POINTER(C.c_int32)())
             keep = (day, hour, sc, tw, wb, o)
             optr = C.byref(o)
         with self.torch.cuda.device(self.device):

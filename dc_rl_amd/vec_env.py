@@ -162,6 +162,14 @@ def _merge_args(env_args: Optional[dict]) -> dict:
     if env_args:
         a.update(env_args)
     L.reward_codes(a)   # NotImplementedError for a reward method the device does not run
+    # options of the reference's HARL layer that change what the runner receives: never silently ignored
+    if not a.get("nonoverlapping_shared_obs_space", True):
+        raise NotImplementedError("nonoverlapping_shared_obs_space=False (the 3 x 26 concatenated shared observation of "
+                                  "harlsustaindc_env.py:83-85) is not produced by the device; the 29-float layout is")
+    if not a.get("partial_obs", True):
+        raise NotImplementedError("Fully observable states are no longer supported. Please set 'partial_obs' to True.")
+    if a.get("actions_are_logits", False):
+        raise NotImplementedError("actions_are_logits=True: the device takes discrete actions {0,1,2}")
     unknown = [x for x in a["agents"] if x not in AGENTS]
     if unknown:
         raise ValueError(f"unknown agents {unknown}; the environment has {AGENTS}")

@@ -170,6 +170,13 @@ typedef struct {
   const double* t_max;
   const double* t_win;  /* [N][weather_window_len]: T[cursor0 + k] after noise+roll+clip */
   const double* wb_win; /* [N][weather_window_len]: wet bulb likewise */
+  /* Alternative injection one level earlier (noise != NULL; ci_min .. wb_win are then ignored and may be NULL): the
+   * draws of Weather_Manager.reset themselves -- the year's coherent-noise array as CoherentNoise.generate returned it
+   * (managers.py:35-48) and the roll in days (:601) -- next to day / hour.  The device then does what it does after
+   * its own draws: add the noise to the location's T / WB tables, roll, clip to [0, 45], take the 30-day min / max
+   * from the cursor (managers.py:596-613) and the CI bounds (:435-437). */
+  const double* noise;     /* [N][SDC_TABLE_LEN] or NULL */
+  const int32_t* roll_days; /* [N], with noise */
 } sdc_reset_override;
 
 const char* sdc_last_error(void);

@@ -16,8 +16,13 @@ def pytest_configure(config):
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
+# fixtures with their own layout and their own tests (not single-env episode fixtures)
+OTHER_FIXTURES = {"weather_resets", "harl_ny_n4", "rbc_ny_m7"}
+
+
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    """The single-env episode fixtures (tests/golden/gen_golden.py SPECS)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f[:-4] not in OTHER_FIXTURES)
 
 
 @pytest.fixture(scope="session")

@@ -284,6 +284,170 @@ SPECS = {
 }
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# weather fixture: pre-noise tables + reference resets
+
+def gen_weather_resets():
+    """`Weather_Manager` (utils/managers.py:488-628) for three locations: the pre-noise 15-minute tables it keeps
+    (`original_temp_data` / `original_wb_data`, :560-561) and, for a few seeded resets, the coherent noise, the roll and
+    the resulting episode windows / 30-day normalisation bounds.  The noise itself is not stored (280 KB per reset): it
+    is `np.random.seed(s); np.cumsum(0.02 * np.random.normal(0, 1, 35040))` rescaled (managers.py:45-47) -- NumPy's
+    legacy MT19937 stream is frozen -- and the fixture keeps every 32nd sample so a test can confirm that it regenerated
+    the same array."""
+    from utils.managers import Weather_Manager
+    from utils.utils_cf import obtain_paths
+    out = {"meta_locations": np.array(["ny", "az", "wa"])}
+    cases = [("ny", 101, 181, 13, 0), ("az", 102, 10, 0, 0), ("wa", 103, 300, 23, 0), ("ny", 104, 333, 5, 5)]
+    mgr = {}
+    for loc in ("ny", "az", "wa"):
+        _, wea = obtain_paths(loc)
+        for tz in sorted({c[4] for c in cases if c[0] == loc}):
+            wm = Weather_Manager(location=wea, timezone_shift=tz)
+            mgr[(loc, tz)] = wm
+            if tz == 0:
+                out[f"{loc}_T"] = np.asarray(wm.original_temp_data, dtype=np.float64)
+                out[f"{loc}_WB"] = np.asarray(wm.original_wb_data, dtype=np.float64)
+    W = 2880 + 18 + 96    # episode window of a 30-day episode (+18) and a day beyond
+    for k, (loc, seed, day, hour, tz) in enumerate(cases):
+        wm = mgr[(loc, tz)]
+        np.random.seed(seed)
+        wm.reset(init_day=day, init_hour=hour)
+        c0 = wm.time_step
+        # replay the same draws to capture what reset() consumed (same call sequence: generate(), then randint)
+        np.random.seed(seed)
+        noise = wm.coherent_noise.generate(len(wm.original_temp_data))
+        roll = int(np.random.randint(0, 14))
+        t_full = np.clip(np.roll(wm.original_temp_data + noise, roll * 96), 0, 45)
+        assert np.array_equal(t_full, wm.temperature_data), "replayed draws do not reproduce the reset"
+        pre = f"case{k}_"
+        out[pre + "loc"] = np.array(loc)
+        out[pre + "seed"] = np.array(seed)
+        out[pre + "day"] = np.array(day)
+        out[pre + "hour"] = np.array(hour)
+        out[pre + "tz"] = np.array(tz)
+        out[pre + "cursor0"] = np.array(c0)
+        out[pre + "roll_days"] = np.array(roll)
+        out[pre + "noise_sub32"] = np.asarray(noise[::32], dtype=np.float64)
+        out[pre + "noise_std_target"] = np.array(float(np.std(noise)))
+        out[pre + "T_win"] = np.asarray(wm.temperature_data[c0:c0 + W], dtype=np.float64)
+        out[pre + "WB_win"] = np.asarray(wm.wet_bulb_data[c0:c0 + W], dtype=np.float64)
+        out[pre + "NT_win"] = np.asarray(wm.norm_temp_data[c0:c0 + W], dtype=np.float64)
+        out[pre + "t_min30"] = np.array(np.min(wm.temperature_data[c0:c0 + 2880]))
+        out[pre + "t_max30"] = np.array(np.max(wm.temperature_data[c0:c0 + 2880]))
+        if tz != 0:
+            out[pre + "T_orig_sub16"] = np.asarray(wm.original_temp_data[::16], dtype=np.float64)
+    out["meta_cases"] = np.array(len(cases))
+    out["meta_window"] = np.array(W)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HARL layer fixture (VERDICT r1 item 8): the reference's own HARLSustainDCEnv + ShareDummyVecEnv
+
+def _load_by_path(name, relpath):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def gen_harl_layer(n_envs=4, days=1, n_steps=200, seed=21):
+    """N reference environments behind the reference's HARL adaptation layer (harlsustaindc_env.py:10-131 over
+    sustaindc_ptzoo.py, with pad_observations_v0) and its in-process vector wrapper (env_wrappers.py:301-350,
+    auto-reset at :321-343), built by the rule of harl/utils/envs_tools.py:49-71 (month = rank, seed + rank * 1000).
+    Records what the runner sees -- obs [N,3,26], share_obs [N,3,29], rews [N,3,1], dones [N,3], available actions,
+    `original_obs` / `original_state` on the done step -- plus every episode's inputs for injection.
+
+    The reference runs one OS process per env, so `reward_creator.energy_history` (a module global) is per env; with
+    ShareDummyVecEnv the envs share one process, so each env gets its own deque here (swapped in around its calls)."""
+    import collections
+    from utils import reward_creator
+    _load_by_path("harl.envs.sustaindc.sustaindc_ptzoo", "harl/envs/sustaindc/sustaindc_ptzoo.py")
+    hmod = _load_by_path("harl.envs.sustaindc.harlsustaindc_env", "harl/envs/sustaindc/harlsustaindc_env.py")
+    wmod = _load_by_path("harl.envs.env_wrappers", "harl/envs/env_wrappers.py")
+    steps = days * 96
+    base_args = {"location": "ny", "days_per_episode": days, "datacenter_capacity_mw": 1, "dc_config_file": "dc_config.json",
+                 "agents": ["agent_ls", "agent_dc", "agent_bat"], "partial_obs": True,
+                 "nonoverlapping_shared_obs_space": True}
+
+    class OwnHistory:
+        """One env with its own energy history (= its own process in the reference's ShareSubprocVecEnv)."""
+
+        def __init__(self, env):
+            self.env = env
+            self.hist = collections.deque(maxlen=10000)
+            self.observation_space, self.share_observation_space = env.observation_space, env.share_observation_space
+            self.action_space, self.n_agents = env.action_space, env.n_agents
+
+        def step(self, a):
+            reward_creator.energy_history = self.hist
+            return self.env.step(a)
+
+        def reset(self):
+            reward_creator.energy_history = self.hist
+            return self.env.reset()
+
+        def close(self):
+            pass
+
+    random.seed(seed)
+    np.random.seed(seed)
+
+    def get_env_fn(rank):
+        def init_env():
+            args = dict(base_args)
+            args["month"] = rank % 12 if rank < 12 else rank % 3 + 5
+            env = hmod.HARLSustainDCEnv(args)
+            env.seed(seed + rank * 1000)
+            return OwnHistory(env)
+        return init_env
+
+    venv = wmod.ShareDummyVecEnv([get_env_fn(i) for i in range(n_envs)])
+    inner = [e.env.env.unwrapped.env for e in venv.envs]     # the SustainDC objects
+    rng = np.random.default_rng(seed)
+    out = {f"static_{k}": v for k, v in _static_block(inner[0]).items()}
+    out["meta_n_envs"] = np.array(n_envs)
+    out["meta_steps"] = np.array(steps)
+    out["meta_n_steps"] = np.array(n_steps)
+    out["meta_months"] = np.array([e.month for e in inner])
+    out["init_stpt"] = np.array(inner[0].dc_env.raw_curr_stpt, dtype=np.float64)
+    obs, share, avail = venv.reset()
+    out["reset_obs"], out["reset_share"], out["reset_avail"] = (np.asarray(x, dtype=np.float32) for x in (obs, share, avail))
+    n_ep = np.zeros(n_envs, dtype=int)
+
+    def record_inputs(i):
+        for k, v in _episode_inputs(inner[i], steps).items():
+            out[f"env{i}_ep{n_ep[i]}_{k}"] = np.asarray(v)
+        n_ep[i] += 1
+
+    for i in range(n_envs):
+        record_inputs(i)
+    acts = rng.integers(0, 3, size=(n_steps, n_envs, 3, 1))
+    O = np.zeros((n_steps, n_envs, 3, 26), np.float32)
+    S = np.zeros((n_steps, n_envs, 3, 29), np.float32)
+    R = np.zeros((n_steps, n_envs, 3, 1), np.float64)
+    D = np.zeros((n_steps, n_envs, 3), np.uint8)
+    A = np.zeros((n_steps, n_envs, 3, 3), np.float32)
+    OO = np.zeros((n_steps, n_envs, 3, 26), np.float32)
+    OS = np.zeros((n_steps, n_envs, 3, 29), np.float32)
+    for t in range(n_steps):
+        obs, share, rews, dones, infos, avail = venv.step(acts[t])
+        O[t], S[t], R[t], D[t], A[t] = obs, share, rews, dones, avail
+        for i in range(n_envs):
+            if np.all(dones[i]):
+                OO[t, i] = infos[i][0]["original_obs"]
+                OS[t, i] = infos[i][0]["original_state"]
+                assert np.array_equal(infos[i][0]["original_avail_actions"], np.ones((3, 3)))
+                record_inputs(i)      # the wrapper has already reset the env: its managers hold the next episode
+    out.update(actions=acts.astype(np.int32), obs=O, share_obs=S, rews=R, dones=D, avail=A, original_obs=OO, original_state=OS)
+    out["meta_episodes"] = n_ep
+    out["share_space_shape"] = np.array(venv.share_observation_space[0].shape)
+    out["obs_space_shape"] = np.array(venv.observation_space[0].shape)
+    return out
+
+
 def _find_early_seed():
     """Seed for which (day 0, hour < 4) -> cursor < 16; uses python `random` exactly like reset()."""
     for s in range(1000):
@@ -298,8 +462,18 @@ def _find_early_seed():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--extras", action="store_true", help="with no --only: also regenerate weather_resets / harl_ny_n4")
     args = ap.parse_args()
     _install_shims()
+    extra = {"weather_resets": gen_weather_resets, "harl_ny_n4": gen_harl_layer}
+    for name, fn in extra.items():
+        if args.only == name or (args.only is None and args.extras):
+            out = fn()
+            path = os.path.join(HERE, name + ".npz")
+            np.savez_compressed(path, **out)
+            print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+    if args.only in extra:
+        return
     SPECS["ny_m0_early_cursor"]["seed"] = _find_early_seed()
     for name, spec in SPECS.items():
         if args.only and name != args.only:

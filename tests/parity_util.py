@@ -14,6 +14,7 @@ from dc_rl_amd import dc_config, traces
 from dc_rl_amd.engine import SdcEngine
 from oracle import pyoracle as po
 from tests import gpu_helpers as G
+from tests.reset_ref import reference_weather_reset
 
 TL = L.TABLE_LEN
 
@@ -30,9 +31,9 @@ def host_reset_draw(rng, tables, day_lo, day_hi, steps, noise_std=0.75, noise_we
     walk = np.cumsum(noise_weight * rng.normal(0.0, 1.0, TL))
     noise = (walk / np.std(walk)) * noise_std
     roll = int(rng.integers(0, 14))
-    T = np.clip(np.roll(tables["T"] + noise, roll * 96), 0, 45)
-    WB = np.clip(np.roll(tables["WB"] + noise, roll * 96), 0, 45)
-    tmin, tmax = T[c0:c0 + 2880].min(), T[c0:c0 + 2880].max()
+    # the arithmetic of Weather_Manager.reset, pinned against the reference by tests/golden/weather_resets.npz
+    r = reference_weather_reset(tables["T"], tables["WB"], noise, roll, c0, TL)
+    T, WB, tmin, tmax = r["T_full"], r["WB_full"], r["t_min"], r["t_max"]
     C = tables["C"]
     cmin, cmax = C[c0:c0 + 2880].min(), C[c0:c0 + 2880].max()
     return dict(day=day, hour=hour, c0=c0, T=T, WB=WB, t_min=tmin, t_max=tmax, ci_min=cmin, ci_max=cmax)

@@ -51,6 +51,9 @@ def test_env_config_defaults_match_reference_keys():
         _merge_args({"ls_reward": "renewable_energy_reward"})
     with pytest.raises(NotImplementedError):      # every default_ls_reward call appends to the shared history
         _merge_args({"dc_reward": "default_ls_reward"})
+    for bad in ({"nonoverlapping_shared_obs_space": False}, {"partial_obs": False}, {"actions_are_logits": True}):
+        with pytest.raises(NotImplementedError):  # options that change what a runner receives are never silently ignored
+            _merge_args(bad)
     with pytest.raises(NotImplementedError):      # subsets of agents: through SustainDC only
         _merge_args({"agents": ["agent_ls", "agent_dc"]})
     assert _merge_args({"agents": ["agent_ls", "agent_dc"], "_allow_agent_subset": True})["agents"] == ["agent_ls", "agent_dc"]
