@@ -21,7 +21,7 @@ QWIN = 64          # csrc/sdc_device.hpp SDC_WIN: keys per rank window (4 window
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
-SOURCES = ["sdc_capi.hip", "sdc_dynamics.hip", "sdc_features.hip", "sdc_verify.hip", "sdc_reset.hip"]
+SOURCES = ["sdc_capi.hip", "sdc_step.hip", "sdc_dynamics.hip", "sdc_features.hip", "sdc_verify.hip", "sdc_reset.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 # info column names = the reference's info keys (sustaindc_hip.h enum sdc_info_col)
@@ -49,6 +49,7 @@ class SdcConfig(C.Structure):
         ("auto_reset", C.c_int32), ("seed", C.c_uint64), ("weather_noise_std", C.c_double),
         ("weather_noise_weight", C.c_double), ("max_roll_days", C.c_int32), ("debug_flags", C.c_int32),
         ("reward_method", C.c_int32 * 3), ("env_index_base", C.c_int32),
+        ("policy", C.c_int32 * 3), ("reserved2", C.c_int32), ("trim_and_respond_limit", C.c_double),
     ]
 
 
@@ -156,7 +157,7 @@ def load():
     L.sdc_assign_envs.argtypes = [vp, ip, ip, ip, ip]
     L.sdc_reset.argtypes = [vp, u8p, C.POINTER(SdcResetOverride), fp, fp, vp]
     L.sdc_step.argtypes = [vp, vp, fp, fp, fp, vp, fp, fp, vp]
-    L.sdc_rollout.argtypes = [vp, C.c_int, vp, fp, fp, fp, vp, fp, fp, vp]
+    L.sdc_rollout.argtypes = [vp, C.c_int, vp, fp, fp, fp, vp, fp, fp, vp, vp]
     L.sdc_steps_to_episode_end.argtypes = [vp]
     L.sdc_get_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_set_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -21,6 +22,10 @@ extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
 extern "C" __global__ void sdc_features_kernel(SdcDev S);
 extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                               unsigned char* done, float* info, float* final_obs, float* rew);
+extern "C" __global__ void sdc_dynamics_kernel_v1(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
+                                                  unsigned char* done, float* info, float* final_obs, float* rew);
+extern "C" __global__ void sdc_rollout_kernel_v1(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
+                                                 unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
                                             const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
                                             const double* ovr_t_max, int only_done, float* obs, float* share_obs,
@@ -60,6 +65,8 @@ struct sdc_handle {
   sdc_config cfg;
   SdcDev d;
   int rel_hint = -1;   // the episode step all envs are at, if they are in lock-step (else -1)
+  int step_no = 3;           // steps launched (stamps the deferred window re-centrings; starts above the stamps of zeroed memory)
+  bool old_kernel = false;   // development A/B switch (env SDC_OLD_KERNEL): the round-1 one-env-per-wavefront kernel
   int device;
   std::vector<void*> allocs;
   std::vector<Field> fields;
@@ -88,6 +95,12 @@ struct sdc_handle {
 namespace {
 
 constexpr int PROF_SLOTS = 256;
+constexpr int SWEEP_BLOCKS = SDC_RQ_MAX / 4;   // csrc/sdc_step.hip: one spare wavefront per possible re-centring request
+constexpr int STEP_WPB = 4;   // csrc/sdc_step.hip SDC_STEP_WPB: env pairs (wavefronts) per workgroup of the step kernel
+int step_blocks(int n_envs) { return ((n_envs + 1) / 2 + STEP_WPB - 1) / STEP_WPB; }
+bool all_policies(const sdc_handle* h) {
+  return h->d.policy[0] != SDC_POLICY_EXTERNAL && h->d.policy[1] != SDC_POLICY_EXTERNAL && h->d.policy[2] != SDC_POLICY_EXTERNAL;
+}
 
 template <typename T>
 int dev_alloc(sdc_handle* h, T** p, size_t count, bool zero = true) {
@@ -188,6 +201,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
 
   sdc_handle* h = new sdc_handle();
   h->cfg = *cfg;
+  h->old_kernel = std::getenv("SDC_OLD_KERNEL") != nullptr;
   h->device = cfg->device;
   SdcDev& d = h->d;
   std::memset(&d, 0, sizeof(d));
@@ -211,6 +225,18 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
     }
     d.reward_method[a] = cfg->reward_method[a];
   }
+  for (int a = 0; a < 3; a++) {
+    const int pol = cfg->policy[a];
+    const bool ok = pol == SDC_POLICY_EXTERNAL || pol == SDC_POLICY_DO_NOTHING || (a == 2 && pol == SDC_POLICY_RBC) ||
+                    (a == 1 && pol == SDC_POLICY_TRIM_AND_RESPOND);
+    if (!ok) {
+      sdc_destroy(h);
+      return fail_msg("sdc_create: policy must be EXTERNAL or DO_NOTHING, RBC for the battery slot, TRIM_AND_RESPOND for the dc slot");
+    }
+    d.policy[a] = pol;
+  }
+  d.tr_limit = cfg->trim_and_respond_limit;
+  d.actions_out = nullptr;
   d.seed = cfg->seed;
   d.noise_std = cfg->weather_noise_std;
   d.noise_weight = cfg->weather_noise_weight;
@@ -249,6 +275,9 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   d.feat = nullptr;
   if (sizeof(double) * (size_t)(cfg->episode_steps + 25 + d.lw) <= 50 * 1024)   // the features kernel's LDS windows (+ 8.4 KB tile)
     A(d.feat, (size_t)N * (size_t)(cfg->episode_steps + 1) * SDC_FEAT_ROW);
+  A(d.rq_count, 4);
+  A(d.rq, 3 * SDC_RQ_MAX);
+  A(d.rs, 3 * SDC_RQ_MAX);
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
@@ -358,6 +387,7 @@ int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
     *rcs[i] = 1.0 / divisors[i];
   }
   e.k_outlet = 1.918 / (p->c_air * p->rho_air * 0.526);
+  e.n_racks_f = (double)p->n_racks;
   HIP_TRY(hipMemcpy(const_cast<SdcDcDev*>(h->d.dc) + cfg_id, &e, sizeof(e), hipMemcpyHostToDevice));
   return 0;
 }
@@ -478,7 +508,8 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
 
 int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs, float* rew, uint8_t* done,
              float* info, float* final_obs, void* stream) {
-  if (!h || !actions || !obs || !rew || !done) return fail_msg("sdc_step: null argument");
+  if (!h || !obs || !rew || !done) return fail_msg("sdc_step: null argument");
+  if (!actions && !all_policies(h)) return fail_msg("sdc_step: actions may only be NULL when every agent slot has a policy");
   if (!h->started) return fail_msg("sdc_step: sdc_reset must be called first");
   if (h->steps_to_terminal <= 0)
     return fail_msg("sdc_step: an environment has finished its episode; call sdc_reset (auto_reset is off)");
@@ -491,8 +522,14 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
     d.prof_ts = h->prof_buf + (size_t)h->prof_used * 3 * N * 2;
     h->prof_has_reset[h->prof_used] = 0;
   }
-  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, h->rel_hint, actions, obs, share_obs, done, info,
-                     final_obs, rew);
+  if (h->old_kernel)
+    hipLaunchKernelGGL(sdc_dynamics_kernel_v1, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, h->rel_hint, actions, obs, share_obs, done, info,
+                       final_obs, rew);
+  else {
+    d.step_no = h->step_no++;
+    hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, h->rel_hint,
+                       actions, obs, share_obs, done, info, final_obs, rew);
+  }
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
   HIP_TRY(hipGetLastError());
   h->steps_to_terminal -= 1;
@@ -520,8 +557,9 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
 }
 
 int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, float* share_obs, float* rew,
-                uint8_t* done, float* info, float* final_obs, void* stream) {
-  if (!h || !actions || !obs || !rew || !done) return fail_msg("sdc_rollout: null argument");
+                uint8_t* done, float* info, float* final_obs, int32_t* actions_out, void* stream) {
+  if (!h || !obs || !rew || !done) return fail_msg("sdc_rollout: null argument");
+  if (!actions && !all_policies(h)) return fail_msg("sdc_rollout: actions may only be NULL when every agent slot has a policy");
   if (!h->started) return fail_msg("sdc_rollout: sdc_reset must be called first");
   if (n_steps <= 0) return fail_msg("sdc_rollout: n_steps must be positive");
   if (n_steps > h->steps_to_terminal)
@@ -532,8 +570,19 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int N = h->cfg.n_envs;
   SdcDev d = h->d;
-  hipLaunchKernelGGL(sdc_rollout_kernel, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, n_steps,
-                     h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+  d.actions_out = actions_out;
+  if (h->old_kernel)
+    hipLaunchKernelGGL(sdc_rollout_kernel_v1, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, n_steps,
+                       h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+  else {
+    // (a multi-step launch has no spare wavefronts between its steps: it re-centres inline, and requests left by the
+    // step before it are dropped -- their results would describe a ring several steps old)
+    d.step_no = h->step_no;
+    h->step_no += n_steps + 3;
+    HIP_TRY(hipMemsetAsync(d.rq_count, 0, sizeof(int) * 4, st));
+    hipLaunchKernelGGL(sdc_rollout_kernel, dim3(step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, n_steps, h->rel_hint, actions,
+                       obs, share_obs, done, info, final_obs, rew);
+  }
   HIP_TRY(hipGetLastError());
   h->steps_to_terminal -= n_steps;
   h->pending += n_steps;

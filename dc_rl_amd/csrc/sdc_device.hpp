@@ -58,6 +58,7 @@ enum SdcRec {
   R_CFG,          //             data-centre parameter set
   R_DAY_LO,       //             inclusive range of the random start day
   R_DAY_HI,
+  R_TR_COUNT,     // trim-and-respond policy: response_duration_counter (utils/trim_and_respond.py:22)
   R_F64 = 24,     // doubles from here, two dwords each
   R_STPT = 24,
   R_BAT = 26,
@@ -68,7 +69,8 @@ enum SdcRec {
   R_HIST_REF = 36,
   R_FEAT_OK = 38,    // 1: the episode's observation feature rows (SdcDev::feat) are valid (sdc_features.hip); cleared by
                      // a reset (whose features kernel sets it again) and by any host write to the env's state
-  R_END = 39,
+  R_LAST_ROOM = 40,  // f64: dc_int_temperature the previous step reported (what the trim-and-respond policy monitors)
+  R_END = 42,
   SDC_REC_DWORDS = 64
 };
 
@@ -86,6 +88,10 @@ enum SdcHdr {
   H_QC = 29,      // [2]: how many keys lie at or beyond last step's clip bound.  With H_QS1 / H_QS2 these running
                   // sums make the tail corrections O(1): a step only touches the keys the bound has moved across.
   H_Q3 = 32,      // rank window of the upper quartile
+  H_PEND = 34,    // [4] per rank window: a deferred re-centring in flight (0: none), (request step << 8) | (request index + 1)
+  H_LAST_XNEW = 38,   // the previous step's appended key, evicted key (KEY_NONE: none) and history length before it:
+  H_LAST_XOLD = 39,   // what a re-centred window that describes the ring one step back has to catch up with
+  H_LAST_NPREV = 40,
   H_QS2_HI = 46,  // f64: sum of v^2, upper side
   H_STICKY = 48,  // sticky diagnostics (bit 0: a verify-mode mismatch was seen)
   H_KB = 49,      // last step's clip bounds in flipped key space: [0] upper (kub), [1] lower (~(klb - 1))
@@ -114,6 +120,27 @@ struct SdcDcDev {
   sdc_dc_params p;
   double rc_n_racks, rc_itfan_ref_v_ratio, rc_rho_air, rc_ctafr, rc_bat_capacity;
   double k_outlet;   // 1.918 / (c_air rho_air 0.526): the constant factor of the rack outlet-temperature rise
+  double n_racks_f;  // p.n_racks as a double (the step kernel hands the scalars from p.m_cpu to here round as doubles)
+};
+
+// DEFERRED WINDOW RE-CENTRING.  A rank window that the next step could exhaust has to be re-centred with one sweep over
+// the env's 40 KB ring (sdc_ringpath.hpp qt_refill, ~5 us) -- done inline that sweep made its wavefront the straggler of
+// nearly every launch.  Instead the step that sees the need (step t) files a REQUEST with a snapshot of the window;
+// spare wavefronts at the front of the NEXT launch (step t + 1) do the sweep against the ring as it was after step t
+// (the one slot step t + 1 overwrites is patched with its old content, carried in the request) and leave the
+// re-centred window as a RESULT; the env's own wavefront picks it up at step t + 2, replays step t + 1's one
+// insertion / eviction on it (remembered in the header) and carries on.  The old window stays valid through step
+// t + 1 (that is what "ahead of need" guarantees).  Three request / result sets rotate with the step number.
+#define SDC_RQ_MAX 128
+struct SdcRefillReq {
+  int env, win, dir, kt, n, r0, hi, patch_slot;
+  unsigned patch_x;
+  int step, pad0, pad1;
+  unsigned keys[SDC_WIN];
+};
+struct SdcRefillRes {
+  int r0, hi, step, env_win;
+  unsigned keys[SDC_WIN];
 };
 
 struct SdcDev {
@@ -121,6 +148,13 @@ struct SdcDev {
   int env_base;     // global index of env 0 (sdc_config.env_index_base): keys the reset RNG
   int debug_flags;  // bit 0: cross-check the tracked order statistics against the bisection every step
   int reward_method[3];   // sdc_reward_method per agent slot (ls, dc, bat)
+  int policy[3];          // sdc_policy per agent slot: who chooses the action
+  double tr_limit;        // trim-and-respond: TandR_monitor_limit
+  int32_t* actions_out;   // [N][3] the actions the step applied, or nullptr (sdc_step); sdc_rollout passes its own
+  int step_no;            // steps launched so far (host counter): stamps the deferred re-centring requests / results
+  int* rq_count;          // [3] requests filed into each set
+  SdcRefillReq* rq;       // [3][SDC_RQ_MAX]
+  SdcRefillRes* rs;       // [3][SDC_RQ_MAX]
   unsigned long long seed;
   double noise_std, noise_weight;
   // shared, read-only

@@ -803,7 +803,7 @@ __device__ __forceinline__ void env_step(const SdcDev& S, DynShared& sh, const i
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics_kernel(SdcDev S, const int rel_hint, const int32_t* __restrict__ actions,
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics_kernel_v1(SdcDev S, const int rel_hint, const int32_t* __restrict__ actions,
                                                                                 float* __restrict__ obs,
                                                                                 float* __restrict__ share_obs,
                                                                                 unsigned char* __restrict__ done,
@@ -830,7 +830,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_dynamics
 // between steps; the dispatch ramp, the launch gap and the tail of a launch are paid once per K steps.  actions
 // [K][N][3]; obs [K][N][3][26], share_obs [K][N][29] (or null), rew [K][N][3], done [K][N], info [K][N][44] (or null)
 // hold every step's outputs.  The host keeps K within the episode (sdc_rollout).
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_rollout_kernel(SdcDev S, const int K, const int rel_hint,
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_WPB, 4) void sdc_rollout_kernel_v1(SdcDev S, const int K, const int rel_hint,
                                                                                const int32_t* __restrict__ actions,
                                                                                float* __restrict__ obs,
                                                                                float* __restrict__ share_obs,

@@ -1,0 +1,1327 @@
+// sdc_step.hip -- the coupled per-timestep dynamics, TWO ENVIRONMENTS PER WAVEFRONT (block = 4 wavefronts = 8 envs).
+//
+// Most of a step is "scalar" physics: the load-shifting queue algebra, the set-point integrator, chiller / cooling tower /
+// water, the battery, the reward arithmetic -- one value per ENV, not per rack.  With one wavefront per env those
+// instructions ran on 64 lanes that all held the same number (round 1: 1 400 VALU instructions per env-step, the SIMDs'
+// VALU issue was the bound).  Here lanes 0..31 of a wavefront carry env 2w and lanes 32..63 env 2w + 1: every
+// per-env instruction is issued ONCE for two envs, the rack model runs lane = rack inside each half (<= 32 racks per
+// pass), half-wave reductions stay on the DPP path (+ one v_permlane16_swap to join the two rows of a half), and a
+// launch needs half the wavefronts (half the dispatch ramp, two instead of four resident waves per SIMD).
+//
+// Per-env values live in LDS as the wavefront's "scalar register file": each half stages its env's 256-byte state
+// record, the 25 scalars of its data-centre config and its step inputs there with coalesced loads, and every lane reads
+// the field it needs (a broadcast read inside its half).
+//
+// Memory plan per wavefront (two dependent round trips, as before):
+//   level 0  the pair's two records (512 contiguous bytes, one dwordx2 per lane), both headers, the 2 x 3 actions and --
+//            when the host knows the episode step (lock-step batch) -- each env's feature row + queue probes;
+//   level 1  config scalars + per-rack constants, the step inputs that level 0 could not address, the evicted ring key;
+//   (level 2 only on steps that pop tasks: the 32-ary search for the new oldest task in the queue.)
+// The history-normalised rewards keep their per-env, whole-wavefront form (four 64-key rank windows, one key per lane:
+// sdc_trackers.hpp / sdc_ringpath.hpp); the wavefront runs that part for its two envs one after the other.
+//
+// Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
+#include "sdc_ringpath.hpp"
+#include "sdc_halfwin.hpp"
+
+namespace {
+
+constexpr int EPW = 2;    // envs per wavefront
+constexpr int HL = 32;    // lanes per env
+
+// gather slots (8 bytes each) of one env
+enum {
+  G_W0 = 0, G_W1, G_W2,   // W[i], W[i+1], W[i+2]
+  G_C0,                   // C[i]
+  G_T0, G_WB0, G_T1,      // T[i], WB[i], T[i+1] from the env's weather window
+  G_LUT,                  // hour LUT {cos, sin} is 16 bytes: two slots
+  G_LUT2,
+  G_Q97, G_Q24, G_Q48, G_Q72, G_Q96,   // queue prefix counts cum[now - a]
+  G_NCN = 14,             // NC[i'+1] (norm_CI of the reward) when the episode has feature rows
+  G_C3 = 15,              // C[i+3]: the rule-based battery policy's forecast sample
+  G_NC = 16,              // 25 slots: C[i'-16 .. i'+8]
+  G_NT = 41,              // 17 slots: T[i' .. i'+16]
+  G_END = 58
+};
+
+// the scalars of a data-centre config, in the order they lie in SdcDcDev from sdc_dc_params::m_cpu on
+enum {
+  P_M_CPU = 0, P_C_CPU, P_RS_CPU, P_M_FAN, P_C_FAN, P_RS_FAN, P_ITFAN_REF_P, P_ITFAN_REF_V_RATIO, P_IT_FAN_FULL_LOAD_V,
+  P_C_AIR, P_RHO_AIR, P_CRAC_SUPPLY_PU, P_CT_FAN_REF_P, P_CTAFR, P_MIN_TEMP, P_MAX_TEMP, P_INIT_SETPOINT, P_BAT_CAP,
+  P_RC_N_RACKS, P_RC_ITFAN_REF_V_RATIO, P_RC_RHO_AIR, P_RC_CTAFR, P_RC_BAT_CAP, P_K_OUTLET, P_N_RACKS, P_COUNT
+};
+static_assert(offsetof(SdcDcDev, k_outlet) - offsetof(SdcDcDev, p.m_cpu) == P_K_OUTLET * sizeof(double), "config scalars must be contiguous");
+static_assert(offsetof(SdcDcDev, n_racks_f) - offsetof(SdcDcDev, p.m_cpu) == P_N_RACKS * sizeof(double), "config scalars must be contiguous");
+static_assert(P_COUNT <= HL, "one config scalar per lane of a half");
+
+struct PairShared {
+  double g[EPW][64];                   // gathered step inputs; g[G_NC..] / g[G_NT..] are normalised in place to NC / NT
+  double prm[EPW][HL];                 // config scalars (P_*)
+  double osc[EPW][16];                 // step-dependent observation scalars, for the in-step feature path only
+  unsigned rec[EPW][SDC_REC_DWORDS];   // state records: loaded, read field by field, patched, stored
+  unsigned hdr[EPW][SDC_HDR_DWORDS];   // reward-side headers, likewise (fast path; the slow path works on registers)
+  float pool[EPW][32];                 // observation pool (see build_obs_pool)
+  float info[EPW][SDC_INFO_DIM];
+  unsigned long long dbg_t[2];
+  sdc_rw::TailLds tl;                  // scratch of the ring paths (window refill, rebuild): one env at a time
+};
+
+// sum over the 32 lanes of each half; every lane gets its half's sum.  Same tree as the round-1 64-lane reduction
+// restricted to a half (strides 1, 2, 4, 8 inside the rows, then the two rows), so the rack sums round identically.
+__device__ __forceinline__ double half_sum_f64(double v) {
+  v += dpp_f64<SDC_DPP_XOR1>(v);
+  v += dpp_f64<SDC_DPP_XOR2>(v);
+  v += dpp_f64<SDC_DPP_HALF_MIRROR>(v);
+  v += dpp_f64<SDC_DPP_MIRROR>(v);          // every lane of a row: the row's total
+  // v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the second: from two copies
+  // of v, a = {r0, r0, r2, r2} and b = {r1, r1, r3, r3}
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto slo = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto shi = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double a = __hiloint2double((int)shi[0], (int)slo[0]), b = __hiloint2double((int)shi[1], (int)slo[1]);
+  return b + a;   // (row 1 + row 0, as row_bcast15 added them)
+}
+// the 32 ballot bits of this lane's half
+__device__ __forceinline__ unsigned half_ballot(const bool p, const int h) {
+  const unsigned long long m = __ballot(p);
+  return h ? (unsigned)(m >> 32) : (unsigned)m;
+}
+
+// envs/datacenter.py:356-429 calculate_chiller_power
+__device__ __forceinline__ double chiller_power(double max_cooling_cap, double load, double ambient_temp) {
+  const double min_plr = 0.05, max_plr = 1.0, design_cond_temp = 35.0, design_evp_out_temp = 6.67;
+  // temp_rise_coef = 2.778, rated_cop = 3.0 (divisors below)
+  const double delta_temp = SDC_DIV_CONST(ambient_temp - design_cond_temp, 2.778) - (design_evp_out_temp - design_cond_temp);
+  const double cap_rat = 0.94483600 + -0.05700880 * delta_temp + 0.00185486 * (delta_temp * delta_temp);
+  const double avail = cap_rat != 0 ? max_cooling_cap * cap_rat : 0.0;
+  const double fpr = 2.333 + -1.975 * cap_rat + 0.6121 * (cap_rat * cap_rat);
+  const double ratio = load / avail;       // (one division: the reference evaluates load / avail three times)
+  const double plr = avail > 0 ? fmax(min_plr, fmin(ratio, max_plr)) : 0.0;
+  const double fflp = 0.03303 + 0.6852 * plr + 0.2818 * (plr * plr);
+  double oper;
+  if (avail > 0)
+    oper = (ratio < min_plr) ? ratio : plr;
+  else
+    oper = 0.0;
+  const double frac = oper < min_plr ? fmin(1.0, SDC_DIV_CONST(oper, 0.05)) : 1.0;   // / min_plr
+  const double power = SDC_DIV_CONST(fflp * fpr * avail, 3.0) * frac;
+  return oper > 0 ? power : 0.0;
+}
+
+// what the per-env reward part needs from the dynamics, one value per lane (uniform inside a half)
+struct DynOut {
+  double energy, e_off, norm_ci, oldest_norm, p_it, total_kw, water;
+  int overdue, hourq_n, hl, slot;
+  unsigned x_new;
+};
+
+// LDS record access: this lane's env record
+__device__ __forceinline__ int lrec_i32(const unsigned* rp, int idx) { return (int)rp[idx]; }
+__device__ __forceinline__ double lrec_f64(const unsigned* rp, int idx) { return *reinterpret_cast<const double*>(rp + idx); }
+
+// ------------------------------------------------------------------------------------------------
+// the coupled dynamics at cursor i and the observation at i' = i + 1 of BOTH envs of the wavefront: lane = (half h, l)
+__device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc, const int h, const int l, const int a_ls,
+                                                const int a_dc_in, const int a_bat_in, unsigned fault, const bool feat_ok,
+                                                const float frow, int32_t* __restrict__ actions_out, PairShared& sh) {
+  const unsigned* rp = sh.rec[h];
+  const double* g = sh.g[h];
+  const double* pr = sh.prm[h];
+  const int i = lrec_i32(rp, R_CURSOR);
+  const int rel = lrec_i32(rp, R_TREL);
+  const int day = lrec_i32(rp, R_DAY);
+  const int hourq = lrec_i32(rp, R_HOURQ);
+  const double hour = (double)hourq * 0.25;
+  const double wl = g[G_W0], w_ip = g[G_W1], w_ip1 = g[G_W2];
+  const double ci_i = g[G_C0];
+  const double amb = g[G_T0], wet_bulb = g[G_WB0], amb_next = g[G_T1];
+  // norm_CI = NC[i'+1] (sustaindc_env.py:681): from the episode's feature row, or from the window gathered by this step
+  const double norm_ci = feat_ok ? g[G_NCN] : g[G_NC + 17];
+
+  // ---- load shifting: envs/carbon_ls.py:172-324 ------------------------------------------------
+  // The reference keeps a deque of per-task enqueue timestamps and only ever removes a FIFO prefix
+  // (overdue `remove()` loop :225-226 and popleft :257-258).  Equivalent state: cum[t] = tasks ever
+  // enqueued up to step t of the episode, popped = tasks ever removed.  Tasks still queued that were
+  // enqueued at or before step t: max(0, cum[t] - popped).
+  if (wl < 0 || wl > 1) fault |= SDC_FAULT_WORKLOAD;
+  const double flex = 0.2;        // class default; make_ls_env never forwards flexible_load (make_envs_pyenv.py:37-41)
+  const double nonflex = 1 - flex;
+  const int ns = (int)ceil(wl * nonflex * 100);
+  const int shf = (int)floor(wl * flex * 100);
+  const uint2* qt = S.qtab + (size_t)envc * S.qstride;
+  const int now = rel;
+  const int popped0 = lrec_i32(rp, R_QPOPPED);
+  int popped = popped0;
+  const int cum_prev = lrec_i32(rp, R_QCUM);
+  const unsigned cumT_prev = (unsigned)lrec_i32(rp, R_QCUMT);
+  auto cum_g = [&](int slot) -> int { return (int)(unsigned)__double2loint(g[slot]); };  // .x of the gathered uint2 (0 if t < 0)
+  // overdue: age > 24 h  <=>  enqueued at step <= now - 97  (carbon_ls.py:208)
+  const int overdue = max(0, cum_g(G_Q97) - popped);
+  int avail = 90 - (ns + shf);
+  int od_proc = 0;
+  if (avail > 0 && overdue > 0) od_proc = min(overdue, avail);
+  popped += od_proc;
+  avail = 90 - (ns + shf + od_proc);
+  int add = 0, dropped = 0, processed = 0;
+  int util_tasks;   // the flexible part of the utilisation, in tasks
+  if (a_ls == 0) {
+    const int room = S.queue_max - (cum_prev - popped);
+    add = min(shf, room);
+    dropped = shf - add;
+    util_tasks = od_proc + (shf - add);
+  } else if (a_ls == 2 && avail >= 1) {
+    processed = min(min(shf, avail), cum_prev - popped);
+    popped += processed;
+    util_tasks = shf + processed + od_proc;
+  } else {
+    util_tasks = shf + od_proc;
+  }
+  double util = SDC_DIV_CONST((double)util_tasks, 100);
+  util += SDC_DIV_CONST((double)ns, 100);
+  const int cum_now = cum_prev + add;
+  const unsigned cumT_now = cumT_prev + (unsigned)add * (unsigned)now;
+  const int total = cum_now - popped;
+  // age histogram, bins [0,6,12,18,24,inf] hours = [0,24,48,72,96,inf) steps (carbon_ls.py:63-73)
+  const int a24 = max(0, cum_g(G_Q24) - popped), a48 = max(0, cum_g(G_Q48) - popped);
+  const int a72 = max(0, cum_g(G_Q72) - popped), a96 = max(0, cum_g(G_Q96) - popped);
+  double hist[5];
+  const double den = (double)max(total, 1), rden = 1.0 / den;   // (an integer <= 1000: significand never all ones)
+  {
+    // four divisions by the same count: one reciprocal, then the exact 3-instruction form (sdc_div_const)
+    hist[0] = sdc_div_const((double)(total - a24), den, rden);
+    hist[1] = sdc_div_const((double)(a24 - a48), den, rden);
+    hist[2] = sdc_div_const((double)(a48 - a72), den, rden);
+    hist[3] = sdc_div_const((double)(a72 - a96), den, rden);
+    hist[4] = a96 > 0 ? 1.0 : 0.0;
+  }
+  // oldest task: smallest step hd in [head, now] with cum[hd] > popped.  It only moves when tasks were popped
+  // (or the queue was empty): then a 32-ary search over the half's lanes (<= 2 rounds) finds it and cum/cumT[hd-1]
+  // are cached.
+  int head = lrec_i32(rp, R_QHEAD);
+  int cum_hm1 = lrec_i32(rp, R_QCUM_HM1);
+  unsigned cumT_hm1 = (unsigned)lrec_i32(rp, R_QCUMT_HM1);
+  double oldest = 0.0, avg = 0.0;
+  {
+    const bool was_empty = (cum_prev - popped0) == 0;
+    const bool need = total > 0 && !was_empty && popped != popped0;   // this half searches
+    if (__builtin_expect(__ballot(need) != 0ull, 0)) {
+      int lo = head, hi = now;
+      while (__ballot(need && hi - lo + 1 > HL) != 0ull) {
+        const bool act = need && hi - lo + 1 > HL;
+        const int len = hi - lo + 1;
+        const int stride = (len + HL - 1) / HL;
+        const int t = min(lo + (l + 1) * stride - 1, hi);
+        int c = 0;
+        if (act) c = (t == now) ? cum_now : (int)qt[t].x;
+        const unsigned m = half_ballot(act && c > popped, h);
+        const int f = __ffs((int)m) - 1;  // exists: cum[now] > popped
+        if (act) {
+          const int nlo = lo + f * stride;
+          hi = min(lo + (f + 1) * stride - 1, hi);
+          lo = nlo;
+        }
+      }
+      {
+        const int t = lo + l;
+        int c = 0;
+        if (need && t <= hi) c = (t == now) ? cum_now : (int)qt[t].x;
+        const unsigned m = half_ballot(need && t <= hi && c > popped, h);
+        if (need) head = lo + (__ffs((int)m) - 1);
+      }
+      if (need) {
+        if (head == 0) {
+          cum_hm1 = 0;
+          cumT_hm1 = 0;
+        } else if (head == now) {
+          cum_hm1 = cum_prev;
+          cumT_hm1 = cumT_prev;
+        } else {
+          const uint2 e = qt[head - 1];
+          cum_hm1 = (int)e.x;
+          cumT_hm1 = e.y;
+        }
+      }
+    }
+    if (total > 0) {
+      if (was_empty) {          // everything queued was enqueued now
+        head = now;
+        cum_hm1 = cum_prev;
+        cumT_hm1 = cumT_prev;
+      }
+      // sum of enqueue steps over the queued tasks = cumT[now] - cumT[h-1] - (popped - cum[h-1]) * h
+      const long long sum_t = (long long)cumT_now - (long long)cumT_hm1 - (long long)(popped - cum_hm1) * head;
+      const long long sum_age_steps = (long long)total * now - sum_t;
+      oldest = (double)(now - head) * 0.25;                  // hours, exact
+      avg = sdc_div_const((double)sum_age_steps * 0.25, den, rden);  // / total (> 0 here); sum(ages) is exact in the reference too
+    } else {
+      head = now;
+      cum_hm1 = cum_now;
+      cumT_hm1 = cumT_now;
+    }
+  }
+  const double normq = sdc_div_const((double)total, (double)S.queue_max, S.rc_queue_max);
+  const double oldest_norm = SDC_DIV_CONST(oldest, 24), avg_norm = SDC_DIV_CONST(avg, 24);
+
+  // ---- rule-based policies for agent_dc / agent_bat (sdc_config.policy; 0 = the caller's action) ----------------------
+  int a_dc = a_dc_in, a_bat = a_bat_in;
+  int tr_count = lrec_i32(rp, R_TR_COUNT);
+  if (S.policy[1] == SDC_POLICY_TRIM_AND_RESPOND) {
+    // utils/trim_and_respond.py:28-38 on the room temperature the previous step reported (dc_int_temperature)
+    const double room = lrec_f64(rp, R_LAST_ROOM);
+    if (S.tr_limit >= room) {
+      if (tr_count > 4) {        // response_duration_limit = 4
+        tr_count = 0;
+        a_dc = 2;
+      } else {
+        tr_count += 1;
+        a_dc = 1;
+      }
+    } else {
+      a_dc = 0;
+    }
+  }
+  if (S.policy[2] == SDC_POLICY_RBC) {
+    // utils/rbc_agents.py:21-47 (look_ahead 3, smooth_window 1) on [ci, ci_future] of the step's info: charge when the
+    // carbon intensity three steps ahead is above the current one, else discharge
+    a_bat = g[G_C3] > ci_i ? 0 : 1;
+  }
+
+  // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 ----------------------------------------
+  if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
+  const int delta = a_dc - 1;  // make_envs_pyenv.py:127-131
+  int last_delta = lrec_i32(rp, R_LAST_DELTA), consecutive = lrec_i32(rp, R_CONSEC), scale = lrec_i32(rp, R_SCALE);
+  if (last_delta != -2 && delta == last_delta && a_dc != 0) {
+    consecutive += 1;
+  } else {
+    consecutive = 1;
+    scale = 1;
+  }
+  if (consecutive > 3) scale += 1;
+  double stpt = lrec_f64(rp, R_STPT) + (double)(delta * scale);
+  stpt = fmax(fmin(stpt, pr[P_MAX_TEMP]), pr[P_MIN_TEMP]);
+
+  // ---- rack model, lane = rack inside the half: envs/datacenter.py:250-317, :157-181 ------------------
+  const sdc_dc_params& P = S.dc[lrec_i32(rp, R_CFG)].p;
+  const int R = (int)pr[P_N_RACKS];
+  const double load_pct = util * 100;
+  double pcpu = 0.0, pfan = 0.0, outlet = 0.0, ret_plus_out = 0.0;
+  bool bad_delta = false;
+  {
+    const double m_cpu = pr[P_M_CPU], c_cpu = pr[P_C_CPU], rs_cpu = pr[P_RS_CPU];
+    const double m_fan = pr[P_M_FAN], c_fan = pr[P_C_FAN], rs_fan = pr[P_RS_FAN];
+    const double cpu_shift = rs_cpu * SDC_DIV_CONST(load_pct, 100), fan_shift = rs_fan * SDC_DIV_CONST(load_pct, 20);
+#pragma unroll 1
+    for (int rk = l; rk < R; rk += HL) {      // (one pass for the shipped 16 / 20 / 25-rack configs)
+      const double sa = fmax(3.8, fmin(P.rack_supply[rk], 5.3));  // datacenter.py:209-215
+      const double inlet = sa + stpt;
+      const double ratio = ((m_cpu + 0.05) * inlet + c_cpu) + cpu_shift;
+      const double cpu1 = fmax(P.rack_idle[rk], P.rack_full[rk] * ratio);
+      const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
+      const double fan1 = pr[P_ITFAN_REF_P] * sdc_div_const(v, pr[P_ITFAN_REF_V_RATIO], pr[P_RC_ITFAN_REF_V_RATIO]);
+      const double vf1 = pr[P_IT_FAN_FULL_LOAD_V] * v;
+      const double n = P.rack_n[rk];
+      const double pc = n * cpu1, pf = n * fan1;
+      const double vtot = n * vf1;
+      // x^y as exp2(y log2 x): <= 3e-15 relative against the correctly rounded power (the reference's libm pow is
+      // <= 1.3e-16), nine orders below the fp32 outputs' resolution, at less than half the instructions of pow()
+      // ... and power^1.096 / airflow^0.824 as ONE exp2 of the difference of the two scaled logarithms
+      const double rise = exp2(1.096 * log2(pc + pf) - 0.824 * log2(vtot));
+      const double out = inlet + pr[P_K_OUTLET] * rise + -14.01;   // 1.918 power^1.096 / (c_air rho_air airflow^0.824 0.526) - 14.01
+      if (out - inlet < 2) bad_delta = true;
+      pcpu += pc;
+      pfan += pf;
+      outlet += out;
+      ret_plus_out += P.rack_return[rk] + out;
+    }
+  }
+  if (half_ballot(bad_delta, h) != 0u) fault |= SDC_FAULT_OUTLET_DELTA;
+  const double sum_cpu = half_sum_f64(pcpu), sum_fan = half_sum_f64(pfan);
+  const double avg_ret = sdc_div_const(half_sum_f64(ret_plus_out), (double)R, pr[P_RC_N_RACKS]);  // datacenter.py:531-541
+  const double mean_outlet = sdc_div_const(half_sum_f64(outlet), (double)R, pr[P_RC_N_RACKS]);
+  const double p_it = sum_cpu + sum_fan;
+
+  // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 ------------------------------------------
+  const double c_air = pr[P_C_AIR], rho_air = pr[P_RHO_AIR], ct_fan_ref_p = pr[P_CT_FAN_REF_P];
+  const double m_sys = rho_air * pr[P_CRAC_SUPPLY_PU] * p_it;
+  const double q_cool = m_sys * c_air * fmax(0.0, avg_ret - stpt);
+  const double comp = chiller_power(ct_fan_ref_p, q_cool, amb);
+  double ct;
+  {
+    const double dlt = fmax(50 - (amb - stpt), 1);
+    const double m_air = q_cool / (c_air * dlt);
+    const double v_air = sdc_div_const(m_air, rho_air, pr[P_RC_RHO_AIR]);
+    const double x = fmin(sdc_div_const(v_air, pr[P_CTAFR], pr[P_RC_CTAFR]), 1);
+    ct = amb < 5 ? 0.0 : ct_fan_ref_p * (x * x * x);
+  }
+  double water;
+  {
+    const double range_temp = avg_ret - stpt;
+    const double y_int = 0.3528 * range_temp + 0.101;
+    double w = 0.044 * wet_bulb + y_int;
+    if (w < 0) w = 0;
+    w += w * 0.01;
+    water = np_round((w * 1000) / 4, 1e4);
+  }
+  const double total_kw = SDC_DIV_CONST(p_it + ct + comp, 1e3);
+
+  // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ----------------------
+  // charge and discharge share one sigmoid and one division (selected operands, the reference's expressions)
+  const double cap = pr[P_BAT_CAP];
+  const double dcload = SDC_DIV_CONST(total_kw, 1e3);  // MW (sustaindc_env.py:652)
+  double bat_load = lrec_f64(rp, R_BAT);
+  const double e_nobat = dcload * 1e3 * 0.25;
+  double energy = e_nobat, co2;
+  if (a_bat != 2) {
+    const bool chg = a_bat == 0;
+    const double soc = sdc_div_const(bat_load - 0, cap - 0, pr[P_RC_BAT_CAP]);
+    const double sg = 1 / (1 + exp(-(10 * (soc - (chg ? 0.5 : 0.25)))));       // sigmoid
+    const double rate = chg ? np_round(0.5 * (1 - sg), 1e4) : fmax(0.5, 4 * sg);
+    const double tu = SDC_DIV_CONST(rate * 15, 60);
+    // charge:    (1 * cap - bat_load) / ((1 * tu) - (-0.04))        discharge: (bat_load - 0 * cap) / (0.01 + (1 * tu))
+    const double quo = (chg ? cap - bat_load : bat_load) / (chg ? tu + 0.04 : 0.01 + tu);
+    if (chg) {
+      const double max_charge = fmin((cap / 1) * 0.1, quo);
+      const double charging_load = fmin(max_charge, cap) * 1 * tu;
+      bat_load = np_round(bat_load + charging_load, 1e8);
+      energy = e_nobat + charging_load * 1e3;
+    } else {
+      const double max_d = fmin(fmin((cap / 1) * 1, quo), dcload * 0.25);   // dcload / 4
+      bat_load = np_round(bat_load - (fmin(max_d, cap) * 1 * tu), 1e8);
+      const double discharge = max_d < cap ? max_d * tu : cap * tu;
+      if (!(e_nobat >= discharge * 1e3)) fault |= SDC_FAULT_BAT_DISCHARGE;
+      energy = e_nobat - discharge * 1e3;
+    }
+  }
+  co2 = (a_bat == 1 ? fmax(energy, 0.0) : energy) * ci_i;
+  const double soc_after = sdc_div_const(bat_load, cap, pr[P_RC_BAT_CAP]);
+
+  // ---- time: utils/managers.py:127-147 -------------------------------------------------------------
+  int hourq_n = hourq + 1, day_n = day;
+  if (hourq_n >= 96) {
+    hourq_n = 0;
+    day_n += 1;
+  }
+  const int ip = i + 1;
+
+  // ---- observations at i' (sustaindc_env.py:565-585) ----------------------------------------------------------------
+  if (feat_ok) {
+    // the trace-only entries come from the episode's feature row (sdc_features.hip), one float per lane of the half;
+    // lane 1 adds the nine entries that depend on the step
+    constexpr unsigned TRACE_ONLY = 0x7u | (0x7Fu << SDC_P_CI7) | (1u << SDC_P_W) | (1u << SDC_P_NT) | (1u << SDC_P_TSLOPE) |
+                                    (0x1Fu << SDC_P_T5) | (1u << SDC_P_WNEXT) | (1u << SDC_P_NTNEXT);
+    float* pool = sh.pool[h];
+    if (l < SDC_POOL_DIM && ((TRACE_ONLY >> l) & 1u)) pool[l] = frow;
+    if (l == 1) {
+      pool[SDC_P_OLDEST] = (float)oldest_norm;
+      pool[SDC_P_AVG] = (float)avg_norm;
+      pool[SDC_P_NORMQ] = (float)normq;
+      for (int b = 0; b < 5; b++) pool[SDC_P_HIST + b] = (float)hist[b];
+      pool[SDC_P_SOC] = (float)soc_after;
+    }
+  } else if (l == 0) {
+    // no feature rows for this episode: the wavefront computes the features of this env below (whole-wave, per env)
+    double* o = sh.osc[h];
+    o[0] = g[G_LUT]; o[1] = g[G_LUT2]; o[2] = w_ip; o[3] = w_ip1; o[4] = soc_after; o[5] = normq; o[6] = oldest_norm;
+    o[7] = avg_norm;
+    for (int b = 0; b < 5; b++) o[8 + b] = hist[b];
+    o[13] = ip >= 16 ? 1.0 : 0.0;
+  }
+
+  // ---- history append (utils/reward_creator.py:7-14) --------------------------------------------------------
+  // The ring holds fp32 OFFSETS from the env's first energy value (kept in fp64): normalize_energy is
+  // shift-invariant, and offsets keep the fp32 rounding error proportional to the spread of the history
+  // instead of to the ~300 kWh magnitude (two nearly equal energies would otherwise lose the z-score).
+  // Stored as order-preserving keys for the order-statistic trackers.
+  // As in the reference, only default_ls_reward appends (reward_creator.py:63): with another ls reward method the
+  // history stays as it is and the other agents' footprint rewards are normalised against it.
+  const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;
+  int hl = lrec_i32(rp, R_HIST_LEN), hpos = lrec_i32(rp, R_HIST_POS);
+  const double href = hl == 0 ? energy : lrec_f64(rp, R_HIST_REF);
+  const double e_off = energy - href;
+  int slot;
+  if (!append) {
+    slot = -1;
+  } else if (hl < S.hist_cap) {
+    slot = hl;
+    hl += 1;
+  } else {
+    slot = hpos;
+    hpos = hpos + 1 == S.hist_cap ? 0 : hpos + 1;
+  }
+  const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
+
+  wave_sync();     // every lane has read what it needs from the records: lane 0 of each half may now patch its record
+  if (l == 0) {
+    // ---- info block --------------------------------------------------------------------------------
+    float* inf = sh.info[h];
+    inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)wl;
+    inf[SDC_INFO_LS_SHIFTED_WORKLOAD] = (float)util;
+    inf[SDC_INFO_LS_TASKS_IN_QUEUE] = (float)total;
+    inf[SDC_INFO_LS_NORM_TASKS_IN_QUEUE] = (float)normq;
+    inf[SDC_INFO_LS_TASKS_DROPPED] = (float)dropped;
+    inf[SDC_INFO_LS_TASKS_PROCESSED] = (float)processed;
+    inf[SDC_INFO_LS_OLDEST_TASK_AGE] = (float)oldest_norm;
+    inf[SDC_INFO_LS_AVERAGE_TASK_AGE] = (float)avg_norm;
+    inf[SDC_INFO_LS_OVERDUE_PENALTY] = (float)overdue;
+    inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(util * 100);
+    inf[SDC_INFO_LS_CURRENT_HOUR] = (float)hour;
+    for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
+    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(p_it, 1e3);
+    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(ct, 1e3);
+    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(comp, 1e3);
+    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(ct + comp, 1e3);
+    inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
+    inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
+    inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
+    inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)util;
+    inf[SDC_INFO_DC_INT_TEMPERATURE] = (float)mean_outlet;
+    inf[SDC_INFO_DC_EXTERIOR_AMBIENT_TEMP] = (float)amb;
+    inf[SDC_INFO_DC_WATER_USAGE] = (float)water;
+    inf[SDC_INFO_BAT_ACTION] = (float)a_bat;
+    inf[SDC_INFO_BAT_SOC] = (float)soc_after;
+    inf[SDC_INFO_BAT_CO2_FOOTPRINT] = (float)co2;
+    inf[SDC_INFO_BAT_AVG_CI] = (float)ci_i;
+    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH] = (float)e_nobat;
+    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH] = (float)energy;
+    inf[SDC_INFO_NORM_CI] = (float)norm_ci;
+    inf[SDC_INFO_OUTSIDE_TEMP] = (float)amb_next;
+    inf[SDC_INFO_DAY] = (float)day_n;
+    inf[SDC_INFO_HOUR] = (float)((double)hourq_n * 0.25);
+    const unsigned f_all = (unsigned)lrec_i32(rp, R_FAULT) | fault;
+    inf[SDC_INFO_FAULT] = (float)f_all;
+    inf[SDC_INFO_ENERGY_Z] = 0.0f;       // the five columns below are filled by the reward part of the step
+    inf[SDC_INFO_RESERVED] = 0.0f;
+    inf[SDC_INFO_EP_RETURN_LS] = 0.0f;
+    inf[SDC_INFO_EP_RETURN_DC] = 0.0f;
+    inf[SDC_INFO_EP_RETURN_BAT] = 0.0f;
+    inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
+
+    // ---- history append: the ring slot gets this step's key; the queue table this step's prefix counts ----------
+    if (append) S.hist[(size_t)envc * SDC_HIST_STRIDE + slot] = x_new;
+    S.qtab[(size_t)envc * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
+
+    // ---- new state record ------------------------------------------------------------------------------------
+    unsigned* o = sh.rec[h];
+    o[R_CURSOR] = (unsigned)ip;
+    o[R_TREL] = (unsigned)(rel + 1);
+    o[R_DAY] = (unsigned)day_n;
+    o[R_HOURQ] = (unsigned)hourq_n;
+    o[R_QPOPPED] = (unsigned)popped;
+    o[R_QCUM] = (unsigned)cum_now;
+    o[R_QCUMT] = cumT_now;
+    o[R_QHEAD] = (unsigned)head;
+    o[R_QCUM_HM1] = (unsigned)cum_hm1;
+    o[R_QCUMT_HM1] = cumT_hm1;
+    o[R_LAST_DELTA] = (unsigned)delta;
+    o[R_CONSEC] = (unsigned)consecutive;
+    o[R_SCALE] = (unsigned)scale;
+    o[R_HIST_LEN] = (unsigned)hl;
+    o[R_HIST_POS] = (unsigned)hpos;
+    o[R_FAULT] = f_all;
+    o[R_TR_COUNT] = (unsigned)tr_count;
+    *reinterpret_cast<double*>(o + R_STPT) = stpt;
+    *reinterpret_cast<double*>(o + R_BAT) = bat_load;
+    *reinterpret_cast<double*>(o + R_HIST_REF) = href;
+    *reinterpret_cast<double*>(o + R_LAST_ROOM) = mean_outlet;
+    if (actions_out) {     // the actions the step applied (rule-based policies: what they chose)
+      actions_out[(size_t)envc * 3 + 0] = a_ls;
+      actions_out[(size_t)envc * 3 + 1] = a_dc;
+      actions_out[(size_t)envc * 3 + 2] = a_bat;
+    }
+  }
+  DynOut o;
+  o.energy = energy; o.e_off = e_off; o.norm_ci = norm_ci; o.oldest_norm = oldest_norm; o.p_it = p_it;
+  o.total_kw = total_kw; o.water = water; o.overdue = overdue; o.hourq_n = hourq_n; o.hl = hl; o.slot = slot;
+  o.x_new = x_new;
+  return o;
+}
+
+// per-env scalars out of the halves: lane 32 * e holds env e's value
+__device__ __forceinline__ int pick_i32(int v, int e) { return __builtin_amdgcn_readlane(v, e * HL); }
+__device__ __forceinline__ double pick_f64(double v, int e) { return readlane_f64(v, e * HL); }
+
+// ------------------------------------------------------------------------------------------------
+// rewards of ONE env (utils/reward_creator.py:16-130), whole wavefront, wave-uniform control flow.  Four rank windows and
+// running sums (sdc_trackers.hpp) normally answer without reading the history ring; a miss rebuilds them from the ring
+// right here.  hd0: the env's header (lane i = dword i), qw: its rank windows (lane i = key i of each).
+__device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const int lane, const unsigned hd0, const uint4 qw,
+                                           const int hl, const int slot, const unsigned x_new_v, const unsigned x_old,
+                                           const double e_off, const double energy, const double norm_ci,
+                                           const double oldest_norm, const int overdue, const int hourq_n, const double p_it,
+                                           const double total_kw, const double water, float* __restrict__ rew,
+                                           float* __restrict__ inf_row, sdc_rw::TailLds& tl) {
+  using namespace sdc_rw;
+  const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;
+  const unsigned x_new = sfl(x_new_v);
+  const int n = (int)sfl((unsigned)hl);
+  const bool has_old = append && x_old != KEY_NONE;
+  unsigned o0 = hd0;
+  double mean = 0.0, sd = 0.0;
+  int path = 0;   // diagnostics: 0 no ring read, 1 a window re-centred ahead of need, 3 rebuilt
+  const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), slot, x_new};
+  if (__builtin_expect(n >= 2, 1)) {
+    int k1, k3;
+    quartile_ranks(n, k1, k3);
+    // quartile windows q1 / q3; clip-bound windows bu (upper bound, keys as they are) / bl (lower bound, keys
+    // complemented, so that on both sides "beyond the bound" means "at or above it")
+    QTrack q1 = qt_load(hd0, H_Q1, qw.x), q3 = qt_load(hd0, H_Q3, qw.y);
+    QTrack bu = qt_load(hd0, H_BU, qw.z), bl = qt_load(hd0, H_BL, qw.w);
+    bool wd1 = false, wd3 = false, wdu = false, wdl = false;   // a window goes back to memory only if its lanes changed
+    double A1 = rec_f64(hd0, H_A1), A2 = rec_f64(hd0, H_A2);
+    bool ok = n >= SMALL_N && qt_valid(q1) && qt_valid(q3) && qt_valid(bu) && qt_valid(bl) && rec_i32(hd0, H_VALID) == 1;
+    int why = ok ? 0 : 1;                            // diagnostics (debug_flags bit 1): why a rebuild was needed
+    if (__builtin_expect(ok && append, 1)) {
+      // O(1) updates: running sums, the four windows
+      const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
+      const int n_prev = has_old ? n : n - 1;
+      A1 += vn - vo;
+      A2 += vn * vn - vo * vo;
+      wd1 = qt_update(q1, x_new, x_old, has_old, n_prev, lane);
+      wd3 = qt_update(q3, x_new, x_old, has_old, n_prev, lane);
+      wdu = qt_update(bu, x_new, x_old, has_old, n_prev, lane);
+      wdl = qt_update(bl, ~x_new, ~x_old, has_old, n_prev, lane);
+      if (!(qt_valid(q1) && qt_valid(q3) && qt_valid(bu) && qt_valid(bl))) { ok = false; why = 2; }
+    }
+    unsigned kb0 = 0u, kb1 = 0u;
+    // running (count, sum v, sum v^2) over the keys at or beyond each clip bound
+    int qc0 = 0, qc1 = 0;
+    double qs1_0 = 0.0, qs1_1 = 0.0, qs2_0 = 0.0, qs2_1 = 0.0;
+    bool done_eval = false;
+    if (__builtin_expect(ok, 1)) {
+      unsigned a1, b1, a3, b3;
+      if (__builtin_expect(qt_resolve(q1, k1, n, a1, b1) && qt_resolve(q3, k3, n, a3, b3), 1)) {
+        const Bounds b = clip_bounds(n, a1, b1, a3, b3);
+        kb0 = b.kub;               // upper tail: keys >= kub
+        kb1 = ~(b.klb - 1u);       // lower tail, flipped: ~x >= ~(klb-1)  <=>  x < klb
+        // first the value that came and the one that went against last step's bounds kbl, then the keys the bounds
+        // have moved across since -- which a bound's window lists, as long as both the old and the new bound lie
+        // inside its span
+        const unsigned kbl0 = (unsigned)rec_i32(hd0, H_KB), kbl1 = (unsigned)rec_i32(hd0, H_KB + 1);
+        qc0 = rec_i32(hd0, H_QC);
+        qc1 = rec_i32(hd0, H_QC + 1);
+        qs1_0 = rec_f64(hd0, H_QS1);
+        qs1_1 = rec_f64(hd0, H_QS1 + 2);
+        qs2_0 = rec_f64(hd0, H_QS2_HI);
+        qs2_1 = rec_f64(hd0, H_QS2_LO);
+        if (append) {
+          const double vn = key_f64(x_new), vo = key_f64(x_old);
+          if (has_old && x_old >= kbl0) { qc0 -= 1; qs1_0 -= vo; qs2_0 -= vo * vo; }
+          if (has_old && ~x_old >= kbl1) { qc1 -= 1; qs1_1 -= vo; qs2_1 -= vo * vo; }
+          if (x_new >= kbl0) { qc0 += 1; qs1_0 += vn; qs2_0 += vn * vn; }
+          if (~x_new >= kbl1) { qc1 += 1; qs1_1 += vn; qs2_1 += vn * vn; }
+        }
+        const unsigned lo0 = min(kb0, kbl0), hi0 = max(kb0, kbl0), lo1 = min(kb1, kbl1), hi1 = max(kb1, kbl1);
+        const bool cov0 = kb0 == kbl0 || qt_spans(bu, lo0, hi0, n), cov1 = kb1 == kbl1 || qt_spans(bl, lo1, hi1, n);
+        if (__builtin_expect(cov0 && cov1, 1)) {
+          int dc0 = 0, dc1 = 0;
+          double d1_0 = 0.0, d2_0 = 0.0, d1_1 = 0.0, d2_1 = 0.0;
+          const bool x0 = kb0 != kbl0 && win_crossing(bu, lo0, hi0, 0u, dc0, d1_0, d2_0);
+          const bool x1 = kb1 != kbl1 && win_crossing(bl, lo1, hi1, KEY_NONE, dc1, d1_1, d2_1);
+          if (__builtin_expect(x0, 0)) {
+            const double sg = kb0 > kbl0 ? -1.0 : 1.0;   // bound moved out: the keys in between leave the tail
+            qc0 += (kb0 > kbl0 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc0);
+            qs1_0 += sg * wave_sum_f64(d1_0);
+            qs2_0 += sg * wave_sum_f64(d2_0);
+          }
+          if (__builtin_expect(x1, 0)) {
+            const double sg = kb1 > kbl1 ? -1.0 : 1.0;
+            qc1 += (kb1 > kbl1 ? -1 : 1) * (int)wave_sum_u32((unsigned)dc1);
+            qs1_1 += sg * wave_sum_f64(d1_1);
+            qs2_1 += sg * wave_sum_f64(d2_1);
+          }
+          // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
+          const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
+          const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
+          clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
+          done_eval = true;
+        } else {
+          why = cov0 ? 7 : 6;
+        }
+      } else {
+        why = 4;
+      }
+    }
+    bool valid = true;
+    if (__builtin_expect(!done_eval, 0)) {
+      // miss (no state yet, a window that did not cover, an inconsistency): rebuild everything from the ring
+      const Rebuilt rb = rebuild_state(R, lane, n, tl);
+      if (n < SMALL_N || !rb.ok) {   // tiny history (nothing to keep), or a ring no window can describe
+        mean = rb.mean;
+        sd = rb.sd;
+        q1.hi = q3.hi = bu.hi = bl.hi = 0;
+        valid = false;
+      } else {
+        q1 = rb.q1;
+        q3 = rb.q3;
+        bu = rb.bu;
+        bl = rb.bl;
+        wd1 = wd3 = wdu = wdl = true;
+        A1 = rb.A1;
+        A2 = rb.A2;
+        kb0 = rb.b.kub;
+        kb1 = ~(rb.b.klb - 1u);
+        qc0 = rb.qc[0]; qc1 = rb.qc[1];
+        qs1_0 = rb.qs1[0]; qs1_1 = rb.qs1[1];
+        qs2_0 = rb.qs2[0]; qs2_1 = rb.qs2[1];
+        const double t1 = (qs1_0 - (double)qc0 * rb.b.ub) + (qs1_1 - (double)qc1 * rb.b.lb);
+        const double t2 = (qs2_0 - (double)qc0 * (rb.b.ub * rb.b.ub)) + (qs2_1 - (double)qc1 * (rb.b.lb * rb.b.lb));
+        clipped_moments(n, rb.b, A1, A2, t1, t2, mean, sd);
+      }
+      path = 3 + ((S.debug_flags & 2) ? why : 0);
+    }
+    put_u32(o0, H_KB, kb0);
+    put_u32(o0, H_KB + 1, kb1);
+    put_u32(o0, H_VALID, valid ? 1u : 0u);
+    put_f64(o0, H_A1, A1);
+    put_f64(o0, H_A2, A2);
+    put_running_tails(o0, qc0, qc1, qs1_0, qs1_1, qs2_0, qs2_1);
+    // Windows AHEAD of need: if, in the worst case for the keys the next step removes and adds, a window would no
+    // longer cover what is asked of it, re-centre it now -- at the end of this wavefront's life, when the memory
+    // system is quiet and the other wavefronts of its SIMD are finishing -- instead of at the start of the next
+    // launch, where the sweep's loads would queue behind every env's start-of-step traffic.
+    if (__builtin_expect(valid && n >= SMALL_N, 1)) {
+      int k1n, k3n;
+      quartile_ranks((append && n < S.hist_cap) ? n + 1 : n, k1n, k3n);
+      // a bound's window is centred on the rank of the first key beyond the bound
+      const int req = qt_refill_ahead(q1, k1n, n, 3, 6) | (qt_refill_ahead(q3, k3n, n, 3, 6) << 2) |
+                      (qt_refill_ahead(bu, n - qc0, n, 10, 10) << 4) | (qt_refill_ahead(bl, n - qc1, n, 10, 10) << 6);
+      if (__builtin_expect(req != 0, 0)) {
+        __builtin_amdgcn_s_setprio(3);   // the step ends when the slowest wavefront does: let this one issue first
+        // one copy of the refill code: the windows take turns through it
+#pragma unroll 1
+        for (int t = 0; t < 4; t++) {
+          const int d = (req >> (2 * t)) & 3;
+          if (d == REFILL_NONE) continue;
+          QTrack A = t == 0 ? q1 : (t == 1 ? q3 : (t == 2 ? bu : bl));
+          const int kt = t == 0 ? k1n : (t == 1 ? k3n : (t == 2 ? n - qc0 : n - qc1));
+          qt_refill(A, d, kt, n, R, lane, tl, t == 3 ? KEY_NONE : 0u);
+          if (t == 0) { q1 = A; wd1 = true; }
+          if (t == 1) { q3 = A; wd3 = true; }
+          if (t == 2) { bu = A; wdu = true; }
+          if (t == 3) { bl = A; wdl = true; }
+        }
+        path = max(path, 1);
+      }
+    }
+    qt_put(o0, H_Q1, q1);
+    qt_put(o0, H_Q3, q3);
+    qt_put(o0, H_BU, bu);
+    qt_put(o0, H_BL, bl);
+    if (wd1 || wd3 || wdu || wdl)
+      reinterpret_cast<uint4*>(S.qwin)[(size_t)env * SDC_WIN + lane] = make_uint4(q1.w, q3.w, bu.w, bl.w);
+  } else {
+    put_u32(o0, H_VALID, 0u);
+  }
+  put_u32(o0, H_N, (unsigned)n);
+  // (this path re-centres inline and rebuilds: deferred re-centrings in flight for this env are dropped)
+  put_u32(o0, H_PEND, 0u); put_u32(o0, H_PEND + 1, 0u); put_u32(o0, H_PEND + 2, 0u); put_u32(o0, H_PEND + 3, 0u);
+  put_f64(o0, H_EOFF, e_off);                                 // bat_total_energy_with_battery_KWh - hist_ref
+  const double z = n < 2 ? 0.0 : (e_off - mean) / (sd > 0 ? sd : 1.0);
+  const RewardIn rin = {z, norm_ci, oldest_norm, (double)overdue, energy, (double)hourq_n * 0.25, SDC_DIV_CONST(p_it, 1e3), total_kw, water};
+  const Rewards rr = step_rewards(rin, S.reward_method, hd0);
+  put_f64(o0, H_RET, rr.ret[0]);
+  put_f64(o0, H_RET + 2, rr.ret[1]);
+  put_f64(o0, H_RET + 4, rr.ret[2]);
+  if (lane == 0) store_rewards(rr, z, path, env, rew, inf_row);
+  __builtin_nontemporal_store(o0, &S.hdr[(size_t)env * SDC_HDR_DWORDS + lane]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rewards of BOTH envs at once (utils/reward_creator.py:16-130): the O(1) path of env_reward() below in half-wave form
+// (sdc_halfwin.hpp) -- running sums, the four rank windows, clip bounds, tail sums, moments, z, the three rewards, the new
+// header -- same arithmetic in the same order, so both paths give the same bits.  An env whose step needs anything else
+// (no valid reward state yet, a window that does not cover, a window to re-centre ahead of need, fewer than SMALL_N
+// keys, a non-appending reward configuration) is left untouched and reported in the returned mask: env_reward()
+// then redoes it from its unmodified state.  wa / wb: the lane's keys 2l / 2l + 1 of {Q1, Q3, BU, BL}.
+// Returns the ballot of lanes whose env was completed here.
+__device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, const int envc, const bool active, const int h,
+                                                               const int l, const uint4 wa, const uint4 wb, const DynOut& d,
+                                                               const unsigned x_old, float* __restrict__ rew, PairShared& sh,
+                                                               const int step_no, const bool defer) {
+  using namespace sdc_rw;
+  using namespace sdc_hw;
+  const unsigned* hp = sh.hdr[h];
+  const int n = d.hl;
+  const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;
+  const bool has_old = x_old != KEY_NONE;
+  const unsigned x_new = d.x_new;
+  int k1, k3;
+  quartile_ranks(n, k1, k3);
+  HWin q1 = {wa.x, wb.x, (int)hp[H_Q1 + T_R0], (int)hp[H_Q1 + T_HI]};
+  HWin q3 = {wa.y, wb.y, (int)hp[H_Q3 + T_R0], (int)hp[H_Q3 + T_HI]};
+  HWin bu = {wa.z, wb.z, (int)hp[H_BU + T_R0], (int)hp[H_BU + T_HI]};
+  HWin bl = {wa.w, wb.w, (int)hp[H_BL + T_R0], (int)hp[H_BL + T_HI]};
+  double A1 = lrec_f64(hp, H_A1), A2 = lrec_f64(hp, H_A2);
+  bool ok = append && n >= SMALL_N && q1.hi > 0 && q3.hi > 0 && bu.hi > 0 && bl.hi > 0 && (int)hp[H_VALID] == 1;
+  // ---- deferred re-centrings (SdcRefillReq / SdcRefillRes): a window requested two steps ago arrives now --------------
+  unsigned pend0 = hp[H_PEND], pend1 = hp[H_PEND + 1], pend2 = hp[H_PEND + 2], pend3 = hp[H_PEND + 3];
+  bool wdc = false;    // a window was replaced
+  if (__builtin_expect(__ballot((pend0 | pend1 | pend2 | pend3) != 0u) != 0ull, 0)) {
+    const unsigned lx_new = hp[H_LAST_XNEW], lx_old = hp[H_LAST_XOLD];
+    const int l_nprev = (int)hp[H_LAST_NPREV];
+    auto arrive = [&](HWin& q, unsigned& pd, const int w, const unsigned flip) __attribute__((always_inline)) {
+      const int rstep = (int)(pd >> 8), idx = (int)(pd & 0xFFu) - 1;
+      const bool due = pd != 0u && (step_no >= rstep + 2 || step_no < rstep);   // (else: still being swept; a stamp from the future: restored state)
+      const SdcRefillRes* rs = S.rs + ((rstep + 1) % 3) * SDC_RQ_MAX + (idx < 0 ? 0 : idx);
+      int4 hd = make_int4(0, 0, -1, -1);
+      unsigned ka = KEY_NONE, kb = KEY_NONE;
+      if (due) {
+        hd = *reinterpret_cast<const int4*>(rs);
+        ka = rs->keys[2 * l];
+        kb = rs->keys[2 * l + 1];
+      }
+      HWin r = {ka, kb, hd.x, hd.y};
+      const bool good = due && step_no == rstep + 2 && hd.z == rstep + 1 && hd.w == envc * 4 + w && r.hi > 0 && ok;
+      // the result describes the ring as the request's step left it: replay the previous step's insertion / eviction
+      hw_update(r, lx_new ^ flip, lx_old ^ flip, lx_old != KEY_NONE, l_nprev, good, h, l);
+      if (good && r.hi > 0) {
+        q = r;
+        wdc = true;
+      }
+      if (due) pd = 0u;
+    };
+    arrive(q1, pend0, 0, 0u);
+    arrive(q3, pend1, 1, 0u);
+    arrive(bu, pend2, 2, 0u);
+    arrive(bl, pend3, 3, KEY_NONE);
+  }
+  // O(1) updates: running sums, the four windows
+  const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
+  const int n_prev = has_old ? n : n - 1;
+  A1 += vn - vo;
+  A2 += vn * vn - vo * vo;
+  const bool wd1 = hw_update(q1, x_new, x_old, has_old, n_prev, ok, h, l);
+  const bool wd3 = hw_update(q3, x_new, x_old, has_old, n_prev, ok, h, l);
+  const bool wdu = hw_update(bu, x_new, x_old, has_old, n_prev, ok, h, l);
+  const bool wdl = hw_update(bl, ~x_new, ~x_old, has_old, n_prev, ok, h, l);
+  ok = ok && q1.hi > 0 && q3.hi > 0 && bu.hi > 0 && bl.hi > 0;
+  unsigned a1, b1, a3, b3;
+  const bool r1 = hw_resolve(q1, k1, n, h, a1, b1), r3 = hw_resolve(q3, k3, n, h, a3, b3);
+  ok = ok && r1 && r3;
+  const Bounds b = clip_bounds(n, a1, b1, a3, b3);
+  const unsigned kb0 = b.kub;               // upper tail: keys >= kub
+  const unsigned kb1 = ~(b.klb - 1u);       // lower tail, flipped: ~x >= ~(klb-1)  <=>  x < klb
+  // first the value that came and the one that went against last step's bounds kbl, then the keys the bounds have
+  // moved across since -- which a bound's window lists, as long as both the old and the new bound lie inside its span
+  const unsigned kbl0 = hp[H_KB], kbl1 = hp[H_KB + 1];
+  int qc0 = (int)hp[H_QC], qc1 = (int)hp[H_QC + 1];
+  double qs1_0 = lrec_f64(hp, H_QS1), qs1_1 = lrec_f64(hp, H_QS1 + 2);
+  double qs2_0 = lrec_f64(hp, H_QS2_HI), qs2_1 = lrec_f64(hp, H_QS2_LO);
+  {
+    const double vo2 = key_f64(x_old);
+    if (has_old && x_old >= kbl0) { qc0 -= 1; qs1_0 -= vo2; qs2_0 -= vo2 * vo2; }
+    if (has_old && ~x_old >= kbl1) { qc1 -= 1; qs1_1 -= vo2; qs2_1 -= vo2 * vo2; }
+    if (x_new >= kbl0) { qc0 += 1; qs1_0 += vn; qs2_0 += vn * vn; }
+    if (~x_new >= kbl1) { qc1 += 1; qs1_1 += vn; qs2_1 += vn * vn; }
+  }
+  const unsigned lo0 = min(kb0, kbl0), hi0 = max(kb0, kbl0), lo1 = min(kb1, kbl1), hi1 = max(kb1, kbl1);
+  const bool sp0 = hw_spans(bu, lo0, hi0, n, h), sp1 = hw_spans(bl, lo1, hi1, n, h);
+  ok = ok && (kb0 == kbl0 || sp0) && (kb1 == kbl1 || sp1);
+  {
+    // the keys a bound has crossed: this lane's share over its two keys, then the half's total (rare: skipped as a
+    // whole when no lane of the wavefront has one)
+    const bool x0a = ok && kb0 != kbl0 && bu.a >= lo0 && bu.a < hi0, x0b = ok && kb0 != kbl0 && bu.b >= lo0 && bu.b < hi0;
+    const bool x1a = ok && kb1 != kbl1 && bl.a >= lo1 && bl.a < hi1, x1b = ok && kb1 != kbl1 && bl.b >= lo1 && bl.b < hi1;
+    if (__builtin_expect(__ballot(x0a || x0b) != 0ull, 0)) {
+      const double va = x0a ? key_f64(bu.a) : 0.0, vb = x0b ? key_f64(bu.b) : 0.0;
+      const unsigned c = half_sum_u32((x0a ? 1u : 0u) + (x0b ? 1u : 0u));
+      const double s1 = half_sum_f64(va + vb), s2 = half_sum_f64(va * va + vb * vb);
+      const double sg = kb0 > kbl0 ? -1.0 : 1.0;   // bound moved out: the keys in between leave the tail
+      qc0 += (kb0 > kbl0 ? -1 : 1) * (int)c;
+      qs1_0 += sg * s1;
+      qs2_0 += sg * s2;
+    }
+    if (__builtin_expect(__ballot(x1a || x1b) != 0ull, 0)) {
+      const double va = x1a ? key_f64(~bl.a) : 0.0, vb = x1b ? key_f64(~bl.b) : 0.0;
+      const unsigned c = half_sum_u32((x1a ? 1u : 0u) + (x1b ? 1u : 0u));
+      const double s1 = half_sum_f64(va + vb), s2 = half_sum_f64(va * va + vb * vb);
+      const double sg = kb1 > kbl1 ? -1.0 : 1.0;
+      qc1 += (kb1 > kbl1 ? -1 : 1) * (int)c;
+      qs1_1 += sg * s1;
+      qs2_1 += sg * s2;
+    }
+  }
+  // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
+  const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
+  const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
+  double mean, sd;
+  clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
+  // a window that the next step could exhaust is re-centred by the slow path (which then redoes this step)
+  {
+    int k1n, k3n;
+    quartile_ranks(n < S.hist_cap ? n + 1 : n, k1n, k3n);
+    auto ahead = [&](const HWin& q, const int k_next, const int m_lo, const int m_hi) __attribute__((always_inline)) {
+      const int t = k_next - q.r0;
+      return (t > q.hi - m_hi && q.r0 + q.hi < n) || (t < m_lo && q.r0 > 0);
+    };
+    const bool w0 = pend0 == 0u && ahead(q1, k1n, 3, 6), w1 = pend1 == 0u && ahead(q3, k3n, 3, 6);
+    const bool w2 = pend2 == 0u && ahead(bu, n - qc0, 10, 10), w3 = pend3 == 0u && ahead(bl, n - qc1, 10, 10);
+    if (__builtin_expect(__ballot(ok && (w0 || w1 || w2 || w3)) != 0ull, 0)) {
+      if (!defer) {
+        ok = ok && !(w0 || w1 || w2 || w3);      // (multi-step launches re-centre inline: the slow path redoes this step)
+      } else {
+        // file a request per window: a snapshot of the window as this step leaves it, the rank it should be centred on,
+        // and the content of the ring slot the NEXT step overwrites (the sweep must see the ring as it is now)
+        const int set = (step_no + 1) % 3;
+        const int slot_next = n < S.hist_cap ? n : (d.slot + 1 == S.hist_cap ? 0 : d.slot + 1);
+        unsigned patch_x = KEY_NONE;
+        if (ok && (w0 || w1 || w2 || w3)) patch_x = S.hist[(size_t)envc * SDC_HIST_STRIDE + slot_next];
+        auto request = [&](const HWin& q, unsigned& pd, const bool want, const int w, const int kt) __attribute__((always_inline)) {
+          int idx = -1;
+          if (want && ok && active && l == 0) idx = atomicAdd(&S.rq_count[set], 1);
+          idx = __builtin_amdgcn_ds_bpermute((h << 5) << 2, idx);       // lane 0 of the half tells the others
+          if (want && ok) {
+            if (idx < 0 || idx >= SDC_RQ_MAX) {
+              ok = false;                          // no room (or a missing env): re-centre inline on the slow path
+            } else {
+              SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + idx;
+              rq->keys[2 * l] = q.a;
+              rq->keys[2 * l + 1] = q.b;
+              if (l == 0) {
+                const int t = kt - q.r0;
+                rq->env = envc; rq->win = w;
+                rq->dir = (t > q.hi - (w < 2 ? 6 : 10) && q.r0 + q.hi < n) ? REFILL_UP : REFILL_DOWN;
+                rq->kt = kt; rq->n = n; rq->r0 = q.r0; rq->hi = q.hi;
+                rq->patch_slot = slot_next; rq->patch_x = patch_x; rq->step = step_no;
+              }
+              pd = ((unsigned)step_no << 8) | (unsigned)(idx + 1);
+            }
+          }
+        };
+        request(q1, pend0, w0, 0, k1n);
+        request(q3, pend1, w1, 1, k3n);
+        request(bu, pend2, w2, 2, n - qc0);
+        request(bl, pend3, w3, 3, n - qc1);
+      }
+    }
+  }
+  const double z = (d.e_off - mean) / (sd > 0 ? sd : 1.0);     // (n >= SMALL_N >= 2 here)
+  // rewards (step_rewards), per lane
+  double r[3], ret[3];
+  {
+    const double foot = -1.0 * (d.norm_ci * z / 0.50);
+    const double overdue_pen = -0.3 * sqrt((double)d.overdue) + 0.3;
+    const double age_pen = -0.1 * d.oldest_norm;
+    double rls = foot + overdue_pen + age_pen;
+    rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
+    const double ite_kw = SDC_DIV_CONST(d.p_it, 1e3), hour = (double)d.hourq_n * 0.25;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      double v;
+      switch (S.reward_method[a]) {   // wave-uniform
+        case SDC_REWARD_DEFAULT: v = a == 0 ? rls : foot; break;
+        case SDC_REWARD_FOOTPRINT: v = foot; break;
+        case SDC_REWARD_TOU: v = -1.0 * d.energy * tou_price((int)hour % 24); break;
+        case SDC_REWARD_ENERGY_EFFICIENCY: v = ite_kw / d.total_kw; break;
+        case SDC_REWARD_PUE: v = -fabs((ite_kw != 0 ? d.total_kw / ite_kw : (double)INFINITY) - 1); break;
+        case SDC_REWARD_WATER: v = -0.01 * d.water; break;
+        default: v = 0.0;   // SDC_REWARD_CUSTOM: custom_agent_reward returns 0
+      }
+      r[a] = v;
+      ret[a] = lrec_f64(hp, H_RET + 2 * a) + v;
+    }
+  }
+  wave_sync();   // every lane has read the header fields it needs
+  const bool commit = ok && active;
+  if (commit) {
+    if (wd1 || wd3 || wdu || wdl || wdc) {
+      uint4* qw = reinterpret_cast<uint4*>(S.qwin) + (size_t)envc * SDC_WIN + 2 * l;
+      qw[0] = make_uint4(q1.a, q3.a, bu.a, bl.a);
+      qw[1] = make_uint4(q1.b, q3.b, bu.b, bl.b);
+    }
+    if (l == 0) {
+      unsigned* o = sh.hdr[h];
+      auto put64 = [&](int idx, double v) { *reinterpret_cast<double*>(o + idx) = v; };
+      o[H_KB] = kb0;
+      o[H_KB + 1] = kb1;
+      o[H_VALID] = 1u;
+      put64(H_A1, A1);
+      put64(H_A2, A2);
+      o[H_QC] = (unsigned)qc0;
+      o[H_QC + 1] = (unsigned)qc1;
+      put64(H_QS1, qs1_0);
+      put64(H_QS1 + 2, qs1_1);
+      put64(H_QS2_HI, qs2_0);
+      put64(H_QS2_LO, qs2_1);
+      o[H_Q1 + T_R0] = (unsigned)q1.r0; o[H_Q1 + T_HI] = (unsigned)q1.hi;
+      o[H_Q3 + T_R0] = (unsigned)q3.r0; o[H_Q3 + T_HI] = (unsigned)q3.hi;
+      o[H_BU + T_R0] = (unsigned)bu.r0; o[H_BU + T_HI] = (unsigned)bu.hi;
+      o[H_BL + T_R0] = (unsigned)bl.r0; o[H_BL + T_HI] = (unsigned)bl.hi;
+      o[H_N] = (unsigned)n;
+      o[H_PEND] = pend0; o[H_PEND + 1] = pend1; o[H_PEND + 2] = pend2; o[H_PEND + 3] = pend3;
+      o[H_LAST_XNEW] = x_new;
+      o[H_LAST_XOLD] = x_old;
+      o[H_LAST_NPREV] = (unsigned)n_prev;
+      put64(H_EOFF, d.e_off);
+      put64(H_RET, ret[0]);
+      put64(H_RET + 2, ret[1]);
+      put64(H_RET + 4, ret[2]);
+      rew[envc * 3 + 0] = (float)r[0];
+      rew[envc * 3 + 1] = (float)r[1];
+      rew[envc * 3 + 2] = (float)r[2];
+      float* inf = sh.info[h];
+      inf[SDC_INFO_ENERGY_Z] = (float)z;
+      inf[SDC_INFO_RESERVED] = wdc ? 2.0f : 0.0f;   // no ring read by this wavefront (2: a deferred re-centred window arrived)
+      inf[SDC_INFO_EP_RETURN_LS] = (float)ret[0];
+      inf[SDC_INFO_EP_RETURN_DC] = (float)ret[1];
+      inf[SDC_INFO_EP_RETURN_BAT] = (float)ret[2];
+    }
+  }
+  wave_sync();
+  if (commit)
+    __builtin_nontemporal_store(reinterpret_cast<const unsigned long long*>(sh.hdr[h])[l],
+                                reinterpret_cast<unsigned long long*>(S.hdr + (size_t)envc * SDC_HDR_DWORDS) + l);
+  return __ballot(ok);
+}
+
+// a rank window one step from the point where it is re-centred (a sweep over the env's 40 KB ring at the END of the
+// step) makes its wavefront the likely straggler of the launch
+__device__ __forceinline__ bool near_refill(const SdcDev& S, const unsigned hd0, const int hl0) {
+  int k1, k3;
+  sdc_rw::quartile_ranks(hl0 < S.hist_cap ? hl0 + 1 : hl0, k1, k3);
+  const int r1 = rec_i32(hd0, H_Q1 + T_R0), h1 = rec_i32(hd0, H_Q1 + T_HI);
+  const int r3 = rec_i32(hd0, H_Q3 + T_R0), h3 = rec_i32(hd0, H_Q3 + T_HI);
+  const bool near1 = h1 > 0 && ((k1 - r1 >= h1 - 7 && r1 + h1 < hl0) || (k1 - r1 <= 4 && r1 > 0));
+  const bool near3 = h3 > 0 && ((k3 - r3 >= h3 - 7 && r3 + h3 < hl0) || (k3 - r3 <= 4 && r3 > 0));
+  // (likewise a clip-bound window whose bound sits within a dozen ranks of its edge)
+  const int ru = rec_i32(hd0, H_BU + T_R0), hu = rec_i32(hd0, H_BU + T_HI), tu = hl0 - rec_i32(hd0, H_QC) - ru;
+  const int rl = rec_i32(hd0, H_BL + T_R0), hl_ = rec_i32(hd0, H_BL + T_HI), tl = hl0 - rec_i32(hd0, H_QC + 1) - rl;
+  const bool nearu = hu > 0 && ((tu >= hu - 12 && ru + hu < hl0) || (tu <= 12 && ru > 0));
+  const bool nearl = hl_ > 0 && ((tl >= hl_ - 12 && rl + hl_ < hl0) || (tl <= 12 && rl > 0));
+  return near1 || near3 || nearu || nearl;
+}
+
+// One env-step of the env pair (env0, env0 + 1) by its wavefront: loads the state, runs the dynamics of both, the rewards
+// and the reward-state upkeep of each, stores the new state and the outputs.
+__device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const int env0, const int lane, const int rel_hint,
+                                          const int32_t* __restrict__ actions, float* __restrict__ obs,
+                                          float* __restrict__ share_obs, unsigned char* __restrict__ done,
+                                          float* __restrict__ info, float* __restrict__ final_obs,
+                                          float* __restrict__ rew, int32_t* __restrict__ actions_out, const int step_no,
+                                          const bool defer) {
+  const int TL = S.table_len;
+  const int h = lane >> 5, l = lane & (HL - 1);
+  const int n_here = min(EPW, S.n_envs - env0);           // envs of this pair that exist (1 for the last pair of an odd batch)
+  const int envc = env0 + min(h, n_here - 1);             // this lane's env (the missing one mirrors the last)
+  const bool active = h < n_here;                         // lanes of a missing env compute, but store nothing
+  const int env1c = env0 + n_here - 1;
+
+  // When the host knows the episode step every env is at (envs in lock-step: rel_hint >= 0), the step's feature row
+  // -- which also holds its trace inputs -- and its queue-history probes are requested together with the state
+  // record: ONE memory round trip before the dynamics start instead of two (record, then what it points to).
+  const bool pre = rel_hint >= 0 && S.feat != nullptr;
+  float frow_pre = 0.0f;
+  double q_pre = 0.0;
+  if (pre) {
+    frow_pre = S.feat[((size_t)envc * (S.episode_steps + 1) + (rel_hint + 1)) * SDC_FEAT_ROW + l];
+    if (l >= G_Q97 && l <= G_Q96) {
+      const int back = l == G_Q97 ? 97 : 24 * (l - G_Q97);   // 97, 24, 48, 72, 96
+      const int t = rel_hint - back;
+      if (t >= 0) q_pre = *reinterpret_cast<const double*>(S.qtab + (size_t)envc * S.qstride + t);
+    }
+  }
+  const unsigned long long dbg_entry = (S.debug_flags & 16) ? wall_clock64() : 0ull;
+
+  // ---- level 0: the two state records (one dwordx2 per lane, 512 contiguous bytes), headers, actions ----------------
+  uint2* recp = reinterpret_cast<uint2*>(S.rec + (size_t)envc * SDC_REC_DWORDS) + l;
+  const uint2 rr = *recp;
+  const unsigned hdA = S.hdr[(size_t)env0 * SDC_HDR_DWORDS + lane];      // reward-side state: returns, trackers, sums
+  const unsigned hdB = S.hdr[(size_t)env1c * SDC_HDR_DWORDS + lane];
+  int a_ls = 1, a_dc = 1, a_bat = 2;       // (rule-based slots never read the caller's array, which may be null)
+  if (S.policy[0] == SDC_POLICY_EXTERNAL) a_ls = actions[envc * 3 + 0];
+  if (S.policy[1] == SDC_POLICY_EXTERNAL) a_dc = actions[envc * 3 + 1];
+  if (S.policy[2] == SDC_POLICY_EXTERNAL) a_bat = actions[envc * 3 + 2];
+  reinterpret_cast<uint2*>(sh.rec[h])[l] = rr;
+  sh.hdr[0][lane] = hdA;
+  sh.hdr[1][lane] = hdB;
+  wave_sync();
+  const unsigned* rp = sh.rec[h];
+  const int i = lrec_i32(rp, R_CURSOR), rel = lrec_i32(rp, R_TREL);
+  const int loc = lrec_i32(rp, R_LOC);
+  const SdcDcDev* PD = &S.dc[lrec_i32(rp, R_CFG)];
+  const int hourq = lrec_i32(rp, R_HOURQ);
+  const int hourq_n = hourq + 1 >= 96 ? 0 : hourq + 1;
+  unsigned fault = 0;
+  if (i + 9 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
+  // actions outside {0,1,2}: the reference's dict lookups raise (envs/dc_gym.py:160, bat_env_fwd_view.py:99); here
+  // the step flags SDC_FAULT_ACTION and treats the action as "do nothing" / "no change" / "idle"
+  if (__builtin_expect((unsigned)a_ls > 2u || (unsigned)a_dc > 2u || (unsigned)a_bat > 2u, 0)) {
+    fault |= SDC_FAULT_ACTION;
+    if ((unsigned)a_ls > 2u) a_ls = 1;
+    if ((unsigned)a_dc > 2u) a_dc = 1;
+    if ((unsigned)a_bat > 2u) a_bat = 2;
+  }
+  // ---- level 1 ----------------------------------------------------------------------------------------------------------
+  // config scalars: lane j of the half fetches scalar j of its env's config (one coalesced 8-byte load), LDS hands them round
+  if (l < P_COUNT) sh.prm[h][l] = reinterpret_cast<const double*>(&PD->p.m_cpu)[l];
+  // the ring slot this step's energy will overwrite: its current key is the evicted value the reward state's
+  // order-statistic trackers need (0xFFFFFFFF while the ring is still filling)
+  const int hl0 = lrec_i32(rp, R_HIST_LEN);
+  const int slot0 = hl0 < S.hist_cap ? hl0 : lrec_i32(rp, R_HIST_POS);
+  unsigned x_old_l = 0xFFFFFFFFu;
+  const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;   // else the history does not change this step
+  if (hl0 >= S.hist_cap && append) x_old_l = S.hist[(size_t)envc * SDC_HIST_STRIDE + slot0];   // (one address per half)
+  // A wavefront with an env one step from a window re-centring: give it issue priority from the start and pull that
+  // ring into L2 now (one dword per 128-byte line, 5 loads per lane, results unused), so that the sweep finds it there.
+  if (append) {
+#pragma unroll
+    for (int e = 0; e < EPW; e++) {
+      const int hl_e = pick_i32(hl0, e);
+      if (e < n_here && hl_e >= sdc_rw::SMALL_N && __builtin_expect(near_refill(S, e == 0 ? hdA : hdB, hl_e), 0)) {
+        __builtin_amdgcn_s_setprio(2);
+        const volatile unsigned* ring = S.hist + (size_t)(env0 + e) * SDC_HIST_STRIDE;
+#pragma unroll
+        for (int j = 0; j < SDC_HIST_STRIDE / 32 / SDC_WAVE; j++) (void)ring[(j * SDC_WAVE + lane) * 32];
+      }
+    }
+  }
+  // The trace-only observation entries of this step come precomputed (sdc_features.hip), unless the episode has no
+  // feature rows (a host write since the reset, an episode too long for that kernel): then the CI / temperature
+  // windows are gathered and the features computed here.
+  const bool feat_ok = S.feat != nullptr && lrec_i32(rp, R_FEAT_OK) == 1;
+  const bool fast = pre && feat_ok && rel == rel_hint;   // what was requested up front is what this step needs
+  float frow = frow_pre;
+  if (feat_ok && !fast) frow = S.feat[((size_t)envc * (S.episode_steps + 1) + (rel + 1)) * SDC_FEAT_ROW + l];
+  const bool want_c3 = S.policy[2] == SDC_POLICY_RBC;
+  {
+    const double ci_min = lrec_f64(rp, R_CI_MIN), ci_den = lrec_f64(rp, R_CI_DEN);
+    const double t_min = lrec_f64(rp, R_T_MIN), t_den = lrec_f64(rp, R_T_DEN);
+    auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
+    const double* tW = S.tabW + (size_t)loc * TL;
+    const double* tC = S.tabC + (size_t)loc * TL;
+    const double* tw = S.t_win + (size_t)envc * S.lw + rel;
+    const double* wbw = S.wb_win + (size_t)envc * S.lw + rel;
+    const uint2* qt = S.qtab + (size_t)envc * S.qstride;
+    auto gather = [&](const int s) -> double {
+      const double* src = nullptr;
+      if (s <= (feat_ok ? G_W0 : G_W2)) src = tW + tix(i + s);   // (W[i+1], W[i+2], the hour LUT: observations only)
+      else if (s == G_C0) src = tC + tix(i);
+      else if (s == G_T0) src = tw;
+      else if (s == G_WB0) src = wbw;
+      else if (s == G_T1) src = tw + 1;
+      else if (!feat_ok && s == G_LUT) src = S.hour_lut + 2 * hourq_n;
+      else if (!feat_ok && s == G_LUT2) src = S.hour_lut + 2 * hourq_n + 1;
+      else if (s >= G_Q97 && s <= G_Q96) {
+        const int back = s == G_Q97 ? 97 : 24 * (s - G_Q97);   // 97, 24, 48, 72, 96
+        const int t = rel - back;
+        if (t >= 0) src = reinterpret_cast<const double*>(qt + t);
+      } else if (s == G_C3 && want_c3) src = tC + tix(i + 3);
+      else if (!feat_ok && s >= G_NC && s < G_NC + 25) src = tC + tix(i + 1 - 16 + (s - G_NC));
+      else if (!feat_ok && s >= G_NT && s < G_NT + 17) src = tw + 1 + (s - G_NT);
+      double v = 0.0;
+      if (src) v = *src;
+      if (!feat_ok) {
+        // NC = (C - min) / (max - min) (utils/managers.py:437), NT likewise (:608): ONE division sequence for both windows
+        const bool is_nc = s >= G_NC && s < G_NC + 25, is_nt = s >= G_NT && s < G_NT + 17;
+        if (is_nc || is_nt) v = (v - (is_nc ? ci_min : t_min)) / (is_nc ? ci_den : t_den);
+      }
+      return v;
+    };
+    double* gh = sh.g[h];
+    if (__builtin_expect(fast, 1)) {
+      // the row's input slots and the probes go to the places the gather would have put them
+      unsigned* g32 = reinterpret_cast<unsigned*>(gh);
+      const unsigned fb = (unsigned)__float_as_int(frow);
+      if (l == SDC_FEAT_W || l == SDC_FEAT_W + 1) g32[2 * G_W0 + (l - SDC_FEAT_W)] = fb;
+      if (l == SDC_FEAT_C || l == SDC_FEAT_C + 1) g32[2 * G_C0 + (l - SDC_FEAT_C)] = fb;
+      if (l == SDC_FEAT_T || l == SDC_FEAT_T + 1) g32[2 * G_T0 + (l - SDC_FEAT_T)] = fb;
+      if (l == SDC_FEAT_WB || l == SDC_FEAT_WB + 1) g32[2 * G_WB0 + (l - SDC_FEAT_WB)] = fb;
+      if (l == SDC_FEAT_NCNEXT || l == SDC_FEAT_NCNEXT + 1) g32[2 * G_NCN + (l - SDC_FEAT_NCNEXT)] = fb;
+      if (l == SDC_FEAT_T1) gh[G_T1] = (double)frow;
+      if (l >= G_Q97 && l <= G_Q96) gh[l] = q_pre;
+      if (l == G_C3 && want_c3) gh[G_C3] = gather(G_C3);
+    } else {
+      if (l != G_NCN) gh[l] = gather(l);
+      if (feat_ok) {
+        unsigned* g32 = reinterpret_cast<unsigned*>(gh);
+        if (l == SDC_FEAT_NCNEXT || l == SDC_FEAT_NCNEXT + 1) g32[2 * G_NCN + (l - SDC_FEAT_NCNEXT)] = (unsigned)__float_as_int(frow);
+      } else {
+        gh[HL + l] = gather(HL + l);
+      }
+    }
+  }
+  wave_sync();
+
+  unsigned long long dbg_a0 = 0ull;
+  if (__builtin_expect((S.debug_flags & 8) != 0, 0)) dbg_a0 = wall_clock64();
+  // the rank windows of both envs, one key each per lane: wanted at the end of the step, so the loads are issued here --
+  // after the start-of-launch burst of every env's record / header / gather loads -- and ride along in 8 registers
+  const uint4 wka = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l];       // keys 2l of the 4 windows
+  const uint4 wkb = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l + 1];   // keys 2l + 1
+  const DynOut d = pair_dynamics(S, envc, h, l, a_ls, a_dc, a_bat, fault, feat_ok, frow, actions_out, sh);
+  wave_sync();
+
+  // ---- episodes without feature rows: the observation features of such an env, all 64 lanes cooperating ---------------
+  if (__builtin_expect(__ballot(!feat_ok) != 0ull, 0)) {
+    for (int e = 0; e < n_here; e++) {
+      if (pick_i32(feat_ok ? 1 : 0, e)) continue;
+      const double* os = sh.osc[e];
+      ObsScalars o;
+      o.cos_h = os[0]; o.sin_h = os[1]; o.w_cur = os[2]; o.w_next = os[3]; o.soc = os[4]; o.normq = os[5];
+      o.oldest = os[6]; o.avg = os[7];
+      for (int b = 0; b < 5; b++) o.hist[b] = os[8 + b];
+      o.have_past = os[13] != 0.0;
+      build_obs_pool(sh.g[e] + G_NC, sh.g[e] + G_NT, o, sh.pool[e], lane);
+    }
+    wave_sync();
+  }
+  if (__builtin_expect((S.debug_flags & 8) != 0, 0) && lane == 0) sh.dbg_t[0] = wall_clock64();
+
+  // ---- rewards + reward-state upkeep: both envs at once on the O(1) path; an env that needs its ring (or anything
+  // unusual) is redone whole-wavefront from its untouched state ------------------------------------------------------------
+  const unsigned long long fast_m = pair_reward_fast(S, envc, active, h, l, wka, wkb, d, x_old_l, rew, sh, step_no, defer);
+#pragma unroll 1
+  for (int e = 0; e < n_here; e++) {
+    if (__builtin_expect((fast_m >> (e * HL)) & 1ull, 1)) continue;
+    const unsigned x_old = (unsigned)__builtin_amdgcn_readlane((int)x_old_l, e * HL);
+    const uint4 qw_e = reinterpret_cast<const uint4*>(S.qwin)[(size_t)(env0 + e) * SDC_WIN + lane];
+    env_reward(S, env0 + e, lane, e == 0 ? hdA : hdB, qw_e, pick_i32(d.hl, e), pick_i32(d.slot, e),
+               (unsigned)pick_i32((int)d.x_new, e), x_old, pick_f64(d.e_off, e), pick_f64(d.energy, e),
+               pick_f64(d.norm_ci, e), pick_f64(d.oldest_norm, e), pick_i32(d.overdue, e), pick_i32(d.hourq_n, e),
+               pick_f64(d.p_it, e), pick_f64(d.total_kw, e), pick_f64(d.water, e), rew, sh.info[e], sh.tl);
+  }
+  if (__builtin_expect((S.debug_flags & 8) != 0, 0)) {
+    wave_sync();
+    if (lane == 0) {
+      const unsigned long long dbg_a3 = wall_clock64();
+      for (int e = 0; e < n_here; e++) {
+        float* inf = sh.info[e];
+        inf[40] = (S.debug_flags & 16) ? (float)(dbg_a0 & 0xFFFFFull) : 0.0f;
+        inf[41] = (S.debug_flags & 16) ? (float)(dbg_a0 - dbg_entry) : (float)(sh.dbg_t[0] - dbg_a0);
+        inf[42] = (float)(dbg_a3 - sh.dbg_t[0]);
+        inf[43] = (S.debug_flags & 16) ? (float)(dbg_a3 & 0xFFFFFull) : (float)(dbg_a3 - dbg_a0);
+      }
+    }
+  }
+  wave_sync();
+
+  // (non-temporal: nothing in this launch reads them again, and whole lines that have already left the L2 shorten the
+  // write-back at the end of the launch; partial-line stores -- rew, done, the ring slot -- must NOT be: they turn
+  // into read-modify-writes at the memory and add 10 us)
+  // ---- coalesced stores: records, obs [3][26] (78 floats per env), share_obs [29], info [44]: the pair's rows are adjacent --
+  if (active) __builtin_nontemporal_store(reinterpret_cast<const unsigned long long*>(sh.rec[h])[l], reinterpret_cast<unsigned long long*>(recp));
+  const int rel_now = lrec_i32(sh.rec[h], R_TREL);     // (patched: rel + 1)
+  const bool terminal = rel_now >= S.episode_steps;
+  const unsigned long long term_m = __ballot(terminal && active);
+#pragma unroll
+  for (int k = 0; k < (EPW * SDC_OBS_OUT + SDC_WAVE - 1) / SDC_WAVE; k++) {
+    const int idx = k * SDC_WAVE + lane;
+    if (idx < n_here * SDC_OBS_OUT) {
+      const int e = idx >= SDC_OBS_OUT ? 1 : 0, j = idx - e * SDC_OBS_OUT;
+      const float v = obs_padded_at(sh.pool[e], j);
+      __builtin_nontemporal_store(v, &obs[(size_t)env0 * SDC_OBS_OUT + idx]);
+      if (final_obs && ((term_m >> (e * HL)) & 1ull)) final_obs[(size_t)env0 * SDC_OBS_OUT + idx] = v;
+    }
+  }
+  if (share_obs && lane < n_here * SDC_SHARE_OBS_DIM) {
+    const int e = lane >= SDC_SHARE_OBS_DIM ? 1 : 0, j = lane - e * SDC_SHARE_OBS_DIM;
+    __builtin_nontemporal_store(share_obs_at(sh.pool[e], j), &share_obs[(size_t)env0 * SDC_SHARE_OBS_DIM + lane]);
+  }
+  if (info) {
+#pragma unroll
+    for (int k = 0; k < (EPW * SDC_INFO_DIM + SDC_WAVE - 1) / SDC_WAVE; k++) {
+      const int idx = k * SDC_WAVE + lane;
+      if (idx < n_here * SDC_INFO_DIM) {
+        const int e = idx >= SDC_INFO_DIM ? 1 : 0, j = idx - e * SDC_INFO_DIM;
+        __builtin_nontemporal_store(sh.info[e][j], &info[(size_t)env0 * SDC_INFO_DIM + idx]);
+      }
+    }
+  }
+  if (l == 0 && active) done[envc] = (unsigned char)(terminal ? 1 : 0);
+}
+
+}  // namespace
+
+#define SDC_STEP_WPB 4   // wavefronts (= env pairs) per workgroup; the wavefronts of a workgroup share nothing (no s_barrier)
+
+// block -> first env pair of the block.  Workgroup b runs on XCD b % 8 (the dispatcher deals workgroups round-robin to
+// the 8 XCDs, each with its own L2): give every XCD a CONTIGUOUS range of envs, so that output lines shared by
+// neighbouring envs (rew, done, the unaligned obs rows) are assembled in one L2 instead of being written back in pieces
+// from several.
+__device__ __forceinline__ int first_pair_of_block(const int first_block) {
+  const int nb = (int)gridDim.x - first_block, bi = (int)blockIdx.x - first_block;
+  const int vb = (nb % 8 == 0) ? (bi % 8) * (nb / 8) + bi / 8 : bi;
+  return vb * SDC_STEP_WPB;
+}
+
+// The spare wavefronts at the front of a step launch: wavefront j serves re-centring request j of the previous step (see
+// SdcRefillReq): one sweep over that env's ring as the previous step left it, the re-centred window out as a result.
+#define SDC_SWEEP_BLOCKS (SDC_RQ_MAX / SDC_STEP_WPB)
+__device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const int j, const int lane, sdc_rw::TailLds& tl) {
+  using namespace sdc_rw;
+  const int set = S.step_no % 3;
+  if (j == 0 && lane == 0) S.rq_count[(S.step_no + 2) % 3] = 0;     // the set the NEXT step's requests go to
+  const int cnt = min(S.rq_count[set], SDC_RQ_MAX);
+  if (j >= cnt) return;
+  const SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + j;
+  if (rq->step != S.step_no - 1) return;                            // stale (a multi-step launch came in between)
+  const int env = rq->env, w = rq->win, n = rq->n;
+  QTrack A = {rq->keys[lane], rq->r0, rq->hi};
+  const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), rq->patch_slot, rq->patch_x};
+  qt_refill(A, rq->dir, rq->kt, n, R, lane, tl, w == 3 ? KEY_NONE : 0u);
+  SdcRefillRes* rs = S.rs + set * SDC_RQ_MAX + j;
+  rs->keys[lane] = A.w;
+  if (lane == 0) {
+    rs->r0 = A.r0;
+    rs->hi = A.hi;
+    rs->step = S.step_no;
+    rs->env_win = env * 4 + w;
+  }
+}
+
+// One launch of this kernel is one env-step of all N environments.
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 3) void sdc_dynamics_kernel(
+    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
+    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+  __shared__ PairShared shs[SDC_STEP_WPB];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
+  const int lane = threadIdx.x % SDC_WAVE;
+  if (blockIdx.x < SDC_SWEEP_BLOCKS) {     // dispatched first: their sweeps run under the start of everybody else's step
+    serve_recentring_requests(S, (int)blockIdx.x * SDC_STEP_WPB + wave, lane, shs[wave].tl);
+    return;
+  }
+  const int env0 = (first_pair_of_block(SDC_SWEEP_BLOCKS) + wave) * EPW;
+  if (env0 >= S.n_envs) return;
+  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
+  pair_step(S, shs[wave], env0, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew, S.actions_out, S.step_no,
+            true);
+  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 1);
+}
+
+// K env-steps per launch for action sequences that are known up front or chosen by the built-in rule-based policies
+// (scripted evaluation, the reference's RBC / do-nothing baselines): every wavefront advances its own two envs K times
+// -- envs do not interact, so there is nothing to wait for between steps; the dispatch ramp, the launch gap and the
+// tail of a launch are paid once per K steps.  actions [K][N][3] (or null when every agent slot has a policy);
+// obs [K][N][3][26], share_obs [K][N][29] (or null), rew [K][N][3], done [K][N], info [K][N][44] (or null) hold every
+// step's outputs.  The host keeps K within the episode (sdc_rollout).
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 2) void sdc_rollout_kernel(
+    SdcDev S, const int K, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs,
+    float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs,
+    float* __restrict__ rew) {
+  __shared__ PairShared shs[SDC_STEP_WPB];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
+  const int env0 = (first_pair_of_block(0) + wave) * EPW;
+  const int lane = threadIdx.x % SDC_WAVE;
+  const size_t N = (size_t)S.n_envs;
+  if (env0 >= S.n_envs) return;
+  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
+  int32_t* const aout = S.actions_out;
+#pragma unroll 1
+  for (int k = 0; k < K; k++) {
+    __builtin_amdgcn_s_setprio(0);
+    // (opaque copies: otherwise every per-env / per-lane address of the step is hoisted out of the loop and held in
+    // registers across it)
+    int env_k = env0, lane_k = lane;
+    asm volatile("" : "+s"(env_k), "+v"(lane_k));
+    pair_step(S, shs[wave], env_k, lane_k, rel_hint >= 0 ? rel_hint + k : -1, actions ? actions + (size_t)k * N * 3 : nullptr,
+              obs + (size_t)k * N * SDC_OBS_OUT, share_obs ? share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM : nullptr,
+              done + (size_t)k * N, info ? info + (size_t)k * N * SDC_INFO_DIM : nullptr, k == K - 1 ? final_obs : nullptr,
+              rew + (size_t)k * N * 3, aout ? aout + (size_t)k * N * 3 : nullptr, S.step_no + k, false);
+    // this wavefront's stores of step k are the loads of its step k + 1: complete them and drop stale lines of the
+    // CU's vector L1 (workgroup scope: the L2 behind it is the same for both)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_sync();
+  }
+  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 1);
+}

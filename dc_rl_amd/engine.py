@@ -56,7 +56,8 @@ class SdcEngine:
     def __init__(self, n_envs: int, episode_steps: int = 672, device: int = 0, n_locations: int = 1,
                  n_dc_configs: int = 1, auto_reset: bool = True, seed: int = 0, hist_cap: int = 10000,
                  queue_max_len: int = 1000, weather_noise_std: float = 0.75, weather_noise_weight: float = 0.02,
-                 max_roll_days: int = 14, debug_flags: int = 0, reward_method=(0, 0, 0), env_index_base: int = 0):
+                 max_roll_days: int = 14, debug_flags: int = 0, reward_method=(0, 0, 0), env_index_base: int = 0,
+                 policy=(0, 0, 0), trim_and_respond_limit: float = 27.0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("SdcEngine needs an MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is False); "
@@ -73,7 +74,9 @@ class SdcEngine:
                           weather_noise_std=weather_noise_std, weather_noise_weight=weather_noise_weight,
                           max_roll_days=max_roll_days, debug_flags=debug_flags,
                           reward_method=(C.c_int32 * 3)(*[int(m) for m in reward_method]),
-                          env_index_base=int(env_index_base))
+                          env_index_base=int(env_index_base), policy=(C.c_int32 * 3)(*[int(x) for x in policy]),
+                          trim_and_respond_limit=float(trim_and_respond_limit))
+        self.policy = tuple(int(x) for x in policy)
         self._h = C.c_void_p()
         self._pinned_stream = None
         self._pinned_stream_obj = None
@@ -203,31 +206,48 @@ class SdcEngine:
     def steps_to_episode_end(self) -> int:
         return int(self.lib.sdc_steps_to_episode_end(self._h))
 
-    def rollout(self, actions, want_info: bool = True):
+    def rollout_policy(self, n_steps: int, actions=None, want_info: bool = True):
+        """`rollout` for engines whose agent slots (some or all) are played by built-in policies (`policy=`): closed-loop
+        episodes at rollout speed.  actions: None when every slot has a policy, else [K, N, 3] (slots with a policy
+        ignore their column).  Returns (obs, share_obs, rew, done, info, actions_applied [K, N, 3] int32)."""
+        return self.rollout(actions, want_info=want_info, n_steps=n_steps, want_actions=True)
+
+    def rollout(self, actions, want_info: bool = True, n_steps: int = None, want_actions: bool = False):
         """K env-steps in one launch for an action sequence known up front (scripted / rule-based policies, open-loop
         evaluation).  actions: int32 device tensor [K, N, 3]; K must not run past the end of an episode
         (steps_to_episode_end()).  Returns fresh device tensors holding every step's outputs:
         obs [K,N,3,26], share_obs [K,N,29], rew [K,N,3], done [K,N] (uint8), info [K,N,44] (or None).
         Same results as K calls of step()."""
         t = self.torch
-        if not (isinstance(actions, t.Tensor) and actions.dtype == t.int32 and actions.is_cuda and
-                actions.is_contiguous() and actions.dim() == 3 and tuple(actions.shape[1:]) == (self.n_envs, 3)):
-            raise ValueError("actions must be a contiguous int32 CUDA tensor of shape (K, n_envs, 3)")
-        K, N = int(actions.shape[0]), self.n_envs
+        if actions is None:
+            if n_steps is None or any(p == 0 for p in self.policy):
+                raise ValueError("actions=None needs n_steps and a built-in policy on every agent slot")
+            K = int(n_steps)
+        else:
+            if not (isinstance(actions, t.Tensor) and actions.dtype == t.int32 and actions.is_cuda and
+                    actions.is_contiguous() and actions.dim() == 3 and tuple(actions.shape[1:]) == (self.n_envs, 3)):
+                raise ValueError("actions must be a contiguous int32 CUDA tensor of shape (K, n_envs, 3)")
+            K = int(actions.shape[0])
+            if n_steps is not None and int(n_steps) != K:
+                raise ValueError("n_steps does not match the action sequence")
+        N = self.n_envs
         kw = dict(device=self.device)
         obs = t.empty((K, N, L.N_AGENTS, L.OBS_PAD), dtype=t.float32, **kw)
         share = t.empty((K, N, L.SHARE_OBS_DIM), dtype=t.float32, **kw)
         rew = t.empty((K, N, L.N_AGENTS), dtype=t.float32, **kw)
         done = t.empty((K, N), dtype=t.uint8, **kw)
         info = t.empty((K, N, L.INFO_DIM), dtype=t.float32, **kw) if want_info else None
+        aout = t.empty((K, N, 3), dtype=t.int32, **kw) if want_actions else None
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         with t.cuda.device(self.device):
             L.check(self.lib.sdc_rollout(self._h, K, p(actions), p(obs), p(share), p(rew), p(done), p(info),
-                                         p(self.final_obs), self._stream()))
+                                         p(self.final_obs), p(aout), self._stream()))
         # the engine's single-step views follow the last step
         self.obs.copy_(obs[-1]); self.share_obs.copy_(share[-1]); self.rew.copy_(rew[-1]); self.done.copy_(done[-1])
         if info is not None:
             self.info.copy_(info[-1])
+        if want_actions:
+            return obs, share, rew, done, info, aout
         return obs, share, rew, done, info
 
     # ------------------------------------------------------------------ state access (parity injection / checkpoint)

@@ -71,8 +71,10 @@ enum sdc_info_col {
   SDC_INFO_FAULT,    /* bit mask, see SDC_FAULT_* (the reference raises / asserts instead) */
   SDC_INFO_ENERGY_Z, /* normalize_energy() output shared by the three rewards */
   SDC_INFO_RESERVED, /* diagnostic: how this step's reward normalisation was served: 0 incremental state only (no
-                        history read), 1 a rank window was re-centred over the history ahead of need, 3 the state
-                        was rebuilt from the history */
+                        history read), 1 a rank window was re-centred over the history inline, 2 incremental state
+                        only and a window re-centred by a spare wavefront of the previous launch was taken over,
+                        3 the state was rebuilt from the history.  Scheduling-dependent (which requests find a free
+                        slot), unlike every other output */
   /* running return of the current episode INCLUDING this step (== the episode return on the done step);
    * feeds the return statistics the runners log (harl/common/base_logger.py:75-88) without host sums */
   SDC_INFO_EP_RETURN_LS,
@@ -125,7 +127,19 @@ typedef struct {
                               so a job draws the same start day / hour / roll / weather noise for global env i whatever
                               the number of GPUs it is sharded over (harl/utils/envs_tools.py:56-65 keys months and
                               seeds on the global rank the same way) */
+  int32_t policy[3];       /* who chooses each agent slot's action (ls, dc, bat): SDC_POLICY_EXTERNAL the caller's
+                              actions array; SDC_POLICY_DO_NOTHING the reference's base agents (utils/base_agents.py:
+                              ls 1, dc 1, bat 2 -- what SustainDC plays for agents that are not trained,
+                              sustaindc_env.py:172-191, :623-655); SDC_POLICY_RBC (bat slot) RBCBatteryAgent
+                              (utils/rbc_agents.py:21-47, look_ahead 3, smooth_window 1); SDC_POLICY_TRIM_AND_RESPOND
+                              (dc slot) trim_and_respond_ctrl (utils/trim_and_respond.py:8-38).  The policies run inside
+                              the step kernel, so sdc_rollout can run closed-loop episodes without an action array. */
+  int32_t reserved2;
+  double trim_and_respond_limit; /* TandR_monitor_limit (27 in the reference), compared with the room temperature
+                                    (dc_int_temperature) the previous step reported */
 } sdc_config;
+
+enum sdc_policy { SDC_POLICY_EXTERNAL = 0, SDC_POLICY_DO_NOTHING = 1, SDC_POLICY_RBC = 2, SDC_POLICY_TRIM_AND_RESPOND = 3 };
 
 enum sdc_reward_method {
   SDC_REWARD_DEFAULT = 0,
@@ -225,9 +239,11 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
  * rew [n_steps][N][3], done [n_steps][N], info [n_steps][N][SDC_INFO_DIM] receive every step's outputs (share_obs /
  * info / final_obs may be NULL).  n_steps must not exceed sdc_steps_to_episode_end(); if it reaches the episode's
  * end and auto_reset is on, the finished envs are reset as in sdc_step (the last step's obs slice holds the reset
- * observation, final_obs [N][3][26] the pre-reset one).  Same results as n_steps calls of sdc_step. */
+ * observation, final_obs [N][3][26] the pre-reset one).  Same results as n_steps calls of sdc_step.
+ * Agent slots with a built-in policy (sdc_config.policy) ignore `actions`, which may be NULL when all three have one;
+ * actions_out [n_steps][N][3] (device, or NULL) receives the actions every step applied. */
 int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, float* share_obs, float* rew,
-                uint8_t* done, float* info, float* final_obs, void* stream);
+                uint8_t* done, float* info, float* final_obs, int32_t* actions_out, void* stream);
 /* steps until the first env finishes its episode (0: a reset is due) */
 int sdc_steps_to_episode_end(const sdc_handle* h);
 

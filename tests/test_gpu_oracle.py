@@ -126,10 +126,9 @@ def test_clip_bound_windows_heavy_tails_and_drifting_bounds():
         assert np.isfinite(rew.cpu().numpy()).all()
         paths += np.bincount(inf[:, 39].astype(int), minlength=4)[:4]
     assert (eng.get_state("order_stat_sticky") == 0).all()
-    print("paths (no ring read, a window re-centred ahead of need, -, rebuilt):", paths)
-    assert paths[2] == 0
+    print("paths (no ring read, a window re-centred inline, a deferred re-centred window taken over, rebuilt):", paths)
     assert paths[3] <= 2 * N                # one rebuild each after the injection, not one per step -- heavy tails included
-    assert paths[0] > 20 * (paths[1] + paths[3])   # the incremental state serves nearly every step
+    assert paths[0] + paths[2] > 20 * (paths[1] + paths[3])   # the incremental state serves nearly every step
     eng.close()
 
 

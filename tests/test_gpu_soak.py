@@ -61,9 +61,11 @@ def test_reward_state_soak(hist_cap, steps_total):
     # a mismatch at any step of any env leaves the sticky bit set
     assert (eng.get_state("order_stat_sticky") == 0).all()
     assert (eng.get_state("hist_len") == hist_cap).all()
-    print("soak hist_cap", hist_cap, "paths sampled (no ring read, a window re-centred ahead of need, -, rebuilt):", paths)
-    assert paths[0] > 0 and paths[1] > 0 and paths[3] > 0   # every way of serving a step was exercised
-    assert paths[3] < paths[1]                              # ... and rebuilds stay the exception
+    print("soak hist_cap", hist_cap, "paths sampled (no ring read, a window re-centred inline, a deferred re-centred "
+          "window taken over, rebuilt):", paths)
+    assert paths[0] > 0 and paths[1] + paths[2] > 0 and paths[3] > 0   # every way of serving a step was exercised
+    assert paths[2] > 0                                     # the spare-wavefront re-centrings arrive and verify
+    assert paths[3] < paths[1] + paths[2]                   # ... and rebuilds stay the exception
     eng.close()
 
 

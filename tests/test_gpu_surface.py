@@ -223,7 +223,9 @@ def test_rollout_matches_single_steps():
             np.testing.assert_array_equal(s1.cpu().numpy(), share[k].cpu().numpy())
             np.testing.assert_array_equal(r1.cpu().numpy(), rew[k].cpu().numpy())
             np.testing.assert_array_equal(d1.cpu().numpy(), done[k].cpu().numpy())
-            np.testing.assert_array_equal(i1.cpu().numpy(), info[k].cpu().numpy())
+            ia, ib = i1.cpu().numpy().copy(), info[k].cpu().numpy().copy()
+            ia[:, 39] = ib[:, 39] = 0      # the one scheduling-dependent column: WHO re-centred a rank window (diagnostic)
+            np.testing.assert_array_equal(ia, ib)
         np.testing.assert_array_equal(a.final_obs.cpu().numpy(), b.final_obs.cpu().numpy())
         t += K
     assert b.steps_to_episode_end() == EP
