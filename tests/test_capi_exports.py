@@ -24,11 +24,36 @@ def test_library_builds_and_exports_all_declared_symbols():
     assert set(names) == set(L.EXPORTS)
 
 
-def test_struct_sizes_match_header():
-    # sdc_dc_params: 2 x int32 + 5 x 64 doubles + 18 doubles
-    assert C.sizeof(L.SdcDcParams) == 8 + 8 * (5 * 64 + 18)
-    # sdc_config: 8 x int32, uint64, 2 doubles, 2 x int32, reward_method[3] + reserved
-    assert C.sizeof(L.SdcConfig) == 8 * 4 + 8 + 8 + 8 + 8 + 16
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors of the header's structs against the C compiler's view of include/sustaindc_hip.h: sizes and
+    the offset of every member."""
+    import subprocess
+    members = {
+        "sdc_config": ["n_envs", "device", "episode_steps", "hist_cap", "queue_max_len", "n_locations", "n_dc_configs",
+                       "auto_reset", "seed", "weather_noise_std", "weather_noise_weight", "max_roll_days", "debug_flags",
+                       "reward_method", "env_index_base", "policy", "reserved2", "trim_and_respond_limit"],
+        "sdc_dc_params": ["n_racks", "rack_n", "rack_full", "rack_idle", "rack_supply", "rack_return", "m_cpu",
+                          "itfan_ref_p", "c_air", "ct_fan_ref_p", "min_temp", "init_setpoint", "bat_capacity_mwh"],
+        "sdc_reset_override": ["day", "hour", "ci_min", "ci_max", "t_min", "t_max", "t_win", "wb_win", "noise", "roll_days"],
+    }
+    mirror = {"sdc_config": L.SdcConfig, "sdc_dc_params": L.SdcDcParams, "sdc_reset_override": L.SdcResetOverride}
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "sustaindc_hip.h")}"',
+           "int main(void) {"]
+    for st, ms in members.items():
+        src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for m in ms:
+            src.append(f'  printf("{st}.{m} %zu\\n", offsetof({st}, {m}));')
+    src += ["  return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-o", exe, str(c)], check=True)
+    out = dict(ln.split() for ln in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines())
+    for st, ms in members.items():
+        assert int(out[st]) == C.sizeof(mirror[st]), st
+        for m in ms:
+            assert int(out[f"{st}.{m}"]) == getattr(mirror[st], m).offset, (st, m)
+    assert [f[0] for f in L.SdcConfig._fields_] == members["sdc_config"]     # every member of sdc_config is mirrored
     assert len(L.INFO_COLS) == L.INFO_DIM
 
 
