@@ -21,7 +21,7 @@ QWIN = 64          # csrc/sdc_device.hpp SDC_WIN: keys per rank window (4 window
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
-SOURCES = ["sdc_capi.hip", "sdc_step.hip", "sdc_dynamics.hip", "sdc_features.hip", "sdc_verify.hip", "sdc_reset.hip"]
+SOURCES = ["sdc_capi.hip", "sdc_step.hip", "sdc_features.hip", "sdc_verify.hip", "sdc_reset.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 # info column names = the reference's info keys (sustaindc_hip.h enum sdc_info_col)

@@ -9,7 +9,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,10 +21,7 @@ extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
 extern "C" __global__ void sdc_features_kernel(SdcDev S);
 extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                               unsigned char* done, float* info, float* final_obs, float* rew);
-extern "C" __global__ void sdc_dynamics_kernel_v1(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
-                                                  unsigned char* done, float* info, float* final_obs, float* rew);
-extern "C" __global__ void sdc_rollout_kernel_v1(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
-                                                 unsigned char* done, float* info, float* final_obs, float* rew);
+
 extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
                                             const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
                                             const double* ovr_t_max, int only_done, float* obs, float* share_obs,
@@ -66,7 +62,6 @@ struct sdc_handle {
   SdcDev d;
   int rel_hint = -1;   // the episode step all envs are at, if they are in lock-step (else -1)
   int step_no = 3;           // steps launched (stamps the deferred window re-centrings; starts above the stamps of zeroed memory)
-  bool old_kernel = false;   // development A/B switch (env SDC_OLD_KERNEL): the round-1 one-env-per-wavefront kernel
   int device;
   std::vector<void*> allocs;
   std::vector<Field> fields;
@@ -201,7 +196,6 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
 
   sdc_handle* h = new sdc_handle();
   h->cfg = *cfg;
-  h->old_kernel = std::getenv("SDC_OLD_KERNEL") != nullptr;
   h->device = cfg->device;
   SdcDev& d = h->d;
   std::memset(&d, 0, sizeof(d));
@@ -522,14 +516,9 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
     d.prof_ts = h->prof_buf + (size_t)h->prof_used * 3 * N * 2;
     h->prof_has_reset[h->prof_used] = 0;
   }
-  if (h->old_kernel)
-    hipLaunchKernelGGL(sdc_dynamics_kernel_v1, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, h->rel_hint, actions, obs, share_obs, done, info,
-                       final_obs, rew);
-  else {
-    d.step_no = h->step_no++;
-    hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, h->rel_hint,
-                       actions, obs, share_obs, done, info, final_obs, rew);
-  }
+  d.step_no = h->step_no++;
+  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, h->rel_hint,
+                     actions, obs, share_obs, done, info, final_obs, rew);
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
   HIP_TRY(hipGetLastError());
   h->steps_to_terminal -= 1;
@@ -571,10 +560,7 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
   const int N = h->cfg.n_envs;
   SdcDev d = h->d;
   d.actions_out = actions_out;
-  if (h->old_kernel)
-    hipLaunchKernelGGL(sdc_rollout_kernel_v1, dim3((N + SDC_WPB - 1) / SDC_WPB), dim3(SDC_WAVE * SDC_WPB), 0, st, d, n_steps,
-                       h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
-  else {
+  {
     // (a multi-step launch has no spare wavefronts between its steps: it re-centres inline, and requests left by the
     // step before it are dropped -- their results would describe a ring several steps old)
     d.step_no = h->step_no;

@@ -1,10 +1,11 @@
 // sdc_device.hpp -- device-side state layout and shared device functions of the SustainDC step.
 //
 // Written for gfx950 (MI355X, CDNA4) only: 64-lane wavefronts.  One kernel per timestep:
-// sdc_dynamics_kernel -- one wavefront per environment instance integrates the coupled dynamics (lanes = racks for
-// the IT model, wave shuffles for the rack reductions), writes obs / info, appends the step's energy to the env's
-// history ring and produces the history-normalised rewards from O(1) incremental state (sdc_trackers.hpp); the
-// ring itself (40 KB per env) is swept only every few steps, in-wave and ahead of need (sdc_ringpath.hpp).
+// sdc_dynamics_kernel (sdc_step.hip) -- one wavefront per PAIR of environment instances (a half-wave each) integrates
+// the coupled dynamics (lanes of a half = racks for the IT model, DPP reductions inside the half), writes obs / info,
+// appends the step's energy to the env's history ring and produces the history-normalised rewards from O(1)
+// incremental state (sdc_trackers.hpp / sdc_halfwin.hpp); the ring itself (40 KB per env) is swept only every few
+// hundred steps, by spare wavefronts of the following launch (SdcRefillReq below; sdc_ringpath.hpp).
 //
 // Arithmetic: fp64 for the dynamics, observation features and reductions (the reference is Python
 // float / NumPy float64, and its integer / decimal-rounding cliffs only reproduce in fp64);
@@ -21,10 +22,6 @@
 
 #define SDC_BLOCK 256
 #define SDC_WAVE 64
-#ifndef SDC_WPB
-#define SDC_WPB 4   // wavefronts (= envs) per workgroup of the step kernel: the dispatcher starts workgroups, not wavefronts,
-                    // at a fixed rate, and the wavefronts of a workgroup share nothing (no s_barrier anywhere)
-#endif
 #define SDC_HIST_PER_THREAD 40  // 10 x float4 per thread -> 10240 ring slots per env
 #define SDC_HIST_STRIDE (SDC_BLOCK * SDC_HIST_PER_THREAD)
 #define SDC_NORM_WINDOW 2880    // 30 days x 96 (utils/managers.py:435, :606)

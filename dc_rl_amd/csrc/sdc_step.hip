@@ -974,23 +974,6 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   return __ballot(ok);
 }
 
-// a rank window one step from the point where it is re-centred (a sweep over the env's 40 KB ring at the END of the
-// step) makes its wavefront the likely straggler of the launch
-__device__ __forceinline__ bool near_refill(const SdcDev& S, const unsigned hd0, const int hl0) {
-  int k1, k3;
-  sdc_rw::quartile_ranks(hl0 < S.hist_cap ? hl0 + 1 : hl0, k1, k3);
-  const int r1 = rec_i32(hd0, H_Q1 + T_R0), h1 = rec_i32(hd0, H_Q1 + T_HI);
-  const int r3 = rec_i32(hd0, H_Q3 + T_R0), h3 = rec_i32(hd0, H_Q3 + T_HI);
-  const bool near1 = h1 > 0 && ((k1 - r1 >= h1 - 7 && r1 + h1 < hl0) || (k1 - r1 <= 4 && r1 > 0));
-  const bool near3 = h3 > 0 && ((k3 - r3 >= h3 - 7 && r3 + h3 < hl0) || (k3 - r3 <= 4 && r3 > 0));
-  // (likewise a clip-bound window whose bound sits within a dozen ranks of its edge)
-  const int ru = rec_i32(hd0, H_BU + T_R0), hu = rec_i32(hd0, H_BU + T_HI), tu = hl0 - rec_i32(hd0, H_QC) - ru;
-  const int rl = rec_i32(hd0, H_BL + T_R0), hl_ = rec_i32(hd0, H_BL + T_HI), tl = hl0 - rec_i32(hd0, H_QC + 1) - rl;
-  const bool nearu = hu > 0 && ((tu >= hu - 12 && ru + hu < hl0) || (tu <= 12 && ru > 0));
-  const bool nearl = hl_ > 0 && ((tl >= hl_ - 12 && rl + hl_ < hl0) || (tl <= 12 && rl > 0));
-  return near1 || near3 || nearu || nearl;
-}
-
 // One env-step of the env pair (env0, env0 + 1) by its wavefront: loads the state, runs the dynamics of both, the rewards
 // and the reward-state upkeep of each, stores the new state and the outputs.
 __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const int env0, const int lane, const int rel_hint,
@@ -1025,15 +1008,11 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   // ---- level 0: the two state records (one dwordx2 per lane, 512 contiguous bytes), headers, actions ----------------
   uint2* recp = reinterpret_cast<uint2*>(S.rec + (size_t)envc * SDC_REC_DWORDS) + l;
   const uint2 rr = *recp;
-  const unsigned hdA = S.hdr[(size_t)env0 * SDC_HDR_DWORDS + lane];      // reward-side state: returns, trackers, sums
-  const unsigned hdB = S.hdr[(size_t)env1c * SDC_HDR_DWORDS + lane];
   int a_ls = 1, a_dc = 1, a_bat = 2;       // (rule-based slots never read the caller's array, which may be null)
   if (S.policy[0] == SDC_POLICY_EXTERNAL) a_ls = actions[envc * 3 + 0];
   if (S.policy[1] == SDC_POLICY_EXTERNAL) a_dc = actions[envc * 3 + 1];
   if (S.policy[2] == SDC_POLICY_EXTERNAL) a_bat = actions[envc * 3 + 2];
   reinterpret_cast<uint2*>(sh.rec[h])[l] = rr;
-  sh.hdr[0][lane] = hdA;
-  sh.hdr[1][lane] = hdB;
   wave_sync();
   const unsigned* rp = sh.rec[h];
   const int i = lrec_i32(rp, R_CURSOR), rel = lrec_i32(rp, R_TREL);
@@ -1058,23 +1037,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   // order-statistic trackers need (0xFFFFFFFF while the ring is still filling)
   const int hl0 = lrec_i32(rp, R_HIST_LEN);
   const int slot0 = hl0 < S.hist_cap ? hl0 : lrec_i32(rp, R_HIST_POS);
-  unsigned x_old_l = 0xFFFFFFFFu;
   const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;   // else the history does not change this step
-  if (hl0 >= S.hist_cap && append) x_old_l = S.hist[(size_t)envc * SDC_HIST_STRIDE + slot0];   // (one address per half)
-  // A wavefront with an env one step from a window re-centring: give it issue priority from the start and pull that
-  // ring into L2 now (one dword per 128-byte line, 5 loads per lane, results unused), so that the sweep finds it there.
-  if (append) {
-#pragma unroll
-    for (int e = 0; e < EPW; e++) {
-      const int hl_e = pick_i32(hl0, e);
-      if (e < n_here && hl_e >= sdc_rw::SMALL_N && __builtin_expect(near_refill(S, e == 0 ? hdA : hdB, hl_e), 0)) {
-        __builtin_amdgcn_s_setprio(2);
-        const volatile unsigned* ring = S.hist + (size_t)(env0 + e) * SDC_HIST_STRIDE;
-#pragma unroll
-        for (int j = 0; j < SDC_HIST_STRIDE / 32 / SDC_WAVE; j++) (void)ring[(j * SDC_WAVE + lane) * 32];
-      }
-    }
-  }
   // The trace-only observation entries of this step come precomputed (sdc_features.hip), unless the episode has no
   // feature rows (a host write since the reset, an episode too long for that kernel): then the CI / temperature
   // windows are gathered and the features computed here.
@@ -1146,6 +1109,13 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   if (__builtin_expect((S.debug_flags & 8) != 0, 0)) dbg_a0 = wall_clock64();
   // the rank windows of both envs, one key each per lane: wanted at the end of the step, so the loads are issued here --
   // after the start-of-launch burst of every env's record / header / gather loads -- and ride along in 8 registers
+  // reward-side state (headers: returns, trackers, sums; the rank windows' keys; the evicted ring key): wanted at the end of
+  // the step, so these loads are issued here -- after the start-of-launch burst of every env's record / gather loads
+  // (measured: whatever joins that burst makes every wavefront's start slower) -- and ride along in registers
+  const unsigned hdA = S.hdr[(size_t)env0 * SDC_HDR_DWORDS + lane];
+  const unsigned hdB = S.hdr[(size_t)env1c * SDC_HDR_DWORDS + lane];
+  unsigned x_old_l = 0xFFFFFFFFu;
+  if (hl0 >= S.hist_cap && append) x_old_l = S.hist[(size_t)envc * SDC_HIST_STRIDE + slot0];   // (one address per half)
   const uint4 wka = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l];       // keys 2l of the 4 windows
   const uint4 wkb = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l + 1];   // keys 2l + 1
   const DynOut d = pair_dynamics(S, envc, h, l, a_ls, a_dc, a_bat, fault, feat_ok, frow, actions_out, sh);
@@ -1169,6 +1139,9 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
 
   // ---- rewards + reward-state upkeep: both envs at once on the O(1) path; an env that needs its ring (or anything
   // unusual) is redone whole-wavefront from its untouched state ------------------------------------------------------------
+  sh.hdr[0][lane] = hdA;
+  sh.hdr[1][lane] = hdB;
+  wave_sync();
   const unsigned long long fast_m = pair_reward_fast(S, envc, active, h, l, wka, wkb, d, x_old_l, rew, sh, step_no, defer);
 #pragma unroll 1
   for (int e = 0; e < n_here; e++) {
