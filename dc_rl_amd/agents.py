@@ -68,3 +68,42 @@ class RBCBatteryAgent:
         x = carbon_intensity_values
         sm = x.unfold(1, w, 1).sum(-1) / w if w > 1 else x
         return torch.where(sm[:, self.look_ahead] > x[:, 0], 0, 1).to(torch.int32)
+
+
+class trim_and_respond_ctrl:
+    """utils/trim_and_respond.py:8-38 -- "trim and respond" supply-air reset for agent_dc: while the monitored
+    temperature stays at or below the limit, hold the set-point (1) and every fifth consecutive call trim it up (2);
+    above the limit respond by lowering it (0).  Same class name, constructor arguments and `action()` as the reference."""
+
+    def __init__(self, TandR_monitor_idx=6, TandR_monitor: str = "avg_room_temp", TandR_monitor_limit: float = 27):
+        assert (TandR_monitor == "avg_room_temp") | (TandR_monitor == "crac_return_temp"), \
+            f"invalid TandR_monitor monitor string : {TandR_monitor}"
+        self.TandR_monitor = TandR_monitor
+        self.TandR_monitor_limit = TandR_monitor_limit
+        self.TandR_monitor_idx = TandR_monitor_idx
+        self.response_duration_counter = 0
+        self.response_duration_limit = 4  # 1 hour at a 15-minute sampling interval
+
+    def set_limit(self, x):
+        self.TandR_monitor_limit = x
+
+    def action(self, obs):
+        curr_val = obs
+        if self.TandR_monitor_limit >= curr_val:
+            if self.response_duration_counter > self.response_duration_limit:
+                self.response_duration_counter = 0
+                return 2
+            self.response_duration_counter += 1
+            return 1
+        return 0
+
+
+# Device-side counterparts: `SdcEngine(policy=(ls, dc, bat))` / sdc_config.policy run these inside the step kernel
+# (include/sustaindc_hip.h enum sdc_policy), so `SdcEngine.rollout_policy` plays whole episodes closed-loop without an
+# action array:
+#   BaseLoadShiftingAgent / BaseHVACAgent / BaseBatteryAgent -> POLICY_DO_NOTHING on that slot
+#   RBCBatteryAgent(look_ahead=3, smooth_window=1)           -> POLICY_RBC on the battery slot: fed [ci, ci_future...] of the
+#                                                               env's `infos["__common__"]` (sustaindc_env.py:601-603)
+#   trim_and_respond_ctrl(limit)                              -> POLICY_TRIM_AND_RESPOND on the dc slot: fed the
+#                                                               dc_int_temperature the previous step reported
+POLICY_EXTERNAL, POLICY_DO_NOTHING, POLICY_RBC, POLICY_TRIM_AND_RESPOND = 0, 1, 2, 3

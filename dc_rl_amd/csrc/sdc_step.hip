@@ -283,7 +283,9 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   if (S.policy[2] == SDC_POLICY_RBC) {
     // utils/rbc_agents.py:21-47 (look_ahead 3, smooth_window 1) on [ci, ci_future] of the step's info: charge when the
     // carbon intensity three steps ahead is above the current one, else discharge
-    a_bat = g[G_C3] > ci_i ? 0 : 1;
+    // (on the NORMALISED values the reference's agent is given: managers.py:437)
+    const double cmin = lrec_f64(rp, R_CI_MIN), cden = lrec_f64(rp, R_CI_DEN);
+    a_bat = (g[G_C3] - cmin) / cden > (ci_i - cmin) / cden ? 0 : 1;
   }
 
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 ----------------------------------------

@@ -185,14 +185,18 @@ class SdcEngine:
         """actions: int32 device tensor [N, 3] (ls, dc, bat).  Returns views of the engine's buffers:
         obs [N,3,26], share_obs [N,29], rew [N,3], done [N] (uint8), info [N,40]."""
         t = self.torch
-        if not (isinstance(actions, t.Tensor) and actions.dtype == t.int32 and actions.is_cuda and
-                actions.is_contiguous() and tuple(actions.shape) == (self.n_envs, 3)):
+        if actions is None:
+            if any(p == 0 for p in self.policy):
+                raise ValueError("actions=None needs a built-in policy on every agent slot (SdcEngine(policy=...))")
+        elif not (isinstance(actions, t.Tensor) and actions.dtype == t.int32 and actions.is_cuda and
+                  actions.is_contiguous() and tuple(actions.shape) == (self.n_envs, 3)):
             raise ValueError("actions must be a contiguous int32 CUDA tensor of shape (n_envs, 3)")
         p = self._out_ptrs
         if p is None:   # the output tensors live as long as the engine: take their addresses once
             p = self._out_ptrs = tuple(C.c_void_p(x.data_ptr()) for x in
                                        (self.obs, self.share_obs, self.rew, self.done, self.info, self.final_obs))
-        args = (self._h, C.c_void_p(actions.data_ptr()), p[0], p[1], p[2], p[3], p[4] if want_info else None, p[5],
+        args = (self._h, C.c_void_p(actions.data_ptr()) if actions is not None else None, p[0], p[1], p[2], p[3],
+                p[4] if want_info else None, p[5],
                 self._stream())
         if t.cuda.current_device() == self.device_index:   # the usual case (one process per GPU): no device switch
             rc = self.lib.sdc_step(*args)

@@ -448,6 +448,83 @@ def gen_harl_layer(n_envs=4, days=1, n_steps=200, seed=21):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# rule-based baseline episode: the reference env driven by the reference's own controllers
+
+def gen_rbc_episode(location="ny", month=7, seed=31, episodes=2, tr_limit=None):
+    """SustainDC stepped closed-loop by the reference's rule-based agents: BaseLoadShiftingAgent (do nothing),
+    trim_and_respond_ctrl on agent_dc (utils/trim_and_respond.py, fed the dc_int_temperature of the previous step's info,
+    0.0 before the first step; its counter is never reset) and RBCBatteryAgent on agent_bat (utils/rbc_agents.py, fed
+    [ci] + ci_future of `env.infos["__common__"]`, sustaindc_env.py:601-603).  An ordinary episode fixture whose
+    `actions` are what the controllers chose."""
+    from utils import reward_creator
+    from utils.base_agents import BaseLoadShiftingAgent
+    from utils.rbc_agents import RBCBatteryAgent
+    from utils.trim_and_respond import trim_and_respond_ctrl
+    from sustaindc_env import SustainDC
+    reward_creator.energy_history.clear()
+    random.seed(seed)
+    np.random.seed(seed)
+    env = SustainDC({"location": location, "month": month, "days_per_episode": 7, "datacenter_capacity_mw": 1,
+                     "dc_config_file": "dc_config.json", "agents": ["agent_ls", "agent_dc", "agent_bat"]})
+    steps = 7 * 96
+    ls_agent, bat_agent = BaseLoadShiftingAgent(), RBCBatteryAgent()
+    out = {f"static_{k}": v for k, v in _static_block(env).items()}
+    reset_obs = _flat_obs(env.reset())
+    if tr_limit is None:      # a limit both branches of the controller see: the median room temperature of a dry run
+        probe = []
+        for t in range(96):
+            o, r, te, tr, inf = env.step({"agent_ls": 1, "agent_dc": 1, "agent_bat": 2})
+            probe.append(float(inf["agent_ls"]["dc_int_temperature"]))
+        tr_limit = float(np.round(np.median(probe), 1))
+        reward_creator.energy_history.clear()
+        random.seed(seed)
+        np.random.seed(seed)
+        env = SustainDC({"location": location, "month": month, "days_per_episode": 7, "datacenter_capacity_mw": 1,
+                         "dc_config_file": "dc_config.json", "agents": ["agent_ls", "agent_dc", "agent_bat"]})
+        reset_obs = _flat_obs(env.reset())
+    dc_agent = trim_and_respond_ctrl(TandR_monitor_limit=tr_limit)
+    out.update(meta_location=np.array(location), meta_month=np.array(month), meta_steps=np.array(steps),
+               meta_episodes=np.array(episodes), meta_seed=np.array(seed), meta_policy=np.array("rbc"),
+               meta_capacity_mw=np.array(1.0), meta_dc_config=np.array("dc_config.json"), meta_days=np.array(7),
+               meta_info_keys=np.array(INFO_KEYS), meta_tr_limit=np.array(tr_limit),
+               meta_device_policy=np.array([1, 3, 2], dtype=np.int32),
+               init_stpt=np.array(env.dc_env.raw_curr_stpt, dtype=np.float64))
+    last_room = 0.0
+    for ep in range(episodes):
+        inputs = _episode_inputs(env, steps)
+        acts = np.zeros((steps, 3), np.int32)
+        obs = np.zeros((steps, 53), dtype=np.float32)
+        rew = np.zeros((steps, 3), dtype=np.float64)
+        done = np.zeros(steps, dtype=np.uint8)
+        info = np.zeros((steps, len(INFO_KEYS)), dtype=np.float64)
+        hist = np.zeros((steps, 5), dtype=np.float64)
+        hist_len0 = len(reward_creator.energy_history)
+        stpt0 = env.dc_env.raw_curr_stpt
+        for t in range(steps):
+            common = env.infos["__common__"]
+            ci_values = np.concatenate([[common["ci"]], np.asarray(common["ci_future"])])
+            soc = env.bat_env.get_battery_soc() if hasattr(env.bat_env, "get_battery_soc") else 0.0
+            a = [int(ls_agent.do_nothing_action()), int(dc_agent.action(last_room)), int(bat_agent.act(ci_values, soc))]
+            acts[t] = a
+            o, r, term, trunc, inf = env.step({"agent_ls": a[0], "agent_dc": a[1], "agent_bat": a[2]})
+            obs[t] = _flat_obs(o)
+            rew[t] = [r["agent_ls"], r["agent_dc"], r["agent_bat"]]
+            done[t] = 1 if (trunc["__all__"] or term["__all__"]) else 0
+            c = inf["agent_ls"]
+            info[t] = [float(c[k]) for k in INFO_KEYS]
+            hist[t] = np.asarray(c["ls_task_age_histogram"], dtype=np.float64)
+            last_room = float(c["dc_int_temperature"])
+        p = f"ep{ep}_"
+        for k, v in inputs.items():
+            out[p + k] = np.asarray(v)
+        out.update({p + "reset_obs": reset_obs, p + "actions": acts, p + "obs": obs, p + "rew": rew, p + "done": done,
+                    p + "info": info, p + "age_hist": hist, p + "hist_len0": np.array(hist_len0),
+                    p + "stpt0": np.array(stpt0, dtype=np.float64)})
+        reset_obs = _flat_obs(env.reset())
+    return out
+
+
 def _find_early_seed():
     """Seed for which (day 0, hour < 4) -> cursor < 16; uses python `random` exactly like reset()."""
     for s in range(1000):
@@ -465,7 +542,7 @@ def main():
     ap.add_argument("--extras", action="store_true", help="with no --only: also regenerate weather_resets / harl_ny_n4")
     args = ap.parse_args()
     _install_shims()
-    extra = {"weather_resets": gen_weather_resets, "harl_ny_n4": gen_harl_layer}
+    extra = {"weather_resets": gen_weather_resets, "harl_ny_n4": gen_harl_layer, "rbc_ny_m7": gen_rbc_episode}
     for name, fn in extra.items():
         if args.only == name or (args.only is None and args.extras):
             out = fn()
