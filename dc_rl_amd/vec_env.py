@@ -12,8 +12,10 @@ the same step call, the returned obs are the reset obs, and `infos[i][0]["origin
 Outputs are NumPy arrays by default (what `ShareSubprocVecEnv` returns after `np.stack`); with
 `return_torch=True` they are device tensors (views of the engine's buffers, valid until the next call) so that a
 GPU policy never round-trips through the host.  `infos` is a lazy sequence: the N x 3 dicts of the reference are
-materialised only for the entries a caller touches; `info_sums()` gives the logger's per-step sums
-(harl/envs/sustaindc/sustaindc_logger.py:87-101) as one device reduction.
+materialised only for the entries a caller touches (from a snapshot of the step's info block, so it stays valid -- for
+two further steps in NumPy mode, where the snapshot lives in the pinned double buffer until first touched);
+`accumulate_logger_sums()` / `read_logger_sums()` keep the logger's per-step sums
+(harl/envs/sustaindc/sustaindc_logger.py:87-101) in a device-side accumulator that is read once per episode.
 """
 from __future__ import annotations
 
@@ -143,7 +145,8 @@ class LazyInfos(Sequence):
 
     def rows(self):
         if self._rows is None:
-            self._rows = self._t.detach().cpu().numpy() if hasattr(self._t, "detach") else np.asarray(self._t)
+            # (a copy: the pinned host buffers are reused two steps later)
+            self._rows = self._t.detach().cpu().numpy().copy() if hasattr(self._t, "detach") else np.array(self._t)
         return self._rows
 
     def __len__(self):
@@ -173,9 +176,8 @@ def _merge_args(env_args: Optional[dict]) -> dict:
     unknown = [x for x in a["agents"] if x not in AGENTS]
     if unknown:
         raise ValueError(f"unknown agents {unknown}; the environment has {AGENTS}")
-    if list(a["agents"]) != AGENTS and not a.get("_allow_agent_subset"):
-        raise NotImplementedError("the batched HARL surface steps all three agents; a subset of agents (the others "
-                                  "played by the reference's base do-nothing agents) is available through SustainDC")
+    if not a["agents"]:
+        raise ValueError("at least one agent must be trained")
     return a
 
 
@@ -193,8 +195,18 @@ class SustainDCVecEnv(ShareVecEnv):
         if len(rcodes) != 1:
             raise ValueError("all envs of one batch must share ls_reward / dc_reward / bat_reward")
         self.reward_method = rcodes.pop()
-        self.n_agents = 3
-        self.agents = list(AGENTS)
+        # A subset of agents (sustaindc_env.py:172-191, :623-655): the others are played by the reference's base
+        # do-nothing agents -- on the device (sdc_config.policy = DO_NOTHING for their slots) -- and the surface carries
+        # the trained agents only, in the reference's order.  (`_allow_agent_subset`: the single-env facade SustainDC
+        # keeps the three-agent arrays and plays the base agents itself.)
+        subsets = {tuple(x for x in AGENTS if x in a["agents"]) for a in per_env}
+        if len(subsets) != 1:
+            raise ValueError("all envs of one batch must train the same agents")
+        full = bool(per_env[0].get("_allow_agent_subset"))
+        self.agents = list(AGENTS) if full else list(subsets.pop())
+        self._agent_idx = [AGENTS.index(x) for x in self.agents]
+        self.n_agents = len(self.agents)
+        self.policy = tuple(0 if (full or x in self.agents) else 1 for x in AGENTS)
         self.return_torch = return_torch
         self.episode_steps = int(days.pop()) * 96
         if months is None:
@@ -227,7 +239,7 @@ class SustainDCVecEnv(ShareVecEnv):
         self.bat_env.dcload_min = self.dc_env.power_lb_kW / 4
         self.engine = SdcEngine(n_envs, episode_steps=self.episode_steps, device=device, n_locations=len(loc_keys),
                                 n_dc_configs=len(cfg_keys), auto_reset=auto_reset, seed=seed, queue_max_len=1000,
-                                reward_method=self.reward_method, env_index_base=env_index_base)
+                                reward_method=self.reward_method, env_index_base=env_index_base, policy=self.policy)
         for i, tb in enumerate(self.tables):
             self.engine.set_tables(i, tb["W"], tb["C"], tb["T"], tb["WB"])
         for i, e in enumerate(self.dc_envs):
@@ -249,14 +261,16 @@ class SustainDCVecEnv(ShareVecEnv):
                 "bat_dcload_max": e.power_ub_kW / 4,
             })
         # HARL pads every agent to the widest space (harlsustaindc_env.py:25-26, :30-33)
-        obs_space = [Box(low=-2.0, high=2.0, shape=(L.OBS_PAD,), dtype=np.float32) for _ in AGENTS]
-        share_space = [Box(low=-2.0, high=2.0, shape=(L.SHARE_OBS_DIM,), dtype=np.float32) for _ in AGENTS]
-        act_space = [Discrete(3) for _ in AGENTS]
+        obs_space = [Box(low=-2.0, high=2.0, shape=(L.OBS_PAD,), dtype=np.float32) for _ in self.agents]
+        share_space = [Box(low=-2.0, high=2.0, shape=(L.SHARE_OBS_DIM,), dtype=np.float32) for _ in self.agents]
+        act_space = [Discrete(3) for _ in self.agents]
         ShareVecEnv.__init__(self, n_envs, obs_space, share_space, act_space)
         import torch
         self._torch = torch
-        self._avail = torch.ones((n_envs, 3, 3), dtype=torch.float32, device=self.engine.device)
-        self._avail_np = np.ones((n_envs, 3, 3), dtype=np.float32)
+        self._avail = torch.ones((n_envs, self.n_agents, 3), dtype=torch.float32, device=self.engine.device)
+        self._avail_np = np.ones((n_envs, self.n_agents, 3), dtype=np.float32)
+        self._idx_t = torch.as_tensor(self._agent_idx, device=self.engine.device)
+        self._logger_acc = None
         self._actions = None
         self._need_reset = True
         self._host = None       # pinned host output buffers (NumPy outputs only)
@@ -267,8 +281,12 @@ class SustainDCVecEnv(ShareVecEnv):
         return t if self.return_torch else t.cpu().numpy()
 
     def _share3(self, share):
-        # the same 29-vector for the three agents (harlsustaindc_env.py:85 `repeat`)
-        return share.unsqueeze(1).expand(-1, 3, -1)
+        # the same 29-vector for every trained agent (harlsustaindc_env.py:85 `repeat`)
+        return share.unsqueeze(1).expand(-1, self.n_agents, -1)
+
+    def _sel(self, x):
+        # the trained agents' rows of a [N, 3, ...] array (all of them in the usual three-agent case)
+        return x if self.n_agents == 3 else x[:, self._agent_idx]
 
     def seed(self, seed: int):
         self.engine.set_seed(seed)
@@ -277,18 +295,23 @@ class SustainDCVecEnv(ShareVecEnv):
     def reset(self):
         obs, share = self.engine.reset()
         self._need_reset = False
-        return self._out(obs), self._out(self._share3(share)), (self._avail if self.return_torch else self._avail_np)
+        return self._out(self._sel(obs)), self._out(self._share3(share)), (self._avail if self.return_torch else self._avail_np)
 
     def step_async(self, actions):
         t = self._torch
         if not isinstance(actions, t.Tensor):
             actions = t.as_tensor(np.asarray(actions))
-        a = actions.reshape(self.num_envs, 3).to(device=self.engine.device, dtype=t.int32).contiguous()
-        self._actions = a
+        a = actions.reshape(self.num_envs, self.n_agents).to(device=self.engine.device, dtype=t.int32)
+        if self.n_agents != 3:      # the other slots are played on the device; their columns are never read
+            full = t.ones((self.num_envs, 3), dtype=t.int32, device=self.engine.device)
+            full[:, self._agent_idx] = a
+            a = full
+        self._actions = a.contiguous()
 
     def step_wait(self):
         if self._need_reset:
             raise RuntimeError("call reset() before step()")
+        t = self._torch
         a = self._actions
         self._actions = None
         obs, share, rew, done, info = self.engine.step(a)
@@ -298,7 +321,7 @@ class SustainDCVecEnv(ShareVecEnv):
             # NumPy outputs: four asynchronous copies into pinned host buffers, ONE synchronisation (two buffer sets
             # alternate, so the arrays of a step stay valid until the step after next)
             hb = self._host_buffers()
-            for k, src in (("obs", obs), ("share", share), ("rew", rew), ("done", done)):
+            for k, src in (("obs", obs), ("share", share), ("rew", rew), ("done", done), ("info", info)):
                 hb[k].copy_(src, non_blocking=True)
             self._torch.cuda.current_stream(self.engine.device).synchronize()
             done_h = hb["done"].numpy().astype(bool)
@@ -308,26 +331,58 @@ class SustainDCVecEnv(ShareVecEnv):
             for i in np.nonzero(done_h)[0]:
                 # states[2][-1] of the PADDED obs: agent_bat's zero padding (harlsustaindc_env.py:25-26, :80)
                 raw = np.concatenate([fo[i, 0, :26], fo[i, 1, 11:12], fo[i, 1, 13:14], fo[i, 2, 25:26]])
-                extra[(int(i), 0)] = {"original_obs": fo[i].copy(),
-                                      "original_state": np.repeat(raw[None, :], 3, axis=0),
-                                      "original_avail_actions": np.ones((3, 3), dtype=np.float32)}
-        infos = LazyInfos(info, a, done_h, self._const, extra)
+                extra[(int(i), 0)] = {"original_obs": fo[i][self._agent_idx].copy(),
+                                      "original_state": np.repeat(raw[None, :], self.n_agents, axis=0),
+                                      "original_avail_actions": np.ones((self.n_agents, 3), dtype=np.float32)}
+        # `infos` stays valid after later steps (the reference returns materialised dicts): it reads from a snapshot of
+        # the step's [N, 44] info block -- a pinned host copy made with the other outputs (NumPy mode), a device clone
+        # otherwise (copied to the host on first access only)
+        info_src = hb["info"] if not self.return_torch else info.clone()
+        infos = LazyInfos(info_src, a, done_h, self._const, extra)
+        if self._logger_acc is not None:      # device-side logger sums: one small reduction per step, no read-back
+            self._logger_acc.add_(info[:, self._logger_idx].sum(0, dtype=t.float64))
+            self._logger_steps += 1
+        k = self.n_agents
         if self.return_torch:
-            dones3 = done.bool().unsqueeze(1).expand(-1, 3)
-            return obs, self._share3(share), rew.unsqueeze(-1), dones3, infos, self._avail
-        share3 = np.broadcast_to(hb["share"].numpy()[:, None, :], (self.num_envs, 3, hb["share"].shape[1]))
-        return (hb["obs"].numpy(), share3, hb["rew"].numpy()[..., None], np.repeat(done_h[:, None], 3, axis=1), infos,
-                self._avail_np)
+            dones3 = done.bool().unsqueeze(1).expand(-1, k)
+            return self._sel(obs), self._share3(share), self._sel(rew).unsqueeze(-1), dones3, infos, self._avail
+        share3 = np.broadcast_to(hb["share"].numpy()[:, None, :], (self.num_envs, k, hb["share"].shape[1]))
+        return (self._sel(hb["obs"].numpy()), share3, self._sel(hb["rew"].numpy())[..., None],
+                np.repeat(done_h[:, None], k, axis=1), infos, self._avail_np)
 
     def _host_buffers(self):
         t = self._torch
         if self._host is None:
             e = self.engine
             self._host = [{k: t.empty(v.shape, dtype=v.dtype, pin_memory=True)
-                           for k, v in (("obs", e.obs), ("share", e.share_obs), ("rew", e.rew), ("done", e.done))}
+                           for k, v in (("obs", e.obs), ("share", e.share_obs), ("rew", e.rew), ("done", e.done),
+                                        ("info", e.info))}
                           for _ in range(2)]
         self._host_flip ^= 1
         return self._host[self._host_flip]
+
+    def accumulate_logger_sums(self, keys: Sequence[str] = LOGGER_KEYS, enable: bool = True):
+        """Keep the SustainDC logger's per-step sums (harl/envs/sustaindc/sustaindc_logger.py:87-101: each key summed over
+        the envs, every step) in a device-side accumulator: one small reduction per step on the stream, no host
+        synchronisation; `read_logger_sums()` brings the totals over once per episode / log interval."""
+        t = self._torch
+        self._logger_keys = [k for k in keys]
+        self._logger_idx = [L.INFO_IDX[k] for k in keys if k in L.INFO_IDX]
+        self._logger_acc = t.zeros(len(self._logger_idx), dtype=t.float64, device=self.engine.device) if enable else None
+        self._logger_steps = 0
+
+    def read_logger_sums(self, reset: bool = True):
+        """-> ({key: sum over envs and steps since the last read}, steps accumulated).  ONE device->host copy."""
+        if self._logger_acc is None:
+            raise RuntimeError("call accumulate_logger_sums() first")
+        vals = self._logger_acc.cpu().numpy()
+        out = {k: 0.0 for k in self._logger_keys}       # keys the env does not track (constant 0 in the reference too)
+        out.update({k: float(v) for k, v in zip([k for k in self._logger_keys if k in L.INFO_IDX], vals)})
+        n = self._logger_steps
+        if reset:
+            self._logger_acc.zero_()
+            self._logger_steps = 0
+        return out, n
 
     def info_sums(self, keys: Sequence[str] = LOGGER_KEYS):
         """Sum over envs of the given info columns for the last step, computed on the device."""

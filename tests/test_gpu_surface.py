@@ -233,3 +233,47 @@ def test_rollout_matches_single_steps():
         b.rollout(acts[:EP + 1])                   # would run past the end of the episode
     a.close()
     b.close()
+
+
+def test_vec_env_agent_subset_and_device_logger_sums():
+    """Two trained agents: agent_dc is played by the base do-nothing agent ON THE DEVICE (policy slot), the surface
+    carries two agents; the logger sums accumulate on the device and are read once."""
+    from dc_rl_amd import SustainDCVecEnv
+    N = 16
+    args = dict(ENV_ARGS, agents=["agent_ls", "agent_bat"])
+    sub = SustainDCVecEnv(args, n_envs=N, seed=3, months=[6] * N)
+    ref = SustainDCVecEnv(dict(ENV_ARGS), n_envs=N, seed=3, months=[6] * N)
+    assert sub.n_agents == 2 and sub.agents == ["agent_ls", "agent_bat"] and sub.policy == (0, 1, 0)
+    assert len(sub.observation_space) == len(sub.action_space) == len(sub.share_observation_space) == 2
+    o1, s1, a1 = sub.reset()
+    o3, s3, a3 = ref.reset()
+    assert o1.shape == (N, 2, 26) and s1.shape == (N, 2, 29) and a1.shape == (N, 2, 3)
+    np.testing.assert_array_equal(o1, o3[:, [0, 2]])
+    ref.accumulate_logger_sums()
+    rng = np.random.default_rng(5)
+    manual = {k: 0.0 for k in ("bat_CO2_footprint", "dc_water_usage", "ls_tasks_in_queue")}
+    kept = None
+    for t in range(40):
+        a2 = rng.integers(0, 3, size=(N, 2, 1))
+        full = np.ones((N, 3, 1), dtype=np.int64)
+        full[:, [0, 2]] = a2
+        o1, s1, r1, d1, i1, _ = sub.step(a2)
+        o3, s3, r3, d3, i3, _ = ref.step(full)          # the same thing spelled out: agent_dc always holds (1)
+        assert r1.shape == (N, 2, 1) and d1.shape == (N, 2)
+        np.testing.assert_array_equal(o1, o3[:, [0, 2]])
+        np.testing.assert_array_equal(r1, r3[:, [0, 2]])
+        np.testing.assert_array_equal(s1[:, 0], s3[:, 0])
+        assert i1[3][0]["dc_crac_setpoint_delta"] == 0.0
+        for k in manual:
+            manual[k] += sum(i3[i][0][k] for i in range(N))
+        if t == 10:
+            kept = (i3, float(i3[2][0]["bat_SOC"]), float(i3[5][0]["dc_total_power_kW"]))
+    # an infos object read later still shows ITS step (snapshot), not the latest one
+    assert float(kept[0][2][0]["bat_SOC"]) == kept[1] and float(kept[0][5][0]["dc_total_power_kW"]) == kept[2]
+    sums, n = ref.read_logger_sums()
+    assert n == 40
+    for k, v in manual.items():
+        assert sums[k] == pytest.approx(v, rel=1e-5)
+    assert sums["ls_unasigned_day_load_left"] == 0.0
+    sub.close()
+    ref.close()

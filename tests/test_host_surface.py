@@ -54,9 +54,10 @@ def test_env_config_defaults_match_reference_keys():
     for bad in ({"nonoverlapping_shared_obs_space": False}, {"partial_obs": False}, {"actions_are_logits": True}):
         with pytest.raises(NotImplementedError):  # options that change what a runner receives are never silently ignored
             _merge_args(bad)
-    with pytest.raises(NotImplementedError):      # subsets of agents: through SustainDC only
-        _merge_args({"agents": ["agent_ls", "agent_dc"]})
-    assert _merge_args({"agents": ["agent_ls", "agent_dc"], "_allow_agent_subset": True})["agents"] == ["agent_ls", "agent_dc"]
+    # a subset of agents is accepted (the other slots are played by the base agents on the device); none is not
+    assert _merge_args({"agents": ["agent_ls", "agent_dc"]})["agents"] == ["agent_ls", "agent_dc"]
+    with pytest.raises(ValueError):
+        _merge_args({"agents": []})
     with pytest.raises(ValueError):
         _merge_args({"agents": ["agent_x"]})
 
