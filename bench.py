@@ -383,7 +383,7 @@ def main():
     if world > 1:
         dt = float(all_reduce(torch.tensor([dt], dtype=torch.float64, device=cdev), dist.ReduceOp.MAX).item())
     faults = int((eng.info[:, 37] != 0).sum().item())
-    fallbacks = [int((eng.info[:, 39] == v).sum().item()) for v in (1, 3)]
+    fallbacks = [int((eng.info[:, 39] == v).sum().item()) for v in (1, 3, 2)]
     timed_steps = K * R
 
     # the amortised cost of the episode boundary (device-side reset + the episode's feature rows), measured on its own:
@@ -406,7 +406,6 @@ def main():
         b = alg_bytes_per_env_step(hlen)
         nst = max(1, prof["steps"])
         k_dyn = prof["dynamics_ms"] / nst * 1e-3     # first wavefront's entry -> last one's exit, in-kernel stamps
-        k_rst = prof["reset_ms"] / max(1, prof["resets"]) * 1e-3
         # the step is ONE kernel: HIP-event time over the timed launches / launches = its average launch duration
         # with the dispatch gaps between back-to-back launches (and the ~1/672 auto-resets) included
         k_evt = ev_ms * 1e-3 / timed_steps
@@ -426,7 +425,8 @@ def main():
                        "history_fill_steps": fill, "auto_reset": True, "actions": "i.i.d. uniform {0,1,2}, device-resident pool of 1024 steps",
                        "parallelism": f"env-shard x{world}", "faults": faults,
                        "return_stats_all_reduces_in_timed_region": n_collectives - coll0,
-                       "ring_read_envs_last_step": {"window_recentred_ahead_of_need": fallbacks[0], "rebuild": fallbacks[1]}},
+                       "reward_state_last_step": {"envs_recentring_inline": fallbacks[0], "envs_rebuilding": fallbacks[1],
+                                                  "envs_taking_over_a_deferred_recentred_window": fallbacks[2]}},
             "return_stats": {"episodes": int(ret_stats[6].item()),
                              "mean_return": [round(float(x), 3) for x in (ret_stats[0:3] / max(1.0, float(ret_stats[6].item())))]},
         }
@@ -474,7 +474,6 @@ def main():
             "effective_hbm_GBps": round(eff, 1), "effective_hbm_frac": round(eff / HBM_PEAK_GBPS, 4),
             "effective_hbm_frac_without_history_term": round(ALG_BYTES_FIXED * N / k_evt / 1e9 / HBM_PEAK_GBPS, 5),
             "pmc_source": pmc_src, "pmc_current": bool(pmc and pmc.get("csrc_sha") == here), "csrc_sha": here,
-            "other_kernels": {"sdc_reset_kernel_avg_us": round(k_rst * 1e6, 2), "auto_resets_sampled": prof["resets"]},
             "note": "frac = VALU-busy fraction (physical, <= 1); hbm_frac = PMC bytes / kernel time / 8 TB/s (physical); "
                     "effective_hbm_* price the REFERENCE algorithm's bytes (whole history window read every step), "
                     "which this kernel does not move -- not a physical bandwidth (DESIGN.md section 4)",

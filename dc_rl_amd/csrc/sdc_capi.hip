@@ -90,8 +90,11 @@ struct sdc_handle {
 namespace {
 
 constexpr int PROF_SLOTS = 256;
-constexpr int SWEEP_BLOCKS = SDC_RQ_MAX / 4;   // csrc/sdc_step.hip: one spare wavefront per possible re-centring request
-constexpr int STEP_WPB = 4;   // csrc/sdc_step.hip SDC_STEP_WPB: env pairs (wavefronts) per workgroup of the step kernel
+#ifndef SDC_STEP_WPB
+#define SDC_STEP_WPB 4
+#endif
+constexpr int SWEEP_BLOCKS = SDC_RQ_MAX / SDC_STEP_WPB;   // csrc/sdc_step.hip: one spare wavefront per possible re-centring request
+constexpr int STEP_WPB = SDC_STEP_WPB;   // csrc/sdc_step.hip SDC_STEP_WPB: env pairs (wavefronts) per workgroup of the step kernel
 int step_blocks(int n_envs) { return ((n_envs + 1) / 2 + STEP_WPB - 1) / STEP_WPB; }
 bool all_policies(const sdc_handle* h) {
   return h->d.policy[0] != SDC_POLICY_EXTERNAL && h->d.policy[1] != SDC_POLICY_EXTERNAL && h->d.policy[2] != SDC_POLICY_EXTERNAL;

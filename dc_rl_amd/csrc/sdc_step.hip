@@ -1207,7 +1207,10 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
 
 }  // namespace
 
-#define SDC_STEP_WPB 4   // wavefronts (= env pairs) per workgroup; the wavefronts of a workgroup share nothing (no s_barrier)
+#ifndef SDC_STEP_WPB
+#define SDC_STEP_WPB 4
+#endif
+// wavefronts (= env pairs) per workgroup; the wavefronts of a workgroup share nothing (no s_barrier)
 
 // block -> first env pair of the block.  Workgroup b runs on XCD b % 8 (the dispatcher deals workgroups round-robin to
 // the 8 XCDs, each with its own L2): give every XCD a CONTIGUOUS range of envs, so that output lines shared by
@@ -1245,7 +1248,7 @@ __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const
 }
 
 // One launch of this kernel is one env-step of all N environments.
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 3) void sdc_dynamics_kernel(
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_WPB) void sdc_dynamics_kernel(
     SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
     unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
   __shared__ PairShared shs[SDC_STEP_WPB];
@@ -1269,7 +1272,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 3) void sdc_dyn
 // tail of a launch are paid once per K steps.  actions [K][N][3] (or null when every agent slot has a policy);
 // obs [K][N][3][26], share_obs [K][N][29] (or null), rew [K][N][3], done [K][N], info [K][N][44] (or null) hold every
 // step's outputs.  The host keeps K within the episode (sdc_rollout).
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 2) void sdc_rollout_kernel(
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WPB) void sdc_rollout_kernel(
     SdcDev S, const int K, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs,
     float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs,
     float* __restrict__ rew) {

@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 for N in (2048, 4096, 8192, 16384):
     eng, tb, params = bench.build_engine(N, 672, 0, seed=1234)

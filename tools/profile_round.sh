@@ -1,0 +1,33 @@
+#!/bin/bash
+# One gpurun call that produces everything profiles/ and DESIGN.md quote for a round:  bash tools/profile_round.sh r2
+# (rocprofv3 passes run from /tmp with TMPDIR=/tmp; --pmc passes -- inside bench.py -- use --kernel-trace only)
+set -x
+TAG=${1:-r2}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+# 1. kernel trace + stats of the default bench command (without the PMC sub-passes, which are separate processes)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --steps 2000 --no-pmc --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/trace.err
+cd $R
+python tools/trace_summary.py $O/trace --last 1500 --out $O/kernel_trace_steady_state.json 2>&1 | tail -3
+cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+find $O -name "*kernel_trace.csv" -size +1M -delete; find $O -name "*.db" -delete
+# 2. the bench line itself (with its live PMC passes and the CPU baseline); keeps the counters as profiles/pmc_latest.json
+SDC_WRITE_PMC=1 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+cp profiles/pmc_latest.json $O/pmc.json
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2>> $O/bench.err
+timeout 600 python bench.py --mixed-racks --no-cpu-baseline --no-pmc > $O/bench_mixed_racks.json 2>> $O/bench.err
+# 3. side measurements DESIGN.md quotes
+timeout 600 python tools/batch_scan.py > $O/batch_scan.txt 2>&1
+timeout 600 python tools/wave_phases.py > $O/wave_phases.txt 2>&1
+timeout 600 python tools/rollout_rate.py > $O/rollout_rate.txt 2>&1
+SDC_GROUPS=2 SDC_N=4096 timeout 600 python tools/two_streams.py > $O/two_streams.txt 2>&1
+SDC_GROUPS=2 SDC_N=8192 timeout 600 python tools/two_streams.py >> $O/two_streams.txt 2>&1
+timeout 600 python tools/surface_rates.py > $O/surface_rates.txt 2>&1
+timeout 600 python tools/action_mix.py > $O/action_mix.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/launch_floor.hip -o /tmp/launch_floor 2>/dev/null && /tmp/launch_floor > $O/launch_floor.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/dispatch_rate.hip -o /tmp/dispatch_rate 2>/dev/null && /tmp/dispatch_rate > $O/dispatch_rate.txt 2>&1
+grep -v amdgpu.ids $O/*.txt | tail -60
+cut -c1-600 $O/bench.json
+ls $O

@@ -6,14 +6,14 @@ N = int(os.environ.get("SDC_N", "4096"))
 dbg = int(os.environ.get("SDC_DBG", "0"))
 eng, tb, params = bench.build_engine(N, 672, 0, seed=1234, debug_flags=dbg)
 g = torch.Generator(device="cpu").manual_seed(1234)
-pool = torch.randint(0, 3, (64, N, 3), dtype=torch.int32, generator=g).to("cuda:0")
+pool = torch.randint(0, 3, (256, N, 3), dtype=torch.int32, generator=g).to("cuda:0")
 eng.reset()
 for i in range(10300):
-    eng.step(pool[i & 63])
+    eng.step(pool[i & 255])
 eng.profile(8); eng.profile_read(reset=True)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(2000):
-    eng.step(pool[i & 63])
+    eng.step(pool[i & 255])
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 p = eng.profile_read(reset=True)
 import numpy as np

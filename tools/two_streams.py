@@ -11,7 +11,7 @@ engs, pools, streams = [], [], []
 for gi in range(G):
     eng, tb, params = bench.build_engine(n, 672, 0, seed=1234 + gi, debug_flags=0)
     gen = torch.Generator(device="cpu").manual_seed(1234 + gi)
-    pools.append(torch.randint(0, 3, (64, n, 3), dtype=torch.int32, generator=gen).to("cuda:0"))
+    pools.append(torch.randint(0, 3, (256, n, 3), dtype=torch.int32, generator=gen).to("cuda:0"))
     engs.append(eng)
     streams.append(torch.cuda.Stream())
     eng.use_stream(streams[-1])
@@ -20,7 +20,7 @@ torch.cuda.synchronize()
 def run(k):
     for i in range(k):
         for gi in range(G):
-            engs[gi].step(pools[gi][i & 63])
+            engs[gi].step(pools[gi][i & 255])
 run(10300)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = 2000
