@@ -164,3 +164,34 @@ def test_out_of_range_actions_set_the_fault_bit():
             oo, orew, odone, oinfo = orc.step(acts[i])
             assert G.rel_err(eo[i], oo).max() <= TOL and G.rel_err(er[i], orew).max() <= TOL
     rig.eng.close()
+
+
+def test_odd_batch_and_more_than_32_racks_vs_oracle(tmp_path):
+    """Two corners of the two-envs-per-wavefront kernel: an ODD number of envs (the last wavefront carries one env; its
+    other half mirrors it and stores nothing) and a data centre with MORE RACKS THAN A HALF-WAVE HAS LANES (40 racks: the
+    rack model takes a second pass), mixed with the default 20-rack config in one batch."""
+    import json
+    import os
+    from dc_rl_amd import dc_config
+    src = os.path.join(os.path.dirname(dc_config.__file__), "configs", "dc_config.json")
+    cfg = json.load(open(src))
+    d = cfg["data_center_configuration"]
+    d["NUM_ROWS"], d["NUM_RACKS_PER_ROW"] = 8, 5
+    d["RACK_SUPPLY_APPROACH_TEMP_LIST"] = (d["RACK_SUPPLY_APPROACH_TEMP_LIST"] * 2)[:40]
+    d["RACK_RETURN_APPROACH_TEMP_LIST"] = (d["RACK_RETURN_APPROACH_TEMP_LIST"] * 2)[:40]
+    sv = cfg["server_characteristics"]
+    sv["DEFAULT_SERVER_POWER_CHARACTERISTICS"] = (sv["DEFAULT_SERVER_POWER_CHARACTERISTICS"] * 2)[:40]
+    big = str(tmp_path / "dc_config_r40.json")
+    json.dump(cfg, open(big, "w"))
+    N, steps = 7, 96
+    rig = P.ParityRig(N, episode_steps=steps, seed=41, dc_files=("dc_config.json", big))
+    assert sorted({len(p["rack_n"]) for p in rig.params}) == [20, 40]
+    arng = np.random.default_rng(42)
+    worst = dict(obs=0.0, rew=0.0, info=0.0)
+    eobs, oobs = rig.reset_all()
+    _check_reset_obs(eobs, oobs, worst)
+    for t in range(steps):
+        P.compare_step(rig, arng.integers(0, 3, size=(N, 3)).astype(np.int32), worst)
+    print("odd batch, 20 + 40 racks:", worst)
+    assert worst["obs"] <= TOL and worst["rew"] <= TOL and worst["info"] <= 2e-6
+    rig.eng.close()
