@@ -89,11 +89,17 @@ class SdcEngine:
         self.queue_stride = self.lib.sdc_queue_stride(self._h)
         N = self.n_envs
         kw = dict(device=self.device)
-        self.obs = torch.zeros((N, L.N_AGENTS, L.OBS_PAD), dtype=torch.float32, **kw)
-        self.share_obs = torch.zeros((N, L.SHARE_OBS_DIM), dtype=torch.float32, **kw)
-        self.rew = torch.zeros((N, L.N_AGENTS), dtype=torch.float32, **kw)
-        self.done = torch.zeros((N,), dtype=torch.uint8, **kw)
-        self.info = torch.zeros((N, L.INFO_DIM), dtype=torch.float32, **kw)
+        # the step's outputs are views of ONE device allocation (obs | share_obs | rew | info as floats, then done as
+        # bytes), so that a host-side consumer can fetch a whole step with a single device->host copy (`out_flat`)
+        n_f = N * (L.N_AGENTS * L.OBS_PAD + L.SHARE_OBS_DIM + L.N_AGENTS + L.INFO_DIM)
+        self.out_flat = torch.zeros(n_f * 4 + N, dtype=torch.uint8, **kw)
+        fl = self.out_flat[:n_f * 4].view(torch.float32)
+        o = 0
+        self.obs = fl[o:o + N * L.N_AGENTS * L.OBS_PAD].view(N, L.N_AGENTS, L.OBS_PAD); o += N * L.N_AGENTS * L.OBS_PAD
+        self.share_obs = fl[o:o + N * L.SHARE_OBS_DIM].view(N, L.SHARE_OBS_DIM); o += N * L.SHARE_OBS_DIM
+        self.rew = fl[o:o + N * L.N_AGENTS].view(N, L.N_AGENTS); o += N * L.N_AGENTS
+        self.info = fl[o:o + N * L.INFO_DIM].view(N, L.INFO_DIM); o += N * L.INFO_DIM
+        self.done = self.out_flat[n_f * 4:]
         self.final_obs = torch.zeros((N, L.N_AGENTS, L.OBS_PAD), dtype=torch.float32, **kw)
 
     # ------------------------------------------------------------------ setup
@@ -206,6 +212,17 @@ class SdcEngine:
         if rc != 0:
             L.check(rc)
         return self.obs, self.share_obs, self.rew, self.done, self.info
+
+    def split_out_flat(self, flat):
+        """Views (obs, share_obs, rew, done, info) over a host / device copy of `out_flat` (a uint8 tensor of the same size)."""
+        t, N = self.torch, self.n_envs
+        n_f = N * (L.N_AGENTS * L.OBS_PAD + L.SHARE_OBS_DIM + L.N_AGENTS + L.INFO_DIM)
+        fl = flat[:n_f * 4].view(t.float32)
+        a = N * L.N_AGENTS * L.OBS_PAD
+        b = a + N * L.SHARE_OBS_DIM
+        c = b + N * L.N_AGENTS
+        return (fl[:a].view(N, L.N_AGENTS, L.OBS_PAD), fl[a:b].view(N, L.SHARE_OBS_DIM), fl[b:c].view(N, L.N_AGENTS),
+                flat[n_f * 4:], fl[c:].view(N, L.INFO_DIM))
 
     def steps_to_episode_end(self) -> int:
         return int(self.lib.sdc_steps_to_episode_end(self._h))

@@ -275,6 +275,8 @@ class SustainDCVecEnv(ShareVecEnv):
         self._need_reset = True
         self._host = None       # pinned host output buffers (NumPy outputs only)
         self._host_flip = 0
+        self._act_pin = None    # pinned host staging of NumPy actions
+        self._act_flip = 0
 
     # ------------------------------------------------------------------ helpers
     def _out(self, t):
@@ -300,7 +302,14 @@ class SustainDCVecEnv(ShareVecEnv):
     def step_async(self, actions):
         t = self._torch
         if not isinstance(actions, t.Tensor):
-            actions = t.as_tensor(np.asarray(actions))
+            # host actions: through a pinned int32 staging buffer, asynchronously (two alternate: the copy of step k may
+            # still be in flight when step k + 1's actions arrive)
+            if self._act_pin is None:
+                self._act_pin = [t.empty((self.num_envs, self.n_agents), dtype=t.int32, pin_memory=True) for _ in range(2)]
+            self._act_flip ^= 1
+            pin = self._act_pin[self._act_flip]
+            pin.numpy()[...] = np.asarray(actions).reshape(self.num_envs, self.n_agents)
+            actions = pin.to(self.engine.device, non_blocking=True)
         a = actions.reshape(self.num_envs, self.n_agents).to(device=self.engine.device, dtype=t.int32)
         if self.n_agents != 3:      # the other slots are played on the device; their columns are never read
             full = t.ones((self.num_envs, 3), dtype=t.int32, device=self.engine.device)
@@ -318,11 +327,10 @@ class SustainDCVecEnv(ShareVecEnv):
         if self.return_torch:
             done_h = done.cpu().numpy().astype(bool)
         else:
-            # NumPy outputs: four asynchronous copies into pinned host buffers, ONE synchronisation (two buffer sets
-            # alternate, so the arrays of a step stay valid until the step after next)
+            # NumPy outputs: ONE asynchronous copy of the step's outputs (one device allocation) into a pinned host buffer,
+            # ONE synchronisation (two buffer sets alternate, so the arrays of a step stay valid until the step after next)
             hb = self._host_buffers()
-            for k, src in (("obs", obs), ("share", share), ("rew", rew), ("done", done), ("info", info)):
-                hb[k].copy_(src, non_blocking=True)
+            hb["flat"].copy_(self.engine.out_flat, non_blocking=True)     # the whole step in ONE device->host copy
             self._torch.cuda.current_stream(self.engine.device).synchronize()
             done_h = hb["done"].numpy().astype(bool)
         extra = {}
@@ -354,10 +362,11 @@ class SustainDCVecEnv(ShareVecEnv):
         t = self._torch
         if self._host is None:
             e = self.engine
-            self._host = [{k: t.empty(v.shape, dtype=v.dtype, pin_memory=True)
-                           for k, v in (("obs", e.obs), ("share", e.share_obs), ("rew", e.rew), ("done", e.done),
-                                        ("info", e.info))}
-                          for _ in range(2)]
+            self._host = []
+            for _ in range(2):
+                flat = t.empty(e.out_flat.shape, dtype=t.uint8, pin_memory=True)
+                o, sh, r, d, i = e.split_out_flat(flat)
+                self._host.append({"flat": flat, "obs": o, "share": sh, "rew": r, "done": d, "info": i})
         self._host_flip ^= 1
         return self._host[self._host_flip]
 
