@@ -25,12 +25,15 @@ struct ResetShared {
   unsigned rec[SDC_REC_DWORDS];
 };
 
-__device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double u = __shfl_up(v, o);
-    if (lane >= o) v += u;
-  }
+// inclusive prefix sum over the 64 lanes on the DPP data path (no LDS round trips: this scan runs 137 times per reset):
+// row_shr 1, 2, 4, 8 scan each row of 16, row_bcast15 / row_bcast31 carry the row totals upwards
+__device__ __forceinline__ double wave_incl_scan_f64(double v, int) {
+  v += dpp_f64<0x111>(v);
+  v += dpp_f64<0x112>(v);
+  v += dpp_f64<0x114>(v);
+  v += dpp_f64<0x118>(v);
+  v += dpp_f64<SDC_DPP_BCAST15, 0xA>(v);
+  v += dpp_f64<SDC_DPP_BCAST31, 0xC>(v);
   return v;
 }
 
@@ -135,7 +138,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
         }
         const double incl = wave_incl_scan_f64(acc, lane);
         const double off = carry + (incl - acc);
-        carry += __shfl(incl, 63);
+        carry += readlane_f64(incl, 63);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int j = j0 + k;
