@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -96,6 +97,15 @@ constexpr int PROF_SLOTS = 256;
 constexpr int SWEEP_BLOCKS = SDC_RQ_MAX / SDC_STEP_WPB;   // csrc/sdc_step.hip: one spare wavefront per possible re-centring request
 constexpr int STEP_WPB = SDC_STEP_WPB;   // csrc/sdc_step.hip SDC_STEP_WPB: env pairs (wavefronts) per workgroup of the step kernel
 int step_blocks(int n_envs) { return ((n_envs + 1) / 2 + STEP_WPB - 1) / STEP_WPB; }
+// The step counter that stamps re-centring requests wraps at 3 * 2^22: a multiple of the 3 rotating request sets and of
+// the 2^22 the header stamps are taken modulo, so set rotation and stamp ages stay continuous across the wrap (the one
+// request in flight at the wrap misses its full-width result stamp and falls back to the inline sweep).
+constexpr int STEP_WRAP = 3 << 22;
+int next_step_no(int s, int by) {
+  if (by == 0) return s > STEP_WRAP - 4096 ? s % 3 + 3 : s;     // a multi-step launch must not straddle the wrap
+  s += by;
+  return s >= STEP_WRAP ? s - STEP_WRAP : s;
+}
 bool all_policies(const sdc_handle* h) {
   return h->d.policy[0] != SDC_POLICY_EXTERNAL && h->d.policy[1] != SDC_POLICY_EXTERNAL && h->d.policy[2] != SDC_POLICY_EXTERNAL;
 }
@@ -199,6 +209,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
 
   sdc_handle* h = new sdc_handle();
   h->cfg = *cfg;
+  if (const char* t = std::getenv("SDC_TEST_STEP_NO")) h->step_no = std::atoi(t) % STEP_WRAP;   // test hook: start near the wrap
   h->device = cfg->device;
   SdcDev& d = h->d;
   std::memset(&d, 0, sizeof(d));
@@ -519,7 +530,8 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
     d.prof_ts = h->prof_buf + (size_t)h->prof_used * 3 * N * 2;
     h->prof_has_reset[h->prof_used] = 0;
   }
-  d.step_no = h->step_no++;
+  d.step_no = h->step_no;
+  h->step_no = next_step_no(h->step_no, 1);
   hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, h->rel_hint,
                      actions, obs, share_obs, done, info, final_obs, rew);
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
@@ -566,8 +578,9 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
   {
     // (a multi-step launch has no spare wavefronts between its steps: it re-centres inline, and requests left by the
     // step before it are dropped -- their results would describe a ring several steps old)
+    h->step_no = next_step_no(h->step_no, 0);        // (room for the launch's n_steps stamps below the wrap)
     d.step_no = h->step_no;
-    h->step_no += n_steps + 3;
+    h->step_no = next_step_no(h->step_no, n_steps + 3);
     HIP_TRY(hipMemsetAsync(d.rq_count, 0, sizeof(int) * 4, st));
     hipLaunchKernelGGL(sdc_rollout_kernel, dim3(step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, n_steps, h->rel_hint, actions,
                        obs, share_obs, done, info, final_obs, rew);

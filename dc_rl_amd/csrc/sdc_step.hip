@@ -762,9 +762,11 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     const unsigned lx_new = hp[H_LAST_XNEW], lx_old = hp[H_LAST_XOLD];
     const int l_nprev = (int)hp[H_LAST_NPREV];
     auto arrive = [&](HWin& q, unsigned& pd, const int w, const unsigned flip) __attribute__((always_inline)) {
-      const int rstep = (int)(pd >> 8), idx = (int)(pd & 0xFFu) - 1;
-      const bool due = pd != 0u && (step_no >= rstep + 2 || step_no < rstep);   // (else: still being swept; a stamp from the future: restored state)
-      const SdcRefillRes* rs = S.rs + ((rstep + 1) % 3) * SDC_RQ_MAX + (idx < 0 ? 0 : idx);
+      // pd = (request step mod 2^22) << 10 | result set << 8 | request index + 1
+      const int idx = (int)(pd & 0xFFu) - 1, set = (int)((pd >> 8) & 3u);
+      const unsigned age = ((unsigned)step_no - (pd >> 10)) & 0x3FFFFFu;      // steps since the request (mod 2^22)
+      const bool due = pd != 0u && age >= 2u;   // (1: being swept right now; anything else but 2: stale -- a multi-step launch, restored state)
+      const SdcRefillRes* rs = S.rs + (set > 2 ? 0 : set) * SDC_RQ_MAX + (idx < 0 ? 0 : idx);
       int4 hd = make_int4(0, 0, -1, -1);
       unsigned ka = KEY_NONE, kb = KEY_NONE;
       if (due) {
@@ -773,7 +775,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
         kb = rs->keys[2 * l + 1];
       }
       HWin r = {ka, kb, hd.x, hd.y};
-      const bool good = due && step_no == rstep + 2 && hd.z == rstep + 1 && hd.w == envc * 4 + w && r.hi > 0 && ok;
+      const bool good = due && age == 2u && hd.z == step_no - 1 && hd.w == envc * 4 + w && r.hi > 0 && ok;
       // the result describes the ring as the request's step left it: replay the previous step's insertion / eviction
       hw_update(r, lx_new ^ flip, lx_old ^ flip, lx_old != KEY_NONE, l_nprev, good, h, l);
       if (good && r.hi > 0) {
@@ -886,7 +888,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
                 rq->kt = kt; rq->n = n; rq->r0 = q.r0; rq->hi = q.hi;
                 rq->patch_slot = slot_next; rq->patch_x = patch_x; rq->step = step_no;
               }
-              pd = ((unsigned)step_no << 8) | (unsigned)(idx + 1);
+              pd = (((unsigned)step_no & 0x3FFFFFu) << 10) | ((unsigned)set << 8) | (unsigned)(idx + 1);
             }
           }
         };

@@ -101,3 +101,37 @@ def test_rank_windows_small_histories(hist_cap):
     print("hist_cap", hist_cap, "paths once the ring is full (windows only, re-centred, -, rebuilt):", paths)
     assert paths[3] * 20 < paths[0]      # a full ring is served by the windows, not by rebuilds
     eng.close()
+
+
+def test_deferred_recentring_across_the_step_counter_wrap(monkeypatch):
+    """The host's step counter (stamps of the re-centring requests) wraps at 3 * 2^22; start just below it and run across
+    the wrap in verify mode: requests keep being served and taken over on both sides, nothing mismatches."""
+    import torch
+    monkeypatch.setenv("SDC_TEST_STEP_NO", str((3 << 22) - 150))
+    N, ep, cap = 512, 96, 1500
+    rig = P.ParityRig(N, episode_steps=ep, seed=91, hist_cap=cap, with_oracle=False)
+    eng = rig.eng
+    rng = np.random.default_rng(91)
+    hist = np.full((N, eng.hist_stride), np.nan, np.float32)
+    hist[:, :cap] = (rng.standard_normal((N, cap)) * (10.0 + 40.0 * rng.random((N, 1)))).astype(np.float32)
+    eng.set_state("hist", hist)
+    eng.set_state("hist_len", np.full(N, cap, np.int32))
+    eng.set_state("hist_pos", np.zeros(N, np.int32))
+    rig.reset_all()
+    before = after = 0
+    for t in range(384):
+        a = torch.randint(0, 3, (N, 3), dtype=torch.int32, device=eng.device)
+        obs, share, rew, done, info = eng.step(a)
+        inf = info.cpu().numpy()
+        assert (inf[:, L.INFO_IDX["fault"]] == 0).all(), t
+        taken = int((inf[:, 39] == 2).sum())
+        if 20 <= t < 148:
+            before += taken
+        if t >= 170:
+            after += taken
+        if (t + 1) % ep == 0:
+            rig.reset_all()
+    assert (eng.get_state("order_stat_sticky") == 0).all()
+    print("deferred take-overs before / after the wrap:", before, after)
+    assert before > 0 and after > 0
+    eng.close()
