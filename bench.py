@@ -179,7 +179,7 @@ def _pmc_parse(dirname, last):
     return out
 
 
-def pmc_collect(args, timeout_s=240):
+def pmc_collect(args, timeout_s=90):
     """Counters of the step kernel from separate rocprofv3 passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE
     cannot share a pass; --pmc with --kernel-trace only).  Returns (dict, error string or None)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -200,8 +200,8 @@ def pmc_collect(args, timeout_s=240):
                 p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                    timeout=timeout_s)
             except subprocess.TimeoutExpired:
-                errs.append(f"rocprofv3 pass '{name}' timed out")
-                continue
+                errs.append(f"rocprofv3 pass '{name}' timed out; remaining passes skipped")
+                break
             got = _pmc_parse(d, last=32)
             if not any(c in got for c in ctrs):
                 errs.append(f"rocprofv3 pass '{name}' gave no counters (rc {p.returncode}): " +
