@@ -85,6 +85,9 @@ enum SdcHdr {
   H_QC = 29,      // [2]: how many keys lie at or beyond last step's clip bound.  With H_QS1 / H_QS2 these running
                   // sums make the tail corrections O(1): a step only touches the keys the bound has moved across.
   H_Q3 = 32,      // rank window of the upper quartile
+  H_WFIRST = 22,  // [4] first key of each rank window {Q1, Q3, BU, BL} (in the window's own key space) ...
+  H_WLAST = 52,   // [4] ... and its last valid key: a step whose appended / evicted keys lie outside [first, last] of a
+                  // window only moves that window's ranks -- decided from these two numbers, without touching its lanes
   H_PEND = 34,    // [4] per rank window: a deferred re-centring in flight (0: none): request step mod 2^22 << 10 | result set << 8 | request index + 1
   H_LAST_XNEW = 38,   // the previous step's appended key, evicted key (KEY_NONE: none) and history length before it:
   H_LAST_XOLD = 39,   // what a re-centred window that describes the ring one step back has to catch up with

@@ -709,6 +709,11 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
     qt_put(o0, H_Q3, q3);
     qt_put(o0, H_BU, bu);
     qt_put(o0, H_BL, bl);
+    // first / last key of every window (what the O(1) path's outside-the-window test reads)
+    put_u32(o0, H_WFIRST + 0, lane_key(q1.w, 0)); put_u32(o0, H_WLAST + 0, lane_key(q1.w, max(q1.hi - 1, 0)));
+    put_u32(o0, H_WFIRST + 1, lane_key(q3.w, 0)); put_u32(o0, H_WLAST + 1, lane_key(q3.w, max(q3.hi - 1, 0)));
+    put_u32(o0, H_WFIRST + 2, lane_key(bu.w, 0)); put_u32(o0, H_WLAST + 2, lane_key(bu.w, max(bu.hi - 1, 0)));
+    put_u32(o0, H_WFIRST + 3, lane_key(bl.w, 0)); put_u32(o0, H_WLAST + 3, lane_key(bl.w, max(bl.hi - 1, 0)));
     if (wd1 || wd3 || wdu || wdl)
       reinterpret_cast<uint4*>(S.qwin)[(size_t)env * SDC_WIN + lane] = make_uint4(q1.w, q3.w, bu.w, bl.w);
   } else {
@@ -794,10 +799,45 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   const int n_prev = has_old ? n : n - 1;
   A1 += vn - vo;
   A2 += vn * vn - vo * vo;
-  const bool wd1 = hw_update(q1, x_new, x_old, has_old, n_prev, ok, h, l);
-  const bool wd3 = hw_update(q3, x_new, x_old, has_old, n_prev, ok, h, l);
-  const bool wdu = hw_update(bu, x_new, x_old, has_old, n_prev, ok, h, l);
-  const bool wdl = hw_update(bl, ~x_new, ~x_old, has_old, n_prev, ok, h, l);
+  // Most steps neither key lands INSIDE a window (a window lists 64 of the 10 000 keys): it lies below (the window's
+  // ranks move by one) or above (nothing moves).  That is decided per window from its cached first / last key --
+  // per-lane arithmetic on values that are uniform in the half, no ballots, no LDS permutes; only when some window of
+  // either env does have a key inside (or starts / ends the history where the key would land) do the lanes run the
+  // general update (hw_update), which also refreshes the cache.
+  unsigned wf0 = hp[H_WFIRST], wf1 = hp[H_WFIRST + 1], wf2 = hp[H_WFIRST + 2], wf3 = hp[H_WFIRST + 3];
+  unsigned wl0 = hp[H_WLAST], wl1 = hp[H_WLAST + 1], wl2 = hp[H_WLAST + 2], wl3 = hp[H_WLAST + 3];
+  const int m_hist = has_old ? n_prev - 1 : n_prev;
+  auto outside = [&](const HWin& q, const unsigned first, const unsigned last, const unsigned flip, int& r0n) __attribute__((always_inline)) {
+    const unsigned y = x_old ^ flip, x = x_new ^ flip;
+    const bool e_below = has_old && y < first;
+    const bool e_ok = !has_old || y > last || e_below;          // (evicted key above the window / below it)
+    const int r0e = q.r0 - (e_below ? 1 : 0);
+    const bool ends = r0e + q.hi == m_hist;
+    const bool i_below = x < first && r0e != 0;
+    const bool i_ok = i_below || (x >= last && !ends);          // (appended key below the window / above it)
+    r0n = r0e + (i_below ? 1 : 0);
+    return e_ok && i_ok;
+  };
+  int r0n1, r0n3, r0nu, r0nl;
+  const bool out1 = outside(q1, wf0, wl0, 0u, r0n1), out3 = outside(q3, wf1, wl1, 0u, r0n3);
+  const bool outu = outside(bu, wf2, wl2, 0u, r0nu), outl = outside(bl, wf3, wl3, KEY_NONE, r0nl);
+  bool wd1 = false, wd3 = false, wdu = false, wdl = false;
+  if (__builtin_expect(__ballot((ok && !(out1 && out3 && outu && outl)) || wdc) != 0ull, 0)) {
+    wd1 = hw_update(q1, x_new, x_old, has_old, n_prev, ok, h, l);
+    wd3 = hw_update(q3, x_new, x_old, has_old, n_prev, ok, h, l);
+    wdu = hw_update(bu, x_new, x_old, has_old, n_prev, ok, h, l);
+    wdl = hw_update(bl, ~x_new, ~x_old, has_old, n_prev, ok, h, l);
+    const int base = h << 5;
+    wf0 = key_at(q1.a, q1.b, 0, base); wl0 = key_at(q1.a, q1.b, q1.hi - 1, base);
+    wf1 = key_at(q3.a, q3.b, 0, base); wl1 = key_at(q3.a, q3.b, q3.hi - 1, base);
+    wf2 = key_at(bu.a, bu.b, 0, base); wl2 = key_at(bu.a, bu.b, bu.hi - 1, base);
+    wf3 = key_at(bl.a, bl.b, 0, base); wl3 = key_at(bl.a, bl.b, bl.hi - 1, base);
+  } else {
+    q1.r0 = r0n1;
+    q3.r0 = r0n3;
+    bu.r0 = r0nu;
+    bl.r0 = r0nl;
+  }
   ok = ok && q1.hi > 0 && q3.hi > 0 && bu.hi > 0 && bl.hi > 0;
   unsigned a1, b1, a3, b3;
   const bool r1 = hw_resolve(q1, k1, n, h, a1, b1), r3 = hw_resolve(q3, k3, n, h, a3, b3);
@@ -819,7 +859,8 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     if (~x_new >= kbl1) { qc1 += 1; qs1_1 += vn; qs2_1 += vn * vn; }
   }
   const unsigned lo0 = min(kb0, kbl0), hi0 = max(kb0, kbl0), lo1 = min(kb1, kbl1), hi1 = max(kb1, kbl1);
-  const bool sp0 = hw_spans(bu, lo0, hi0, n, h), sp1 = hw_spans(bl, lo1, hi1, n, h);
+  const bool sp0 = bu.hi > 0 && (bu.r0 == 0 || wf2 < lo0) && (bu.r0 + bu.hi >= n || hi0 <= wl2);   // (hw_spans on the cached keys)
+  const bool sp1 = bl.hi > 0 && (bl.r0 == 0 || wf3 < lo1) && (bl.r0 + bl.hi >= n || hi1 <= wl3);
   ok = ok && (kb0 == kbl0 || sp0) && (kb1 == kbl1 || sp1);
   {
     // the keys a bound has crossed: this lane's share over its two keys, then the half's total (rare: skipped as a
@@ -953,6 +994,8 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
       o[H_BL + T_R0] = (unsigned)bl.r0; o[H_BL + T_HI] = (unsigned)bl.hi;
       o[H_N] = (unsigned)n;
       o[H_PEND] = pend0; o[H_PEND + 1] = pend1; o[H_PEND + 2] = pend2; o[H_PEND + 3] = pend3;
+      o[H_WFIRST] = wf0; o[H_WFIRST + 1] = wf1; o[H_WFIRST + 2] = wf2; o[H_WFIRST + 3] = wf3;
+      o[H_WLAST] = wl0; o[H_WLAST + 1] = wl1; o[H_WLAST + 2] = wl2; o[H_WLAST + 3] = wl3;
       o[H_LAST_XNEW] = x_new;
       o[H_LAST_XOLD] = x_old;
       o[H_LAST_NPREV] = (unsigned)n_prev;

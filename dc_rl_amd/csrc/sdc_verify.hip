@@ -227,6 +227,8 @@ extern "C" __global__ __launch_bounds__(SDC_BLOCK, 2) void sdc_reward_verify_ker
     const QTrack& q = wave == 0 ? q1 : (wave == 1 ? q3 : (wave == 2 ? bu : bl));
     const unsigned flip = wave == 3 ? KEY_NONE : 0u;
     if (q.hi <= 0 || q.hi > SDC_WIN || q.r0 < 0 || q.r0 + q.hi > n) bad = true;
+    else if (lane_key(q.w, 0) != (unsigned)rec_i32(hd0, H_WFIRST + wave) || lane_key(q.w, q.hi - 1) != (unsigned)rec_i32(hd0, H_WLAST + wave))
+      bad = true;      // the cached first / last key of the window (what the step's outside-the-window test reads)
     else if (lane < q.hi) {
       int clt = 0, cle = 0;
       for (int j = 0; j < SDC_HIST_STRIDE / 4; j++) {
