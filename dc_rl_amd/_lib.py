@@ -109,6 +109,7 @@ class SdcResetOverride(C.Structure):
 EXPORTS = [
     "sdc_last_error", "sdc_version", "sdc_create", "sdc_destroy", "sdc_set_seed", "sdc_weather_window_len", "sdc_set_tables",
     "sdc_set_dc_params", "sdc_assign_envs", "sdc_reset", "sdc_step", "sdc_rollout", "sdc_steps_to_episode_end",
+    "sdc_last_done",
     "sdc_get_state", "sdc_set_state",
     "sdc_hist_stride", "sdc_queue_stride", "sdc_profile_enable", "sdc_profile_read",
 ]
@@ -159,6 +160,7 @@ def load():
     L.sdc_step.argtypes = [vp, vp, fp, fp, fp, vp, fp, fp, vp]
     L.sdc_rollout.argtypes = [vp, C.c_int, vp, fp, fp, fp, vp, fp, fp, vp, vp]
     L.sdc_steps_to_episode_end.argtypes = [vp]
+    L.sdc_last_done.argtypes = [vp, u8p]
     L.sdc_get_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_set_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_profile_enable.argtypes = [vp, C.c_int]

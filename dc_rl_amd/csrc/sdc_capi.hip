@@ -77,6 +77,8 @@ struct sdc_handle {
   std::vector<int> host_t_rel;  // exact at the last sync point
   int pending = 0;              // steps launched since then (every env advances by one per step)
   int steps_to_terminal = 0;
+  std::vector<unsigned char> last_done;   // which envs finished in the last sdc_step / sdc_rollout call (host mirror)
+  int n_last_done = 0;
   bool tables_set = false, assigned = false, started = false;
   // optional per-kernel timing: the kernels stamp the device wall clock per workgroup into one slot per sampled step
   int prof = 0;       // sample every `prof`-th step (0 = off)
@@ -164,6 +166,18 @@ int invalidate_trackers(sdc_handle* h) {
   std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
   if (rec_put(h, H_VALID, 1, z.data(), 1)) return -1;
   return 0;
+}
+
+// the envs whose episode ended with the step(s) just launched, from the host mirror of the step counters
+void note_done(sdc_handle* h) {
+  const int N = h->cfg.n_envs;
+  h->last_done.assign((size_t)N, 0);
+  h->n_last_done = 0;
+  for (int e = 0; e < N; e++)
+    if (h->host_t_rel[e] >= h->cfg.episode_steps) {
+      h->last_done[e] = 1;
+      h->n_last_done += 1;
+    }
 }
 
 void recompute_steps_to_terminal(sdc_handle* h) {
@@ -536,6 +550,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
                      actions, obs, share_obs, done, info, final_obs, rew);
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
   HIP_TRY(hipGetLastError());
+  h->n_last_done = 0;
   h->steps_to_terminal -= 1;
   h->pending += 1;
   if (h->rel_hint >= 0) h->rel_hint += 1;
@@ -543,6 +558,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
     // At least one env just finished.  Episodes have a fixed length and every env advances one step per
     // launch, so the host knows this from its mirror of the step counters -- no device read-back.
     sync_mirror(h);
+    note_done(h);
     if (h->cfg.auto_reset) {
       // harl/envs/env_wrappers.py:176-190: reset inside the same step call and return the reset obs
       d.reset_mask = nullptr;
@@ -586,11 +602,13 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
                        obs, share_obs, done, info, final_obs, rew);
   }
   HIP_TRY(hipGetLastError());
+  h->n_last_done = 0;
   h->steps_to_terminal -= n_steps;
   h->pending += n_steps;
   if (h->rel_hint >= 0) h->rel_hint += n_steps;
   if (h->steps_to_terminal == 0) {
     sync_mirror(h);
+    note_done(h);
     if (h->cfg.auto_reset) {
       // as in sdc_step: the finished envs are reset inside the call; the LAST step's obs / share_obs slices receive
       // the reset observation, final_obs the pre-reset one
@@ -610,6 +628,12 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
 }
 
 int sdc_steps_to_episode_end(const sdc_handle* h) { return h ? h->steps_to_terminal : -1; }
+
+int sdc_last_done(const sdc_handle* h, uint8_t* done_host) {
+  if (!h) return -1;
+  if (h->n_last_done > 0 && done_host) std::memcpy(done_host, h->last_done.data(), (size_t)h->cfg.n_envs);
+  return h->n_last_done;
+}
 
 int sdc_profile_enable(sdc_handle* h, int enable) {
   if (!h) return fail_msg("sdc_profile_enable: null handle");

@@ -81,6 +81,7 @@ class SdcEngine:
         self._pinned_stream = None
         self._pinned_stream_obj = None
         self._out_ptrs = None
+        self._done_buf = None
         with torch.cuda.device(self.device):
             torch.cuda.init()
             L.check(self.lib.sdc_create(C.byref(cfg), C.byref(self._h)))
@@ -223,6 +224,17 @@ class SdcEngine:
         c = b + N * L.N_AGENTS
         return (fl[:a].view(N, L.N_AGENTS, L.OBS_PAD), fl[a:b].view(N, L.SHARE_OBS_DIM), fl[b:c].view(N, L.N_AGENTS),
                 flat[n_f * 4:], fl[c:].view(N, L.INFO_DIM))
+
+    def last_done(self):
+        """bool [N]: which envs finished in the last step() / rollout() -- from the host's mirror of the step counters, no
+        device synchronisation.  None when no env finished."""
+        if self._done_buf is None:
+            self._done_buf = np.zeros(self.n_envs, dtype=np.uint8)
+            self._done_ptr = self._done_buf.ctypes.data_as(C.POINTER(C.c_uint8))
+        n = self.lib.sdc_last_done(self._h, self._done_ptr)
+        if n < 0:
+            L.check(n)
+        return self._done_buf.astype(bool) if n > 0 else None
 
     def steps_to_episode_end(self) -> int:
         return int(self.lib.sdc_steps_to_episode_end(self._h))

@@ -12,8 +12,8 @@ the same step call, the returned obs are the reset obs, and `infos[i][0]["origin
 Outputs are NumPy arrays by default (what `ShareSubprocVecEnv` returns after `np.stack`); with
 `return_torch=True` they are device tensors (views of the engine's buffers, valid until the next call) so that a
 GPU policy never round-trips through the host.  `infos` is a lazy sequence: the N x 3 dicts of the reference are
-materialised only for the entries a caller touches (from a snapshot of the step's info block, so it stays valid -- for
-two further steps in NumPy mode, where the snapshot lives in the pinned double buffer until first touched);
+materialised only for the entries a caller touches; an `infos` object read after its info block has been overwritten
+raises (never another step's values), `snapshot_infos=True` gives every step's `infos` its own copy;
 `accumulate_logger_sums()` / `read_logger_sums()` keep the logger's per-step sums
 (harl/envs/sustaindc/sustaindc_logger.py:87-101) in a device-side accumulator that is read once per episode.
 """
@@ -132,19 +132,48 @@ class _InfoDict(Mapping):
         return sum(1 for _ in self)
 
 
+class _FinalObs:
+    """The `original_obs / original_state / original_avail_actions` entries of the envs that finished in a step
+    (env_wrappers.py:176-190 puts them into agent 0's info), built per env on first access from one host copy of the
+    step's pre-reset observations."""
+
+    def __init__(self, final_obs: np.ndarray, done: np.ndarray, agent_idx, n_agents: int):
+        self._fo, self._done, self._idx, self._k = final_obs, done, agent_idx, n_agents
+        self._made = {}
+
+    def get(self, key, default=None):
+        e, a = key
+        if a != 0 or not self._done[e]:
+            return default
+        d = self._made.get(e)
+        if d is None:
+            fo = self._fo[e]
+            # states[2][-1] of the PADDED obs: agent_bat's zero padding (harlsustaindc_env.py:25-26, :80)
+            raw = np.concatenate([fo[0, :26], fo[1, 11:12], fo[1, 13:14], fo[2, 25:26]])
+            d = self._made[e] = {"original_obs": fo[self._idx].copy(),
+                                 "original_state": np.repeat(raw[None, :], self._k, axis=0),
+                                 "original_avail_actions": np.ones((self._k, 3), dtype=np.float32)}
+        return d
+
+
 class LazyInfos(Sequence):
     """`infos` of a step: tuple[N] of list[3] of dict in the reference; here views over one [N, K] array."""
 
-    def __init__(self, info_tensor, actions, done, const, extra):
+    def __init__(self, info_tensor, actions, done, const, extra, owner=None, valid_for=0):
         self._t = info_tensor
         self._rows = None
         self.actions = actions
         self.done = done
         self.const = const
         self.extra = extra
+        self._owner, self._gen, self._valid_for = owner, (owner._gen if owner is not None else 0), valid_for
 
     def rows(self):
         if self._rows is None:
+            # the block this object reads from is reused by later steps: never hand out another step's values
+            if self._owner is not None and self._owner._gen - self._gen > self._valid_for:
+                raise RuntimeError("these infos belong to an earlier step whose info block has been overwritten; read them "
+                                   "before stepping again or construct the env with snapshot_infos=True")
             # (a copy: the pinned host buffers are reused two steps later)
             self._rows = self._t.detach().cpu().numpy().copy() if hasattr(self._t, "detach") else np.array(self._t)
         return self._rows
@@ -184,7 +213,8 @@ def _merge_args(env_args: Optional[dict]) -> dict:
 class SustainDCVecEnv(ShareVecEnv):
     def __init__(self, env_args: Union[dict, List[dict], None] = None, n_envs: int = 1, seed: int = 0,
                  months: Optional[Sequence[int]] = None, device: int = 0, return_torch: bool = False,
-                 auto_reset: bool = True, data_root: Optional[str] = None, env_index_base: int = 0):
+                 auto_reset: bool = True, data_root: Optional[str] = None, env_index_base: int = 0,
+                 snapshot_infos: bool = False):
         per_env = [_merge_args(a) for a in env_args] if isinstance(env_args, (list, tuple)) else [_merge_args(env_args)] * n_envs
         if len(per_env) != n_envs:
             raise ValueError("env_args list must have n_envs entries")
@@ -275,6 +305,10 @@ class SustainDCVecEnv(ShareVecEnv):
         self._need_reset = True
         self._host = None       # pinned host output buffers (NumPy outputs only)
         self._host_flip = 0
+        self._no_done = np.zeros(n_envs, dtype=bool)
+        self._gen = 0
+        self._torch_views = None
+        self.snapshot_infos = bool(snapshot_infos)
         self._act_pin = None    # pinned host staging of NumPy actions
         self._act_flip = 0
 
@@ -310,7 +344,9 @@ class SustainDCVecEnv(ShareVecEnv):
             pin = self._act_pin[self._act_flip]
             pin.numpy()[...] = np.asarray(actions).reshape(self.num_envs, self.n_agents)
             actions = pin.to(self.engine.device, non_blocking=True)
-        a = actions.reshape(self.num_envs, self.n_agents).to(device=self.engine.device, dtype=t.int32)
+        a = actions.reshape(self.num_envs, self.n_agents)
+        if a.dtype != t.int32 or a.device != self.engine.device:
+            a = a.to(device=self.engine.device, dtype=t.int32)
         if self.n_agents != 3:      # the other slots are played on the device; their columns are never read
             full = t.ones((self.num_envs, 3), dtype=t.int32, device=self.engine.device)
             full[:, self._agent_idx] = a
@@ -325,7 +361,10 @@ class SustainDCVecEnv(ShareVecEnv):
         self._actions = None
         obs, share, rew, done, info = self.engine.step(a)
         if self.return_torch:
-            done_h = done.cpu().numpy().astype(bool)
+            # no host synchronisation on the device-resident path: which envs finished comes from the engine's host
+            # mirror of the step counters (sdc_last_done)
+            ld = self.engine.last_done()
+            done_h = ld if ld is not None else self._no_done
         else:
             # NumPy outputs: ONE asynchronous copy of the step's outputs (one device allocation) into a pinned host buffer,
             # ONE synchronisation (two buffer sets alternate, so the arrays of a step stay valid until the step after next)
@@ -334,26 +373,35 @@ class SustainDCVecEnv(ShareVecEnv):
             self._torch.cuda.current_stream(self.engine.device).synchronize()
             done_h = hb["done"].numpy().astype(bool)
         extra = {}
-        if done_h.any():
-            fo = self.engine.final_obs.cpu().numpy()
-            for i in np.nonzero(done_h)[0]:
-                # states[2][-1] of the PADDED obs: agent_bat's zero padding (harlsustaindc_env.py:25-26, :80)
-                raw = np.concatenate([fo[i, 0, :26], fo[i, 1, 11:12], fo[i, 1, 13:14], fo[i, 2, 25:26]])
-                extra[(int(i), 0)] = {"original_obs": fo[i][self._agent_idx].copy(),
-                                      "original_state": np.repeat(raw[None, :], self.n_agents, axis=0),
-                                      "original_avail_actions": np.ones((self.n_agents, 3), dtype=np.float32)}
-        # `infos` stays valid after later steps (the reference returns materialised dicts): it reads from a snapshot of
-        # the step's [N, 44] info block -- a pinned host copy made with the other outputs (NumPy mode), a device clone
-        # otherwise (copied to the host on first access only)
-        info_src = hb["info"] if not self.return_torch else info.clone()
-        infos = LazyInfos(info_src, a, done_h, self._const, extra)
+        if done_h.any():    # ONE host copy of the pre-reset observations; the per-env entries are built when read
+            extra = _FinalObs(self.engine.final_obs.cpu().numpy(), done_h, self._agent_idx, self.n_agents)
+        # `infos` (lazy): reads the step's [N, 44] info block on first access -- from the pinned host copy made with the
+        # other outputs (NumPy mode: valid for one more step), from the device otherwise.  An access after the block has
+        # been overwritten RAISES instead of returning a later step's values; `snapshot_infos=True` makes every infos
+        # object own a copy (the reference returns materialised dicts).
+        self._gen += 1
+        if self.return_torch:
+            # device-resident path: a device clone only when asked for (snapshot_infos) or when an episode ended (the
+            # runners read the final step's infos after the auto-reset); else a guarded view of the engine's buffer
+            snap = self.snapshot_infos or bool(extra)
+            infos = LazyInfos(info.clone() if snap else info, a, done_h, self._const, extra, None if snap else self, 0)
+        else:
+            infos = LazyInfos(hb["info"], a, done_h, self._const, extra, self, 1)   # pinned double buffer: one more step
+            if self.snapshot_infos:
+                infos.rows()
         if self._logger_acc is not None:      # device-side logger sums: one small reduction per step, no read-back
             self._logger_acc.add_(info[:, self._logger_idx].sum(0, dtype=t.float64))
             self._logger_steps += 1
         k = self.n_agents
         if self.return_torch:
-            dones3 = done.bool().unsqueeze(1).expand(-1, k)
-            return self._sel(obs), self._share3(share), self._sel(rew).unsqueeze(-1), dones3, infos, self._avail
+            # the engine's output tensors are persistent, so the shaped views are too (uint8 0/1 -> bool is a reinterpret)
+            v = self._torch_views
+            if v is None:
+                v = (self._share3(share), done.view(t.bool).unsqueeze(1).expand(-1, k),
+                     (obs, rew.unsqueeze(-1)) if k == 3 else None)
+                self._torch_views = v
+            o, r = v[2] if v[2] is not None else (self._sel(obs), self._sel(rew).unsqueeze(-1))
+            return o, v[0], r, v[1], infos, self._avail
         share3 = np.broadcast_to(hb["share"].numpy()[:, None, :], (self.num_envs, k, hb["share"].shape[1]))
         return (self._sel(hb["obs"].numpy()), share3, self._sel(hb["rew"].numpy())[..., None],
                 np.repeat(done_h[:, None], k, axis=1), infos, self._avail_np)

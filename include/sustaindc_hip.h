@@ -246,6 +246,11 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
                 uint8_t* done, float* info, float* final_obs, int32_t* actions_out, void* stream);
 /* steps until the first env finishes its episode (0: a reset is due) */
 int sdc_steps_to_episode_end(const sdc_handle* h);
+/* which envs finished their episode in the last sdc_step / sdc_rollout call -- the `done` output, but from the host's
+ * mirror of the step counters (episodes have a fixed length), so a caller that keeps everything on the device learns
+ * about episode boundaries (harl/envs/env_wrappers.py:176-190: "original_obs" bookkeeping) without a device->host
+ * read.  Returns the number of finished envs; done_host [N] (host, may be NULL) is filled only when it is > 0. */
+int sdc_last_done(const sdc_handle* h, uint8_t* done_host);
 
 /* parity injection + env checkpoint: copy one named state field to / from HOST memory, dense per env.
  * int32[N]:  cursor t_rel day hourq q_popped q_cum q_cumT q_head q_cum_hm1 q_cumT_hm1 last_delta consecutive

@@ -14,6 +14,17 @@ for i in range(K): o, s, r, d, info, a = envs.step(acts[i & 63])
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("HARL surface, NumPy outputs (device->host copies every step): %.1f us/step, %.1f M env-steps/s" % (dt / K * 1e6, 4096 * K / dt / 1e6))
 envs.close()
+# (1b) the same surface with device-resident outputs and actions (a GPU policy): no copies, no host synchronisation
+envs = make_train_env("sustaindc", 1, 4096, env_args, return_torch=True)
+envs.reset()
+acts_t = torch.from_numpy(acts).cuda()
+for i in range(50): envs.step(acts_t[i & 63])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+K = 2000
+for i in range(K): o, s, r, d, info, a = envs.step(acts_t[i & 63])
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("HARL surface, torch outputs (everything stays on the device): %.1f us/step, %.1f M env-steps/s" % (dt / K * 1e6, 4096 * K / dt / 1e6))
+envs.close()
 # (2) single env latency through SustainDC
 from dc_rl_amd import SustainDC
 e = SustainDC({"location": "ny", "month": 6, "days_per_episode": 7})
