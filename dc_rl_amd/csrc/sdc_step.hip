@@ -261,6 +261,37 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   }
   const double normq = sdc_div_const((double)total, (double)S.queue_max, S.rc_queue_max);
   const double oldest_norm = SDC_DIV_CONST(oldest, 24), avg_norm = SDC_DIV_CONST(avg, 24);
+  // the load-shifting entries of the observation pool and of the info block leave for LDS here (lane 1 / lane 0 of the
+  // half), so that none of them stays in registers across the rack model below
+  if (feat_ok) {
+    if (l == 1) {
+      float* pool = sh.pool[h];
+      pool[SDC_P_OLDEST] = (float)oldest_norm;
+      pool[SDC_P_AVG] = (float)avg_norm;
+      pool[SDC_P_NORMQ] = (float)normq;
+      for (int b = 0; b < 5; b++) pool[SDC_P_HIST + b] = (float)hist[b];
+    }
+  } else if (l == 0) {
+    double* o = sh.osc[h];
+    o[5] = normq; o[6] = oldest_norm; o[7] = avg_norm;
+    for (int b = 0; b < 5; b++) o[8 + b] = hist[b];
+  }
+  if (l == 0) {
+    float* inf = sh.info[h];
+    inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)wl;
+    inf[SDC_INFO_LS_SHIFTED_WORKLOAD] = (float)util;
+    inf[SDC_INFO_LS_TASKS_IN_QUEUE] = (float)total;
+    inf[SDC_INFO_LS_NORM_TASKS_IN_QUEUE] = (float)normq;
+    inf[SDC_INFO_LS_TASKS_DROPPED] = (float)dropped;
+    inf[SDC_INFO_LS_TASKS_PROCESSED] = (float)processed;
+    inf[SDC_INFO_LS_OLDEST_TASK_AGE] = (float)oldest_norm;
+    inf[SDC_INFO_LS_AVERAGE_TASK_AGE] = (float)avg_norm;
+    inf[SDC_INFO_LS_OVERDUE_PENALTY] = (float)overdue;
+    inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(util * 100);
+    inf[SDC_INFO_LS_CURRENT_HOUR] = (float)hour;
+    for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
+    inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)util;
+  }
 
   // ---- rule-based policies for agent_dc / agent_bat (sdc_config.policy; 0 = the caller's action) ----------------------
   int a_dc = a_dc_in, a_bat = a_bat_in;
@@ -413,19 +444,11 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
                                     (0x1Fu << SDC_P_T5) | (1u << SDC_P_WNEXT) | (1u << SDC_P_NTNEXT);
     float* pool = sh.pool[h];
     if (l < SDC_POOL_DIM && ((TRACE_ONLY >> l) & 1u)) pool[l] = frow;
-    if (l == 1) {
-      pool[SDC_P_OLDEST] = (float)oldest_norm;
-      pool[SDC_P_AVG] = (float)avg_norm;
-      pool[SDC_P_NORMQ] = (float)normq;
-      for (int b = 0; b < 5; b++) pool[SDC_P_HIST + b] = (float)hist[b];
-      pool[SDC_P_SOC] = (float)soc_after;
-    }
+    if (l == 1) pool[SDC_P_SOC] = (float)soc_after;
   } else if (l == 0) {
     // no feature rows for this episode: the wavefront computes the features of this env below (whole-wave, per env)
     double* o = sh.osc[h];
-    o[0] = g[G_LUT]; o[1] = g[G_LUT2]; o[2] = w_ip; o[3] = w_ip1; o[4] = soc_after; o[5] = normq; o[6] = oldest_norm;
-    o[7] = avg_norm;
-    for (int b = 0; b < 5; b++) o[8 + b] = hist[b];
+    o[0] = g[G_LUT]; o[1] = g[G_LUT2]; o[2] = w_ip; o[3] = w_ip1; o[4] = soc_after;
     o[13] = ip >= 16 ? 1.0 : 0.0;
   }
 
@@ -456,18 +479,6 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   if (l == 0) {
     // ---- info block --------------------------------------------------------------------------------
     float* inf = sh.info[h];
-    inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)wl;
-    inf[SDC_INFO_LS_SHIFTED_WORKLOAD] = (float)util;
-    inf[SDC_INFO_LS_TASKS_IN_QUEUE] = (float)total;
-    inf[SDC_INFO_LS_NORM_TASKS_IN_QUEUE] = (float)normq;
-    inf[SDC_INFO_LS_TASKS_DROPPED] = (float)dropped;
-    inf[SDC_INFO_LS_TASKS_PROCESSED] = (float)processed;
-    inf[SDC_INFO_LS_OLDEST_TASK_AGE] = (float)oldest_norm;
-    inf[SDC_INFO_LS_AVERAGE_TASK_AGE] = (float)avg_norm;
-    inf[SDC_INFO_LS_OVERDUE_PENALTY] = (float)overdue;
-    inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(util * 100);
-    inf[SDC_INFO_LS_CURRENT_HOUR] = (float)hour;
-    for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
     inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(p_it, 1e3);
     inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(ct, 1e3);
     inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(comp, 1e3);
@@ -475,7 +486,6 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
     inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
     inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
-    inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)util;
     inf[SDC_INFO_DC_INT_TEMPERATURE] = (float)mean_outlet;
     inf[SDC_INFO_DC_EXTERIOR_AMBIENT_TEMP] = (float)amb;
     inf[SDC_INFO_DC_WATER_USAGE] = (float)water;
