@@ -123,7 +123,8 @@ __device__ __forceinline__ double lrec_f64(const unsigned* rp, int idx) { return
 // the coupled dynamics at cursor i and the observation at i' = i + 1 of BOTH envs of the wavefront: lane = (half h, l)
 __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc, const int h, const int l, const int a_ls,
                                                 const int a_dc_in, const int a_bat_in, unsigned fault, const bool feat_ok,
-                                                const float frow, int32_t* __restrict__ actions_out, PairShared& sh) {
+                                                const float frow, const uint2 q_ahead, const bool q_ahead_ok,
+                                                int32_t* __restrict__ actions_out, PairShared& sh) {
   const unsigned* rp = sh.rec[h];
   const double* g = sh.g[h];
   const double* pr = sh.prm[h];
@@ -204,7 +205,28 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   {
     const bool was_empty = (cum_prev - popped0) == 0;
     const bool need = total > 0 && !was_empty && popped != popped0;   // this half searches
-    if (__builtin_expect(__ballot(need) != 0ull, 0)) {
+    // The usual case needs no memory round trip in the middle of the step: the 32 table entries from the old head on
+    // were requested with the step's inputs (q_ahead: lane l holds cum / cumT of step head + l) whenever the action can
+    // pop tasks; the new head is almost always among them (it moves past <= 90 tasks, and a step's defer adds ~5-15).
+    bool need_search = need;
+    if (q_ahead_ok) {
+      const int t = head + l;
+      const int c = (t == now) ? cum_now : (int)q_ahead.x;
+      const unsigned m = half_ballot(need && t <= now && c > popped, h);
+      const int f = __ffs((int)m) - 1;
+      const int src = (h << 5) + max(f - 1, 0);
+      const int c_m1 = __shfl((int)q_ahead.x, src), ct_m1 = __shfl((int)q_ahead.y, src);
+      if (need && m != 0u) {
+        need_search = false;
+        if (f > 0) {            // (f == 0: the head stays, and so do the cached cum / cumT of the step before it)
+          head += f;
+          cum_hm1 = c_m1;
+          cumT_hm1 = (unsigned)ct_m1;
+        }
+      }
+    }
+    if (__builtin_expect(__ballot(need_search) != 0ull, 0)) {
+      const bool need = need_search;
       int lo = head, hi = now;
       while (__ballot(need && hi - lo + 1 > HL) != 0ull) {
         const bool act = need && hi - lo + 1 > HL;
@@ -1103,6 +1125,13 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   float frow = frow_pre;
   if (feat_ok && !fast) frow = S.feat[((size_t)envc * (S.episode_steps + 1) + (rel + 1)) * SDC_FEAT_ROW + l];
   const bool want_c3 = S.policy[2] == SDC_POLICY_RBC;
+  // the queue table from the oldest task's step on (pair_dynamics: where the new oldest task is after tasks were popped)
+  const bool q_ahead_ok = a_ls == 2;
+  uint2 q_ahead = make_uint2(0u, 0u);
+  if (q_ahead_ok) {
+    const int t = lrec_i32(rp, R_QHEAD) + l;
+    if (t < rel) q_ahead = (S.qtab + (size_t)envc * S.qstride)[t];
+  }
   {
     const double ci_min = lrec_f64(rp, R_CI_MIN), ci_den = lrec_f64(rp, R_CI_DEN);
     const double t_min = lrec_f64(rp, R_T_MIN), t_den = lrec_f64(rp, R_T_DEN);
@@ -1175,7 +1204,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   if (hl0 >= S.hist_cap && append) x_old_l = S.hist[(size_t)envc * SDC_HIST_STRIDE + slot0];   // (one address per half)
   const uint4 wka = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l];       // keys 2l of the 4 windows
   const uint4 wkb = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l + 1];   // keys 2l + 1
-  const DynOut d = pair_dynamics(S, envc, h, l, a_ls, a_dc, a_bat, fault, feat_ok, frow, actions_out, sh);
+  const DynOut d = pair_dynamics(S, envc, h, l, a_ls, a_dc, a_bat, fault, feat_ok, frow, q_ahead, q_ahead_ok, actions_out, sh);
   wave_sync();
 
   // ---- episodes without feature rows: the observation features of such an env, all 64 lanes cooperating ---------------
