@@ -54,6 +54,10 @@ static_assert(offsetof(SdcDcDev, k_outlet) - offsetof(SdcDcDev, p.m_cpu) == P_K_
 static_assert(offsetof(SdcDcDev, n_racks_f) - offsetof(SdcDcDev, p.m_cpu) == P_N_RACKS * sizeof(double), "config scalars must be contiguous");
 static_assert(P_COUNT <= HL, "one config scalar per lane of a half");
 
+#ifndef SDC_PRIO_DROP
+#define SDC_PRIO_DROP 2
+#endif
+
 struct PairShared {
   double g[EPW][64];                   // gathered step inputs; g[G_NC..] / g[G_NT..] are normalised in place to NC / NT
   double prm[EPW][HL];                 // config scalars (P_*)
@@ -389,6 +393,9 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       ret_plus_out += P.rack_return[rk] + out;
     }
   }
+#if SDC_PRIO_DROP == 1
+  __builtin_amdgcn_s_setprio(0);
+#endif
   if (half_ballot(bad_delta, h) != 0u) fault |= SDC_FAULT_OUTLET_DELTA;
   const double sum_cpu = half_sum_f64(pcpu), sum_fan = half_sum_f64(pfan);
   const double avg_ret = sdc_div_const(half_sum_f64(ret_plus_out), (double)R, pr[P_RC_N_RACKS]);  // datacenter.py:531-541
@@ -1221,6 +1228,9 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
     }
     wave_sync();
   }
+#if SDC_PRIO_DROP == 2
+  __builtin_amdgcn_s_setprio(0);
+#endif
   if (__builtin_expect((S.debug_flags & 8) != 0, 0) && lane == 0) sh.dbg_t[0] = wall_clock64();
 
   // ---- rewards + reward-state upkeep: both envs at once on the O(1) path; an env that needs its ring (or anything
@@ -1300,8 +1310,8 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
 // the 8 XCDs, each with its own L2): give every XCD a CONTIGUOUS range of envs, so that output lines shared by
 // neighbouring envs (rew, done, the unaligned obs rows) are assembled in one L2 instead of being written back in pieces
 // from several.
-__device__ __forceinline__ int first_pair_of_block(const int first_block) {
-  const int nb = (int)gridDim.x - first_block, bi = (int)blockIdx.x - first_block;
+__device__ __forceinline__ int first_pair_of_block(const int first_block, const int nb) {
+  const int bi = (int)blockIdx.x - first_block;
   const int vb = (nb % 8 == 0) ? (bi % 8) * (nb / 8) + bi / 8 : bi;
   return vb * SDC_STEP_WPB;
 }
@@ -1309,6 +1319,10 @@ __device__ __forceinline__ int first_pair_of_block(const int first_block) {
 // The spare wavefronts at the front of a step launch: wavefront j serves re-centring request j of the previous step (see
 // SdcRefillReq): one sweep over that env's ring as the previous step left it, the re-centred window out as a result.
 #define SDC_SWEEP_BLOCKS (SDC_RQ_MAX / SDC_STEP_WPB)
+#define SDC_CUS 256
+#ifndef SDC_LATE_PRIO
+#define SDC_LATE_PRIO 1
+#endif
 __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const int j, const int lane, sdc_rw::TailLds& tl) {
   using namespace sdc_rw;
   const int set = S.step_no % 3;
@@ -1338,12 +1352,19 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_W
   __shared__ PairShared shs[SDC_STEP_WPB];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
   const int lane = threadIdx.x % SDC_WAVE;
-  if (blockIdx.x < SDC_SWEEP_BLOCKS) {     // dispatched first: their sweeps run under the start of everybody else's step
-    serve_recentring_requests(S, (int)blockIdx.x * SDC_STEP_WPB + wave, lane, shs[wave].tl);
+  const int pair_blocks = (int)gridDim.x - SDC_SWEEP_BLOCKS;
+  if ((int)blockIdx.x >= pair_blocks) {
+    // dispatched last: the env pairs' workgroups fill the CUs evenly (two rounds of 256 at 4096 envs), and a sweep -- most
+    // launches have none or a few -- rides as a third wavefront on its SIMD
+    serve_recentring_requests(S, ((int)blockIdx.x - pair_blocks) * SDC_STEP_WPB + wave, lane, shs[wave].tl);
     return;
   }
-  const int env0 = (first_pair_of_block(SDC_SWEEP_BLOCKS) + wave) * EPW;
+  const int env0 = (first_pair_of_block(0, pair_blocks) + wave) * EPW;
   if (env0 >= S.n_envs) return;
+  // A SIMD issues from its oldest wavefront first: of the two env pairs that share a SIMD at 4096 envs, the one whose
+  // workgroup arrived in the second round of 256 (one per CU) would finish ~1.8 us after the other.  Raised priority for
+  // the later rounds evens the two out, and the launch ends when the slower one does.
+  if ((int)blockIdx.x >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
   if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
   pair_step(S, shs[wave], env0, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew, S.actions_out, S.step_no,
             true);
@@ -1362,7 +1383,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WP
     float* __restrict__ rew) {
   __shared__ PairShared shs[SDC_STEP_WPB];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
-  const int env0 = (first_pair_of_block(0) + wave) * EPW;
+  const int env0 = (first_pair_of_block(0, (int)gridDim.x) + wave) * EPW;
   const int lane = threadIdx.x % SDC_WAVE;
   const size_t N = (size_t)S.n_envs;
   if (env0 >= S.n_envs) return;
@@ -1370,7 +1391,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WP
   int32_t* const aout = S.actions_out;
 #pragma unroll 1
   for (int k = 0; k < K; k++) {
-    __builtin_amdgcn_s_setprio(0);
+    if ((int)blockIdx.x >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);    // (see sdc_dynamics_kernel)
     // (opaque copies: otherwise every per-env / per-lane address of the step is hoisted out of the loop and held in
     // registers across it)
     int env_k = env0, lane_k = lane;
