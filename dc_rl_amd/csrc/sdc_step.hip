@@ -801,37 +801,54 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   bool ok = append && n >= SMALL_N && q1.hi > 0 && q3.hi > 0 && bu.hi > 0 && bl.hi > 0 && (int)hp[H_VALID] == 1;
   // ---- deferred re-centrings (SdcRefillReq / SdcRefillRes): a window requested two steps ago arrives now --------------
   unsigned pend0 = hp[H_PEND], pend1 = hp[H_PEND + 1], pend2 = hp[H_PEND + 2], pend3 = hp[H_PEND + 3];
+  // cached first / last key of every window (see below)
+  unsigned wf0 = hp[H_WFIRST], wf1 = hp[H_WFIRST + 1], wf2 = hp[H_WFIRST + 2], wf3 = hp[H_WFIRST + 3];
+  unsigned wl0 = hp[H_WLAST], wl1 = hp[H_WLAST + 1], wl2 = hp[H_WLAST + 2], wl3 = hp[H_WLAST + 3];
   bool wdc = false;    // a window was replaced
   if (__builtin_expect(__ballot((pend0 | pend1 | pend2 | pend3) != 0u) != 0ull, 0)) {
     const unsigned lx_new = hp[H_LAST_XNEW], lx_old = hp[H_LAST_XOLD];
     const int l_nprev = (int)hp[H_LAST_NPREV];
-    auto arrive = [&](HWin& q, unsigned& pd, const int w, const unsigned flip) __attribute__((always_inline)) {
-      // pd = (request step mod 2^22) << 10 | result set << 8 | request index + 1
+    // pd = (request step mod 2^22) << 10 | result set << 8 | request index + 1.  All due results are requested first (ONE
+    // memory round trip whatever the number of windows), then each is replayed and installed; windows with nothing due
+    // in either env are skipped as a whole.
+    struct Arrival { int4 hd; unsigned ka, kb; bool due; unsigned age; };
+    auto fetch = [&](const unsigned pd) __attribute__((always_inline)) {
+      Arrival a;
       const int idx = (int)(pd & 0xFFu) - 1, set = (int)((pd >> 8) & 3u);
-      const unsigned age = ((unsigned)step_no - (pd >> 10)) & 0x3FFFFFu;      // steps since the request (mod 2^22)
-      const bool due = pd != 0u && age >= 2u;   // (1: being swept right now; anything else but 2: stale -- a multi-step launch, restored state)
+      a.age = ((unsigned)step_no - (pd >> 10)) & 0x3FFFFFu;      // steps since the request (mod 2^22)
+      a.due = pd != 0u && a.age >= 2u;   // (1: being swept right now; anything else but 2: stale -- a multi-step launch, restored state)
       const SdcRefillRes* rs = S.rs + (set > 2 ? 0 : set) * SDC_RQ_MAX + (idx < 0 ? 0 : idx);
-      int4 hd = make_int4(0, 0, -1, -1);
-      unsigned ka = KEY_NONE, kb = KEY_NONE;
-      if (due) {
-        hd = *reinterpret_cast<const int4*>(rs);
-        ka = rs->keys[2 * l];
-        kb = rs->keys[2 * l + 1];
+      a.hd = make_int4(0, 0, -1, -1);
+      a.ka = KEY_NONE;
+      a.kb = KEY_NONE;
+      if (a.due) {
+        a.hd = *reinterpret_cast<const int4*>(rs);
+        a.ka = rs->keys[2 * l];
+        a.kb = rs->keys[2 * l + 1];
       }
-      HWin r = {ka, kb, hd.x, hd.y};
-      const bool good = due && age == 2u && hd.z == step_no - 1 && hd.w == envc * 4 + w && r.hi > 0 && ok;
+      return a;
+    };
+    auto install = [&](const Arrival& a, HWin& q, unsigned& pd, unsigned& wf, unsigned& wl, const int w,
+                       const unsigned flip) __attribute__((always_inline)) {
+      if (__ballot(a.due) == 0ull) return;
+      HWin r = {a.ka, a.kb, a.hd.x, a.hd.y};
+      const bool good = a.due && a.age == 2u && a.hd.z == step_no - 1 && a.hd.w == envc * 4 + w && r.hi > 0 && ok;
       // the result describes the ring as the request's step left it: replay the previous step's insertion / eviction
       hw_update(r, lx_new ^ flip, lx_old ^ flip, lx_old != KEY_NONE, l_nprev, good, h, l);
+      const unsigned rf = key_at(r.a, r.b, 0, h << 5), rl = key_at(r.a, r.b, r.hi - 1, h << 5);
       if (good && r.hi > 0) {
         q = r;
+        wf = rf;
+        wl = rl;
         wdc = true;
       }
-      if (due) pd = 0u;
+      if (a.due) pd = 0u;
     };
-    arrive(q1, pend0, 0, 0u);
-    arrive(q3, pend1, 1, 0u);
-    arrive(bu, pend2, 2, 0u);
-    arrive(bl, pend3, 3, KEY_NONE);
+    const Arrival a0 = fetch(pend0), a1 = fetch(pend1), a2 = fetch(pend2), a3 = fetch(pend3);
+    install(a0, q1, pend0, wf0, wl0, 0, 0u);
+    install(a1, q3, pend1, wf1, wl1, 1, 0u);
+    install(a2, bu, pend2, wf2, wl2, 2, 0u);
+    install(a3, bl, pend3, wf3, wl3, 3, KEY_NONE);
   }
   // O(1) updates: running sums, the four windows
   const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
@@ -843,8 +860,6 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   // per-lane arithmetic on values that are uniform in the half, no ballots, no LDS permutes; only when some window of
   // either env does have a key inside (or starts / ends the history where the key would land) do the lanes run the
   // general update (hw_update), which also refreshes the cache.
-  unsigned wf0 = hp[H_WFIRST], wf1 = hp[H_WFIRST + 1], wf2 = hp[H_WFIRST + 2], wf3 = hp[H_WFIRST + 3];
-  unsigned wl0 = hp[H_WLAST], wl1 = hp[H_WLAST + 1], wl2 = hp[H_WLAST + 2], wl3 = hp[H_WLAST + 3];
   const int m_hist = has_old ? n_prev - 1 : n_prev;
   auto outside = [&](const HWin& q, const unsigned first, const unsigned last, const unsigned flip, int& r0n) __attribute__((always_inline)) {
     const unsigned y = x_old ^ flip, x = x_new ^ flip;
@@ -861,7 +876,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   const bool out1 = outside(q1, wf0, wl0, 0u, r0n1), out3 = outside(q3, wf1, wl1, 0u, r0n3);
   const bool outu = outside(bu, wf2, wl2, 0u, r0nu), outl = outside(bl, wf3, wl3, KEY_NONE, r0nl);
   bool wd1 = false, wd3 = false, wdu = false, wdl = false;
-  if (__builtin_expect(__ballot((ok && !(out1 && out3 && outu && outl)) || wdc) != 0ull, 0)) {
+  if (__builtin_expect(__ballot(ok && !(out1 && out3 && outu && outl)) != 0ull, 0)) {
     wd1 = hw_update(q1, x_new, x_old, has_old, n_prev, ok, h, l);
     wd3 = hw_update(q3, x_new, x_old, has_old, n_prev, ok, h, l);
     wdu = hw_update(bu, x_new, x_old, has_old, n_prev, ok, h, l);
