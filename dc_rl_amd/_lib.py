@@ -123,7 +123,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
+    cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("SDC_HIPCC_EXTRA", "").split() + ["-o", LIB_PATH] + srcs   # (experiments: -D...)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -278,7 +278,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   A(tabWB, (size_t)cfg->n_locations * SDC_TABLE_LEN);
   A(hour_lut, 96 * 2);
   A(dcp, cfg->n_dc_configs);
-  d.tabW = tabW; d.tabC = tabC; d.tabT = tabT; d.tabWB = tabWB; d.hour_lut = hour_lut; d.dc = dcp;
+  d.tabW = tabW; d.tabC = tabC; d.tabT = tabT; d.tabWB = tabWB; d.hour_lut = hour_lut; d.dc = dcp; d.n_cfg = cfg->n_dc_configs;
   A(d.rec, (size_t)N * SDC_REC_DWORDS);
   A(d.qtab, (size_t)N * d.qstride);
   A(d.t_win, (size_t)N * d.lw);

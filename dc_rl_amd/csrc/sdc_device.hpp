@@ -163,6 +163,7 @@ struct SdcDev {
   const double* tabT;   // pre-noise dry bulb
   const double* tabWB;  // pre-noise wet bulb
   const SdcDcDev* dc;   // [n_cfg]
+  int n_cfg;
   double rc_queue_max, rc_hist_cap;   // reciprocals of queue_max / hist_cap (see SdcDcDev)
   const double* hour_lut;   // [96][2] = cos, sin (utils/managers.py:66-88)
   // per-env state
@@ -173,7 +174,7 @@ struct SdcDev {
   double* walk_tmp;  // [N][max(SDC_NORM_WINDOW, lw)] scratch of the device-side reset
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
   unsigned* hdr;     // [N][SDC_HDR_DWORDS] per-env header: step hand-off + reward-side state (see SdcHdr)
-  float* feat;       // [N][episode_steps + 1][SDC_FEAT_ROW] the trace-only observation entries of every step of the
+  float* feat;       // [episode_steps + 1][N][SDC_FEAT_ROW] the trace-only observation entries of every step of the
                      // episode, in observation-pool layout (SDC_P_*), + NC[i'+1] as a double at SDC_FEAT_NCNEXT
   unsigned* qwin;    // [N][SDC_WIN][4] rank windows (sdc_trackers.hpp): lane l's keys of {Q1, Q3, upper bound, lower bound}
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
@@ -271,6 +272,12 @@ enum { SDC_P_COS = 0, SDC_P_SIN, SDC_P_NC, SDC_P_CI7 = 3, SDC_P_OLDEST = 10, SDC
        SDC_P_TSLOPE = 15, SDC_P_T5 = 16, SDC_P_HIST = 21, SDC_P_WNEXT = 26, SDC_P_NTNEXT, SDC_P_SOC, SDC_POOL_DIM };
 
 #define SDC_FEAT_ROW 32      // floats per feature row (128 bytes)
+// feature rows are kept step-major: the rows all envs read in one launch (envs in lock-step) are adjacent -- 512 KB at
+// 4096 envs, a handful of pages -- instead of one row per 86 KB
+__device__ __forceinline__ size_t feat_row_offset(const SdcDev& S, const int env, const int s) {
+  return ((size_t)s * (size_t)S.n_envs + (size_t)env) * SDC_FEAT_ROW;
+}
+
 #define SDC_FEAT_NCNEXT 30   // ... the last two hold one double
 // ... and the slots of the step-dependent observation entries hold the inputs of the step that LEADS to the row's
 // observation (row r: the step from episode step r - 1): W[i], C[i], T[i], WB[i] as doubles, T[i+1] as a float

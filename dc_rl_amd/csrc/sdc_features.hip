@@ -101,7 +101,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDe
   for (int j = lane; j < steps + 25; j += SDC_WAVE) ncw[j] = (tC[tix(c0 - 16 + j)] - ci_min) / ci_den;   // managers.py:437
   for (int k = lane; k < S.lw; k += SDC_WAVE) ntw[k] = (tw[k] - t_min) / t_den;                           // managers.py:608
   __syncthreads();
-  float* rows = S.feat + (size_t)env * (steps + 1) * SDC_FEAT_ROW;
   for (int s0 = 0; s0 <= steps; s0 += SDC_WAVE) {
    const int s = s0 + lane;                         // row s: the observation at i' = c0 + s
    if (s <= steps) {
@@ -167,7 +166,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDe
 #pragma unroll 4
    for (int j = 0; j < SDC_WAVE / 2; j++) {
      const int rr = 2 * j + (lane >> 5), k = lane & 31;
-     if (rr < n_rows) rows[(size_t)(s0 + rr) * SDC_FEAT_ROW + k] = tile[rr * TS + k];
+     if (rr < n_rows) S.feat[feat_row_offset(S, env, s0 + rr) + k] = tile[rr * TS + k];
    }
    __syncthreads();
   }

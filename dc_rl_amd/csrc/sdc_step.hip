@@ -1070,8 +1070,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   }
   wave_sync();
   if (commit)
-    __builtin_nontemporal_store(reinterpret_cast<const unsigned long long*>(sh.hdr[h])[l],
-                                reinterpret_cast<unsigned long long*>(S.hdr + (size_t)envc * SDC_HDR_DWORDS) + l);
+    (reinterpret_cast<unsigned long long*>(S.hdr + (size_t)envc * SDC_HDR_DWORDS))[l] = reinterpret_cast<const unsigned long long*>(sh.hdr[h])[l];
   return __ballot(ok);
 }
 
@@ -1090,6 +1089,15 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   const bool active = h < n_here;                         // lanes of a missing env compute, but store nothing
   const int env1c = env0 + n_here - 1;
 
+  // The env's three actions, requested FIRST and by hand: left to the compiler, these loads are scheduled behind the wait
+  // for the state record (their pointer and the policy flags arrive with a later batch of kernel arguments) and cost the
+  // step a second memory round trip.  Memory returns loads in order, so once the record below has arrived these have too.
+  typedef int int3v __attribute__((ext_vector_type(3)));
+  int3v act_v = {1, 1, 2};
+  if (actions != nullptr) {
+    const int32_t* ap = actions + (size_t)envc * 3;
+    asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(act_v) : "v"(ap) : "memory");
+  }
   // When the host knows the episode step every env is at (envs in lock-step: rel_hint >= 0), the step's feature row
   // -- which also holds its trace inputs -- and its queue-history probes are requested together with the state
   // record: ONE memory round trip before the dynamics start instead of two (record, then what it points to).
@@ -1097,22 +1105,36 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   float frow_pre = 0.0f;
   double q_pre = 0.0;
   if (pre) {
-    frow_pre = S.feat[((size_t)envc * (S.episode_steps + 1) + (rel_hint + 1)) * SDC_FEAT_ROW + l];
+    frow_pre = S.feat[feat_row_offset(S, envc, rel_hint + 1) + l];
     if (l >= G_Q97 && l <= G_Q96) {
       const int back = l == G_Q97 ? 97 : 24 * (l - G_Q97);   // 97, 24, 48, 72, 96
       const int t = rel_hint - back;
       if (t >= 0) q_pre = *reinterpret_cast<const double*>(S.qtab + (size_t)envc * S.qstride + t);
     }
   }
+  // with a single data-centre configuration (the usual job) its scalars do not wait for the record either
+  const bool one_cfg = S.n_cfg == 1;
+  double prm_pre = 0.0;
+  if (one_cfg && l < P_COUNT) prm_pre = reinterpret_cast<const double*>(&S.dc[0].p.m_cpu)[l];
   const unsigned long long dbg_entry = (S.debug_flags & 16) ? wall_clock64() : 0ull;
 
   // ---- level 0: the two state records (one dwordx2 per lane, 512 contiguous bytes), headers, actions ----------------
   uint2* recp = reinterpret_cast<uint2*>(S.rec + (size_t)envc * SDC_REC_DWORDS) + l;
   const uint2 rr = *recp;
+  {
+    unsigned r0 = rr.x, r1 = rr.y;
+    asm volatile("" : "+v"(act_v), "+v"(r0), "+v"(r1));     // (the record is here: so are the actions)
+  }
   int a_ls = 1, a_dc = 1, a_bat = 2;       // (rule-based slots never read the caller's array, which may be null)
-  if (S.policy[0] == SDC_POLICY_EXTERNAL) a_ls = actions[envc * 3 + 0];
-  if (S.policy[1] == SDC_POLICY_EXTERNAL) a_dc = actions[envc * 3 + 1];
-  if (S.policy[2] == SDC_POLICY_EXTERNAL) a_bat = actions[envc * 3 + 2];
+  if (S.policy[0] == SDC_POLICY_EXTERNAL) a_ls = act_v.x;
+  if (S.policy[1] == SDC_POLICY_EXTERNAL) a_dc = act_v.y;
+  if (S.policy[2] == SDC_POLICY_EXTERNAL) a_bat = act_v.z;
+  unsigned long long dbg_rec = 0ull;
+  if (__builtin_expect((S.debug_flags & 32) != 0, 0)) {
+    unsigned tmp = rr.x;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(tmp)::"memory");
+    dbg_rec = wall_clock64() + (tmp & 0u);
+  }
   reinterpret_cast<uint2*>(sh.rec[h])[l] = rr;
   wave_sync();
   const unsigned* rp = sh.rec[h];
@@ -1133,7 +1155,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   }
   // ---- level 1 ----------------------------------------------------------------------------------------------------------
   // config scalars: lane j of the half fetches scalar j of its env's config (one coalesced 8-byte load), LDS hands them round
-  if (l < P_COUNT) sh.prm[h][l] = reinterpret_cast<const double*>(&PD->p.m_cpu)[l];
+  if (l < P_COUNT) sh.prm[h][l] = one_cfg ? prm_pre : reinterpret_cast<const double*>(&PD->p.m_cpu)[l];
   // the ring slot this step's energy will overwrite: its current key is the evicted value the reward state's
   // order-statistic trackers need (0xFFFFFFFF while the ring is still filling)
   const int hl0 = lrec_i32(rp, R_HIST_LEN);
@@ -1145,15 +1167,8 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   const bool feat_ok = S.feat != nullptr && lrec_i32(rp, R_FEAT_OK) == 1;
   const bool fast = pre && feat_ok && rel == rel_hint;   // what was requested up front is what this step needs
   float frow = frow_pre;
-  if (feat_ok && !fast) frow = S.feat[((size_t)envc * (S.episode_steps + 1) + (rel + 1)) * SDC_FEAT_ROW + l];
+  if (feat_ok && !fast) frow = S.feat[feat_row_offset(S, envc, rel + 1) + l];
   const bool want_c3 = S.policy[2] == SDC_POLICY_RBC;
-  // the queue table from the oldest task's step on (pair_dynamics: where the new oldest task is after tasks were popped)
-  const bool q_ahead_ok = a_ls == 2;
-  uint2 q_ahead = make_uint2(0u, 0u);
-  if (q_ahead_ok) {
-    const int t = lrec_i32(rp, R_QHEAD) + l;
-    if (t < rel) q_ahead = (S.qtab + (size_t)envc * S.qstride)[t];
-  }
   {
     const double ci_min = lrec_f64(rp, R_CI_MIN), ci_den = lrec_f64(rp, R_CI_DEN);
     const double t_min = lrec_f64(rp, R_T_MIN), t_den = lrec_f64(rp, R_T_DEN);
@@ -1190,16 +1205,17 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
     };
     double* gh = sh.g[h];
     if (__builtin_expect(fast, 1)) {
-      // the row's input slots and the probes go to the places the gather would have put them
+      // the row's input slots and the probes go to the places the gather would have put them: one predicated 4-byte
+      // write (the doubles W, C, T, WB, NC[i'+1] arrive as float pairs of the row), two 8-byte ones -- no per-slot branches
+      static_assert(SDC_FEAT_W == 10 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 && SDC_FEAT_NCNEXT == 30 &&
+                    G_W0 == 0 && G_C0 == 3 && G_T0 == 4 && G_WB0 == 5 && G_NCN == 14, "slot table below");
       unsigned* g32 = reinterpret_cast<unsigned*>(gh);
-      const unsigned fb = (unsigned)__float_as_int(frow);
-      if (l == SDC_FEAT_W || l == SDC_FEAT_W + 1) g32[2 * G_W0 + (l - SDC_FEAT_W)] = fb;
-      if (l == SDC_FEAT_C || l == SDC_FEAT_C + 1) g32[2 * G_C0 + (l - SDC_FEAT_C)] = fb;
-      if (l == SDC_FEAT_T || l == SDC_FEAT_T + 1) g32[2 * G_T0 + (l - SDC_FEAT_T)] = fb;
-      if (l == SDC_FEAT_WB || l == SDC_FEAT_WB + 1) g32[2 * G_WB0 + (l - SDC_FEAT_WB)] = fb;
-      if (l == SDC_FEAT_NCNEXT || l == SDC_FEAT_NCNEXT + 1) g32[2 * G_NCN + (l - SDC_FEAT_NCNEXT)] = fb;
-      if (l == SDC_FEAT_T1) gh[G_T1] = (double)frow;
+      const int off = l < 12 ? SDC_FEAT_W - 2 * G_W0 : l < 26 ? SDC_FEAT_C - 2 * G_C0 : l < 30 ? SDC_FEAT_WB - 2 * G_WB0
+                                                                                              : SDC_FEAT_NCNEXT - 2 * G_NCN;
+      static_assert(SDC_FEAT_T - 2 * G_T0 == SDC_FEAT_C - 2 * G_C0, "C and T share an offset");
+      if ((0xF3C00C00u >> l) & 1u) g32[l - off] = (unsigned)__float_as_int(frow);
       if (l >= G_Q97 && l <= G_Q96) gh[l] = q_pre;
+      if (l == SDC_FEAT_T1) gh[G_T1] = (double)frow;
       if (l == G_C3 && want_c3) gh[G_C3] = gather(G_C3);
     } else {
       if (l != G_NCN) gh[l] = gather(l);
@@ -1220,10 +1236,19 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   // reward-side state (headers: returns, trackers, sums; the rank windows' keys; the evicted ring key): wanted at the end of
   // the step, so these loads are issued here -- after the start-of-launch burst of every env's record / gather loads
   // (measured: whatever joins that burst makes every wavefront's start slower) -- and ride along in registers
-  const unsigned hdA = S.hdr[(size_t)env0 * SDC_HDR_DWORDS + lane];
-  const unsigned hdB = S.hdr[(size_t)env1c * SDC_HDR_DWORDS + lane];
+  // (loads that depend on a condition go FIRST: the hardware's counter of outstanding loads can only express "all but the
+  // last k", so a wait for a value that is followed by a load which may or may not have been issued waits for everything)
+  // the queue table from the oldest task's step on (pair_dynamics: where the new oldest task is after tasks were popped)
+  const bool q_ahead_ok = a_ls == 2;
+  uint2 q_ahead = make_uint2(0u, 0u);
+  if (q_ahead_ok) {
+    const int t = lrec_i32(rp, R_QHEAD) + l;
+    if (t < rel) q_ahead = (S.qtab + (size_t)envc * S.qstride)[t];
+  }
   unsigned x_old_l = 0xFFFFFFFFu;
   if (hl0 >= S.hist_cap && append) x_old_l = S.hist[(size_t)envc * SDC_HIST_STRIDE + slot0];   // (one address per half)
+  const unsigned hdA = S.hdr[(size_t)env0 * SDC_HDR_DWORDS + lane];
+  const unsigned hdB = S.hdr[(size_t)env1c * SDC_HDR_DWORDS + lane];
   const uint4 wka = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l];       // keys 2l of the 4 windows
   const uint4 wkb = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l + 1];   // keys 2l + 1
   const DynOut d = pair_dynamics(S, envc, h, l, a_ls, a_dc, a_bat, fault, feat_ok, frow, q_ahead, q_ahead_ok, actions_out, sh);
@@ -1270,7 +1295,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
       const unsigned long long dbg_a3 = wall_clock64();
       for (int e = 0; e < n_here; e++) {
         float* inf = sh.info[e];
-        inf[40] = (S.debug_flags & 16) ? (float)(dbg_a0 & 0xFFFFFull) : 0.0f;
+        inf[40] = (S.debug_flags & 32) ? (float)(dbg_rec - dbg_entry) : (S.debug_flags & 16) ? (float)(dbg_a0 & 0xFFFFFull) : 0.0f;
         inf[41] = (S.debug_flags & 16) ? (float)(dbg_a0 - dbg_entry) : (float)(sh.dbg_t[0] - dbg_a0);
         inf[42] = (float)(dbg_a3 - sh.dbg_t[0]);
         inf[43] = (S.debug_flags & 16) ? (float)(dbg_a3 & 0xFFFFFull) : (float)(dbg_a3 - dbg_a0);
@@ -1279,11 +1304,11 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   }
   wave_sync();
 
-  // (non-temporal: nothing in this launch reads them again, and whole lines that have already left the L2 shorten the
-  // write-back at the end of the launch; partial-line stores -- rew, done, the ring slot -- must NOT be: they turn
-  // into read-modify-writes at the memory and add 10 us)
   // ---- coalesced stores: records, obs [3][26] (78 floats per env), share_obs [29], info [44]: the pair's rows are adjacent --
-  if (active) __builtin_nontemporal_store(reinterpret_cast<const unsigned long long*>(sh.rec[h])[l], reinterpret_cast<unsigned long long*>(recp));
+  // (outputs non-temporal: nothing in this launch reads them again, and whole lines that have already left the L2 shorten
+  // the write-back at the end of the launch; partial-line stores -- rew, done, the ring slot -- must NOT be: they turn into
+  // read-modify-writes at the memory and add 10 us.  The state records / headers: plain stores, measured the same.)
+  if (active) *reinterpret_cast<unsigned long long*>(recp) = reinterpret_cast<const unsigned long long*>(sh.rec[h])[l];
   const int rel_now = lrec_i32(sh.rec[h], R_TREL);     // (patched: rel + 1)
   const bool terminal = rel_now >= S.episode_steps;
   const unsigned long long term_m = __ballot(terminal && active);
@@ -1338,6 +1363,24 @@ __device__ __forceinline__ int first_pair_of_block(const int first_block, const 
 #ifndef SDC_LATE_PRIO
 #define SDC_LATE_PRIO 1
 #endif
+// The kernel arguments (SdcDev by value + the output pointers: ten 64-byte lines) are read by scalar loads wherever the
+// compiler first needs a field -- several dependent batches, each a miss in the scalar cache at the start of a launch.
+// One load per line up front brings them all in with a single round trip; what follows hits.
+struct KernargTouch { unsigned t[8]; };
+__device__ __forceinline__ KernargTouch kernarg_touch() {
+  KernargTouch k;
+  const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile(
+      "s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\t"
+      "s_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0"
+      : "=&s"(k.t[0]), "=&s"(k.t[1]), "=&s"(k.t[2]), "=&s"(k.t[3]), "=&s"(k.t[4]), "=&s"(k.t[5]), "=&s"(k.t[6]), "=&s"(k.t[7])
+      : "s"(ka));
+  return k;
+}
+__device__ __forceinline__ void kernarg_touch_done(const KernargTouch& k) {     // (the registers stay reserved until here)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(k.t[0]), "s"(k.t[1]), "s"(k.t[2]), "s"(k.t[3]), "s"(k.t[4]), "s"(k.t[5]),
+               "s"(k.t[6]), "s"(k.t[7]));
+}
 __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const int j, const int lane, sdc_rw::TailLds& tl) {
   using namespace sdc_rw;
   const int set = S.step_no % 3;
@@ -1365,8 +1408,10 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_W
     SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
     unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
   __shared__ PairShared shs[SDC_STEP_WPB];
+  const KernargTouch kt = kernarg_touch();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
   const int lane = threadIdx.x % SDC_WAVE;
+  kernarg_touch_done(kt);
   const int pair_blocks = (int)gridDim.x - SDC_SWEEP_BLOCKS;
   if ((int)blockIdx.x >= pair_blocks) {
     // dispatched last: the env pairs' workgroups fill the CUs evenly (two rounds of 256 at 4096 envs), and a sweep -- most
