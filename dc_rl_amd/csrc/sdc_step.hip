@@ -875,23 +875,19 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   int r0n1, r0n3, r0nu, r0nl;
   const bool out1 = outside(q1, wf0, wl0, 0u, r0n1), out3 = outside(q3, wf1, wl1, 0u, r0n3);
   const bool outu = outside(bu, wf2, wl2, 0u, r0nu), outl = outside(bl, wf3, wl3, KEY_NONE, r0nl);
-  bool wd1 = false, wd3 = false, wdu = false, wdl = false;
-  if (__builtin_expect(__ballot(ok && !(out1 && out3 && outu && outl)) != 0ull, 0)) {
-    wd1 = hw_update(q1, x_new, x_old, has_old, n_prev, ok, h, l);
-    wd3 = hw_update(q3, x_new, x_old, has_old, n_prev, ok, h, l);
-    wdu = hw_update(bu, x_new, x_old, has_old, n_prev, ok, h, l);
-    wdl = hw_update(bl, ~x_new, ~x_old, has_old, n_prev, ok, h, l);
-    const int base = h << 5;
-    wf0 = key_at(q1.a, q1.b, 0, base); wl0 = key_at(q1.a, q1.b, q1.hi - 1, base);
-    wf1 = key_at(q3.a, q3.b, 0, base); wl1 = key_at(q3.a, q3.b, q3.hi - 1, base);
-    wf2 = key_at(bu.a, bu.b, 0, base); wl2 = key_at(bu.a, bu.b, bu.hi - 1, base);
-    wf3 = key_at(bl.a, bl.b, 0, base); wl3 = key_at(bl.a, bl.b, bl.hi - 1, base);
-  } else {
-    q1.r0 = r0n1;
-    q3.r0 = r0n3;
-    bu.r0 = r0nu;
-    bl.r0 = r0nl;
-  }
+  // (per window: about one wavefront in ten has a key inside SOME window of one of its envs, almost never inside two)
+  auto update = [&](HWin& q, const bool out, const int r0n, unsigned& wf, unsigned& wl, const unsigned flip) __attribute__((always_inline)) {
+    if (__builtin_expect(__ballot(ok && !out) == 0ull, 1)) {
+      q.r0 = r0n;
+      return false;
+    }
+    const bool wd = hw_update(q, x_new ^ flip, x_old ^ flip, has_old, n_prev, ok, h, l);
+    wf = key_at(q.a, q.b, 0, h << 5);
+    wl = key_at(q.a, q.b, q.hi - 1, h << 5);
+    return wd;
+  };
+  const bool wd1 = update(q1, out1, r0n1, wf0, wl0, 0u), wd3 = update(q3, out3, r0n3, wf1, wl1, 0u);
+  const bool wdu = update(bu, outu, r0nu, wf2, wl2, 0u), wdl = update(bl, outl, r0nl, wf3, wl3, KEY_NONE);
   ok = ok && q1.hi > 0 && q3.hi > 0 && bu.hi > 0 && bl.hi > 0;
   unsigned a1, b1, a3, b3;
   const bool r1 = hw_resolve(q1, k1, n, h, a1, b1), r3 = hw_resolve(q3, k3, n, h, a3, b3);
