@@ -1381,8 +1381,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
 // the 8 XCDs, each with its own L2): give every XCD a CONTIGUOUS range of envs, so that output lines shared by
 // neighbouring envs (rew, done, the unaligned obs rows) are assembled in one L2 instead of being written back in pieces
 // from several.
-__device__ __forceinline__ int first_pair_of_block(const int first_block, const int nb) {
-  const int bi = (int)blockIdx.x - first_block;
+__device__ __forceinline__ int first_pair_of_block(const int bi, const int nb) {
   const int vb = (nb % 8 == 0) ? (bi % 8) * (nb / 8) + bi / 8 : bi;
   return vb * SDC_STEP_WPB;
 }
@@ -1391,6 +1390,12 @@ __device__ __forceinline__ int first_pair_of_block(const int first_block, const 
 // SdcRefillReq): one sweep over that env's ring as the previous step left it, the re-centred window out as a result.
 #define SDC_SWEEP_BLOCKS (SDC_RQ_MAX / SDC_STEP_WPB)
 #define SDC_CUS 256
+#ifndef SDC_SWEEP_PRIO
+#define SDC_SWEEP_PRIO 0
+#endif
+#ifndef SDC_SWEEP_AT
+#define SDC_SWEEP_AT 320
+#endif
 #ifndef SDC_LATE_PRIO
 #define SDC_LATE_PRIO 1
 #endif
@@ -1420,6 +1425,9 @@ __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const
   if (j >= cnt) return;
   const SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + j;
   if (rq->step != S.step_no - 1) return;                            // stale (a multi-step launch came in between)
+  // dispatched last and the youngest wavefront of its SIMD: without priority the sweep is served after both env pairs and
+  // ends the launch (constant policies file ~100 requests per step)
+  __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
   const int env = rq->env, w = rq->win, n = rq->n;
   QTrack A = {rq->keys[lane], rq->r0, rq->hi};
   const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), rq->patch_slot, rq->patch_x};
@@ -1444,18 +1452,26 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_W
   const int lane = threadIdx.x % SDC_WAVE;
   kernarg_touch_done(kt);
   const int pair_blocks = (int)gridDim.x - SDC_SWEEP_BLOCKS;
-  if ((int)blockIdx.x >= pair_blocks) {
-    // dispatched last: the env pairs' workgroups fill the CUs evenly (two rounds of 256 at 4096 envs), and a sweep -- most
-    // launches have none or a few -- rides as a third wavefront on its SIMD
-    serve_recentring_requests(S, ((int)blockIdx.x - pair_blocks) * SDC_STEP_WPB + wave, lane, shs[wave].tl);
+  // where the 32 sweep workgroups sit in the grid: after the first SDC_SWEEP_AT pair workgroups (or last, in a small grid)
+  const int sweep_first = pair_blocks > SDC_SWEEP_AT ? SDC_SWEEP_AT : pair_blocks;
+  const int bx = (int)blockIdx.x;
+  if (bx >= sweep_first && bx < sweep_first + SDC_SWEEP_BLOCKS) {
+    // Not first: the env pairs' workgroups must fill the CUs evenly (two rounds of 256 at 4096 envs), and the sweep
+    // workgroups without a request exit at once -- in front they leave 32 CUs one workgroup short until a third round
+    // lands there.  Not last either: as the youngest wavefronts of their SIMDs the sweeps would be served after both env
+    // pairs and end the launch when there are many of them (constant policies: ~100 requests per step).  Early in the
+    // second round (measured at 128 / 256 / 320 / 384 / last: uniform-random actions 15.7 / 15.5 / 15.6 / 15.6 / 15.6 us
+    // per step, all-idle actions 15.4 / 16.6 / 15.8 / 15.8 / 17.2).
+    serve_recentring_requests(S, (bx - sweep_first) * SDC_STEP_WPB + wave, lane, shs[wave].tl);
     return;
   }
-  const int env0 = (first_pair_of_block(0, pair_blocks) + wave) * EPW;
+  const int pb = bx < sweep_first ? bx : bx - SDC_SWEEP_BLOCKS;          // index among the pair workgroups
+  const int env0 = (first_pair_of_block(pb, pair_blocks) + wave) * EPW;
   if (env0 >= S.n_envs) return;
   // A SIMD issues from its oldest wavefront first: of the two env pairs that share a SIMD at 4096 envs, the one whose
   // workgroup arrived in the second round of 256 (one per CU) would finish ~1.8 us after the other.  Raised priority for
   // the later rounds evens the two out, and the launch ends when the slower one does.
-  if ((int)blockIdx.x >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
+  if (pb >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
   if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
   pair_step(S, shs[wave], env0, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew, S.actions_out, S.step_no,
             true);
@@ -1474,7 +1490,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WP
     float* __restrict__ rew) {
   __shared__ PairShared shs[SDC_STEP_WPB];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
-  const int env0 = (first_pair_of_block(0, (int)gridDim.x) + wave) * EPW;
+  const int env0 = (first_pair_of_block((int)blockIdx.x, (int)gridDim.x) + wave) * EPW;
   const int lane = threadIdx.x % SDC_WAVE;
   const size_t N = (size_t)S.n_envs;
   if (env0 >= S.n_envs) return;
