@@ -54,6 +54,14 @@ static_assert(offsetof(SdcDcDev, k_outlet) - offsetof(SdcDcDev, p.m_cpu) == P_K_
 static_assert(offsetof(SdcDcDev, n_racks_f) - offsetof(SdcDcDev, p.m_cpu) == P_N_RACKS * sizeof(double), "config scalars must be contiguous");
 static_assert(P_COUNT <= HL, "one config scalar per lane of a half");
 
+#ifndef SDC_OUT_NT
+#define SDC_OUT_NT 1
+#endif
+#if SDC_OUT_NT
+#define SDC_OUT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define SDC_OUT_STORE(v, p) (*(p) = (v))
+#endif
 #ifndef SDC_PRIO_DROP
 #define SDC_PRIO_DROP 2
 #endif
@@ -1372,13 +1380,13 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
     if (idx < n_here * SDC_OBS_OUT) {
       const int e = idx >= SDC_OBS_OUT ? 1 : 0, j = idx - e * SDC_OBS_OUT;
       const float v = obs_padded_at(sh.pool[e], j);
-      __builtin_nontemporal_store(v, &obs[(size_t)env0 * SDC_OBS_OUT + idx]);
+      SDC_OUT_STORE(v, &obs[(size_t)env0 * SDC_OBS_OUT + idx]);
       if (final_obs && ((term_m >> (e * HL)) & 1ull)) final_obs[(size_t)env0 * SDC_OBS_OUT + idx] = v;
     }
   }
   if (share_obs && lane < n_here * SDC_SHARE_OBS_DIM) {
     const int e = lane >= SDC_SHARE_OBS_DIM ? 1 : 0, j = lane - e * SDC_SHARE_OBS_DIM;
-    __builtin_nontemporal_store(share_obs_at(sh.pool[e], j), &share_obs[(size_t)env0 * SDC_SHARE_OBS_DIM + lane]);
+    SDC_OUT_STORE(share_obs_at(sh.pool[e], j), &share_obs[(size_t)env0 * SDC_SHARE_OBS_DIM + lane]);
   }
   if (info) {
 #pragma unroll
@@ -1386,7 +1394,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
       const int idx = k * SDC_WAVE + lane;
       if (idx < n_here * SDC_INFO_DIM) {
         const int e = idx >= SDC_INFO_DIM ? 1 : 0, j = idx - e * SDC_INFO_DIM;
-        __builtin_nontemporal_store(sh.info[e][j], &info[(size_t)env0 * SDC_INFO_DIM + idx]);
+        SDC_OUT_STORE(sh.info[e][j], &info[(size_t)env0 * SDC_INFO_DIM + idx]);
       }
     }
   }
