@@ -271,3 +271,16 @@ def test_long_episode_without_feature_rows_vs_oracle():
     w = P.run_engine_vs_oracle(n_envs=16, n_steps=150, episode_steps=4000, seed=17)
     print("long episode", w)
     assert w["obs"] <= TOL and w["rew"] <= TOL and w["info"] <= 2e-6
+
+
+def test_grid_shapes_with_sweep_workgroups_inside_the_grid_vs_oracle():
+    """Batches whose step grid is larger than the point where the 32 spare (sweep) workgroups are inserted (320 pair
+    workgroups = 2560 envs) and NOT a multiple of 8 workgroups (the XCD-contiguous env mapping falls back to the
+    identity), with an odd number of envs: the envs around the insertion point, the first and the last ones against the
+    oracle across an episode boundary."""
+    for n in (2603, 2570):
+        last = n - 1
+        envs = sorted({0, 1, 2, 3, 1279, 1280, 2551, 2552, 2559, 2560, 2561, 2567, 2568, last - 2, last - 1, last})
+        w = P.run_engine_vs_oracle(n_envs=n, n_steps=130, episode_steps=96, seed=31 + n, oracle_envs=envs)
+        print(n, w)
+        assert w["obs"] <= 1e-5 and w["rew"] <= 1e-5 and w["info"] <= 2e-6
