@@ -871,6 +871,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   unsigned wf0 = hp[H_WFIRST], wf1 = hp[H_WFIRST + 1], wf2 = hp[H_WFIRST + 2], wf3 = hp[H_WFIRST + 3];
   unsigned wl0 = hp[H_WLAST], wl1 = hp[H_WLAST + 1], wl2 = hp[H_WLAST + 2], wl3 = hp[H_WLAST + 3];
   bool wdc = false;    // a window was replaced
+  bool filed = false;  // (diagnostics) a re-centring request was filed
   if (__builtin_expect(__ballot((pend0 | pend1 | pend2 | pend3) != 0u) != 0ull, 0)) {
     const unsigned lx_new = hp[H_LAST_XNEW], lx_old = hp[H_LAST_XOLD];
     const int l_nprev = (int)hp[H_LAST_NPREV];
@@ -1046,6 +1047,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
                 rq->patch_slot = slot_next; rq->patch_x = patch_x; rq->step = step_no;
               }
               pd = (((unsigned)step_no & 0x3FFFFFu) << 10) | ((unsigned)set << 8) | (unsigned)(idx + 1);
+              filed = true;
             }
           }
         };
@@ -1124,7 +1126,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
       rew[envc * 3 + 2] = (float)r[2];
       float* inf = sh.info[h];
       inf[SDC_INFO_ENERGY_Z] = (float)z;
-      inf[SDC_INFO_RESERVED] = wdc ? 2.0f : 0.0f;   // no ring read by this wavefront (2: a deferred re-centred window arrived)
+      inf[SDC_INFO_RESERVED] = wdc ? 2.0f : ((S.debug_flags & 8) && filed) ? 4.0f : 0.0f;   // no ring read by this wavefront (2: a deferred re-centred window arrived; 4, with the timing diagnostics on: a request was filed)
       inf[SDC_INFO_EP_RETURN_LS] = (float)ret[0];
       inf[SDC_INFO_EP_RETURN_DC] = (float)ret[1];
       inf[SDC_INFO_EP_RETURN_BAT] = (float)ret[2];

@@ -73,8 +73,9 @@ enum sdc_info_col {
   SDC_INFO_RESERVED, /* diagnostic: how this step's reward normalisation was served: 0 incremental state only (no
                         history read), 1 a rank window was re-centred over the history inline, 2 incremental state
                         only and a window re-centred by a spare wavefront of the previous launch was taken over,
-                        3 the state was rebuilt from the history.  Scheduling-dependent (which requests find a free
-                        slot), unlike every other output */
+                        3 the state was rebuilt from the history (and, only with debug_flags bit 3: 4 incremental
+                        state only and a re-centring request was filed).  Scheduling-dependent (which requests find
+                        a free slot), unlike every other output */
   /* running return of the current episode INCLUDING this step (== the episode return on the done step);
    * feeds the return statistics the runners log (harl/common/base_logger.py:75-88) without host sums */
   SDC_INFO_EP_RETURN_LS,

@@ -25,6 +25,7 @@ feat = {
   "queue non-empty": pair_any(I[:, ix["ls_tasks_in_queue"]] > 0),
   "bat idle both": (A[0::2, 2] == 2) & (A[1::2, 2] == 2), "bat differs": A[0::2, 2] != A[1::2, 2],
   "reward path != 0": pair_any(I[:, 39] != 0), "path 2 (takeover)": pair_any(I[:, 39] == 2),
+  "request filed": pair_any(I[:, 39] == 4),
 }
 print("all waves: total %.2f dyn %.2f rew %.2f   p99 %.2f  max %.2f" % (tot.mean(), dyn.mean(), rw.mean(), np.percentile(tot, 99), tot.max()))
 for k, m in feat.items():
