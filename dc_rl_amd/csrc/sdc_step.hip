@@ -54,6 +54,20 @@ static_assert(offsetof(SdcDcDev, k_outlet) - offsetof(SdcDcDev, p.m_cpu) == P_K_
 static_assert(offsetof(SdcDcDev, n_racks_f) - offsetof(SdcDcDev, p.m_cpu) == P_N_RACKS * sizeof(double), "config scalars must be contiguous");
 static_assert(P_COUNT <= HL, "one config scalar per lane of a half");
 
+// sub-phase timing (tools/phase_scan.sh): a build with -DSDC_STAMP_A=i -DSDC_STAMP_B=j stamps the wall clock at the marks
+// SDC_AT(i) and SDC_AT(j) of the step (lane 0 of the wavefront) and reports the difference in info[42] when debug_flags
+// bit 3 is set; the default build contains no stamp
+#ifndef SDC_STAMP_A
+#define SDC_STAMP_A 0
+#endif
+#ifndef SDC_STAMP_B
+#define SDC_STAMP_B 0
+#endif
+#define SDC_AT(k, SH, LANE0)                                                        \
+  do {                                                                              \
+    if ((k) == SDC_STAMP_A && SDC_STAMP_A != 0 && (LANE0)) (SH).dbg_s[0] = wall_clock64(); \
+    if ((k) == SDC_STAMP_B && SDC_STAMP_B != 0 && (LANE0)) (SH).dbg_s[1] = wall_clock64(); \
+  } while (0)
 #ifndef SDC_OUT_NT
 #define SDC_OUT_NT 1
 #endif
@@ -75,6 +89,7 @@ struct PairShared {
   float pool[EPW][32];                 // observation pool (see build_obs_pool)
   float info[EPW][SDC_INFO_DIM];
   unsigned long long dbg_t[2];
+  unsigned long long dbg_s[2];
   sdc_rw::TailLds tl;                  // scratch of the ring paths (window refill, rebuild): one env at a time
 };
 
@@ -202,6 +217,8 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   // norm_CI = NC[i'+1] (sustaindc_env.py:681): from the episode's feature row, or from the window gathered by this step
   const double norm_ci = feat_ok ? g[G_NCN] : g[G_NC + 17];
 
+  const bool lane0 = h == 0 && l == 0;
+  SDC_AT(1, sh, lane0);
   // ---- load shifting: envs/carbon_ls.py:172-324 ------------------------------------------------
   // The reference keeps a deque of per-task enqueue timestamps and only ever removes a FIFO prefix
   // (overdue `remove()` loop :225-226 and popleft :257-258).  Equivalent state: cum[t] = tasks ever
@@ -258,6 +275,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     hist[3] = sdc_div_const((double)(a72 - a96), den, rden);
     hist[4] = a96 > 0 ? 1.0 : 0.0;
   }
+  SDC_AT(2, sh, lane0);
   // oldest task: smallest step hd in [head, now] with cum[hd] > popped.  It only moves when tasks were popped
   // (or the queue was empty): then a 32-ary search over the half's lanes (<= 2 rounds) finds it and cum/cumT[hd-1]
   // are cached.
@@ -378,6 +396,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)util;
   }
 
+  SDC_AT(3, sh, lane0);
   // ---- rule-based policies for agent_dc / agent_bat (sdc_config.policy; 0 = the caller's action) ----------------------
   int a_dc = a_dc_in, a_bat = a_bat_in;
   int tr_count = lrec_i32(rp, R_TR_COUNT);
@@ -418,6 +437,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   double stpt = lrec_f64(rp, R_STPT) + (double)(delta * scale);
   stpt = fmax(fmin(stpt, pr[P_MAX_TEMP]), pr[P_MIN_TEMP]);
 
+  SDC_AT(4, sh, lane0);
   // ---- rack model, lane = rack inside the half: envs/datacenter.py:250-317, :157-181 ------------------
   const sdc_dc_params& P = S.dc[lrec_i32(rp, R_CFG)].p;
   const int R = (int)pr[P_N_RACKS];
@@ -461,6 +481,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
 #if SDC_PRIO_DROP == 1
   __builtin_amdgcn_s_setprio(0);
 #endif
+  SDC_AT(5, sh, lane0);
   if (half_ballot(bad_delta, h) != 0u) fault |= SDC_FAULT_OUTLET_DELTA;
   // (ONE reduction for CPU + fan power: only their total is used.  The reference sums the two lists separately and adds
   // the totals; the difference is a rounding of the last place)
@@ -468,6 +489,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   const double mean_outlet = sdc_div_const(half_sum_f64(outlet), (double)R, pr[P_RC_N_RACKS]);
   const double p_it = half_sum_f64(pcpu + pfan);
 
+  SDC_AT(6, sh, lane0);
   // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 ------------------------------------------
   const double c_air = pr[P_C_AIR], rho_air = pr[P_RHO_AIR], ct_fan_ref_p = pr[P_CT_FAN_REF_P];
   const double m_sys = rho_air * pr[P_CRAC_SUPPLY_PU] * p_it;
@@ -492,6 +514,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   }
   const double total_kw = SDC_DIV_CONST(p_it + ct + comp, 1e3);
 
+  SDC_AT(7, sh, lane0);
   // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ----------------------
   // charge and discharge share one sigmoid and one division (selected operands, the reference's expressions)
   const double cap = pr[P_BAT_CAP];
@@ -523,6 +546,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   co2 = (a_bat == 1 ? fmax(energy, 0.0) : energy) * ci_i;
   const double soc_after = sdc_div_const(bat_load, cap, pr[P_RC_BAT_CAP]);
 
+  SDC_AT(8, sh, lane0);
   // ---- time: utils/managers.py:127-147 -------------------------------------------------------------
   int hourq_n = hourq + 1, day_n = day;
   if (hourq_n >= 96) {
@@ -570,6 +594,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   }
   const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
 
+  SDC_AT(9, sh, lane0);
   wave_sync();     // every lane has read what it needs from the records: lane 0 of each half may now patch its record
   if (l == 0) {
     // ---- info block --------------------------------------------------------------------------------
@@ -636,6 +661,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       actions_out[(size_t)envc * 3 + 2] = a_bat;
     }
   }
+  SDC_AT(10, sh, lane0);
   DynOut o;
   o.energy = energy; o.e_off = e_off; o.norm_ci = norm_ci; o.oldest_norm = oldest_norm; o.p_it = p_it;
   o.total_kw = total_kw; o.water = water; o.overdue = overdue; o.hourq_n = hourq_n; o.hl = hl; o.slot = slot;
@@ -700,7 +726,7 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
         const Bounds b = clip_bounds(n, a1, b1, a3, b3);
         kb0 = b.kub;               // upper tail: keys >= kub
         kb1 = ~(b.klb - 1u);       // lower tail, flipped: ~x >= ~(klb-1)  <=>  x < klb
-        // first the value that came and the one that went against last step's bounds kbl, then the keys the bounds
+  // first the value that came and the one that went against last step's bounds kbl, then the keys the bounds
         // have moved across since -- which a bound's window lists, as long as both the old and the new bound lie
         // inside its span
         const unsigned kbl0 = (unsigned)rec_i32(hd0, H_KB), kbl1 = (unsigned)rec_i32(hd0, H_KB + 1);
@@ -736,7 +762,7 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
             qs1_1 += sg * wave_sum_f64(d1_1);
             qs2_1 += sg * wave_sum_f64(d2_1);
           }
-          // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
+  // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
           const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
           const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
           clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
@@ -853,6 +879,8 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   using namespace sdc_rw;
   using namespace sdc_hw;
   const unsigned* hp = sh.hdr[h];
+  const bool lane0 = h == 0 && l == 0;
+  SDC_AT(11, sh, lane0);
   const int n = d.hl;
   const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;
   const bool has_old = x_old != KEY_NONE;
@@ -917,6 +945,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     install(a2, bu, pend2, wf2, wl2, 2, 0u);
     install(a3, bl, pend3, wf3, wl3, 3, KEY_NONE);
   }
+  SDC_AT(12, sh, lane0);
   // O(1) updates: running sums, the four windows
   const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
   const int n_prev = has_old ? n : n - 1;
@@ -955,6 +984,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   };
   const bool wd1 = update(q1, out1, r0n1, wf0, wl0, 0u), wd3 = update(q3, out3, r0n3, wf1, wl1, 0u);
   const bool wdu = update(bu, outu, r0nu, wf2, wl2, 0u), wdl = update(bl, outl, r0nl, wf3, wl3, KEY_NONE);
+  SDC_AT(13, sh, lane0);
   ok = ok && q1.hi > 0 && q3.hi > 0 && bu.hi > 0 && bl.hi > 0;
   unsigned a1, b1, a3, b3;
   const bool r1 = hw_resolve(q1, k1, n, h, a1, b1), r3 = hw_resolve(q3, k3, n, h, a3, b3);
@@ -962,6 +992,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   const Bounds b = clip_bounds(n, a1, b1, a3, b3);
   const unsigned kb0 = b.kub;               // upper tail: keys >= kub
   const unsigned kb1 = ~(b.klb - 1u);       // lower tail, flipped: ~x >= ~(klb-1)  <=>  x < klb
+  SDC_AT(14, sh, lane0);
   // first the value that came and the one that went against last step's bounds kbl, then the keys the bounds have
   // moved across since -- which a bound's window lists, as long as both the old and the new bound lie inside its span
   const unsigned kbl0 = hp[H_KB], kbl1 = hp[H_KB + 1];
@@ -1003,6 +1034,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
       qs2_1 += sg * s2;
     }
   }
+  SDC_AT(15, sh, lane0);
   // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
   const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
   const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
@@ -1058,6 +1090,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
       }
     }
   }
+  SDC_AT(16, sh, lane0);
   const double z = (d.e_off - mean) / (sd > 0 ? sd : 1.0);     // (n >= SMALL_N >= 2 here)
   // rewards (step_rewards), per lane
   double r[3], ret[3];
@@ -1084,6 +1117,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
       ret[a] = lrec_f64(hp, H_RET + 2 * a) + v;
     }
   }
+  SDC_AT(17, sh, lane0);
   wave_sync();   // every lane has read the header fields it needs
   const bool commit = ok && active;
   if (commit) {
@@ -1135,6 +1169,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   wave_sync();
   if (commit)
     (reinterpret_cast<unsigned long long*>(S.hdr + (size_t)envc * SDC_HDR_DWORDS))[l] = reinterpret_cast<const unsigned long long*>(sh.hdr[h])[l];
+  SDC_AT(18, sh, lane0);
   return __ballot(ok);
 }
 
@@ -1362,6 +1397,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
         inf[40] = (S.debug_flags & 32) ? (float)(dbg_rec - dbg_entry) : (S.debug_flags & 16) ? (float)(dbg_a0 & 0xFFFFFull) : 0.0f;
         inf[41] = (S.debug_flags & 16) ? (float)(dbg_a0 - dbg_entry) : (float)(sh.dbg_t[0] - dbg_a0);
         inf[42] = (float)(dbg_a3 - sh.dbg_t[0]);
+        if (SDC_STAMP_A != 0 && SDC_STAMP_B != 0) inf[42] = (float)(sh.dbg_s[1] - sh.dbg_s[0]);
         inf[43] = (S.debug_flags & 16) ? (float)(dbg_a3 & 0xFFFFFull) : (float)(dbg_a3 - dbg_a0);
       }
     }
