@@ -1462,6 +1462,9 @@ __device__ __forceinline__ int first_pair_of_block(const int bi, const int nb) {
 #ifndef SDC_SWEEP_PRIO
 #define SDC_SWEEP_PRIO 0
 #endif
+#ifndef SDC_SWEEP_SPREAD
+#define SDC_SWEEP_SPREAD 1
+#endif
 #ifndef SDC_SWEEP_AT
 #define SDC_SWEEP_AT 320
 #endif
@@ -1531,7 +1534,11 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_W
     // pairs and end the launch when there are many of them (constant policies: ~100 requests per step).  Early in the
     // second round (measured at 128 / 256 / 320 / 384 / last: uniform-random actions 15.7 / 15.5 / 15.6 / 15.6 / 15.6 us
     // per step, all-idle actions 15.4 / 16.6 / 15.8 / 15.8 / 17.2).
+#if SDC_SWEEP_SPREAD
+    serve_recentring_requests(S, (bx - sweep_first) + wave * SDC_SWEEP_BLOCKS, lane, shs[wave].tl);   // requests 0..31 on 32 different CUs
+#else
     serve_recentring_requests(S, (bx - sweep_first) * SDC_STEP_WPB + wave, lane, shs[wave].tl);
+#endif
     return;
   }
   const int pb = bx < sweep_first ? bx : bx - SDC_SWEEP_BLOCKS;          // index among the pair workgroups
