@@ -689,7 +689,7 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
   const int n = (int)sfl((unsigned)hl);
   const bool has_old = append && x_old != KEY_NONE;
   unsigned o0 = hd0;
-  double mean = 0.0, sd = 0.0;
+  double mean = 0.0, sd = 0.0, inv_sd = 1.0;
   int path = 0;   // diagnostics: 0 no ring read, 1 a window re-centred ahead of need, 3 rebuilt
   const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), slot, x_new};
   if (__builtin_expect(n >= 2, 1)) {
@@ -765,7 +765,7 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
   // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
           const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
           const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
-          clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
+          clipped_moments(n, b, A1, A2, t1, t2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap);
           done_eval = true;
         } else {
           why = cov0 ? 7 : 6;
@@ -781,6 +781,7 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
       if (n < SMALL_N || !rb.ok) {   // tiny history (nothing to keep), or a ring no window can describe
         mean = rb.mean;
         sd = rb.sd;
+        inv_sd = sd > 0 ? 1.0 / sd : 1.0;
         q1.hi = q3.hi = bu.hi = bl.hi = 0;
         valid = false;
       } else {
@@ -798,7 +799,7 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
         qs2_0 = rb.qs2[0]; qs2_1 = rb.qs2[1];
         const double t1 = (qs1_0 - (double)qc0 * rb.b.ub) + (qs1_1 - (double)qc1 * rb.b.lb);
         const double t2 = (qs2_0 - (double)qc0 * (rb.b.ub * rb.b.ub)) + (qs2_1 - (double)qc1 * (rb.b.lb * rb.b.lb));
-        clipped_moments(n, rb.b, A1, A2, t1, t2, mean, sd);
+        clipped_moments(n, rb.b, A1, A2, t1, t2, mean, sd, inv_sd);
       }
       path = 3 + ((S.debug_flags & 2) ? why : 0);
     }
@@ -854,7 +855,7 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
   // (this path re-centres inline and rebuilds: deferred re-centrings in flight for this env are dropped)
   put_u32(o0, H_PEND, 0u); put_u32(o0, H_PEND + 1, 0u); put_u32(o0, H_PEND + 2, 0u); put_u32(o0, H_PEND + 3, 0u);
   put_f64(o0, H_EOFF, e_off);                                 // bat_total_energy_with_battery_KWh - hist_ref
-  const double z = n < 2 ? 0.0 : (e_off - mean) / (sd > 0 ? sd : 1.0);
+  const double z = n < 2 ? 0.0 : (e_off - mean) * inv_sd;
   const RewardIn rin = {z, norm_ci, oldest_norm, (double)overdue, energy, (double)hourq_n * 0.25, SDC_DIV_CONST(p_it, 1e3), total_kw, water};
   const Rewards rr = step_rewards(rin, S.reward_method, hd0);
   put_f64(o0, H_RET, rr.ret[0]);
@@ -1038,8 +1039,8 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
   const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
   const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
-  double mean, sd;
-  clipped_moments(n, b, A1, A2, t1, t2, mean, sd, S.hist_cap, S.rc_hist_cap);
+  double mean, sd, inv_sd;
+  clipped_moments(n, b, A1, A2, t1, t2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap);
   // a window that the next step could exhaust is re-centred by the slow path (which then redoes this step)
   {
     int k1n, k3n;
@@ -1091,12 +1092,12 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     }
   }
   SDC_AT(16, sh, lane0);
-  const double z = (d.e_off - mean) / (sd > 0 ? sd : 1.0);     // (n >= SMALL_N >= 2 here)
+  const double z = (d.e_off - mean) * inv_sd;     // (n >= SMALL_N >= 2 here)
   // rewards (step_rewards), per lane
   double r[3], ret[3];
   {
     const double foot = -1.0 * (d.norm_ci * z / 0.50);
-    const double overdue_pen = -0.3 * sqrt((double)d.overdue) + 0.3;
+    const double overdue_pen = -0.3 * sdc_rw::sqrt_count((double)d.overdue) + 0.3;
     const double age_pen = -0.1 * d.oldest_norm;
     double rls = foot + overdue_pen + age_pen;
     rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);

@@ -166,11 +166,23 @@ __device__ __forceinline__ Bounds clip_bounds(const int n, unsigned a1, unsigned
   b.kub = min(max(kub, klb), KEY_NONE - 2u);
   return b;
 }
+// 1 / sqrt(v) for v > 0 (fp32-representable magnitude): hardware v_rsq_f32 + two Newton steps in fp64 (<= 3e-16 relative)
+// -- 10 instructions where sqrt() and the division by it are 40
+__device__ __forceinline__ double inv_sqrt_pos(const double v) {
+  double y = (double)__builtin_amdgcn_rsqf((float)v);
+  const double hv = 0.5 * v;
+  y = y * fma(-hv * y, y, 1.5);
+  y = y * fma(-hv * y, y, 1.5);
+  return y;
+}
+// sqrt of a small non-negative integer count, to fp32 accuracy (the overdue penalty: -0.3 sqrt(n) + 0.3)
+__device__ __forceinline__ double sqrt_count(const double n) { return (double)__builtin_sqrtf((float)n); }
+
 // clipped mean / std from the total sums and the tail corrections T1 = sum_{tails} (v - bound), T2 = sum (v^2 - bound^2)
 // (n_full, rc_full: the history capacity and its reciprocal -- once the ring is full, n is that constant and the two
-// divisions take the 3-instruction form)
+// divisions take the 3-instruction form).  inv_sd = 1 / sd, or 1 when sd is 0 (the z-score's divisor, reward_creator.py:44)
 __device__ __forceinline__ void clipped_moments(const int n, const Bounds& b, const double A1, const double A2, const double T1,
-                                                const double T2, double& mean, double& sd, const int n_full = 0,
+                                                const double T2, double& mean, double& sd, double& inv_sd, const int n_full = 0,
                                                 const double rc_full = 0.0) {
   const double C1 = A1 - T1, C2 = A2 - T2;
   double m2;
@@ -182,7 +194,10 @@ __device__ __forceinline__ void clipped_moments(const int n, const Bounds& b, co
     m2 = C2 / (double)n;
   }
   const double var = m2 - mean * mean;
-  sd = (var > 0 && b.ub > b.lb) ? sqrt(var) : 0.0;
+  const bool pos = var > 1e-30 && b.ub > b.lb;
+  const double y = inv_sqrt_pos(pos ? var : 1.0);
+  sd = pos ? var * y : 0.0;
+  inv_sd = pos ? y : 1.0;
 }
 
 
@@ -247,7 +262,7 @@ __device__ __forceinline__ double tou_price(const int h) {   // reward_creator.p
 }
 __device__ __forceinline__ Rewards step_rewards(const RewardIn& in, const int (&method)[3], const unsigned hd0) {
   const double foot = -1.0 * (in.norm_ci_next * in.z / 0.50);
-  const double overdue_pen = -0.3 * sqrt(in.overdue) + 0.3;
+  const double overdue_pen = -0.3 * sqrt_count(in.overdue) + 0.3;
   const double age_pen = -0.1 * in.oldest_norm;
   double rls = foot + overdue_pen + age_pen;
   rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
