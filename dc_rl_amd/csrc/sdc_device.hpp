@@ -257,6 +257,16 @@ __device__ __forceinline__ double sdc_div_const(double x, double c, double rc) {
   const double r = __builtin_fma(-q, c, x);
   return __builtin_fma(r, rc, q);
 }
+// Quotients that feed only powers, temperatures and the info block (never an observation entry or the battery state,
+// which must round like the reference): x * (1 / C) -- one rounding more than the division, 1 instruction instead of 3
+// -- and a / b by hardware reciprocal + two Newton steps (<= 2 ulp, 6 instructions instead of the IEEE sequence's 11)
+#define SDC_MUL_RCP(x, C) ((x) * (1.0 / (double)(C)))
+__device__ __forceinline__ double sdc_div_fast(const double a, const double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  return a * y;
+}
 // np.round(x, d) == rint(x * 10^d) / 10^d   (P10 a literal power of ten)
 #define np_round(x, P10) SDC_DIV_CONST(rint((x) * (P10)), (P10))
 

@@ -169,11 +169,11 @@ __device__ __forceinline__ double exp_plain(const double t) {
 __device__ __forceinline__ double chiller_power(double max_cooling_cap, double load, double ambient_temp) {
   const double min_plr = 0.05, max_plr = 1.0, design_cond_temp = 35.0, design_evp_out_temp = 6.67;
   // temp_rise_coef = 2.778, rated_cop = 3.0 (divisors below)
-  const double delta_temp = SDC_DIV_CONST(ambient_temp - design_cond_temp, 2.778) - (design_evp_out_temp - design_cond_temp);
+  const double delta_temp = SDC_MUL_RCP(ambient_temp - design_cond_temp, 2.778) - (design_evp_out_temp - design_cond_temp);
   const double cap_rat = 0.94483600 + -0.05700880 * delta_temp + 0.00185486 * (delta_temp * delta_temp);
   const double avail = cap_rat != 0 ? max_cooling_cap * cap_rat : 0.0;
   const double fpr = 2.333 + -1.975 * cap_rat + 0.6121 * (cap_rat * cap_rat);
-  const double ratio = load / avail;       // (one division: the reference evaluates load / avail three times)
+  const double ratio = sdc_div_fast(load, avail);   // (one division: the reference evaluates load / avail three times; only used where avail > 0)
   const double plr = avail > 0 ? fmax(min_plr, fmin(ratio, max_plr)) : 0.0;
   const double fflp = 0.03303 + 0.6852 * plr + 0.2818 * (plr * plr);
   double oper;
@@ -181,8 +181,8 @@ __device__ __forceinline__ double chiller_power(double max_cooling_cap, double l
     oper = (ratio < min_plr) ? ratio : plr;
   else
     oper = 0.0;
-  const double frac = oper < min_plr ? fmin(1.0, SDC_DIV_CONST(oper, 0.05)) : 1.0;   // / min_plr
-  const double power = SDC_DIV_CONST(fflp * fpr * avail, 3.0) * frac;
+  const double frac = oper < min_plr ? fmin(1.0, SDC_MUL_RCP(oper, 0.05)) : 1.0;   // / min_plr
+  const double power = SDC_MUL_RCP(fflp * fpr * avail, 3.0) * frac;
   return oper > 0 ? power : 0.0;
 }
 
@@ -455,7 +455,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       const double ratio = ((m_cpu + 0.05) * inlet + c_cpu) + cpu_shift;
       const double cpu1 = fmax(P.rack_idle[rk], P.rack_full[rk] * ratio);
       const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
-      const double fan1 = pr[P_ITFAN_REF_P] * sdc_div_const(v, pr[P_ITFAN_REF_V_RATIO], pr[P_RC_ITFAN_REF_V_RATIO]);
+      const double fan1 = pr[P_ITFAN_REF_P] * (v * pr[P_RC_ITFAN_REF_V_RATIO]);
       const double vf1 = pr[P_IT_FAN_FULL_LOAD_V] * v;
       const double n = P.rack_n[rk];
       const double pc = n * cpu1, pf = n * fan1;
@@ -485,8 +485,8 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   if (half_ballot(bad_delta, h) != 0u) fault |= SDC_FAULT_OUTLET_DELTA;
   // (ONE reduction for CPU + fan power: only their total is used.  The reference sums the two lists separately and adds
   // the totals; the difference is a rounding of the last place)
-  const double avg_ret = sdc_div_const(half_sum_f64(ret_plus_out), (double)R, pr[P_RC_N_RACKS]);  // datacenter.py:531-541
-  const double mean_outlet = sdc_div_const(half_sum_f64(outlet), (double)R, pr[P_RC_N_RACKS]);
+  const double avg_ret = half_sum_f64(ret_plus_out) * pr[P_RC_N_RACKS];  // datacenter.py:531-541
+  const double mean_outlet = half_sum_f64(outlet) * pr[P_RC_N_RACKS];
   const double p_it = half_sum_f64(pcpu + pfan);
 
   SDC_AT(6, sh, lane0);
@@ -498,9 +498,9 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   double ct;
   {
     const double dlt = fmax(50 - (amb - stpt), 1);
-    const double m_air = q_cool / (c_air * dlt);
-    const double v_air = sdc_div_const(m_air, rho_air, pr[P_RC_RHO_AIR]);
-    const double x = fmin(sdc_div_const(v_air, pr[P_CTAFR], pr[P_RC_CTAFR]), 1);
+    const double m_air = sdc_div_fast(q_cool, c_air * dlt);
+    const double v_air = m_air * pr[P_RC_RHO_AIR];
+    const double x = fmin(v_air * pr[P_RC_CTAFR], 1);
     ct = amb < 5 ? 0.0 : ct_fan_ref_p * (x * x * x);
   }
   double water;
@@ -599,10 +599,10 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   if (l == 0) {
     // ---- info block --------------------------------------------------------------------------------
     float* inf = sh.info[h];
-    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(p_it, 1e3);
-    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(ct, 1e3);
-    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(comp, 1e3);
-    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)SDC_DIV_CONST(ct + comp, 1e3);
+    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)SDC_MUL_RCP(p_it, 1e3);
+    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)SDC_MUL_RCP(ct, 1e3);
+    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)SDC_MUL_RCP(comp, 1e3);
+    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)SDC_MUL_RCP(ct + comp, 1e3);
     inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
     inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
     inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
