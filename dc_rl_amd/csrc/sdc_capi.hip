@@ -410,6 +410,8 @@ int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
   }
   e.k_outlet = 1.918 / (p->c_air * p->rho_air * 0.526);
   e.n_racks_f = (double)p->n_racks;
+  e.ret_sum = 0.0;
+  for (int r = 0; r < p->n_racks; r++) e.ret_sum += p->rack_return[r];
   HIP_TRY(hipMemcpy(const_cast<SdcDcDev*>(h->d.dc) + cfg_id, &e, sizeof(e), hipMemcpyHostToDevice));
   return 0;
 }

@@ -121,6 +121,7 @@ struct SdcDcDev {
   double rc_n_racks, rc_itfan_ref_v_ratio, rc_rho_air, rc_ctafr, rc_bat_capacity;
   double k_outlet;   // 1.918 / (c_air rho_air 0.526): the constant factor of the rack outlet-temperature rise
   double n_racks_f;  // p.n_racks as a double (the step kernel hands the scalars from p.m_cpu to here round as doubles)
+  double ret_sum;    // sum of rack_return over the config's racks (the CRAC return temperature is (this + sum of outlets) / racks)
 };
 
 // DEFERRED WINDOW RE-CENTRING.  A rank window that the next step could exhaust has to be re-centred with one sweep over

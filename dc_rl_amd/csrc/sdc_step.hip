@@ -48,10 +48,11 @@ enum {
 enum {
   P_M_CPU = 0, P_C_CPU, P_RS_CPU, P_M_FAN, P_C_FAN, P_RS_FAN, P_ITFAN_REF_P, P_ITFAN_REF_V_RATIO, P_IT_FAN_FULL_LOAD_V,
   P_C_AIR, P_RHO_AIR, P_CRAC_SUPPLY_PU, P_CT_FAN_REF_P, P_CTAFR, P_MIN_TEMP, P_MAX_TEMP, P_INIT_SETPOINT, P_BAT_CAP,
-  P_RC_N_RACKS, P_RC_ITFAN_REF_V_RATIO, P_RC_RHO_AIR, P_RC_CTAFR, P_RC_BAT_CAP, P_K_OUTLET, P_N_RACKS, P_COUNT
+  P_RC_N_RACKS, P_RC_ITFAN_REF_V_RATIO, P_RC_RHO_AIR, P_RC_CTAFR, P_RC_BAT_CAP, P_K_OUTLET, P_N_RACKS, P_RET_SUM, P_COUNT
 };
 static_assert(offsetof(SdcDcDev, k_outlet) - offsetof(SdcDcDev, p.m_cpu) == P_K_OUTLET * sizeof(double), "config scalars must be contiguous");
 static_assert(offsetof(SdcDcDev, n_racks_f) - offsetof(SdcDcDev, p.m_cpu) == P_N_RACKS * sizeof(double), "config scalars must be contiguous");
+static_assert(offsetof(SdcDcDev, ret_sum) - offsetof(SdcDcDev, p.m_cpu) == P_RET_SUM * sizeof(double), "config scalars must be contiguous");
 static_assert(P_COUNT <= HL, "one config scalar per lane of a half");
 
 // sub-phase timing (tools/phase_scan.sh): a build with -DSDC_STAMP_A=i -DSDC_STAMP_B=j stamps the wall clock at the marks
@@ -442,7 +443,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   const sdc_dc_params& P = S.dc[lrec_i32(rp, R_CFG)].p;
   const int R = (int)pr[P_N_RACKS];
   const double load_pct = util * 100;
-  double pcpu = 0.0, pfan = 0.0, outlet = 0.0, ret_plus_out = 0.0;
+  double pcpu = 0.0, pfan = 0.0, outlet = 0.0;
   bool bad_delta = false;
   {
     const double m_cpu = pr[P_M_CPU], c_cpu = pr[P_C_CPU], rs_cpu = pr[P_RS_CPU];
@@ -475,7 +476,6 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       pcpu += pc;
       pfan += pf;
       outlet += out;
-      ret_plus_out += P.rack_return[rk] + out;
     }
   }
 #if SDC_PRIO_DROP == 1
@@ -485,8 +485,11 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   if (half_ballot(bad_delta, h) != 0u) fault |= SDC_FAULT_OUTLET_DELTA;
   // (ONE reduction for CPU + fan power: only their total is used.  The reference sums the two lists separately and adds
   // the totals; the difference is a rounding of the last place)
-  const double avg_ret = half_sum_f64(ret_plus_out) * pr[P_RC_N_RACKS];  // datacenter.py:531-541
-  const double mean_outlet = half_sum_f64(outlet) * pr[P_RC_N_RACKS];
+  // CRAC return temperature (datacenter.py:531-541: the mean of return approach + outlet over the racks): the approach
+  // temperatures are constants of the config, their sum comes from the host
+  const double sum_outlet = half_sum_f64(outlet);
+  const double avg_ret = (pr[P_RET_SUM] + sum_outlet) * pr[P_RC_N_RACKS];
+  const double mean_outlet = sum_outlet * pr[P_RC_N_RACKS];
   const double p_it = half_sum_f64(pcpu + pfan);
 
   SDC_AT(6, sh, lane0);
