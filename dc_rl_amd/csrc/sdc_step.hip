@@ -146,8 +146,10 @@ __device__ __forceinline__ double log2_pos_normal(const double x) {
 
 // exp(t) for |t| <= 700: 2^(t log2 e) with the fraction's power from a degree-12 Taylor polynomial (<= 2e-16 relative)
 // + the scaling by ldexp; 17 instructions against the library's 45
-__device__ __forceinline__ double exp_plain(const double t) {
-  const double y = t * 1.4426950408889634;
+__device__ __forceinline__ double exp2_plain(const double y);
+__device__ __forceinline__ double exp_plain(const double t) { return exp2_plain(t * 1.4426950408889634); }
+// 2^y for |y| <= 1000, same way
+__device__ __forceinline__ double exp2_plain(const double y) {
   const double n = __builtin_rint(y);
   const double f = (y - n) * 0.6931471805599453;     // |f| <= 0.3466
   double p = 1.0 / 479001600.0;
@@ -468,7 +470,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       const bool plain = pw > 1e-300 && pw < 1e300 && vtot > 1e-300 && vtot < 1e300;    // (always, for a valid config)
       double rise;
       if (__builtin_expect(__ballot(!plain) == 0ull, 1))
-        rise = exp2(1.096 * log2_pos_normal(pw) - 0.824 * log2_pos_normal(vtot));
+        rise = exp2_plain(1.096 * log2_pos_normal(pw) - 0.824 * log2_pos_normal(vtot));
       else
         rise = exp2(1.096 * log2(pw) - 0.824 * log2(vtot));
       const double out = inlet + pr[P_K_OUTLET] * rise + -14.01;   // 1.918 power^1.096 / (c_air rho_air airflow^0.824 0.526) - 14.01
