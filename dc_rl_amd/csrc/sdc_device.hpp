@@ -127,7 +127,7 @@ struct SdcDcDev {
 // DEFERRED WINDOW RE-CENTRING.  A rank window that the next step could exhaust has to be re-centred with one sweep over
 // the env's 40 KB ring (sdc_ringpath.hpp qt_refill, ~5 us) -- done inline that sweep made its wavefront the straggler of
 // nearly every launch.  Instead the step that sees the need (step t) files a REQUEST with a snapshot of the window;
-// spare wavefronts at the front of the NEXT launch (step t + 1) do the sweep against the ring as it was after step t
+// spare wavefronts of the NEXT launch (step t + 1) do the sweep against the ring as it was after step t
 // (the one slot step t + 1 overwrites is patched with its old content, carried in the request) and leave the
 // re-centred window as a RESULT; the env's own wavefront picks it up at step t + 2, replays step t + 1's one
 // insertion / eviction on it (remembered in the header) and carries on.  The old window stays valid through step

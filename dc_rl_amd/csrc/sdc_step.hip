@@ -12,13 +12,16 @@
 // record, the 25 scalars of its data-centre config and its step inputs there with coalesced loads, and every lane reads
 // the field it needs (a broadcast read inside its half).
 //
-// Memory plan per wavefront (two dependent round trips, as before):
-//   level 0  the pair's two records (512 contiguous bytes, one dwordx2 per lane), both headers, the 2 x 3 actions and --
-//            when the host knows the episode step (lock-step batch) -- each env's feature row + queue probes;
-//   level 1  config scalars + per-rack constants, the step inputs that level 0 could not address, the evicted ring key;
-//   (level 2 only on steps that pop tasks: the 32-ary search for the new oldest task in the queue.)
-// The history-normalised rewards keep their per-env, whole-wavefront form (four 64-key rank windows, one key per lane:
-// sdc_trackers.hpp / sdc_ringpath.hpp); the wavefront runs that part for its two envs one after the other.
+// Memory plan per wavefront:
+//   level 0  the 2 x 3 actions (hand-issued first), the pair's two records (512 contiguous bytes, one dwordx2 per lane),
+//            the config scalars of a single-config job and -- when the host knows the episode step (lock-step batch) --
+//            each env's feature row + queue probes: ONE round trip before the dynamics in the usual case;
+//   level 1  what level 0 could not address (several configs; a batch that is not in lock-step);
+//   behind the staging, consumed late: the queue table ahead of the oldest task (actions that can pop), the evicted ring
+//            key, both headers, the rank windows' keys.
+// The history-normalised rewards run for both envs at once on the O(1) path (pair_reward_fast: four 64-key rank windows,
+// two keys per lane of the half, sdc_halfwin.hpp); an env that needs its ring falls back to the whole-wavefront form
+// (env_reward: sdc_trackers.hpp / sdc_ringpath.hpp).
 //
 // Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
 #include "sdc_ringpath.hpp"
@@ -1480,7 +1483,7 @@ __device__ __forceinline__ int first_pair_of_block(const int bi, const int nb) {
   return vb * SDC_STEP_WPB;
 }
 
-// The spare wavefronts at the front of a step launch: wavefront j serves re-centring request j of the previous step (see
+// The spare wavefronts of a step launch (32 workgroups early in the second dispatch round): wavefront j serves re-centring request j of the previous step (see
 // SdcRefillReq): one sweep over that env's ring as the previous step left it, the re-centred window out as a result.
 #define SDC_SWEEP_BLOCKS (SDC_RQ_MAX / SDC_STEP_WPB)
 #define SDC_CUS 256
@@ -1522,8 +1525,7 @@ __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const
   if (j >= cnt) return;
   const SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + j;
   if (rq->step != S.step_no - 1) return;                            // stale (a multi-step launch came in between)
-  // dispatched last and the youngest wavefront of its SIMD: without priority the sweep is served after both env pairs and
-  // ends the launch (constant policies file ~100 requests per step)
+  // (issue priority SDC_SWEEP_PRIO; measured: above the env pairs' it costs the random-action case, below it changes nothing)
   __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
   const int env = rq->env, w = rq->win, n = rq->n;
   QTrack A = {rq->keys[lane], rq->r0, rq->hi};
