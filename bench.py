@@ -26,9 +26,15 @@ in this very run (rank 0, N = 1) by short `rocprofv3 --pmc ... --kernel-trace` p
 if rocprofv3 is not usable the numbers fall back to profiles/pmc_latest.json, which carries the hash of the
 kernel sources it was measured at (`pmc_source`, `pmc_current`).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run, one
-rank per GPU; prints ONE JSON line on rank 0.  SDC_DIST_BACKEND=gloo runs the N > 1 path without RCCL (ranks may
-then share a device: LOCAL_RANK is taken modulo the visible device count) -- used by the 2-ranks-on-1-GPU test.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).  For N > 1 it runs one rank
+per GPU over RCCL: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment), or -- when WORLD_SIZE is not set -- bench.py starts those N ranks
+ITSELF (a `torch.distributed.run` re-exec on 127.0.0.1 with a free port) and relays their output, so that
+`python bench.py --gpus 8` never silently measures one GPU.  It exits non-zero when fewer than N devices are visible
+(RCCL needs a device per rank), when WORLD_SIZE and --gpus disagree, or when the ranks that answered the first
+all-reduce are not N.  SDC_DIST_BACKEND=gloo runs the N > 1 path without RCCL (ranks may then share a device:
+LOCAL_RANK is taken modulo the visible device count) -- used by the 2-ranks-on-1-GPU test; `--launch-check` runs only
+the launch + rendezvous + first all-reduce and prints the skeleton line (no device needed: the CPU test of this path).
 """
 from __future__ import annotations
 
@@ -229,6 +235,29 @@ def pmc_summary(c):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (torch.distributed.run, one node,
+    127.0.0.1, a free port), relay their stdout / stderr and exit status.  Returns the process exit code."""
+    import socket
+    backend = os.environ.get("SDC_DIST_BACKEND", "nccl")
+    if backend == "nccl" and "--launch-check" not in sys.argv:
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < n_ranks:
+            print(f"bench.py: --gpus {n_ranks} needs {n_ranks} visible devices (one rank per GPU over RCCL), "
+                  f"found {ndev}", file=sys.stderr)
+            return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,7 +273,14 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="blocks of --steps in the timed region (0 = until >= 200 ms)")
     ap.add_argument("--profile-every", type=int, default=7, help="stamp the kernels' wall-clock entry / exit every k-th step (0 = off)")
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only launch the ranks, rendezvous, all-reduce once and print the skeleton line (no device needed)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (HARL YAML shape, batch scan, closed loop)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))     # no launcher around us: start the ranks ourselves
 
     import torch
     import torch.distributed as dist
@@ -252,10 +288,37 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("SDC_DIST_BACKEND", "nccl")
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: the job would not be the one asked for",
+                  file=sys.stderr)
+        sys.exit(4)
+    if args.launch_check:
+        # the launch path alone (CPU test): rendezvous, one all-reduce of ones, the skeleton of the JSON line
+        seen = 1
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo" if backend != "nccl" or not torch.cuda.is_available() else "nccl")
+            t1 = torch.ones(1, dtype=torch.float64)
+            if dist.get_backend() == "nccl":
+                t1 = t1.cuda(local_rank)
+            dist.all_reduce(t1)
+            seen = int(t1.item())
+        if rank == 0:
+            print(json.dumps({"metric": "coupled env-steps/s", "value": None, "n_gpus": world, "ranks_seen": seen,
+                              "launch_check": True, "dist_backend": (dist.get_backend() if world > 1 else None)}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(0 if seen == world else 5)
     ndev = torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl" and ndev < world:
+            if rank == 0:
+                print(f"bench.py: {world} ranks over RCCL need {world} visible devices, found {ndev}", file=sys.stderr)
+            sys.exit(3)
         dev = local_rank if backend == "nccl" else local_rank % max(1, ndev)
         torch.cuda.set_device(dev)
         if backend == "nccl":
@@ -265,8 +328,6 @@ def main():
     else:
         dev = 0
         torch.cuda.set_device(dev)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     cdev = torch.device("cuda", dev)
 
     def all_reduce(t, op=None):
@@ -285,6 +346,10 @@ def main():
     ranks_seen = 1
     if world > 1:
         ranks_seen = int(all_reduce(torch.ones(1, dtype=torch.float64, device=cdev)).item())
+        if ranks_seen != world:
+            if rank == 0:
+                print(f"bench.py: {ranks_seen} ranks answered the all-reduce, expected {world}", file=sys.stderr)
+            sys.exit(5)
 
     N = args.envs_per_gpu
     dc_files = ("dc_config.json", "dc_config_r16.json", "dc_config_r25.json") if args.mixed_racks else ("dc_config.json",)

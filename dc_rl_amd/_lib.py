@@ -18,6 +18,7 @@ INFO_DIM = 44
 TABLE_LEN = 35040
 HDR_DWORDS = 64    # csrc/sdc_device.hpp SdcHdr: 256-byte per-env header
 QWIN = 64          # csrc/sdc_device.hpp SDC_WIN: keys per rank window (4 windows per env: Q1, Q3, upper / lower clip bound)
+ABI_VERSION = 300  # include/sustaindc_hip.h SDC_ABI_VERSION: the struct layouts and argument lists this binding was written for
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
@@ -167,6 +168,10 @@ def load():
     L.sdc_profile_read.argtypes = [vp, dp, C.c_int]
     for name in EXPORTS:
         getattr(L, name)
+    built = L.sdc_version()
+    if built != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} was built for ABI version {built}, this binding is written for {ABI_VERSION} "
+                           "(include/sustaindc_hip.h SDC_ABI_VERSION): rebuild it with dc_rl_amd._lib.build(force=True)")
     _lib = L
     return L
 

@@ -199,7 +199,7 @@ void recompute_steps_to_terminal(sdc_handle* h) {
 extern "C" {
 
 const char* sdc_last_error(void) { return g_err.c_str(); }
-int sdc_version(void) { return 100; }
+int sdc_version(void) { return SDC_ABI_VERSION; }
 
 int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   if (!cfg || !out) return fail_msg("sdc_create: null argument");
@@ -223,7 +223,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
 
   sdc_handle* h = new sdc_handle();
   h->cfg = *cfg;
-  if (const char* t = std::getenv("SDC_TEST_STEP_NO")) h->step_no = std::atoi(t) % STEP_WRAP;   // test hook: start near the wrap
+  if (cfg->debug_flags & 64)   // test hook (tests of the launch counter's wrap): start the counter where the environment says
+    if (const char* t = std::getenv("SDC_TEST_STEP_NO")) h->step_no = std::atoi(t) % STEP_WRAP;
   h->device = cfg->device;
   SdcDev& d = h->d;
   std::memset(&d, 0, sizeof(d));
@@ -732,6 +733,13 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
     HIP_TRY(hipMemcpy(*f->ptr, host_buf, need, hipMemcpyHostToDevice));
   }
   if (invalidate_features(h)) return -1;   // whatever was written, the precomputed observation rows may no longer match it
+  // Deferred window re-centrings in flight belong to the state that has just been overwritten: a restored header may
+  // carry request stamps (H_PEND) that the NEXT step would find "two steps old" again and take a swept window over --
+  // one that already contains the restored step's own insertion, which the take-over would then replay a second time.
+  // Moving the launch counter past every stamp (3 steps: requests are served at +1 and taken over at +2) makes all of
+  // them stale, in the headers and in the request / result sets alike; the windows concerned are re-requested.
+  h->step_no = next_step_no(h->step_no, 3);
+  HIP_TRY(hipMemset(h->d.rq_count, 0, sizeof(int) * 4));
   if (std::strcmp(field, "t_rel") == 0 || std::strcmp(field, "record") == 0) {
     std::vector<int> tr(h->cfg.n_envs);
     if (rec_get(h, R_TREL, 1, tr.data())) return -1;

@@ -1250,7 +1250,10 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   const uint2 rr = *recp;
   {
     unsigned r0 = rr.x, r1 = rr.y;
-    asm volatile("" : "+v"(act_v), "+v"(r0), "+v"(r1));     // (the record is here: so are the actions)
+    // (the record is here: so are the actions, requested before it -- memory returns loads in order.  The compiler has
+    // waited for r0 / r1 to pass them in; the explicit wait costs nothing then -- no load has been issued since the
+    // record's -- and keeps the actions' arrival independent of how the compiler counts the loads it knows about)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(act_v), "+v"(r0), "+v"(r1));
   }
   int a_ls = 1, a_dc = 1, a_bat = 2;       // (rule-based slots never read the caller's array, which may be null)
   if (S.policy[0] == SDC_POLICY_EXTERNAL) a_ls = act_v.x;
@@ -1503,6 +1506,9 @@ __device__ __forceinline__ int first_pair_of_block(const int bi, const int nb) {
 // compiler first needs a field -- several dependent batches, each a miss in the scalar cache at the start of a launch.
 // One load per line up front brings them all in with a single round trip; what follows hits.
 struct KernargTouch { unsigned t[8]; };
+// (the last touched dword, 0x1c0, must lie inside the kernel-argument segment: SdcDev by value, rel_hint, eight pointers,
+// then the 256 bytes of implicit arguments of code object v5 -- the grid size the kernel reads is among them)
+static_assert(sizeof(SdcDev) + 8 + 8 * sizeof(void*) + 256 >= 0x1c4, "kernarg_touch reads past the kernel-argument segment");
 __device__ __forceinline__ KernargTouch kernarg_touch() {
   KernargTouch k;
   const auto ka = __builtin_amdgcn_kernarg_segment_ptr();

@@ -114,7 +114,7 @@ class _InfoDict(Mapping):
         if key in o.const[self._e]:
             return o.const[self._e][key]
         if key == "ls_action":
-            return int(o.actions[self._e, 0])
+            return int(o.applied_actions()[self._e, 0])
         if key == "bat_a_t":
             return ("charge", "discharge", "idle")[int(o.rows()[self._e, L.INFO_IDX["bat_action"]])]
         if key == "isterminal":
@@ -159,14 +159,29 @@ class _FinalObs:
 class LazyInfos(Sequence):
     """`infos` of a step: tuple[N] of list[3] of dict in the reference; here views over one [N, K] array."""
 
-    def __init__(self, info_tensor, actions, done, const, extra, owner=None, valid_for=0):
+    def __init__(self, info_tensor, actions, done, const, extra, owner=None, valid_for=0, n_agents=3):
         self._t = info_tensor
         self._rows = None
         self.actions = actions
+        # the [N, 3] action tensor may be the caller's own (a GPU policy's output, taken without a copy): remember its
+        # version so that an in-place overwrite is noticed instead of read as this step's actions
+        self._act_version = getattr(actions, "_version", None)
+        self._act_host = None
         self.done = done
         self.const = const
         self.extra = extra
+        self._n_agents = n_agents
         self._owner, self._gen, self._valid_for = owner, (owner._gen if owner is not None else 0), valid_for
+
+    def applied_actions(self):
+        """[N, 3] host copy of the actions this step applied (read once, on first access)."""
+        if self._act_host is None:
+            a = self.actions
+            if self._act_version is not None and a._version != self._act_version:
+                raise RuntimeError("the action tensor passed to step() has been modified in place since; read "
+                                   "infos[...]['ls_action'] before overwriting it, or pass step() a copy")
+            self._act_host = a.detach().cpu().numpy().copy() if hasattr(a, "detach") else np.array(a)
+        return self._act_host
 
     def rows(self):
         if self._rows is None:
@@ -186,7 +201,9 @@ class LazyInfos(Sequence):
             return [self[j] for j in range(*i.indices(len(self)))]
         if i < 0:
             i += len(self)
-        return [_InfoDict(self, i, a) for a in range(3)]
+        # one dict per TRAINED agent, in the reference's order (harlsustaindc_env.py:118-123); position 0 carries the
+        # `original_*` entries of a finished env
+        return [_InfoDict(self, i, a) for a in range(self._n_agents)]
 
 
 def _merge_args(env_args: Optional[dict]) -> dict:
@@ -336,14 +353,23 @@ class SustainDCVecEnv(ShareVecEnv):
     def step_async(self, actions):
         t = self._torch
         if not isinstance(actions, t.Tensor):
-            # host actions: through a pinned int32 staging buffer, asynchronously (two alternate: the copy of step k may
-            # still be in flight when step k + 1's actions arrive)
+            # host actions: through a pinned int32 staging buffer, asynchronously.  Two buffers alternate, and each carries
+            # an event recorded behind its host->device copy: the buffer is rewritten only once that copy has run (with
+            # device-resident outputs nothing else makes the host wait for the stream, so a caller that does not read
+            # results could otherwise run several steps ahead and overwrite actions that have not been copied yet)
             if self._act_pin is None:
                 self._act_pin = [t.empty((self.num_envs, self.n_agents), dtype=t.int32, pin_memory=True) for _ in range(2)]
+                self._act_evt = [t.cuda.Event(), t.cuda.Event()]
+                self._act_rec = [False, False]
             self._act_flip ^= 1
-            pin = self._act_pin[self._act_flip]
+            k = self._act_flip
+            pin = self._act_pin[k]
+            if self._act_rec[k]:
+                self._act_evt[k].synchronize()
             pin.numpy()[...] = np.asarray(actions).reshape(self.num_envs, self.n_agents)
             actions = pin.to(self.engine.device, non_blocking=True)
+            self._act_evt[k].record(t.cuda.current_stream(self.engine.device))
+            self._act_rec[k] = True
         a = actions.reshape(self.num_envs, self.n_agents)
         if a.dtype != t.int32 or a.device != self.engine.device:
             a = a.to(device=self.engine.device, dtype=t.int32)
@@ -384,9 +410,10 @@ class SustainDCVecEnv(ShareVecEnv):
             # device-resident path: a device clone only when asked for (snapshot_infos) or when an episode ended (the
             # runners read the final step's infos after the auto-reset); else a guarded view of the engine's buffer
             snap = self.snapshot_infos or bool(extra)
-            infos = LazyInfos(info.clone() if snap else info, a, done_h, self._const, extra, None if snap else self, 0)
+            infos = LazyInfos(info.clone() if snap else info, a, done_h, self._const, extra, None if snap else self, 0,
+                              self.n_agents)
         else:
-            infos = LazyInfos(hb["info"], a, done_h, self._const, extra, self, 1)   # pinned double buffer: one more step
+            infos = LazyInfos(hb["info"], a, done_h, self._const, extra, self, 1, self.n_agents)   # pinned double buffer: one more step
             if self.snapshot_infos:
                 infos.rows()
         if self._logger_acc is not None:      # device-side logger sums: one small reduction per step, no read-back

@@ -116,7 +116,9 @@ typedef struct {
                               and a direct fp64 pass over each env's history (slow; a mismatch sets
                               SDC_FAULT_ORDER_STAT).  Bits 1, 3, 4: diagnostics in info[reserved] / info[40..43]
                               (why a rebuild happened; per-wavefront phase durations; absolute wavefront start /
-                              end stamps) -- measurement only, they overwrite the episode-return columns */
+                              end stamps) -- measurement only, they overwrite the episode-return columns.
+                              Bit 6 (64): TEST HOOK -- sdc_create reads the environment variable SDC_TEST_STEP_NO and
+                              starts the launch counter there (tests of the counter's wrap); ignored otherwise */
   int32_t reward_method[3]; /* reward function per agent slot (ls, dc, bat), utils/reward_creator.py:322-334:
                                SDC_REWARD_DEFAULT the slot's own default_*_reward, SDC_REWARD_FOOTPRINT
                                default_dc_reward = default_bat_reward, SDC_REWARD_CUSTOM custom_agent_reward (0),
@@ -195,6 +197,12 @@ typedef struct {
 } sdc_reset_override;
 
 const char* sdc_last_error(void);
+/* ABI version of this header: bumped whenever a struct layout or an entry point's arguments change.  sdc_version()
+ * returns the value the library was BUILT with; a caller compares the two before anything else (dc_rl_amd/_lib.py
+ * does) -- the .so is shipped out of band, so a stale one must fail loudly, not corrupt silently.
+ *   100  round 1        300  sdc_config: env_index_base, policy[3], trim_and_respond_limit; sdc_reset_override: noise,
+ *                            roll_days; sdc_rollout: actions_out; debug_flags bit 6 */
+#define SDC_ABI_VERSION 300
 int sdc_version(void);
 
 int sdc_create(const sdc_config* cfg, sdc_handle** out);

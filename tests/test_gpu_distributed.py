@@ -20,12 +20,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(world, extra_env=None):
+def _bench(world, extra_env=None, self_launch=False):
     common = ["--steps", "40", "--warmup", "8", "--envs-per-gpu", "256", "--episode-steps", "96", "--repeats", "6",
               "--no-cpu-baseline", "--no-pmc", "--no-rollout"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
-    if world == 1:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common
+    common += ["--no-secondary"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if world == 1 or self_launch:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + common    # no wrapper: bench.py starts its ranks
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
@@ -53,6 +56,70 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     # 1-rank job: its share of the mean return is the same, the other rank's differs but is of the same size
     m1, m2 = np.array(one["return_stats"]["mean_return"]), np.array(two["return_stats"]["mean_return"])
     assert np.all(np.abs(m2 - m1) < 0.25 * np.abs(m1) + 1.0)
+
+
+def test_bench_self_launch_equals_the_launcher_form():
+    """`python bench.py --gpus 2` with no wrapper (bench.py re-execs itself under torch.distributed.run) gives the job the
+    driver's `torch.distributed.run ... bench.py --gpus 2` form gives: two ranks, the same envs and actions."""
+    a = _bench(2, {"SDC_DIST_BACKEND": "gloo"}, self_launch=True)
+    b = _bench(2, {"SDC_DIST_BACKEND": "gloo"}, self_launch=False)
+    assert a["n_gpus"] == b["n_gpus"] == 2 and a["ranks_seen"] == b["ranks_seen"] == 2
+    assert a["timed_steps"] == b["timed_steps"] and a["return_stats"] == b["return_stats"]
+    # over RCCL a one-GPU lease cannot hold two ranks: refused, not run on one device
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SDC_DIST_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "5"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"visible devices" in p.stderr
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from dc_rl_amd.distributed import ReturnStats, init_process_group, make_sharded_train_env
+    init_process_group("gloo")          # (both ranks share the lease's one MI355X: LOCAL_RANK 0)
+    env, (lo, hi) = make_sharded_train_env("sustaindc", 9, 24, {"days_per_episode": 1}, return_torch=True)
+    obs, share, avail = env.reset()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    acts = torch.randint(0, 3, (100, 24, 3), dtype=torch.int32, generator=g)
+    st = ReturnStats.zeros()
+    outs = []
+    for t in range(100):                 # crosses one auto-reset (96-step episodes)
+        o, s, r, d, infos, av = env.step(acts[t, lo:hi].cuda())
+        outs.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy()))
+        if bool(d.any()):
+            st.add_episode_returns(env.engine.info[:, 40:43].double())
+    tot = st.all_reduce()
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), lo=lo, hi=hi, obs=np.stack([x[0] for x in outs]),
+             rew=np.stack([x[1] for x in outs]), done=np.stack([x[2] for x in outs]), months=np.array(env.months),
+             episodes=int(tot.sums[6].item()))
+    env.close()
+    dist.destroy_process_group()
+
+
+def test_make_sharded_train_env_two_ranks(tmp_path):
+    """dc_rl_amd.distributed.make_sharded_train_env (the HARL-side entry of the N > 1 path: harl/utils/envs_tools.py:49-75
+    with the env range sharded): two gloo ranks on the one MI355X hold envs [0, 12) and [12, 24) of a 24-env job; together
+    they are the unsharded `make_train_env(..., 24)` batch -- months, observations, rewards, dones over an auto-reset --
+    and the all-reduced episode count is the job's."""
+    import torch
+    import torch.multiprocessing as mp
+    from dc_rl_amd.envs_tools import make_train_env
+    mp.spawn(_sharded_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    rs = [np.load(tmp_path / f"s{r}.npz") for r in range(2)]
+    assert (int(rs[0]["lo"]), int(rs[0]["hi"]), int(rs[1]["lo"]), int(rs[1]["hi"])) == (0, 12, 12, 24)
+    whole = make_train_env("sustaindc", 9, 24, {"days_per_episode": 1}, return_torch=True)
+    np.testing.assert_array_equal(np.concatenate([r["months"] for r in rs]), np.array(whole.months))
+    whole.reset()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    acts = torch.randint(0, 3, (100, 24, 3), dtype=torch.int32, generator=g)
+    for t in range(100):
+        o, s, r, d, infos, av = whole.step(acts[t].cuda())
+        np.testing.assert_array_equal(o.cpu().numpy(), np.concatenate([x["obs"][t] for x in rs]), err_msg=str(t))
+        np.testing.assert_array_equal(r.cpu().numpy(), np.concatenate([x["rew"][t] for x in rs]), err_msg=str(t))
+        np.testing.assert_array_equal(d.cpu().numpy(), np.concatenate([x["done"][t] for x in rs]), err_msg=str(t))
+    assert int(rs[0]["episodes"]) == int(rs[1]["episodes"]) == 24
+    whole.close()
 
 
 def test_shard_is_the_same_environments_as_the_unsharded_job():

@@ -284,3 +284,64 @@ def test_grid_shapes_with_sweep_workgroups_inside_the_grid_vs_oracle():
         w = P.run_engine_vs_oracle(n_envs=n, n_steps=130, episode_steps=96, seed=31 + n, oracle_envs=envs)
         print(n, w)
         assert w["obs"] <= 1e-5 and w["rew"] <= 1e-5 and w["info"] <= 2e-6
+
+
+def test_checkpoint_rollback_on_the_same_engine_4096():
+    """state_dict(), one step, load_state_dict() on the SAME engine, the same step again: bit-identical outputs, verify
+    mode on (debug_flags bit 0), 4096 envs with full rings so that deferred window re-centrings are in flight at every
+    checkpoint (a restored header must not take over a window swept for the state it replaced: sdc_set_state moves the
+    launch counter past every request stamp)."""
+    import torch
+    N, steps, cap = 4096, 672, 10000
+    tb = traces.synthetic_tables("ny", 0)
+    p = dc_config.size_datacenter("dc_config.json", 1, 30.0)
+    eng = SdcEngine(N, episode_steps=steps, auto_reset=True, seed=5, debug_flags=1)
+    eng.set_tables(0, tb["W"], tb["C"], tb["T"], tb["WB"])
+    eng.set_dc_params(0, p)
+    eng.assign(0, 0, 174, 188)
+    rng = np.random.default_rng(5)
+    hist = np.full((N, eng.hist_stride), np.nan, np.float32)
+    hist[:, :cap] = (331 + 70 * rng.standard_normal((N, cap))).clip(150, 650).astype(np.float32)
+    eng.set_state("hist", hist)
+    eng.set_state("hist_len", np.full(N, cap, np.int32))
+    eng.set_state("hist_pos", rng.integers(0, cap, N).astype(np.int32))
+    del hist
+    eng.reset()
+    g = torch.Generator(device="cpu").manual_seed(6)
+    taken = 0
+    for t in range(40):
+        eng.step(torch.randint(0, 3, (N, 3), dtype=torch.int32, generator=g).cuda())
+    for rnd in range(3):
+        sd = eng.state_dict()
+        pend = int((sd["header"][:, _hdr_pend()] != 0).any(axis=1).sum())
+        a1 = torch.randint(0, 3, (N, 3), dtype=torch.int32, generator=g).cuda()
+        a2 = torch.randint(0, 3, (N, 3), dtype=torch.int32, generator=g).cuda()
+        first = [[x.clone() for x in eng.step(a1)], [x.clone() for x in eng.step(a2)]]
+        eng.load_state_dict(sd)
+        again = [[x.clone() for x in eng.step(a1)], [x.clone() for x in eng.step(a2)]]
+        for k in range(2):
+            for u, v, nm in zip(first[k], again[k], ("obs", "share_obs", "rew", "done", "info")):
+                if nm == "info":     # (the diagnostics column says HOW the reward state was served, which a restore may change)
+                    u, v = u.clone(), v.clone()
+                    u[:, L.INFO_IDX["reserved"]] = 0
+                    v[:, L.INFO_IDX["reserved"]] = 0
+                assert torch.equal(u, v), (rnd, k, nm)
+        assert (eng.info[:, L.INFO_IDX["fault"]] == 0).all()
+        taken += pend
+        for t in range(7):
+            eng.step(torch.randint(0, 3, (N, 3), dtype=torch.int32, generator=g).cuda())
+            assert (eng.info[:, L.INFO_IDX["fault"]] == 0).all()
+    assert (eng.get_state("order_stat_sticky") == 0).all()
+    print("envs with a re-centring request in flight at the checkpoints:", taken)
+    assert taken > 0
+    eng.close()
+
+
+def _hdr_pend():
+    """dword indices of the four in-flight re-centring stamps in the 256-byte header (csrc/sdc_device.hpp H_PEND)."""
+    import re, os
+    src = open(os.path.join(os.path.dirname(L.LIB_PATH), "sdc_device.hpp")).read()
+    m = re.search(r"H_PEND\s*=\s*(\d+)", src)
+    assert m, "H_PEND not found in sdc_device.hpp"
+    k = int(m.group(1))
+    return [k, k + 1, k + 2, k + 3]

@@ -107,9 +107,9 @@ def test_deferred_recentring_across_the_step_counter_wrap(monkeypatch):
     """The host's step counter (stamps of the re-centring requests) wraps at 3 * 2^22; start just below it and run across
     the wrap in verify mode: requests keep being served and taken over on both sides, nothing mismatches."""
     import torch
-    monkeypatch.setenv("SDC_TEST_STEP_NO", str((3 << 22) - 150))
+    monkeypatch.setenv("SDC_TEST_STEP_NO", str((3 << 22) - 160))     # (read only with debug_flags bit 6; each set_state below moves the counter on by 3)
     N, ep, cap = 512, 96, 1500
-    rig = P.ParityRig(N, episode_steps=ep, seed=91, hist_cap=cap, with_oracle=False)
+    rig = P.ParityRig(N, episode_steps=ep, seed=91, hist_cap=cap, with_oracle=False, debug_flags=1 | 64)
     eng = rig.eng
     rng = np.random.default_rng(91)
     hist = np.full((N, eng.hist_stride), np.nan, np.float32)
