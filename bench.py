@@ -91,20 +91,54 @@ def csrc_hash():
     return h.hexdigest()[:12]
 
 
-def build_engine(n_envs, episode_steps, device, seed, dc_files=("dc_config.json",), debug_flags=0, env_index_base=0):
+def build_engine(n_envs, episode_steps, device, seed, dc_files=("dc_config.json",), debug_flags=0, env_index_base=0,
+                 location="ny"):
     from dc_rl_amd import dc_config, traces
     from dc_rl_amd.engine import SdcEngine
-    tb = traces.synthetic_tables("ny", seed=0)
+    tb = traces.synthetic_tables(location, seed=0)
     eng = SdcEngine(n_envs, episode_steps=episode_steps, device=device, auto_reset=True, seed=seed,
                     n_dc_configs=len(dc_files), debug_flags=debug_flags, env_index_base=env_index_base)
     eng.set_tables(0, tb["W"], tb["C"], tb["T"], tb["WB"])
-    params = [dc_config.size_datacenter(f, 1, traces.max_ambient_for_sizing("NY")) for f in dc_files]
+    params = [dc_config.size_datacenter(f, 1, traces.max_ambient_for_sizing(location.upper())) for f in dc_files]
     for i, p in enumerate(params):
         eng.set_dc_params(i, p)
     e = env_index_base + np.arange(n_envs)                               # GLOBAL env index (sharded jobs)
     init_day = np.array([traces.get_init_day(int(m)) for m in e % 12])   # harl/utils/envs_tools.py:58-59
     eng.assign(0, e % len(dc_files), np.maximum(0, init_day - 7), np.minimum(364, init_day + 7))
     return eng, tb, params
+
+
+def secondary_rate(n_envs, episode_steps, location, device, timed_steps, month=None):
+    """One secondary line: the step's rate at another batch size / episode length, measured like the headline (all
+    rings filled to 10 000 by real steps, i.i.d. device-resident actions, auto-resets inside the timed region)."""
+    import torch
+    eng, _, _ = build_engine(n_envs, episode_steps, device, seed=4321, location=location)
+    if month is not None:
+        from dc_rl_amd import traces
+        d0 = traces.get_init_day(int(month))
+        eng.assign(0, 0, max(0, d0 - 7), min(364, d0 + 7))
+    cdev = torch.device("cuda", device)
+    POOL = 512
+    g = torch.Generator(device=cdev).manual_seed(99)
+    pool = torch.randint(0, 3, (POOL, n_envs, 3), dtype=torch.int32, device=cdev, generator=g)
+    eng.reset()
+    k = 0
+    for _ in range(HIST_CAP + 64):
+        eng.step(pool[k % POOL]); k += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(timed_steps):
+        eng.step(pool[k % POOL]); k += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    faults = int((eng.info[:, 37] != 0).sum().item())
+    hl = int(eng.get_state("hist_len").min())
+    eng.close()
+    del pool
+    torch.cuda.empty_cache()
+    return {"envs": n_envs, "episode_steps": episode_steps, "location": location, "timed_steps": timed_steps,
+            "us_per_step": round(dt / timed_steps * 1e6, 2), "value": round(n_envs * timed_steps / dt, 1),
+            "unit": "env-steps/s", "history_len": hl, "faults": faults}
 
 
 def cpu_baseline(tb, params, episode_steps, budget_s=12.0):
@@ -570,6 +604,27 @@ def main():
                                   "ms_per_step": round(tr / done_steps * 1e3, 5)}
             except Exception as e:
                 out["rollout"] = {"error": repr(e)}
+        if world == 1 and not args.no_secondary:
+            # secondary lines (not `value`): the shape the reference's shipped HARL YAML trains on, and how the rate moves
+            # with the number of envs per GPU -- so that the driver's record, not only profiles/, shows both
+            sec = {}
+            try:
+                # harl/configs/envs_cfgs/sustaindc.yaml: location ca, month 6, days_per_episode 30 (2880 steps; 1.5 GB of
+                # per-episode observation rows at 4096 envs); two full episodes, so two resets, in the timed region
+                sec["harl_yaml_shape"] = secondary_rate(N, 30 * 96, "ca", dev, 2 * 30 * 96, month=6)
+                sec["harl_yaml_shape"]["vs_headline"] = round(sec["harl_yaml_shape"]["value"] / value, 4)
+            except Exception as e:
+                sec["harl_yaml_shape"] = {"error": repr(e)}
+            scan = []
+            for n in (2048, 8192, 16384):
+                try:
+                    r = secondary_rate(n, args.episode_steps, "ny", dev, 2016)
+                    r["rate_vs_4096_envs"] = round(r["value"] / value, 4)
+                    scan.append(r)
+                except Exception as e:
+                    scan.append({"envs": n, "error": repr(e)})
+            sec["batch_scan"] = scan
+            out["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(tb, params, args.episode_steps)

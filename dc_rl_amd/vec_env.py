@@ -137,8 +137,8 @@ class _FinalObs:
     (env_wrappers.py:176-190 puts them into agent 0's info), built per env on first access from one host copy of the
     step's pre-reset observations."""
 
-    def __init__(self, final_obs: np.ndarray, done: np.ndarray, agent_idx, n_agents: int):
-        self._fo, self._done, self._idx, self._k = final_obs, done, agent_idx, n_agents
+    def __init__(self, final_obs: np.ndarray, done: np.ndarray, agent_idx, n_agents: int, concat: bool = False):
+        self._fo, self._done, self._idx, self._k, self._concat = final_obs, done, agent_idx, n_agents, concat
         self._made = {}
 
     def get(self, key, default=None):
@@ -149,7 +149,10 @@ class _FinalObs:
         if d is None:
             fo = self._fo[e]
             # states[2][-1] of the PADDED obs: agent_bat's zero padding (harlsustaindc_env.py:25-26, :80)
-            raw = np.concatenate([fo[0, :26], fo[1, 11:12], fo[1, 13:14], fo[2, 25:26]])
+            if self._concat:    # harlsustaindc_env.py:83-85: the trained agents' padded observations, concatenated
+                raw = fo[self._idx].reshape(-1)
+            else:
+                raw = np.concatenate([fo[0, :26], fo[1, 11:12], fo[1, 13:14], fo[2, 25:26]])
             d = self._made[e] = {"original_obs": fo[self._idx].copy(),
                                  "original_state": np.repeat(raw[None, :], self._k, axis=0),
                                  "original_avail_actions": np.ones((self._k, 3), dtype=np.float32)}
@@ -211,10 +214,12 @@ def _merge_args(env_args: Optional[dict]) -> dict:
     if env_args:
         a.update(env_args)
     L.reward_codes(a)   # NotImplementedError for a reward method the device does not run
-    # options of the reference's HARL layer that change what the runner receives: never silently ignored
-    if not a.get("nonoverlapping_shared_obs_space", True):
-        raise NotImplementedError("nonoverlapping_shared_obs_space=False (the 3 x 26 concatenated shared observation of "
-                                  "harlsustaindc_env.py:83-85) is not produced by the device; the 29-float layout is")
+    # options of the reference's HARL layer that change what the runner receives: never silently ignored.
+    # nonoverlapping_shared_obs_space: harlsustaindc_env.py:53 reads it with .get(..., False) -- an absent key means the
+    # CONCATENATED shared observation (3 x 26 floats, :83-85), True (the shipped YAML) the 29-float layout (:78-80).
+    # (sustaindc_ptzoo.py:29 subscripts the key, so the reference itself raises KeyError when it is absent; the HARL
+    # layer's default is the one taken here.)
+    a["nonoverlapping_shared_obs_space"] = bool(a.get("nonoverlapping_shared_obs_space", False))
     if not a.get("partial_obs", True):
         raise NotImplementedError("Fully observable states are no longer supported. Please set 'partial_obs' to True.")
     if a.get("actions_are_logits", False):
@@ -250,6 +255,10 @@ class SustainDCVecEnv(ShareVecEnv):
         if len(subsets) != 1:
             raise ValueError("all envs of one batch must train the same agents")
         full = bool(per_env[0].get("_allow_agent_subset"))
+        share_modes = {a["nonoverlapping_shared_obs_space"] for a in per_env}
+        if len(share_modes) != 1:
+            raise ValueError("all envs of one batch must share nonoverlapping_shared_obs_space")
+        self.share_concat = not share_modes.pop()
         self.agents = list(AGENTS) if full else list(subsets.pop())
         self._agent_idx = [AGENTS.index(x) for x in self.agents]
         self.n_agents = len(self.agents)
@@ -309,7 +318,13 @@ class SustainDCVecEnv(ShareVecEnv):
             })
         # HARL pads every agent to the widest space (harlsustaindc_env.py:25-26, :30-33)
         obs_space = [Box(low=-2.0, high=2.0, shape=(L.OBS_PAD,), dtype=np.float32) for _ in self.agents]
-        share_space = [Box(low=-2.0, high=2.0, shape=(L.SHARE_OBS_DIM,), dtype=np.float32) for _ in self.agents]
+        if self.share_concat:
+            # sustaindc_ptzoo.py:32-44: max observation width x number of agents, Box(0, 1)
+            self.share_dim = L.OBS_PAD * len(self.agents)
+            share_space = [Box(low=np.float32(0), high=np.float32(1), shape=(self.share_dim,), dtype=np.float32) for _ in self.agents]
+        else:
+            self.share_dim = L.SHARE_OBS_DIM
+            share_space = [Box(low=-2.0, high=2.0, shape=(L.SHARE_OBS_DIM,), dtype=np.float32) for _ in self.agents]
         act_space = [Discrete(3) for _ in self.agents]
         ShareVecEnv.__init__(self, n_envs, obs_space, share_space, act_space)
         import torch
@@ -333,8 +348,13 @@ class SustainDCVecEnv(ShareVecEnv):
     def _out(self, t):
         return t if self.return_torch else t.cpu().numpy()
 
-    def _share3(self, share):
-        # the same 29-vector for every trained agent (harlsustaindc_env.py:85 `repeat`)
+    def _share3(self, share, obs=None):
+        # the same shared vector for every trained agent (harlsustaindc_env.py:87 `repeat`): the 29-float layout the
+        # kernel writes, or -- nonoverlapping_shared_obs_space False -- the concatenation of the trained agents' padded
+        # observations (:83-85), which is a VIEW of the step's obs block (contiguous [N, 3, 26] -> [N, 78])
+        if self.share_concat:
+            o = self._sel(obs)
+            share = o.reshape(o.shape[0], self.share_dim)
         return share.unsqueeze(1).expand(-1, self.n_agents, -1)
 
     def _sel(self, x):
@@ -348,7 +368,7 @@ class SustainDCVecEnv(ShareVecEnv):
     def reset(self):
         obs, share = self.engine.reset()
         self._need_reset = False
-        return self._out(self._sel(obs)), self._out(self._share3(share)), (self._avail if self.return_torch else self._avail_np)
+        return self._out(self._sel(obs)), self._out(self._share3(share, obs)), (self._avail if self.return_torch else self._avail_np)
 
     def step_async(self, actions):
         t = self._torch
@@ -400,7 +420,7 @@ class SustainDCVecEnv(ShareVecEnv):
             done_h = hb["done"].numpy().astype(bool)
         extra = {}
         if done_h.any():    # ONE host copy of the pre-reset observations; the per-env entries are built when read
-            extra = _FinalObs(self.engine.final_obs.cpu().numpy(), done_h, self._agent_idx, self.n_agents)
+            extra = _FinalObs(self.engine.final_obs.cpu().numpy(), done_h, self._agent_idx, self.n_agents, self.share_concat)
         # `infos` (lazy): reads the step's [N, 44] info block on first access -- from the pinned host copy made with the
         # other outputs (NumPy mode: valid for one more step), from the device otherwise.  An access after the block has
         # been overwritten RAISES instead of returning a later step's values; `snapshot_infos=True` makes every infos
@@ -424,12 +444,16 @@ class SustainDCVecEnv(ShareVecEnv):
             # the engine's output tensors are persistent, so the shaped views are too (uint8 0/1 -> bool is a reinterpret)
             v = self._torch_views
             if v is None:
-                v = (self._share3(share), done.view(t.bool).unsqueeze(1).expand(-1, k),
+                v = (self._share3(share, obs), done.view(t.bool).unsqueeze(1).expand(-1, k),
                      (obs, rew.unsqueeze(-1)) if k == 3 else None)
                 self._torch_views = v
             o, r = v[2] if v[2] is not None else (self._sel(obs), self._sel(rew).unsqueeze(-1))
             return o, v[0], r, v[1], infos, self._avail
-        share3 = np.broadcast_to(hb["share"].numpy()[:, None, :], (self.num_envs, k, hb["share"].shape[1]))
+        if self.share_concat:
+            sh = self._sel(hb["obs"].numpy()).reshape(self.num_envs, self.share_dim)
+        else:
+            sh = hb["share"].numpy()
+        share3 = np.broadcast_to(sh[:, None, :], (self.num_envs, k, sh.shape[1]))
         return (self._sel(hb["obs"].numpy()), share3, self._sel(hb["rew"].numpy())[..., None],
                 np.repeat(done_h[:, None], k, axis=1), infos, self._avail_np)
 

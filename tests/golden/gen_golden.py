@@ -287,6 +287,10 @@ SPECS = {
 # ---------------------------------------------------------------------------------------------------------------------
 # weather fixture: pre-noise tables + reference resets
 
+WB_NOTE = ("*_WB / WB_win arrays came through the generator's psychrolib shim (tests/golden/_shims/psychrolib.py), i.e. "
+           "through dc_rl_amd/psychro.py: they pin the interpolation / roll / noise plumbing, NOT PsychroLib's wet-bulb routine")
+
+
 def gen_weather_resets():
     """`Weather_Manager` (utils/managers.py:488-628) for three locations: the pre-noise 15-minute tables it keeps
     (`original_temp_data` / `original_wb_data`, :560-561) and, for a few seeded resets, the coherent noise, the roll and
@@ -338,6 +342,7 @@ def gen_weather_resets():
             out[pre + "T_orig_sub16"] = np.asarray(wm.original_temp_data[::16], dtype=np.float64)
     out["meta_cases"] = np.array(len(cases))
     out["meta_window"] = np.array(W)
+    out["meta_wb_source"] = np.array(WB_NOTE)
     return out
 
 
@@ -353,7 +358,7 @@ def _load_by_path(name, relpath):
     return m
 
 
-def gen_harl_layer(n_envs=4, days=1, n_steps=200, seed=21):
+def gen_harl_layer(n_envs=4, days=1, n_steps=200, seed=21, nonoverlapping=True):
     """N reference environments behind the reference's HARL adaptation layer (harlsustaindc_env.py:10-131 over
     sustaindc_ptzoo.py, with pad_observations_v0) and its in-process vector wrapper (env_wrappers.py:301-350,
     auto-reset at :321-343), built by the rule of harl/utils/envs_tools.py:49-71 (month = rank, seed + rank * 1000).
@@ -361,7 +366,10 @@ def gen_harl_layer(n_envs=4, days=1, n_steps=200, seed=21):
     `original_obs` / `original_state` on the done step -- plus every episode's inputs for injection.
 
     The reference runs one OS process per env, so `reward_creator.energy_history` (a module global) is per env; with
-    ShareDummyVecEnv the envs share one process, so each env gets its own deque here (swapped in around its calls)."""
+    ShareDummyVecEnv the envs share one process, so each env gets its own deque here (swapped in around its calls).
+
+    nonoverlapping=False records the layer's OTHER shared-observation option (harlsustaindc_env.py:53, :83-85: the
+    concatenation of the three padded observations, 78 floats; share space Box(0, 1, (78,)) of sustaindc_ptzoo.py:32-44)."""
     import collections
     from utils import reward_creator
     _load_by_path("harl.envs.sustaindc.sustaindc_ptzoo", "harl/envs/sustaindc/sustaindc_ptzoo.py")
@@ -370,7 +378,7 @@ def gen_harl_layer(n_envs=4, days=1, n_steps=200, seed=21):
     steps = days * 96
     base_args = {"location": "ny", "days_per_episode": days, "datacenter_capacity_mw": 1, "dc_config_file": "dc_config.json",
                  "agents": ["agent_ls", "agent_dc", "agent_bat"], "partial_obs": True,
-                 "nonoverlapping_shared_obs_space": True}
+                 "nonoverlapping_shared_obs_space": bool(nonoverlapping)}
 
     class OwnHistory:
         """One env with its own energy history (= its own process in the reference's ShareSubprocVecEnv)."""
@@ -426,12 +434,13 @@ def gen_harl_layer(n_envs=4, days=1, n_steps=200, seed=21):
         record_inputs(i)
     acts = rng.integers(0, 3, size=(n_steps, n_envs, 3, 1))
     O = np.zeros((n_steps, n_envs, 3, 26), np.float32)
-    S = np.zeros((n_steps, n_envs, 3, 29), np.float32)
+    sdim = int(venv.share_observation_space[0].shape[0])
+    S = np.zeros((n_steps, n_envs, 3, sdim), np.float32)
     R = np.zeros((n_steps, n_envs, 3, 1), np.float64)
     D = np.zeros((n_steps, n_envs, 3), np.uint8)
     A = np.zeros((n_steps, n_envs, 3, 3), np.float32)
     OO = np.zeros((n_steps, n_envs, 3, 26), np.float32)
-    OS = np.zeros((n_steps, n_envs, 3, 29), np.float32)
+    OS = np.zeros((n_steps, n_envs, 3, sdim), np.float32)
     for t in range(n_steps):
         obs, share, rews, dones, infos, avail = venv.step(acts[t])
         O[t], S[t], R[t], D[t], A[t] = obs, share, rews, dones, avail
@@ -444,6 +453,8 @@ def gen_harl_layer(n_envs=4, days=1, n_steps=200, seed=21):
     out.update(actions=acts.astype(np.int32), obs=O, share_obs=S, rews=R, dones=D, avail=A, original_obs=OO, original_state=OS)
     out["meta_episodes"] = n_ep
     out["share_space_shape"] = np.array(venv.share_observation_space[0].shape)
+    out["share_space_low_high"] = np.array([venv.share_observation_space[0].low.min(), venv.share_observation_space[0].high.max()])
+    out["meta_nonoverlapping"] = np.array(bool(nonoverlapping))
     out["obs_space_shape"] = np.array(venv.observation_space[0].shape)
     return out
 
@@ -542,7 +553,8 @@ def main():
     ap.add_argument("--extras", action="store_true", help="with no --only: also regenerate weather_resets / harl_ny_n4")
     args = ap.parse_args()
     _install_shims()
-    extra = {"weather_resets": gen_weather_resets, "harl_ny_n4": gen_harl_layer, "rbc_ny_m7": gen_rbc_episode}
+    extra = {"weather_resets": gen_weather_resets, "harl_ny_n4": gen_harl_layer, "rbc_ny_m7": gen_rbc_episode,
+             "harl_ny_n2_concat": lambda: gen_harl_layer(n_envs=2, n_steps=120, seed=23, nonoverlapping=False)}
     for name, fn in extra.items():
         if args.only == name or (args.only is None and args.extras):
             out = fn()

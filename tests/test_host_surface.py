@@ -51,7 +51,11 @@ def test_env_config_defaults_match_reference_keys():
         _merge_args({"ls_reward": "renewable_energy_reward"})
     with pytest.raises(NotImplementedError):      # every default_ls_reward call appends to the shared history
         _merge_args({"dc_reward": "default_ls_reward"})
-    for bad in ({"nonoverlapping_shared_obs_space": False}, {"partial_obs": False}, {"actions_are_logits": True}):
+    # the shared-observation option defaults like the reference's HARL layer (harlsustaindc_env.py:53: absent -> False,
+    # the 3 x 26 concatenation); the shipped YAML sets True (the 29-float layout)
+    assert _merge_args({})["nonoverlapping_shared_obs_space"] is False
+    assert _merge_args({"nonoverlapping_shared_obs_space": True})["nonoverlapping_shared_obs_space"] is True
+    for bad in ({"partial_obs": False}, {"actions_are_logits": True}):
         with pytest.raises(NotImplementedError):  # options that change what a runner receives are never silently ignored
             _merge_args(bad)
     # a subset of agents is accepted (the other slots are played by the base agents on the device); none is not

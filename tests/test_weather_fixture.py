@@ -69,9 +69,48 @@ def test_epw_loader_matches_reference_tables():
 
 
 def test_wet_bulb_known_answers():
-    """PsychroLib 2.5.0's own SI test suite pins GetTWetBulbFromRelHum(7 C, 0.61, 100 kPa) = 3.92667 C (abs 1e-3)."""
-    assert psychro.t_wet_bulb_from_rel_hum(7.0, 0.61, 100000.0) == pytest.approx(3.92667, abs=1e-3)
+    """The wet-bulb routine (dc_rl_amd/psychro.py, the restatement of PsychroLib==2.5.0's published algorithm;
+    reference call site utils/managers.py:530) against every public known answer there is for it: the values PsychroLib's
+    own SI test suite asserts (tests/test_psychrolib_si.py of the 2.5.0 release, tolerances as stated THERE), and the
+    ASHRAE Handbook - Fundamentals 2017 ch. 1 tables and worked example those tests quote.  PsychroLib itself cannot be
+    run here (not installed, no network), so these are its published numbers, not outputs captured in this container --
+    and the fixtures' own wet bulb came through psychro.py (weather_resets.npz `meta_wb_source`)."""
+    P = psychro
+    # -- PsychroLib: GetTWetBulbFromRelHum (the call the reference makes), rel 1e-3
+    assert P.t_wet_bulb_from_rel_hum(7.0, 0.61, 100000.0) == pytest.approx(3.92667433781955, rel=1e-3)
+    # -- PsychroLib: humidity ratio <-> wet bulb, above freezing (rel 3e-4, then abs 1e-3 on the way back) ...
+    w = P.hum_ratio_from_t_wet_bulb(30.0, 25.0, 95461.0)
+    assert w == pytest.approx(0.0192281274241096, rel=3e-4)
+    assert P.t_wet_bulb_from_hum_ratio(30.0, w, 95461.0) == pytest.approx(25.0, abs=1e-3)
+    # ... and BELOW freezing (the ice branch of the psychrometer equation and of the saturation pressure)
+    w = P.hum_ratio_from_t_wet_bulb(-1.0, -5.0, 95461.0)
+    assert w == pytest.approx(0.00120399819933844, rel=3e-4)
+    assert P.t_wet_bulb_from_hum_ratio(-1.0, w, 95461.0) == pytest.approx(-5.0, abs=1e-3)
+    # humidity ratios below 1e-7 are clamped there
+    assert P.t_wet_bulb_from_hum_ratio(-5.0, 1e-9, 95461.0) == P.t_wet_bulb_from_hum_ratio(-5.0, 1e-7, 95461.0)
+    # -- ASHRAE Table 3 (saturation vapour pressure, Pa), rel 3e-4 (abs 0.01 Pa at -60 C), both branches
+    for t, pws in ((-20, 103.24), (-5, 401.74), (5, 872.6), (25, 3169.7), (50, 12351.3), (100, 101418.0), (150, 476101.4)):
+        assert P.sat_vap_pres(t) == pytest.approx(pws, rel=3e-4), t
+    assert P.sat_vap_pres(-60) == pytest.approx(1.08, abs=0.01)
+    # -- ASHRAE Table 2 (saturation humidity ratio at 101 325 Pa): the table includes the enhancement factor the
+    #    ideal-gas relation leaves out -- "agreement is not terrific, up to 2 %" in PsychroLib's own words
+    for t, ws in ((-50, 0.0000243), (-20, 0.0006373), (-5, 0.0024863), (5, 0.005425), (25, 0.020173), (50, 0.087516),
+                  (85, 0.838105)):
+        assert P.sat_hum_ratio(t, 101325.0) == pytest.approx(ws, rel=0.02), t
+    # -- dew point <-> vapour pressure round trips (PsychroLib: abs 1e-3), ice and liquid
+    assert P.t_dew_point_from_vap_pres(15.0, P.sat_vap_pres(-20.0)) == pytest.approx(-20.0, abs=1e-3)
+    assert P.t_dew_point_from_vap_pres(60.0, P.sat_vap_pres(50.0)) == pytest.approx(50.0, abs=1e-3)
+    # -- ASHRAE worked example 1 (40 C dry bulb, 20 C wet bulb, sea level): W = 0.0065, dew point 7 C, RH 14 %; and
+    #    back from the relative humidity to the wet bulb (abs 0.1, PsychroLib's tolerance)
+    w = P.hum_ratio_from_t_wet_bulb(40.0, 20.0, 101325.0)
+    assert w == pytest.approx(0.0065, abs=1e-4)
+    vap = 101325.0 * w / (0.621945 + w)
+    assert P.t_dew_point_from_vap_pres(40.0, vap) == pytest.approx(7.0, abs=0.5)
+    rh = vap / P.sat_vap_pres(40.0)
+    assert rh == pytest.approx(0.14, abs=0.01)
+    assert P.t_wet_bulb_from_rel_hum(40.0, rh, 101325.0) == pytest.approx(20.0, abs=0.1)
     # saturation: wet bulb == dry bulb; dry air: far below
     for t in (-5.0, 10.0, 30.0):
-        assert psychro.t_wet_bulb_from_rel_hum(t, 1.0, 101325.0) == pytest.approx(t, abs=2e-3)
-        assert psychro.t_wet_bulb_from_rel_hum(t, 0.2, 101325.0) < t - 2.0
+        assert P.t_wet_bulb_from_rel_hum(t, 1.0, 101325.0) == pytest.approx(t, abs=2e-3)
+        assert P.t_wet_bulb_from_rel_hum(t, 0.2, 101325.0) < t - 2.0
+    assert "psychro.py" in str(_fx()["meta_wb_source"])
