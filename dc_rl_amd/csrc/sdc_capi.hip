@@ -18,6 +18,10 @@
 
 extern "C" __global__ void sdc_dynamics_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                                unsigned char* done, float* info, float* final_obs, float* rew);
+extern "C" __global__ void sdc_dynamics_fast_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
+                                                    unsigned char* done, float* info, float* final_obs, float* rew);
+extern "C" __global__ void sdc_rollout_fast_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs,
+                                                   float* share_obs, unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
 extern "C" __global__ void sdc_features_kernel(SdcDev S);
 extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
@@ -77,6 +81,8 @@ struct sdc_handle {
   std::vector<int> host_t_rel;  // exact at the last sync point
   int pending = 0;              // steps launched since then (every env advances by one per step)
   int steps_to_terminal = 0;
+  std::vector<unsigned char> feat_host;   // host mirror of R_FEAT_OK: the env's episode has valid observation feature rows
+  int n_feat_host = 0;                    // how many envs have
   std::vector<unsigned char> last_done;   // which envs finished in the last sdc_step / sdc_rollout call (host mirror)
   int n_last_done = 0;
   bool tables_set = false, assigned = false, started = false;
@@ -158,7 +164,29 @@ int rec_get(sdc_handle* h, int idx, int dwords, void* host, int in_hdr = 0) {
 // the episode's precomputed observation rows follow the traces, the env's location and its weather windows
 int invalidate_features(sdc_handle* h) {
   std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
+  h->feat_host.assign((size_t)h->cfg.n_envs, 0);
+  h->n_feat_host = 0;
   return rec_put(h, R_FEAT_OK, 1, z.data());
+}
+// the envs a reset has just given fresh feature rows (launch_features: every env the reset kernel has reset)
+void note_features(sdc_handle* h, int e) {
+  if (h->d.feat && !h->feat_host[e]) {
+    h->feat_host[e] = 1;
+    h->n_feat_host += 1;
+  }
+}
+// THE COMMON CASE, for which the step / rollout kernels exist in a specialised form (sdc_step.hip, template FAST):
+// every env in lock-step with valid feature rows, one data-centre config, the caller's actions on all three slots, the
+// default reward functions, no diagnostics or profiling, an even number of envs, every output array present.
+// debug_flags bit 0 (the verify kernel, a separate launch) and bit 6 (test hook of sdc_create) do not touch the step;
+// bit 7 forces the general kernel (tests compare the two bit for bit).
+bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_obs, const float* info, bool timed) {
+  const SdcDev& d = h->d;
+  return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs && d.n_cfg == 1 && actions && share_obs &&
+         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64)) == 0 &&
+         d.policy[0] == SDC_POLICY_EXTERNAL && d.policy[1] == SDC_POLICY_EXTERNAL && d.policy[2] == SDC_POLICY_EXTERNAL &&
+         d.reward_method[0] == SDC_REWARD_DEFAULT && d.reward_method[1] == SDC_REWARD_DEFAULT &&
+         d.reward_method[2] == SDC_REWARD_DEFAULT;
 }
 
 // the reward state (rank windows, running sums) describes the ring contents: drop it when the ring is injected
@@ -322,6 +350,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
     }
   }
   h->host_t_rel.assign(N, cfg->episode_steps);  // "finished": a reset is required before stepping
+  h->feat_host.assign(N, 0);
   h->fields = {
       {"cursor", nullptr, 4, R_CURSOR, 1}, {"t_rel", nullptr, 4, R_TREL, 1}, {"day", nullptr, 4, R_DAY, 1},
       {"hourq", nullptr, 4, R_HOURQ, 1}, {"q_popped", nullptr, 4, R_QPOPPED, 1}, {"q_cum", nullptr, 4, R_QCUM, 1},
@@ -525,7 +554,10 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
   if (mask_host) HIP_TRY(hipStreamSynchronize(st));  // mask staging buffer is reused by the next call
   sync_mirror(h);
   for (int e = 0; e < N; e++)
-    if (!mask_host || mask_host[e]) h->host_t_rel[e] = 0;
+    if (!mask_host || mask_host[e]) {
+      h->host_t_rel[e] = 0;
+      note_features(h, e);
+    }
   recompute_steps_to_terminal(h);
   h->started = true;
   return 0;
@@ -549,8 +581,12 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   }
   d.step_no = h->step_no;
   h->step_no = next_step_no(h->step_no, 1);
-  hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, h->rel_hint,
-                     actions, obs, share_obs, done, info, final_obs, rew);
+  if (fast_case(h, actions, share_obs, info, timed))
+    hipLaunchKernelGGL(sdc_dynamics_fast_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
+                       h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+  else
+    hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, h->rel_hint,
+                       actions, obs, share_obs, done, info, final_obs, rew);
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
   HIP_TRY(hipGetLastError());
   h->n_last_done = 0;
@@ -571,7 +607,10 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
       launch_features(h, d, st);
       HIP_TRY(hipGetLastError());
       for (int e = 0; e < N; e++)
-        if (h->host_t_rel[e] >= h->cfg.episode_steps) h->host_t_rel[e] = 0;
+        if (h->host_t_rel[e] >= h->cfg.episode_steps) {
+          h->host_t_rel[e] = 0;
+          note_features(h, e);
+        }
       recompute_steps_to_terminal(h);
     }
   }
@@ -601,8 +640,12 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
     d.step_no = h->step_no;
     h->step_no = next_step_no(h->step_no, n_steps + 3);
     HIP_TRY(hipMemsetAsync(d.rq_count, 0, sizeof(int) * 4, st));
-    hipLaunchKernelGGL(sdc_rollout_kernel, dim3(step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, n_steps, h->rel_hint, actions,
-                       obs, share_obs, done, info, final_obs, rew);
+    if (fast_case(h, actions, share_obs, info, false) && !actions_out)
+      hipLaunchKernelGGL(sdc_rollout_fast_kernel, dim3(step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, n_steps, h->rel_hint,
+                         actions, obs, share_obs, done, info, final_obs, rew);
+    else
+      hipLaunchKernelGGL(sdc_rollout_kernel, dim3(step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, n_steps, h->rel_hint, actions,
+                         obs, share_obs, done, info, final_obs, rew);
   }
   HIP_TRY(hipGetLastError());
   h->n_last_done = 0;
@@ -623,7 +666,10 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
       launch_features(h, d, st);
       HIP_TRY(hipGetLastError());
       for (int e = 0; e < N; e++)
-        if (h->host_t_rel[e] >= h->cfg.episode_steps) h->host_t_rel[e] = 0;
+        if (h->host_t_rel[e] >= h->cfg.episode_steps) {
+          h->host_t_rel[e] = 0;
+          note_features(h, e);
+        }
       recompute_steps_to_terminal(h);
     }
   }

@@ -224,10 +224,20 @@ __device__ __forceinline__ double lrec_f64(const unsigned* rp, int idx) { return
 
 // ------------------------------------------------------------------------------------------------
 // the coupled dynamics at cursor i and the observation at i' = i + 1 of BOTH envs of the wavefront: lane = (half h, l)
+//
+// FAST (here and in pair_reward_fast / pair_step): the launch is the COMMON CASE, which the host checks before it picks
+// the kernel (sdc_capi.hip fast_case) -- every env in lock-step with valid feature rows, one data-centre config, the
+// caller's actions on all three slots, the default reward functions, no diagnostics, an even number of envs, all output
+// arrays present.  What the general code decides at run time is then a compile-time constant: the same source, the
+// same arithmetic in the same order (so both kernels give the same bits), minus the tests, the exec-mask bookkeeping
+// around them and the kernel arguments only the other cases read.
+template <bool FAST>
 __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc, const int h, const int l, const int a_ls,
-                                                const int a_dc_in, const int a_bat_in, unsigned fault, const bool feat_ok,
+                                                const int a_dc_in, const int a_bat_in, unsigned fault, const bool feat_ok_in,
                                                 const float frow, const uint2 q_ahead, const bool q_ahead_ok,
-                                                int32_t* __restrict__ actions_out, PairShared& sh) {
+                                                int32_t* __restrict__ actions_out_in, PairShared& sh) {
+  const bool feat_ok = FAST ? true : feat_ok_in;
+  int32_t* const actions_out = FAST ? nullptr : actions_out_in;
   const unsigned* rp = sh.rec[h];
   const double* g = sh.g[h];
   const double* pr = sh.prm[h];
@@ -425,7 +435,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   // ---- rule-based policies for agent_dc / agent_bat (sdc_config.policy; 0 = the caller's action) ----------------------
   int a_dc = a_dc_in, a_bat = a_bat_in;
   int tr_count = lrec_i32(rp, R_TR_COUNT);
-  if (S.policy[1] == SDC_POLICY_TRIM_AND_RESPOND) {
+  if (!FAST && S.policy[1] == SDC_POLICY_TRIM_AND_RESPOND) {
     // utils/trim_and_respond.py:28-38 on the room temperature the previous step reported (dc_int_temperature)
     const double room = lrec_f64(rp, R_LAST_ROOM);
     if (S.tr_limit >= room) {
@@ -440,7 +450,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       a_dc = 0;
     }
   }
-  if (S.policy[2] == SDC_POLICY_RBC) {
+  if (!FAST && S.policy[2] == SDC_POLICY_RBC) {
     // utils/rbc_agents.py:21-47 (look_ahead 3, smooth_window 1) on [ci, ci_future] of the step's info: charge when the
     // carbon intensity three steps ahead is above the current one, else discharge
     // (on the NORMALISED values the reference's agent is given: managers.py:437)
@@ -464,7 +474,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
 
   SDC_AT(4, sh, lane0);
   // ---- rack model, lane = rack inside the half: envs/datacenter.py:250-317, :157-181 ------------------
-  const sdc_dc_params& P = S.dc[lrec_i32(rp, R_CFG)].p;
+  const sdc_dc_params& P = S.dc[FAST ? 0 : lrec_i32(rp, R_CFG)].p;
   const int R = (int)pr[P_N_RACKS];
   const double load_pct = util * 100;
   double pcpu = 0.0, pfan = 0.0, outlet = 0.0;
@@ -605,7 +615,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   // Stored as order-preserving keys for the order-statistic trackers.
   // As in the reference, only default_ls_reward appends (reward_creator.py:63): with another ls reward method the
   // history stays as it is and the other agents' footprint rewards are normalised against it.
-  const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;
+  const bool append = FAST ? true : S.reward_method[0] == SDC_REWARD_DEFAULT;
   int hl = lrec_i32(rp, R_HIST_LEN), hpos = lrec_i32(rp, R_HIST_POS);
   const double href = hl == 0 ? energy : lrec_f64(rp, R_HIST_REF);
   const double e_off = energy - href;
@@ -900,6 +910,7 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
 // keys, a non-appending reward configuration) is left untouched and reported in the returned mask: env_reward()
 // then redoes it from its unmodified state.  wa / wb: the lane's keys 2l / 2l + 1 of {Q1, Q3, BU, BL}.
 // Returns the ballot of lanes whose env was completed here.
+template <bool FAST>
 __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, const int envc, const bool active, const int h,
                                                                const int l, const uint4 wa, const uint4 wb, const DynOut& d,
                                                                const unsigned x_old, float* __restrict__ rew, PairShared& sh,
@@ -910,7 +921,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   const bool lane0 = h == 0 && l == 0;
   SDC_AT(11, sh, lane0);
   const int n = d.hl;
-  const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;
+  const bool append = FAST ? true : S.reward_method[0] == SDC_REWARD_DEFAULT;
   const bool has_old = x_old != KEY_NONE;
   const unsigned x_new = d.x_new;
   int k1, k3;
@@ -1132,7 +1143,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       double v;
-      switch (S.reward_method[a]) {   // wave-uniform
+      switch (FAST ? (int)SDC_REWARD_DEFAULT : S.reward_method[a]) {   // wave-uniform
         case SDC_REWARD_DEFAULT: v = a == 0 ? rls : foot; break;
         case SDC_REWARD_FOOTPRINT: v = foot; break;
         case SDC_REWARD_TOU: v = -1.0 * d.energy * tou_price((int)hour % 24); break;
@@ -1188,7 +1199,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
       rew[envc * 3 + 2] = (float)r[2];
       float* inf = sh.info[h];
       inf[SDC_INFO_ENERGY_Z] = (float)z;
-      inf[SDC_INFO_RESERVED] = wdc ? 2.0f : ((S.debug_flags & 8) && filed) ? 4.0f : 0.0f;   // no ring read by this wavefront (2: a deferred re-centred window arrived; 4, with the timing diagnostics on: a request was filed)
+      inf[SDC_INFO_RESERVED] = wdc ? 2.0f : (!FAST && (S.debug_flags & 8) && filed) ? 4.0f : 0.0f;   // no ring read by this wavefront (2: a deferred re-centred window arrived; 4, with the timing diagnostics on: a request was filed)
       inf[SDC_INFO_EP_RETURN_LS] = (float)ret[0];
       inf[SDC_INFO_EP_RETURN_DC] = (float)ret[1];
       inf[SDC_INFO_EP_RETURN_BAT] = (float)ret[2];
@@ -1203,6 +1214,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
 
 // One env-step of the env pair (env0, env0 + 1) by its wavefront: loads the state, runs the dynamics of both, the rewards
 // and the reward-state upkeep of each, stores the new state and the outputs.
+template <bool FAST>
 __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const int env0, const int lane, const int rel_hint,
                                           const int32_t* __restrict__ actions, float* __restrict__ obs,
                                           float* __restrict__ share_obs, unsigned char* __restrict__ done,
@@ -1211,7 +1223,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
                                           const bool defer) {
   const int TL = S.table_len;
   const int h = lane >> 5, l = lane & (HL - 1);
-  const int n_here = min(EPW, S.n_envs - env0);           // envs of this pair that exist (1 for the last pair of an odd batch)
+  const int n_here = FAST ? EPW : min(EPW, S.n_envs - env0);   // envs of this pair that exist (1 for the last pair of an odd batch)
   const int envc = env0 + min(h, n_here - 1);             // this lane's env (the missing one mirrors the last)
   const bool active = h < n_here;                         // lanes of a missing env compute, but store nothing
   const int env1c = env0 + n_here - 1;
@@ -1221,14 +1233,14 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   // step a second memory round trip.  Memory returns loads in order, so once the record below has arrived these have too.
   typedef int int3v __attribute__((ext_vector_type(3)));
   int3v act_v = {1, 1, 2};
-  if (actions != nullptr) {
+  if (FAST || actions != nullptr) {
     const int32_t* ap = actions + (size_t)envc * 3;
     asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(act_v) : "v"(ap) : "memory");
   }
   // When the host knows the episode step every env is at (envs in lock-step: rel_hint >= 0), the step's feature row
   // -- which also holds its trace inputs -- and its queue-history probes are requested together with the state
   // record: ONE memory round trip before the dynamics start instead of two (record, then what it points to).
-  const bool pre = rel_hint >= 0 && S.feat != nullptr;
+  const bool pre = FAST ? true : (rel_hint >= 0 && S.feat != nullptr);
   float frow_pre = 0.0f;
   double q_pre = 0.0;
   if (pre) {
@@ -1240,10 +1252,10 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
     }
   }
   // with a single data-centre configuration (the usual job) its scalars do not wait for the record either
-  const bool one_cfg = S.n_cfg == 1;
+  const bool one_cfg = FAST ? true : S.n_cfg == 1;
   double prm_pre = 0.0;
   if (one_cfg && l < P_COUNT) prm_pre = reinterpret_cast<const double*>(&S.dc[0].p.m_cpu)[l];
-  const unsigned long long dbg_entry = (S.debug_flags & 16) ? wall_clock64() : 0ull;
+  const unsigned long long dbg_entry = (!FAST && (S.debug_flags & 16)) ? wall_clock64() : 0ull;
 
   // ---- level 0: the two state records (one dwordx2 per lane, 512 contiguous bytes), headers, actions ----------------
   uint2* recp = reinterpret_cast<uint2*>(S.rec + (size_t)envc * SDC_REC_DWORDS) + l;
@@ -1256,11 +1268,11 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(act_v), "+v"(r0), "+v"(r1));
   }
   int a_ls = 1, a_dc = 1, a_bat = 2;       // (rule-based slots never read the caller's array, which may be null)
-  if (S.policy[0] == SDC_POLICY_EXTERNAL) a_ls = act_v.x;
-  if (S.policy[1] == SDC_POLICY_EXTERNAL) a_dc = act_v.y;
-  if (S.policy[2] == SDC_POLICY_EXTERNAL) a_bat = act_v.z;
+  if (FAST || S.policy[0] == SDC_POLICY_EXTERNAL) a_ls = act_v.x;
+  if (FAST || S.policy[1] == SDC_POLICY_EXTERNAL) a_dc = act_v.y;
+  if (FAST || S.policy[2] == SDC_POLICY_EXTERNAL) a_bat = act_v.z;
   unsigned long long dbg_rec = 0ull;
-  if (__builtin_expect((S.debug_flags & 32) != 0, 0)) {
+  if (!FAST && __builtin_expect((S.debug_flags & 32) != 0, 0)) {
     unsigned tmp = rr.x;
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(tmp)::"memory");
     dbg_rec = wall_clock64() + (tmp & 0u);
@@ -1270,7 +1282,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   const unsigned* rp = sh.rec[h];
   const int i = lrec_i32(rp, R_CURSOR), rel = lrec_i32(rp, R_TREL);
   const int loc = lrec_i32(rp, R_LOC);
-  const SdcDcDev* PD = &S.dc[lrec_i32(rp, R_CFG)];
+  const SdcDcDev* PD = &S.dc[FAST ? 0 : lrec_i32(rp, R_CFG)];
   const int hourq = lrec_i32(rp, R_HOURQ);
   const int hourq_n = hourq + 1 >= 96 ? 0 : hourq + 1;
   unsigned fault = 0;
@@ -1290,15 +1302,15 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   // order-statistic trackers need (0xFFFFFFFF while the ring is still filling)
   const int hl0 = lrec_i32(rp, R_HIST_LEN);
   const int slot0 = hl0 < S.hist_cap ? hl0 : lrec_i32(rp, R_HIST_POS);
-  const bool append = S.reward_method[0] == SDC_REWARD_DEFAULT;   // else the history does not change this step
+  const bool append = FAST ? true : S.reward_method[0] == SDC_REWARD_DEFAULT;   // else the history does not change this step
   // The trace-only observation entries of this step come precomputed (sdc_features.hip), unless the episode has no
   // feature rows (a host write since the reset, an episode too long for that kernel): then the CI / temperature
   // windows are gathered and the features computed here.
-  const bool feat_ok = S.feat != nullptr && lrec_i32(rp, R_FEAT_OK) == 1;
-  const bool fast = pre && feat_ok && rel == rel_hint;   // what was requested up front is what this step needs
+  const bool feat_ok = FAST ? true : (S.feat != nullptr && lrec_i32(rp, R_FEAT_OK) == 1);
+  const bool fast = FAST ? true : (pre && feat_ok && rel == rel_hint);   // what was requested up front is what this step needs
   float frow = frow_pre;
   if (feat_ok && !fast) frow = S.feat[feat_row_offset(S, envc, rel + 1) + l];
-  const bool want_c3 = S.policy[2] == SDC_POLICY_RBC;
+  const bool want_c3 = FAST ? false : S.policy[2] == SDC_POLICY_RBC;
   {
     const double ci_min = lrec_f64(rp, R_CI_MIN), ci_den = lrec_f64(rp, R_CI_DEN);
     const double t_min = lrec_f64(rp, R_T_MIN), t_den = lrec_f64(rp, R_T_DEN);
@@ -1360,7 +1372,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   wave_sync();
 
   unsigned long long dbg_a0 = 0ull;
-  if (__builtin_expect((S.debug_flags & 8) != 0, 0)) dbg_a0 = wall_clock64();
+  if (!FAST && __builtin_expect((S.debug_flags & 8) != 0, 0)) dbg_a0 = wall_clock64();
   // the rank windows of both envs, one key each per lane: wanted at the end of the step, so the loads are issued here --
   // after the start-of-launch burst of every env's record / header / gather loads -- and ride along in 8 registers
   // reward-side state (headers: returns, trackers, sums; the rank windows' keys; the evicted ring key): wanted at the end of
@@ -1381,11 +1393,11 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   const unsigned hdB = S.hdr[(size_t)env1c * SDC_HDR_DWORDS + lane];
   const uint4 wka = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l];       // keys 2l of the 4 windows
   const uint4 wkb = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l + 1];   // keys 2l + 1
-  const DynOut d = pair_dynamics(S, envc, h, l, a_ls, a_dc, a_bat, fault, feat_ok, frow, q_ahead, q_ahead_ok, actions_out, sh);
+  const DynOut d = pair_dynamics<FAST>(S, envc, h, l, a_ls, a_dc, a_bat, fault, feat_ok, frow, q_ahead, q_ahead_ok, actions_out, sh);
   wave_sync();
 
   // ---- episodes without feature rows: the observation features of such an env, all 64 lanes cooperating ---------------
-  if (__builtin_expect(__ballot(!feat_ok) != 0ull, 0)) {
+  if (!FAST && __builtin_expect(__ballot(!feat_ok) != 0ull, 0)) {
     for (int e = 0; e < n_here; e++) {
       if (pick_i32(feat_ok ? 1 : 0, e)) continue;
       const double* os = sh.osc[e];
@@ -1401,14 +1413,14 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
 #if SDC_PRIO_DROP == 2
   __builtin_amdgcn_s_setprio(0);
 #endif
-  if (__builtin_expect((S.debug_flags & 8) != 0, 0) && lane == 0) sh.dbg_t[0] = wall_clock64();
+  if (!FAST && __builtin_expect((S.debug_flags & 8) != 0, 0) && lane == 0) sh.dbg_t[0] = wall_clock64();
 
   // ---- rewards + reward-state upkeep: both envs at once on the O(1) path; an env that needs its ring (or anything
   // unusual) is redone whole-wavefront from its untouched state ------------------------------------------------------------
   sh.hdr[0][lane] = hdA;
   sh.hdr[1][lane] = hdB;
   wave_sync();
-  const unsigned long long fast_m = pair_reward_fast(S, envc, active, h, l, wka, wkb, d, x_old_l, rew, sh, step_no, defer);
+  const unsigned long long fast_m = pair_reward_fast<FAST>(S, envc, active, h, l, wka, wkb, d, x_old_l, rew, sh, step_no, defer);
 #pragma unroll 1
   for (int e = 0; e < n_here; e++) {
     if (__builtin_expect((fast_m >> (e * HL)) & 1ull, 1)) continue;
@@ -1419,7 +1431,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
                pick_f64(d.norm_ci, e), pick_f64(d.oldest_norm, e), pick_i32(d.overdue, e), pick_i32(d.hourq_n, e),
                pick_f64(d.p_it, e), pick_f64(d.total_kw, e), pick_f64(d.water, e), rew, sh.info[e], sh.tl);
   }
-  if (__builtin_expect((S.debug_flags & 8) != 0, 0)) {
+  if (!FAST && __builtin_expect((S.debug_flags & 8) != 0, 0)) {
     wave_sync();
     if (lane == 0) {
       const unsigned long long dbg_a3 = wall_clock64();
@@ -1453,11 +1465,11 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
       if (final_obs && ((term_m >> (e * HL)) & 1ull)) final_obs[(size_t)env0 * SDC_OBS_OUT + idx] = v;
     }
   }
-  if (share_obs && lane < n_here * SDC_SHARE_OBS_DIM) {
+  if ((FAST || share_obs) && lane < n_here * SDC_SHARE_OBS_DIM) {
     const int e = lane >= SDC_SHARE_OBS_DIM ? 1 : 0, j = lane - e * SDC_SHARE_OBS_DIM;
     SDC_OUT_STORE(share_obs_at(sh.pool[e], j), &share_obs[(size_t)env0 * SDC_SHARE_OBS_DIM + lane]);
   }
-  if (info) {
+  if (FAST || info) {
 #pragma unroll
     for (int k = 0; k < (EPW * SDC_INFO_DIM + SDC_WAVE - 1) / SDC_WAVE; k++) {
       const int idx = k * SDC_WAVE + lane;
@@ -1548,10 +1560,11 @@ __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const
 }
 
 // One launch of this kernel is one env-step of all N environments.
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_WPB) void sdc_dynamics_kernel(
-    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
-    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
-  __shared__ PairShared shs[SDC_STEP_WPB];
+template <bool FAST>
+__device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs, const int rel_hint, const int32_t* __restrict__ actions,
+                                                float* __restrict__ obs, float* __restrict__ share_obs,
+                                                unsigned char* __restrict__ done, float* __restrict__ info,
+                                                float* __restrict__ final_obs, float* __restrict__ rew) {
   const KernargTouch kt = kernarg_touch();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
   const int lane = threadIdx.x % SDC_WAVE;
@@ -1581,10 +1594,23 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_W
   // workgroup arrived in the second round of 256 (one per CU) would finish ~1.8 us after the other.  Raised priority for
   // the later rounds evens the two out, and the launch ends when the slower one does.
   if (pb >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
-  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
-  pair_step(S, shs[wave], env0, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew, S.actions_out, S.step_no,
-            true);
-  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 1);
+  if (!FAST && lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
+  pair_step<FAST>(S, shs[wave], env0, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew,
+                  FAST ? nullptr : S.actions_out, S.step_no, true);
+  if (!FAST && lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 1);
+}
+// the general kernel, and the one for the common case (see pair_dynamics; the host picks: sdc_capi.hip fast_case)
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_WPB) void sdc_dynamics_kernel(
+    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
+    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+  __shared__ PairShared shs[SDC_STEP_WPB];
+  dynamics_launch<false>(S, shs, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+}
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_WPB) void sdc_dynamics_fast_kernel(
+    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
+    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+  __shared__ PairShared shs[SDC_STEP_WPB];
+  dynamics_launch<true>(S, shs, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
 }
 
 // K env-steps per launch for action sequences that are known up front or chosen by the built-in rule-based policies
@@ -1593,18 +1619,18 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_W
 // tail of a launch are paid once per K steps.  actions [K][N][3] (or null when every agent slot has a policy);
 // obs [K][N][3][26], share_obs [K][N][29] (or null), rew [K][N][3], done [K][N], info [K][N][44] (or null) hold every
 // step's outputs.  The host keeps K within the episode (sdc_rollout).
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WPB) void sdc_rollout_kernel(
-    SdcDev S, const int K, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs,
-    float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs,
-    float* __restrict__ rew) {
-  __shared__ PairShared shs[SDC_STEP_WPB];
+template <bool FAST>
+__device__ __forceinline__ void rollout_launch(const SdcDev& S, PairShared* shs, const int K, const int rel_hint,
+                                               const int32_t* __restrict__ actions, float* __restrict__ obs,
+                                               float* __restrict__ share_obs, unsigned char* __restrict__ done,
+                                               float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
   const int env0 = (first_pair_of_block((int)blockIdx.x, (int)gridDim.x) + wave) * EPW;
   const int lane = threadIdx.x % SDC_WAVE;
   const size_t N = (size_t)S.n_envs;
   if (env0 >= S.n_envs) return;
-  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
-  int32_t* const aout = S.actions_out;
+  if (!FAST && lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
+  int32_t* const aout = FAST ? nullptr : S.actions_out;
 #pragma unroll 1
   for (int k = 0; k < K; k++) {
     if ((int)blockIdx.x >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);    // (see sdc_dynamics_kernel)
@@ -1612,15 +1638,30 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WP
     // registers across it)
     int env_k = env0, lane_k = lane;
     asm volatile("" : "+s"(env_k), "+v"(lane_k));
-    pair_step(S, shs[wave], env_k, lane_k, rel_hint >= 0 ? rel_hint + k : -1, actions ? actions + (size_t)k * N * 3 : nullptr,
-              obs + (size_t)k * N * SDC_OBS_OUT, share_obs ? share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM : nullptr,
-              done + (size_t)k * N, info ? info + (size_t)k * N * SDC_INFO_DIM : nullptr, k == K - 1 ? final_obs : nullptr,
-              rew + (size_t)k * N * 3, aout ? aout + (size_t)k * N * 3 : nullptr, S.step_no + k, false);
+    pair_step<FAST>(S, shs[wave], env_k, lane_k, (FAST || rel_hint >= 0) ? rel_hint + k : -1,
+                    (FAST || actions) ? actions + (size_t)k * N * 3 : nullptr, obs + (size_t)k * N * SDC_OBS_OUT,
+                    (FAST || share_obs) ? share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM : nullptr, done + (size_t)k * N,
+                    (FAST || info) ? info + (size_t)k * N * SDC_INFO_DIM : nullptr, k == K - 1 ? final_obs : nullptr,
+                    rew + (size_t)k * N * 3, aout ? aout + (size_t)k * N * 3 : nullptr, S.step_no + k, false);
     // this wavefront's stores of step k are the loads of its step k + 1: complete them and drop stale lines of the
     // CU's vector L1 (workgroup scope: the L2 behind it is the same for both)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wave_sync();
   }
-  if (lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 1);
+  if (!FAST && lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 1);
+}
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WPB) void sdc_rollout_kernel(
+    SdcDev S, const int K, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs,
+    float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs,
+    float* __restrict__ rew) {
+  __shared__ PairShared shs[SDC_STEP_WPB];
+  rollout_launch<false>(S, shs, K, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+}
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WPB) void sdc_rollout_fast_kernel(
+    SdcDev S, const int K, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs,
+    float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs,
+    float* __restrict__ rew) {
+  __shared__ PairShared shs[SDC_STEP_WPB];
+  rollout_launch<true>(S, shs, K, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
 }

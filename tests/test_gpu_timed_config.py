@@ -192,3 +192,46 @@ def test_golden_fixtures_as_one_heterogeneous_batch():
         assert (I[:, i, L.INFO_IDX["fault"]] == 0).all(), names[i]
     print("heterogeneous golden batch:", len(names), "fixtures", names, worst)
     eng.close()
+
+
+def test_common_case_kernels_equal_the_general_kernels():
+    """The step / rollout kernels specialised for the common case (lock-step batch with feature rows, one config, external
+    actions, default rewards, no diagnostics: what bench.py times) against the general kernels (debug_flags bit 7 forces
+    them): every output and the whole state bit for bit, over auto-resets, single steps and rollouts."""
+    import torch
+    N, steps, cap = 1024, 96, 10000
+    tb = traces.synthetic_tables("ny", 0)
+    p = dc_config.size_datacenter("dc_config.json", 1, 30.0)
+    rng = np.random.default_rng(3)
+    hist = np.full((N, 10240), np.nan, np.float32)
+    hist[:, :cap] = (331 + 70 * rng.standard_normal((N, cap))).clip(150, 650).astype(np.float32)
+    pos = rng.integers(0, cap, N).astype(np.int32)
+    engs = []
+    for flags in (0, 128):
+        e = SdcEngine(N, episode_steps=steps, auto_reset=True, seed=12, debug_flags=flags)
+        e.set_tables(0, tb["W"], tb["C"], tb["T"], tb["WB"])
+        e.set_dc_params(0, p)
+        e.assign(0, 0, 174, 188)
+        e.set_state("hist", hist)
+        e.set_state("hist_len", np.full(N, cap, np.int32))
+        e.set_state("hist_pos", pos)
+        e.reset()
+        engs.append(e)
+    a, b = engs
+    g = torch.Generator(device="cpu").manual_seed(5)
+    acts = torch.randint(0, 3, (260, N, 3), dtype=torch.int32, generator=g).cuda()
+    for t in range(200):                       # two auto-resets
+        xa = a.step(acts[t])
+        xb = b.step(acts[t])
+        for u, v, nm in zip(xa, xb, ("obs", "share_obs", "rew", "done", "info")):
+            assert torch.equal(u, v), (t, nm)
+    assert torch.equal(a.final_obs, b.final_obs)
+    k = min(48, a.steps_to_episode_end())
+    ra = a.rollout(acts[200:200 + k])
+    rb = b.rollout(acts[200:200 + k])
+    for u, v in zip(ra, rb):
+        assert torch.equal(u, v)
+    for name in ("record", "header", "qwin", "hist", "qtab"):
+        np.testing.assert_array_equal(a.get_state(name), b.get_state(name), err_msg=name)
+    for e in engs:
+        e.close()
