@@ -83,6 +83,7 @@ struct sdc_handle {
   int steps_to_terminal = 0;
   std::vector<unsigned char> feat_host;   // host mirror of R_FEAT_OK: the env's episode has valid observation feature rows
   int n_feat_host = 0;                    // how many envs have
+  int racks_cfg0 = 0;                     // racks of data-centre config 0 (the specialised kernels take <= 32: one pass)
   std::vector<unsigned char> last_done;   // which envs finished in the last sdc_step / sdc_rollout call (host mirror)
   int n_last_done = 0;
   bool tables_set = false, assigned = false, started = false;
@@ -180,10 +181,15 @@ void note_features(sdc_handle* h, int e) {
 // default reward functions, no diagnostics or profiling, an even number of envs, every output array present.
 // debug_flags bit 0 (the verify kernel, a separate launch) and bit 6 (test hook of sdc_create) do not touch the step;
 // bit 7 forces the general kernel (tests compare the two bit for bit).
+#ifndef SDC_FAST_DEBUG
+#define SDC_FAST_DEBUG 0
+#endif
+constexpr int FAST_DEBUG_FLAGS = SDC_FAST_DEBUG ? (8 | 16 | 32 | 256) : 0;   // (measurement builds: see sdc_step.hip)
 bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_obs, const float* info, bool timed) {
   const SdcDev& d = h->d;
-  return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs && d.n_cfg == 1 && actions && share_obs &&
-         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64)) == 0 &&
+  return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs && d.n_cfg == 1 && h->racks_cfg0 > 0 &&
+         h->racks_cfg0 <= 32 && actions && share_obs &&
+         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | FAST_DEBUG_FLAGS)) == 0 &&
          d.policy[0] == SDC_POLICY_EXTERNAL && d.policy[1] == SDC_POLICY_EXTERNAL && d.policy[2] == SDC_POLICY_EXTERNAL &&
          d.reward_method[0] == SDC_REWARD_DEFAULT && d.reward_method[1] == SDC_REWARD_DEFAULT &&
          d.reward_method[2] == SDC_REWARD_DEFAULT;
@@ -443,6 +449,7 @@ int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
   e.ret_sum = 0.0;
   for (int r = 0; r < p->n_racks; r++) e.ret_sum += p->rack_return[r];
   HIP_TRY(hipMemcpy(const_cast<SdcDcDev*>(h->d.dc) + cfg_id, &e, sizeof(e), hipMemcpyHostToDevice));
+  if (cfg_id == 0) h->racks_cfg0 = p->n_racks;
   return 0;
 }
 

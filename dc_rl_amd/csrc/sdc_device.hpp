@@ -210,9 +210,17 @@ enum { SDC_DPP_XOR1 = 0xB1, SDC_DPP_XOR2 = 0x4E, SDC_DPP_HALF_MIRROR = 0x141, SD
        SDC_DPP_BCAST15 = 0x142, SDC_DPP_BCAST31 = 0x143, SDC_DPP_WAVE_SHL1 = 0x130 };
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ double dpp_f64(double v) {   // unwritten lanes (row_mask, out of range) read as 0.0
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
-  return __hiloint2double(hi, lo);
+  if constexpr (ROW_MASK == 0xF) {
+    // every row written: "no source lane -> 0" is the instruction's bound_ctrl, and the destination needs no zero first
+    // (3 instructions per 64-bit stage instead of 5)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  } else {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+  }
 }
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
@@ -413,25 +421,22 @@ __device__ __forceinline__ void build_obs_pool(const double* nc, const double* n
 
 // HARL layout (harlsustaindc_env.py:25-26): obs [3][26] zero padded; idx in [0, 78) -> value from the pool.
 //   agent_dc (14): sustaindc_env.py:386-393   agent_bat (13): sustaindc_env.py:426-432
+// Branch-free: the pool index of entry j (0..77) of the padded [3][26] block, or -1 for a padding zero -- a switch here
+// compiles into a tree of exec-mask branches per output lane group (~100 instructions per 64 outputs).
+__device__ __forceinline__ int obs_pool_index(const int j) {
+  static_assert(SDC_P_W == 13 && SDC_P_NT == 14 && SDC_P_WNEXT == 26 && SDC_P_NTNEXT == 27 && SDC_P_SOC == 28, "byte tables below");
+  const int a = (j >= SDC_OBS_PAD ? 1 : 0) + (j >= 2 * SDC_OBS_PAD ? 1 : 0), k = j - SDC_OBS_PAD * a, t = k - 10;
+  // entries 10.. of agent_dc: {W, W next, NT, NT next}; of agent_bat: {W, NT, SoC} (one byte each, low byte first)
+  const unsigned tab = a == 1 ? 0x1B0E1A0Du : 0x001C0E0Du;
+  const int from_tab = (int)((tab >> (8 * (t & 3))) & 0xFFu);
+  const bool direct = a == 0 || k < 10;                 // agent_ls whole; the ten shared time / CI entries of the others
+  const bool ok = direct || (t >= 0 && t < 5 - a);      // 4 more for agent_dc, 3 for agent_bat, zeros after them
+  return ok ? (direct ? k : from_tab) : -1;
+}
 __device__ __forceinline__ float obs_padded_at(const float* pool, int idx) {
-  const int a = idx / SDC_OBS_PAD, k = idx - a * SDC_OBS_PAD;
-  if (a == 0) return pool[k];
-  if (k < 10) return pool[k];
-  if (a == 1) {
-    switch (k) {
-      case 10: return pool[SDC_P_W];
-      case 11: return pool[SDC_P_WNEXT];
-      case 12: return pool[SDC_P_NT];
-      case 13: return pool[SDC_P_NTNEXT];
-      default: return 0.0f;
-    }
-  }
-  switch (k) {
-    case 10: return pool[SDC_P_W];
-    case 11: return pool[SDC_P_NT];
-    case 12: return pool[SDC_P_SOC];
-    default: return 0.0f;
-  }
+  const int s = obs_pool_index(idx);
+  const float v = pool[s < 0 ? 0 : s];
+  return s < 0 ? 0.0f : v;
 }
 // HARL shared observation (harlsustaindc_env.py:78-80): ls state [0..25], states[1][11] = next workload, states[1][13]
 // = next outside temperature, states[2][-1].  The states are the PADDED 26-vectors (ss.pad_observations_v0 runs before

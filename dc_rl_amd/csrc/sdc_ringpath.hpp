@@ -97,9 +97,11 @@ __device__ __forceinline__ void ring_sweep(const RingView& R, const int lane, F&
     for (int q = 0; q < BATCH; q++) f(v[q].x, v[q].y, v[q].z, v[q].w);
   }
 }
-template <class F>
+// (BATCH: 5 where the sweep runs inside an env pair's wavefront, whose registers are short; 10 in the spare wavefronts
+// that do nothing else -- 13.13 -> 13.00 us per step; 20 no longer fits their registers either: 28 us)
+template <int BATCH, class F>
 __device__ __forceinline__ void ring_sweep_pipelined(const RingView& R, const int lane, F&& f) {
-  constexpr int BATCH = 5, NB = RING_VECS / BATCH;   // 8 batches, taken in pairs
+  constexpr int NB = RING_VECS / BATCH;   // batches of loads in flight, taken in pairs
   static_assert(NB * BATCH == RING_VECS && (NB & 1) == 0, "batching assumes an even number of full batches");
   uint4 a[BATCH], b[BATCH];
 #pragma unroll
@@ -155,6 +157,7 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
 // lane's 4th); those ~45 keys (64 lanes x 4 slots: a birthday bound) are compacted, ranked by counting and placed.
 // A run of equal keys can stop the complete part short; then another sweep continues from that key.
 // `side` = KEY_NONE for a window over complemented keys (the lower clip bound's), else 0.
+template <int BATCH = 5>
 __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k, const int n, const RingView& R, const int lane,
                                           TailLds& L, const unsigned side) {
   // Work in a space where the window grows upwards: for DOWN complement the keys, reverse the window and count ranks
@@ -189,7 +192,7 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
     const unsigned smax = KEY_NONE - pp;                 // a legitimate distance is below this
     unsigned c = 0u;
     unsigned e0 = KEY_NONE, e1 = KEY_NONE, e2 = KEY_NONE, e3 = KEY_NONE;   // this lane's 4 smallest distances, ascending
-    ring_sweep_pipelined(R, lane, [&](unsigned x0, unsigned x1, unsigned x2, unsigned x3) {
+    ring_sweep_pipelined<BATCH>(R, lane, [&](unsigned x0, unsigned x1, unsigned x2, unsigned x3) {
       const unsigned xs[4] = {x0 ^ f, x1 ^ f, x2 ^ f, x3 ^ f};
 #pragma unroll
       for (int i = 0; i < 4; i++) {

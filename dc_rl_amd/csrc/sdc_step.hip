@@ -83,9 +83,82 @@ static_assert(P_COUNT <= HL, "one config scalar per lane of a half");
 #else
 #define SDC_OUT_STORE(v, p) (*(p) = (v))
 #endif
+// (measurement builds only, -DSDC_FAST_DEBUG=1: the kernels specialised for the common case keep the in-kernel clock stamps
+// of debug_flags 8 / 16 / 32, so that tools/wave_timeline.py and tools/wave_phases.py see THEM and not the general ones)
+#ifndef SDC_FAST_DEBUG
+#define SDC_FAST_DEBUG 0
+#endif
+#define SDC_DBG_OK(FAST_) (!(FAST_) || SDC_FAST_DEBUG)
+// which rare paths a wavefront's step took (reported in info[reserved] above bit 3 when debug_flags has bit 3):
+// 1 oldest-task table search, 2 a key inside a rank window, 4 a clip bound crossed keys, 8 a deferred window arrived,
+// 16 a re-centring request filed
+#define SDC_DBG_BIT(FAST_, SH, B)                                                                   \
+  do {                                                                                              \
+    if (SDC_DBG_OK(FAST_) && (S.debug_flags & 8) && (threadIdx.x & 63) == 0) (SH).dbg_bits |= (B); \
+  } while (0)
 #ifndef SDC_PRIO_DROP
 #define SDC_PRIO_DROP 2
 #endif
+#ifndef SDC_BASE_PRIO
+#define SDC_BASE_PRIO 0      // issue priority of the env pairs' wavefronts (the late dispatch round: + 1 during the dynamics)
+#endif
+
+// ---- fp64 CONSTANT TABLE in LDS -------------------------------------------------------------------------------------
+// A double that is not one of the hardware's inline constants (or a value whose low 32 bits are zero) costs TWO
+// instructions every time it is used: two s_mov_b32 (or v_mov_b32) building it.  The step's hot path used ~100 of them:
+// 9 % of its instructions.  Each wavefront instead copies this table from memory to LDS once (two coalesced loads issued
+// with its state record), and a use is a broadcast LDS read -- one instruction per constant, or per PAIR of constants
+// that sit next to each other here (ds_read_b128; the polynomials' coefficients are listed in the order they are used).
+// KC(v) is the table entry holding the literal v, looked up at COMPILE time (a value missing from the list does not
+// compile), so the formulas keep their literals and both kernel variants read the very same bits.
+#define SDC_KVALS_LIST                                                                                                      \
+  /* log2_pos_normal */ 0.70710678118654752, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0, \
+      1.0 / 3.0, 2.8853900817779268, /* the rack model's two exponents */ 1.096, 0.824,                                         \
+      /* exp2_short / exp2_plain */ 0.6931471805599453, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0,     \
+      1.0 / 6.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.4426950408889634,                     \
+      /* chiller_power */ 1.0 / 2.778, 0.94483600, -0.05700880, 0.00185486, 2.333, -1.975, 0.6121, 0.03303, 0.6852, 0.2818,   \
+      0.05, 1.0 / 0.05, 6.67 - 35.0,                                                                           \
+      /* rack model, water, battery, load shifting */ 3.8, 5.3, -14.01, 0.3528, 0.101, 0.044, 0.01, 0.8, 0.2, 1.0 / 100.0,      \
+      1.0 / 20.0, 1.0 / 1e3, 1.0 / 60.0, 1.0 / 1e4, 1.0 / 1e8, 0.04, 0.1, 1e-300, 1e300
+constexpr double SDC_KVALS[] = {SDC_KVALS_LIST};
+constexpr int SDC_K_COUNT = (int)(sizeof(SDC_KVALS) / sizeof(double));
+constexpr int SDC_K_LDS = 128;     // table entries in LDS (two per lane)
+static_assert(SDC_K_COUNT <= SDC_K_LDS, "grow the LDS constant table");
+__device__ const double SDC_KTAB[SDC_K_LDS] = {SDC_KVALS_LIST};
+constexpr int sdc_kfind(const double v) {
+  for (int i = 0; i < SDC_K_COUNT; i++)
+    if (SDC_KVALS[i] == v) return i;
+  return -1;
+}
+template <int I>
+struct SdcKIdx {
+  static_assert(I >= 0, "this literal is not in SDC_KVALS_LIST");
+  static constexpr int idx = I;
+};
+#define KC(LITERAL) (kt[SdcKIdx<sdc_kfind(LITERAL)>::idx])
+// where the formulas get their constants from: the LDS table (the kernels specialised for the common case), or the
+// literals themselves (the general kernels, whose rack loop would otherwise hold the table's values in registers)
+struct KLds {
+  const double* t;
+  __device__ __forceinline__ double operator[](const int i) const { return t[i]; }
+};
+struct KLit {
+  __device__ __forceinline__ constexpr double operator[](const int i) const { return SDC_KVALS[i]; }
+};
+template <bool FAST> struct KSel { using type = KLit; };
+template <> struct KSel<true> { using type = KLds; };
+// x / C and np.round(x, d) with C, 1 / C (10^d, 10^-d) from the table where they are not free literals
+#define KDIV(x, C) sdc_div_const((x), (double)(C), KC(1.0 / (double)(C)))
+#define k_round(x, P10) KDIV(rint((x) * (P10)), (P10))
+// each wavefront copies the table to LDS (the workgroup's wavefronts write the same values: no barrier needed)
+__device__ __forceinline__ void ktab_fetch(const int lane, double& k0, double& k1) {
+  k0 = SDC_KTAB[lane];
+  k1 = SDC_KTAB[lane + SDC_WAVE];
+}
+__device__ __forceinline__ void ktab_store(double* kt, const int lane, const double k0, const double k1) {
+  kt[lane] = k0;
+  kt[lane + SDC_WAVE] = k1;
+}
 
 struct PairShared {
   double g[EPW][64];                   // gathered step inputs; g[G_NC..] / g[G_NT..] are normalised in place to NC / NT
@@ -97,6 +170,7 @@ struct PairShared {
   float info[EPW][SDC_INFO_DIM];
   unsigned long long dbg_t[2];
   unsigned long long dbg_s[2];
+  unsigned dbg_bits;                   // (diagnostics, debug_flags bit 3) which rare paths this wavefront's step took
   sdc_rw::TailLds tl;                  // scratch of the ring paths (window refill, rebuild): one env at a time
 };
 
@@ -125,10 +199,11 @@ __device__ __forceinline__ unsigned half_ballot(const bool p, const int h) {
 // orders below what the fp32 outputs resolve) in 29 instructions -- the library's correctly rounded, every-special-case
 // log2 is 82.  x = m 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.172: the odd
 // series through s^17 leaves 9e-16 relative.
-__device__ __forceinline__ double log2_pos_normal(const double x) {
+template <class KT>
+__device__ __forceinline__ double log2_pos_normal(const double x, const KT kt) {
   double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
   int e = __builtin_amdgcn_frexp_exp(x);
-  const int up = m < 0.70710678118654752 ? 1 : 0;
+  const int up = m < KC(0.70710678118654752) ? 1 : 0;
   m = __builtin_amdgcn_ldexp(m, up);
   e -= up;
   const double f = m - 1.0, d = m + 1.0;
@@ -138,36 +213,39 @@ __device__ __forceinline__ double log2_pos_normal(const double x) {
   double q = f * r;
   q = fma(fma(-d, q, f), r, q);                         // s = f / d to the last place or so
   const double s2 = q * q;
-  double p = 1.0 / 17.0;
-  p = fma(p, s2, 1.0 / 15.0);
-  p = fma(p, s2, 1.0 / 13.0);
-  p = fma(p, s2, 1.0 / 11.0);
-  p = fma(p, s2, 1.0 / 9.0);
-  p = fma(p, s2, 1.0 / 7.0);
-  p = fma(p, s2, 1.0 / 5.0);
-  p = fma(p, s2, 1.0 / 3.0);
+  double p = KC(1.0 / 17.0);
+  p = fma(p, s2, KC(1.0 / 15.0));
+  p = fma(p, s2, KC(1.0 / 13.0));
+  p = fma(p, s2, KC(1.0 / 11.0));
+  p = fma(p, s2, KC(1.0 / 9.0));
+  p = fma(p, s2, KC(1.0 / 7.0));
+  p = fma(p, s2, KC(1.0 / 5.0));
+  p = fma(p, s2, KC(1.0 / 3.0));
   p = fma(p, s2, 1.0);
-  return fma(q * p, 2.8853900817779268 /* 2 / ln 2 */, (double)e);
+  return fma(q * p, KC(2.8853900817779268) /* 2 / ln 2 */, (double)e);
 }
 
 // exp(t) for |t| <= 700: 2^(t log2 e) with the fraction's power from a degree-12 Taylor polynomial (<= 2e-16 relative)
 // + the scaling by ldexp; 17 instructions against the library's 45
-__device__ __forceinline__ double exp2_plain(const double y);
-__device__ __forceinline__ double exp_plain(const double t) { return exp2_plain(t * 1.4426950408889634); }
+template <class KT>
+__device__ __forceinline__ double exp2_plain(const double y, const KT kt);
+template <class KT>
+__device__ __forceinline__ double exp_plain(const double t, const KT kt) { return exp2_plain(t * KC(1.4426950408889634), kt); }
 // 2^y for |y| <= 1000, same way
-__device__ __forceinline__ double exp2_plain(const double y) {
+template <class KT>
+__device__ __forceinline__ double exp2_plain(const double y, const KT kt) {
   const double n = __builtin_rint(y);
-  const double f = (y - n) * 0.6931471805599453;     // |f| <= 0.3466
-  double p = 1.0 / 479001600.0;
-  p = fma(p, f, 1.0 / 39916800.0);
-  p = fma(p, f, 1.0 / 3628800.0);
-  p = fma(p, f, 1.0 / 362880.0);
-  p = fma(p, f, 1.0 / 40320.0);
-  p = fma(p, f, 1.0 / 5040.0);
-  p = fma(p, f, 1.0 / 720.0);
-  p = fma(p, f, 1.0 / 120.0);
-  p = fma(p, f, 1.0 / 24.0);
-  p = fma(p, f, 1.0 / 6.0);
+  const double f = (y - n) * KC(0.6931471805599453);     // |f| <= 0.3466
+  double p = KC(1.0 / 479001600.0);
+  p = fma(p, f, KC(1.0 / 39916800.0));
+  p = fma(p, f, KC(1.0 / 3628800.0));
+  p = fma(p, f, KC(1.0 / 362880.0));
+  p = fma(p, f, KC(1.0 / 40320.0));
+  p = fma(p, f, KC(1.0 / 5040.0));
+  p = fma(p, f, KC(1.0 / 720.0));
+  p = fma(p, f, KC(1.0 / 120.0));
+  p = fma(p, f, KC(1.0 / 24.0));
+  p = fma(p, f, KC(1.0 / 6.0));
   p = fma(p, f, 0.5);
   p = fma(p, f, 1.0);
   p = fma(p, f, 1.0);
@@ -175,15 +253,16 @@ __device__ __forceinline__ double exp2_plain(const double y) {
 }
 
 // 2^y to <= 3e-10 relative (degree 8): for the rack outlet-temperature rise, whose consumers resolve 1e-7 at best
-__device__ __forceinline__ double exp2_short(const double y) {
+template <class KT>
+__device__ __forceinline__ double exp2_short(const double y, const KT kt) {
   const double n = __builtin_rint(y);
-  const double f = (y - n) * 0.6931471805599453;
-  double p = 1.0 / 40320.0;
-  p = fma(p, f, 1.0 / 5040.0);
-  p = fma(p, f, 1.0 / 720.0);
-  p = fma(p, f, 1.0 / 120.0);
-  p = fma(p, f, 1.0 / 24.0);
-  p = fma(p, f, 1.0 / 6.0);
+  const double f = (y - n) * KC(0.6931471805599453);
+  double p = KC(1.0 / 40320.0);
+  p = fma(p, f, KC(1.0 / 5040.0));
+  p = fma(p, f, KC(1.0 / 720.0));
+  p = fma(p, f, KC(1.0 / 120.0));
+  p = fma(p, f, KC(1.0 / 24.0));
+  p = fma(p, f, KC(1.0 / 6.0));
   p = fma(p, f, 0.5);
   p = fma(p, f, 1.0);
   p = fma(p, f, 1.0);
@@ -191,23 +270,24 @@ __device__ __forceinline__ double exp2_short(const double y) {
 }
 
 // envs/datacenter.py:356-429 calculate_chiller_power
-__device__ __forceinline__ double chiller_power(double max_cooling_cap, double load, double ambient_temp) {
-  const double min_plr = 0.05, max_plr = 1.0, design_cond_temp = 35.0, design_evp_out_temp = 6.67;
-  // temp_rise_coef = 2.778, rated_cop = 3.0 (divisors below)
-  const double delta_temp = SDC_MUL_RCP(ambient_temp - design_cond_temp, 2.778) - (design_evp_out_temp - design_cond_temp);
-  const double cap_rat = 0.94483600 + -0.05700880 * delta_temp + 0.00185486 * (delta_temp * delta_temp);
+template <class KT>
+__device__ __forceinline__ double chiller_power(double max_cooling_cap, double load, double ambient_temp, const KT kt) {
+  const double min_plr = KC(0.05), max_plr = 1.0, design_cond_temp = 35.0;
+  // temp_rise_coef = 2.778, rated_cop = 3.0 (divisors below); design_evp_out_temp = 6.67
+  const double delta_temp = (ambient_temp - design_cond_temp) * KC(1.0 / 2.778) - KC(6.67 - 35.0);
+  const double cap_rat = KC(0.94483600) + KC(-0.05700880) * delta_temp + KC(0.00185486) * (delta_temp * delta_temp);
   const double avail = cap_rat != 0 ? max_cooling_cap * cap_rat : 0.0;
-  const double fpr = 2.333 + -1.975 * cap_rat + 0.6121 * (cap_rat * cap_rat);
+  const double fpr = KC(2.333) + KC(-1.975) * cap_rat + KC(0.6121) * (cap_rat * cap_rat);
   const double ratio = sdc_div_fast(load, avail);   // (one division: the reference evaluates load / avail three times; only used where avail > 0)
   const double plr = avail > 0 ? fmax(min_plr, fmin(ratio, max_plr)) : 0.0;
-  const double fflp = 0.03303 + 0.6852 * plr + 0.2818 * (plr * plr);
+  const double fflp = KC(0.03303) + KC(0.6852) * plr + KC(0.2818) * (plr * plr);
   double oper;
   if (avail > 0)
     oper = (ratio < min_plr) ? ratio : plr;
   else
     oper = 0.0;
-  const double frac = oper < min_plr ? fmin(1.0, SDC_MUL_RCP(oper, 0.05)) : 1.0;   // / min_plr
-  const double power = SDC_MUL_RCP(fflp * fpr * avail, 3.0) * frac;
+  const double frac = oper < min_plr ? fmin(1.0, oper * KC(1.0 / 0.05)) : 1.0;   // / min_plr
+  const double power = ((fflp * fpr * avail) * KC(1.0 / 3.0)) * frac;
   return oper > 0 ? power : 0.0;
 }
 
@@ -235,7 +315,9 @@ template <bool FAST>
 __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc, const int h, const int l, const int a_ls,
                                                 const int a_dc_in, const int a_bat_in, unsigned fault, const bool feat_ok_in,
                                                 const float frow, const uint2 q_ahead, const bool q_ahead_ok,
-                                                int32_t* __restrict__ actions_out_in, PairShared& sh) {
+                                                int32_t* __restrict__ actions_out_in, PairShared& sh, const double* kt_lds) {
+  typename KSel<FAST>::type kt{};
+  if constexpr (FAST) kt.t = kt_lds;
   const bool feat_ok = FAST ? true : feat_ok_in;
   int32_t* const actions_out = FAST ? nullptr : actions_out_in;
   const unsigned* rp = sh.rec[h];
@@ -260,8 +342,9 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   // enqueued up to step t of the episode, popped = tasks ever removed.  Tasks still queued that were
   // enqueued at or before step t: max(0, cum[t] - popped).
   if (wl < 0 || wl > 1) fault |= SDC_FAULT_WORKLOAD;
-  const double flex = 0.2;        // class default; make_ls_env never forwards flexible_load (make_envs_pyenv.py:37-41)
-  const double nonflex = 1 - flex;
+  static_assert(1 - 0.2 == 0.8, "nonflex");
+  const double flex = KC(0.2);    // class default; make_ls_env never forwards flexible_load (make_envs_pyenv.py:37-41)
+  const double nonflex = KC(0.8); // 1 - flex
   const int ns = (int)ceil(wl * nonflex * 100);
   const int shf = (int)floor(wl * flex * 100);
   const uint2* qt = S.qtab + (size_t)envc * S.qstride;
@@ -278,22 +361,17 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   if (avail > 0 && overdue > 0) od_proc = min(overdue, avail);
   popped += od_proc;
   avail = 90 - (ns + shf + od_proc);
-  int add = 0, dropped = 0, processed = 0;
-  int util_tasks;   // the flexible part of the utilisation, in tasks
-  if (a_ls == 0) {
-    const int room = S.queue_max - (cum_prev - popped);
-    add = min(shf, room);
-    dropped = shf - add;
-    util_tasks = od_proc + (shf - add);
-  } else if (a_ls == 2 && avail >= 1) {
-    processed = min(min(shf, avail), cum_prev - popped);
-    popped += processed;
-    util_tasks = shf + processed + od_proc;
-  } else {
-    util_tasks = shf + od_proc;
-  }
-  double util = SDC_DIV_CONST((double)util_tasks, 100);
-  util += SDC_DIV_CONST((double)ns, 100);
+  // (selects, not branches: the two envs of a wavefront usually take different actions, and every divergent `if` costs
+  // the pair an exec-mask save / restore and a branch on top of both bodies)
+  const int qlen = cum_prev - popped;                                // queued after the overdue tasks have run
+  const bool defer = a_ls == 0, drain = a_ls == 2 && avail >= 1;
+  const int add = defer ? min(shf, S.queue_max - qlen) : 0;          // a = 0: enqueue what fits, the rest is dropped (:231-242)
+  const int dropped = defer ? shf - add : 0;
+  const int processed = drain ? min(min(shf, avail), qlen) : 0;      // a = 2: pop from the left (:244-264)
+  popped += processed;
+  const int util_tasks = od_proc + (defer ? shf - add : shf + processed);   // the flexible part of the utilisation, in tasks (a = 1: :266-268)
+  double util = KDIV((double)util_tasks, 100);
+  util += KDIV((double)ns, 100);
   const int cum_now = cum_prev + add;
   const unsigned cumT_now = cumT_prev + (unsigned)add * (unsigned)now;
   const int total = cum_now - popped;
@@ -330,8 +408,8 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       const int c = (t == now) ? cum_now : (int)q_ahead.x;
       const unsigned m = half_ballot(need && t <= now && c > popped, h);
       const int f = __ffs((int)m) - 1;
-      const int src = (h << 5) + max(f - 1, 0);
-      const int c_m1 = __shfl((int)q_ahead.x, src), ct_m1 = __shfl((int)q_ahead.y, src);
+      const int src = ((h << 5) + max(f - 1, 0)) << 2;      // (byte address of the source lane, inside this half)
+      const int c_m1 = __builtin_amdgcn_ds_bpermute(src, (int)q_ahead.x), ct_m1 = __builtin_amdgcn_ds_bpermute(src, (int)q_ahead.y);
       if (need && m != 0u) {
         need_search = false;
         if (f > 0) {            // (f == 0: the head stays, and so do the cached cum / cumT of the step before it)
@@ -342,6 +420,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       }
     }
     if (__builtin_expect(__ballot(need_search) != 0ull, 0)) {
+      SDC_DBG_BIT(FAST, sh, 1u);
       const bool need = need_search;
       int lo = head, hi = now;
       while (__ballot(need && hi - lo + 1 > HL) != 0ull) {
@@ -398,7 +477,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     }
   }
   const double normq = sdc_div_const((double)total, (double)S.queue_max, S.rc_queue_max);
-  const double oldest_norm = SDC_DIV_CONST(oldest, 24), avg_norm = SDC_DIV_CONST(avg, 24);
+  const double oldest_norm = KDIV(oldest, 24), avg_norm = KDIV(avg, 24);
   // the load-shifting entries of the observation pool and of the info block leave for LDS here (lane 1 / lane 0 of the
   // half), so that none of them stays in registers across the rack model below
   if (feat_ok) {
@@ -482,12 +561,11 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   {
     const double m_cpu = pr[P_M_CPU], c_cpu = pr[P_C_CPU], rs_cpu = pr[P_RS_CPU];
     const double m_fan = pr[P_M_FAN], c_fan = pr[P_C_FAN], rs_fan = pr[P_RS_FAN];
-    const double cpu_shift = rs_cpu * SDC_DIV_CONST(load_pct, 100), fan_shift = rs_fan * SDC_DIV_CONST(load_pct, 20);
-#pragma unroll 1
-    for (int rk = l; rk < R; rk += HL) {      // (one pass for the shipped 16 / 20 / 25-rack configs)
-      const double sa = fmax(3.8, fmin(P.rack_supply[rk], 5.3));  // datacenter.py:209-215
+    const double cpu_shift = rs_cpu * KDIV(load_pct, 100), fan_shift = rs_fan * KDIV(load_pct, 20);
+    auto rack = [&](const int rk, const bool valid) __attribute__((always_inline)) {
+      const double sa = fmax(KC(3.8), fmin(P.rack_supply[rk], KC(5.3)));  // datacenter.py:209-215
       const double inlet = sa + stpt;
-      const double ratio = ((m_cpu + 0.05) * inlet + c_cpu) + cpu_shift;
+      const double ratio = ((m_cpu + KC(0.05)) * inlet + c_cpu) + cpu_shift;
       const double cpu1 = fmax(P.rack_idle[rk], P.rack_full[rk] * ratio);
       const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
       const double fan1 = pr[P_ITFAN_REF_P] * (v * pr[P_RC_ITFAN_REF_V_RATIO]);
@@ -499,21 +577,30 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       // <= 1.3e-16), eight orders below the fp32 outputs' resolution, at a fifth of the instructions of pow()
       // ... and power^1.096 / airflow^0.824 as ONE exp2 of the difference of the two scaled logarithms
       const double pw = pc + pf;
-      const bool plain = pw > 1e-300 && pw < 1e300 && vtot > 1e-300 && vtot < 1e300;    // (always, for a valid config)
-      double rise;
-      if (__builtin_expect(__ballot(!plain) == 0ull, 1))
-        rise = SDC_RACK_EXP2(1.096 * log2_pos_normal(pw) - 0.824 * log2_pos_normal(vtot));
-      else
-        rise = exp2(1.096 * log2(pw) - 0.824 * log2(vtot));
-      const double out = inlet + pr[P_K_OUTLET] * rise + -14.01;   // 1.918 power^1.096 / (c_air rho_air airflow^0.824 0.526) - 14.01
-      if (out - inlet < 2) bad_delta = true;
-      pcpu += pc;
-      pfan += pf;
-      outlet += out;
+      // (positive, normal, finite -- always, for a valid config.  Anything else has no outlet temperature in the
+      // reference either (a power of a negative number; datacenter.py:295-300 then raises): it is flagged like an outlet
+      // below the inlet and evaluated at 1.  No library-function fallback here: its ~50 constants would be materialised
+      // in front of this loop on every step.)
+      const bool plain = pw > KC(1e-300) && pw < KC(1e300) && vtot > KC(1e-300) && vtot < KC(1e300);
+      const double rise = SDC_RACK_EXP2(KC(1.096) * log2_pos_normal(plain ? pw : 1.0, kt) - KC(0.824) * log2_pos_normal(plain ? vtot : 1.0, kt), kt);
+      const double out = inlet + pr[P_K_OUTLET] * rise + KC(-14.01);   // 1.918 power^1.096 / (c_air rho_air airflow^0.824 0.526) - 14.01
+      if (valid && (out - inlet < 2 || !plain)) bad_delta = true;
+      pcpu += valid ? pc : 0.0;
+      pfan += valid ? pf : 0.0;
+      outlet += valid ? out : 0.0;
+    };
+    if constexpr (FAST) {
+      // the host has checked that the config has <= 32 racks: ONE pass, every lane of the half computing (lanes without
+      // a rack on the table's unused entries: their results are dropped by selects) -- straight-line code.  A loop here
+      // makes the compiler fetch all of the body's ~25 constants in front of it and hold them in registers across it.
+      rack(l, l < R);
+    } else {
+#pragma unroll 1
+      for (int rk = l; rk < R; rk += HL) rack(rk, true);      // (one pass for the shipped 16 / 20 / 25-rack configs)
     }
   }
 #if SDC_PRIO_DROP == 1
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(SDC_BASE_PRIO);
 #endif
   SDC_AT(5, sh, lane0);
   if (half_ballot(bad_delta, h) != 0u) fault |= SDC_FAULT_OUTLET_DELTA;
@@ -531,7 +618,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   const double c_air = pr[P_C_AIR], rho_air = pr[P_RHO_AIR], ct_fan_ref_p = pr[P_CT_FAN_REF_P];
   const double m_sys = rho_air * pr[P_CRAC_SUPPLY_PU] * p_it;
   const double q_cool = m_sys * c_air * fmax(0.0, avg_ret - stpt);
-  const double comp = chiller_power(ct_fan_ref_p, q_cool, amb);
+  const double comp = chiller_power(ct_fan_ref_p, q_cool, amb, kt);
   double ct;
   {
     const double dlt = fmax(50 - (amb - stpt), 1);
@@ -543,38 +630,38 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   double water;
   {
     const double range_temp = avg_ret - stpt;
-    const double y_int = 0.3528 * range_temp + 0.101;
-    double w = 0.044 * wet_bulb + y_int;
+    const double y_int = KC(0.3528) * range_temp + KC(0.101);
+    double w = KC(0.044) * wet_bulb + y_int;
     if (w < 0) w = 0;
-    w += w * 0.01;
-    water = np_round((w * 1000) / 4, 1e4);
+    w += w * KC(0.01);
+    water = k_round((w * 1000) / 4, 1e4);
   }
-  const double total_kw = SDC_DIV_CONST(p_it + ct + comp, 1e3);
+  const double total_kw = KDIV(p_it + ct + comp, 1e3);
 
   SDC_AT(7, sh, lane0);
   // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ----------------------
   // charge and discharge share one sigmoid and one division (selected operands, the reference's expressions)
   const double cap = pr[P_BAT_CAP];
-  const double dcload = SDC_DIV_CONST(total_kw, 1e3);  // MW (sustaindc_env.py:652)
+  const double dcload = KDIV(total_kw, 1e3);  // MW (sustaindc_env.py:652)
   double bat_load = lrec_f64(rp, R_BAT);
   const double e_nobat = dcload * 1e3 * 0.25;
   double energy = e_nobat, co2;
   if (a_bat != 2) {
     const bool chg = a_bat == 0;
     const double soc = sdc_div_const(bat_load - 0, cap - 0, pr[P_RC_BAT_CAP]);
-    const double sg = 1 / (1 + exp_plain(-(10 * (soc - (chg ? 0.5 : 0.25)))));       // sigmoid (|argument| <= 10)
-    const double rate = chg ? np_round(0.5 * (1 - sg), 1e4) : fmax(0.5, 4 * sg);
-    const double tu = SDC_DIV_CONST(rate * 15, 60);
+    const double sg = 1 / (1 + exp_plain(-(10 * (soc - (chg ? 0.5 : 0.25))), kt));       // sigmoid (|argument| <= 10)
+    const double rate = chg ? k_round(0.5 * (1 - sg), 1e4) : fmax(0.5, 4 * sg);
+    const double tu = KDIV(rate * 15, 60);
     // charge:    (1 * cap - bat_load) / ((1 * tu) - (-0.04))        discharge: (bat_load - 0 * cap) / (0.01 + (1 * tu))
-    const double quo = (chg ? cap - bat_load : bat_load) / (chg ? tu + 0.04 : 0.01 + tu);
+    const double quo = (chg ? cap - bat_load : bat_load) / (chg ? tu + KC(0.04) : KC(0.01) + tu);
     if (chg) {
-      const double max_charge = fmin((cap / 1) * 0.1, quo);
+      const double max_charge = fmin((cap / 1) * KC(0.1), quo);
       const double charging_load = fmin(max_charge, cap) * 1 * tu;
-      bat_load = np_round(bat_load + charging_load, 1e8);
+      bat_load = k_round(bat_load + charging_load, 1e8);
       energy = e_nobat + charging_load * 1e3;
     } else {
       const double max_d = fmin(fmin((cap / 1) * 1, quo), dcload * 0.25);   // dcload / 4
-      bat_load = np_round(bat_load - (fmin(max_d, cap) * 1 * tu), 1e8);
+      bat_load = k_round(bat_load - (fmin(max_d, cap) * 1 * tu), 1e8);
       const double discharge = max_d < cap ? max_d * tu : cap * tu;
       if (!(e_nobat >= discharge * 1e3)) fault |= SDC_FAULT_BAT_DISCHARGE;
       energy = e_nobat - discharge * 1e3;
@@ -636,10 +723,10 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   if (l == 0) {
     // ---- info block --------------------------------------------------------------------------------
     float* inf = sh.info[h];
-    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)SDC_MUL_RCP(p_it, 1e3);
-    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)SDC_MUL_RCP(ct, 1e3);
-    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)SDC_MUL_RCP(comp, 1e3);
-    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)SDC_MUL_RCP(ct + comp, 1e3);
+    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)(p_it * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)(ct * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)(comp * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)((ct + comp) * KC(1.0 / 1e3));
     inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
     inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
     inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
@@ -940,6 +1027,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   bool wdc = false;    // a window was replaced
   bool filed = false;  // (diagnostics) a re-centring request was filed
   if (__builtin_expect(__ballot((pend0 | pend1 | pend2 | pend3) != 0u) != 0ull, 0)) {
+    SDC_DBG_BIT(FAST, sh, 8u);
     const unsigned lx_new = hp[H_LAST_XNEW], lx_old = hp[H_LAST_XOLD];
     const int l_nprev = (int)hp[H_LAST_NPREV];
     // pd = (request step mod 2^22) << 10 | result set << 8 | request index + 1.  All due results are requested first (ONE
@@ -1016,6 +1104,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
       q.r0 = r0n;
       return false;
     }
+    SDC_DBG_BIT(FAST, sh, 2u);
     const bool wd = hw_update(q, x_new ^ flip, x_old ^ flip, has_old, n_prev, ok, h, l);
     wf = key_at(q.a, q.b, 0, h << 5);
     wl = key_at(q.a, q.b, q.hi - 1, h << 5);
@@ -1054,6 +1143,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     // whole when no lane of the wavefront has one)
     const bool x0a = ok && kb0 != kbl0 && bu.a >= lo0 && bu.a < hi0, x0b = ok && kb0 != kbl0 && bu.b >= lo0 && bu.b < hi0;
     const bool x1a = ok && kb1 != kbl1 && bl.a >= lo1 && bl.a < hi1, x1b = ok && kb1 != kbl1 && bl.b >= lo1 && bl.b < hi1;
+    if (__builtin_expect(__ballot(x0a || x0b || x1a || x1b) != 0ull, 0)) SDC_DBG_BIT(FAST, sh, 4u);
     if (__builtin_expect(__ballot(x0a || x0b) != 0ull, 0)) {
       const double va = x0a ? key_f64(bu.a) : 0.0, vb = x0b ? key_f64(bu.b) : 0.0;
       const unsigned c = half_sum_u32((x0a ? 1u : 0u) + (x0b ? 1u : 0u));
@@ -1090,6 +1180,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     const bool w0 = pend0 == 0u && ahead(q1, k1n, 3, 6), w1 = pend1 == 0u && ahead(q3, k3n, 3, 6);
     const bool w2 = pend2 == 0u && ahead(bu, n - qc0, 10, 10), w3 = pend3 == 0u && ahead(bl, n - qc1, 10, 10);
     if (__builtin_expect(__ballot(ok && (w0 || w1 || w2 || w3)) != 0ull, 0)) {
+      SDC_DBG_BIT(FAST, sh, 16u);
       if (!defer) {
         ok = ok && !(w0 || w1 || w2 || w3);      // (multi-step launches re-centre inline: the slow path redoes this step)
       } else {
@@ -1199,7 +1290,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
       rew[envc * 3 + 2] = (float)r[2];
       float* inf = sh.info[h];
       inf[SDC_INFO_ENERGY_Z] = (float)z;
-      inf[SDC_INFO_RESERVED] = wdc ? 2.0f : (!FAST && (S.debug_flags & 8) && filed) ? 4.0f : 0.0f;   // no ring read by this wavefront (2: a deferred re-centred window arrived; 4, with the timing diagnostics on: a request was filed)
+      inf[SDC_INFO_RESERVED] = wdc ? 2.0f : (SDC_DBG_OK(FAST) && (S.debug_flags & 8) && filed) ? 4.0f : 0.0f;   // no ring read by this wavefront (2: a deferred re-centred window arrived; 4, with the timing diagnostics on: a request was filed)
       inf[SDC_INFO_EP_RETURN_LS] = (float)ret[0];
       inf[SDC_INFO_EP_RETURN_DC] = (float)ret[1];
       inf[SDC_INFO_EP_RETURN_BAT] = (float)ret[2];
@@ -1220,8 +1311,10 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
                                           float* __restrict__ share_obs, unsigned char* __restrict__ done,
                                           float* __restrict__ info, float* __restrict__ final_obs,
                                           float* __restrict__ rew, int32_t* __restrict__ actions_out, const int step_no,
-                                          const bool defer) {
+                                          const bool defer, double* kt, const bool kt_fill) {
   const int TL = S.table_len;
+  double kt0 = 0.0, kt1 = 0.0;
+  if (kt_fill) ktab_fetch(lane, kt0, kt1);      // (the constant table: requested first, stored with the record)
   const int h = lane >> 5, l = lane & (HL - 1);
   const int n_here = FAST ? EPW : min(EPW, S.n_envs - env0);   // envs of this pair that exist (1 for the last pair of an odd batch)
   const int envc = env0 + min(h, n_here - 1);             // this lane's env (the missing one mirrors the last)
@@ -1255,7 +1348,8 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   const bool one_cfg = FAST ? true : S.n_cfg == 1;
   double prm_pre = 0.0;
   if (one_cfg && l < P_COUNT) prm_pre = reinterpret_cast<const double*>(&S.dc[0].p.m_cpu)[l];
-  const unsigned long long dbg_entry = (!FAST && (S.debug_flags & 16)) ? wall_clock64() : 0ull;
+  const unsigned long long dbg_entry = (SDC_DBG_OK(FAST) && (S.debug_flags & 16)) ? wall_clock64() : 0ull;
+  if (SDC_DBG_OK(FAST) && (S.debug_flags & 8) && lane == 0) sh.dbg_bits = 0u;
 
   // ---- level 0: the two state records (one dwordx2 per lane, 512 contiguous bytes), headers, actions ----------------
   uint2* recp = reinterpret_cast<uint2*>(S.rec + (size_t)envc * SDC_REC_DWORDS) + l;
@@ -1272,12 +1366,13 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   if (FAST || S.policy[1] == SDC_POLICY_EXTERNAL) a_dc = act_v.y;
   if (FAST || S.policy[2] == SDC_POLICY_EXTERNAL) a_bat = act_v.z;
   unsigned long long dbg_rec = 0ull;
-  if (!FAST && __builtin_expect((S.debug_flags & 32) != 0, 0)) {
+  if (SDC_DBG_OK(FAST) && __builtin_expect((S.debug_flags & 32) != 0, 0)) {
     unsigned tmp = rr.x;
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(tmp)::"memory");
     dbg_rec = wall_clock64() + (tmp & 0u);
   }
   reinterpret_cast<uint2*>(sh.rec[h])[l] = rr;
+  if (kt_fill) ktab_store(kt, lane, kt0, kt1);
   wave_sync();
   const unsigned* rp = sh.rec[h];
   const int i = lrec_i32(rp, R_CURSOR), rel = lrec_i32(rp, R_TREL);
@@ -1372,7 +1467,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   wave_sync();
 
   unsigned long long dbg_a0 = 0ull;
-  if (!FAST && __builtin_expect((S.debug_flags & 8) != 0, 0)) dbg_a0 = wall_clock64();
+  if (SDC_DBG_OK(FAST) && __builtin_expect((S.debug_flags & 8) != 0, 0)) dbg_a0 = wall_clock64();
   // the rank windows of both envs, one key each per lane: wanted at the end of the step, so the loads are issued here --
   // after the start-of-launch burst of every env's record / header / gather loads -- and ride along in 8 registers
   // reward-side state (headers: returns, trackers, sums; the rank windows' keys; the evicted ring key): wanted at the end of
@@ -1393,7 +1488,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   const unsigned hdB = S.hdr[(size_t)env1c * SDC_HDR_DWORDS + lane];
   const uint4 wka = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l];       // keys 2l of the 4 windows
   const uint4 wkb = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 2 * l + 1];   // keys 2l + 1
-  const DynOut d = pair_dynamics<FAST>(S, envc, h, l, a_ls, a_dc, a_bat, fault, feat_ok, frow, q_ahead, q_ahead_ok, actions_out, sh);
+  const DynOut d = pair_dynamics<FAST>(S, envc, h, l, a_ls, a_dc, a_bat, fault, feat_ok, frow, q_ahead, q_ahead_ok, actions_out, sh, kt);
   wave_sync();
 
   // ---- episodes without feature rows: the observation features of such an env, all 64 lanes cooperating ---------------
@@ -1411,9 +1506,9 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
     wave_sync();
   }
 #if SDC_PRIO_DROP == 2
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(SDC_BASE_PRIO);
 #endif
-  if (!FAST && __builtin_expect((S.debug_flags & 8) != 0, 0) && lane == 0) sh.dbg_t[0] = wall_clock64();
+  if (SDC_DBG_OK(FAST) && __builtin_expect((S.debug_flags & 8) != 0, 0) && lane == 0) sh.dbg_t[0] = wall_clock64();
 
   // ---- rewards + reward-state upkeep: both envs at once on the O(1) path; an env that needs its ring (or anything
   // unusual) is redone whole-wavefront from its untouched state ------------------------------------------------------------
@@ -1421,6 +1516,10 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   sh.hdr[1][lane] = hdB;
   wave_sync();
   const unsigned long long fast_m = pair_reward_fast<FAST>(S, envc, active, h, l, wka, wkb, d, x_old_l, rew, sh, step_no, defer);
+  // (the loop sits behind its own unlikely test: otherwise the ~50 constants of env_reward, hoisted into the loop's
+  // preheader, are materialised on every step)
+  const bool all_fast = ((fast_m & 1ull) != 0ull) && (n_here < 2 || ((fast_m >> HL) & 1ull) != 0ull);
+  if (__builtin_expect(!all_fast, 0))
 #pragma unroll 1
   for (int e = 0; e < n_here; e++) {
     if (__builtin_expect((fast_m >> (e * HL)) & 1ull, 1)) continue;
@@ -1431,7 +1530,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
                pick_f64(d.norm_ci, e), pick_f64(d.oldest_norm, e), pick_i32(d.overdue, e), pick_i32(d.hourq_n, e),
                pick_f64(d.p_it, e), pick_f64(d.total_kw, e), pick_f64(d.water, e), rew, sh.info[e], sh.tl);
   }
-  if (!FAST && __builtin_expect((S.debug_flags & 8) != 0, 0)) {
+  if (SDC_DBG_OK(FAST) && __builtin_expect((S.debug_flags & 8) != 0, 0)) {
     wave_sync();
     if (lane == 0) {
       const unsigned long long dbg_a3 = wall_clock64();
@@ -1441,6 +1540,9 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
         inf[41] = (S.debug_flags & 16) ? (float)(dbg_a0 - dbg_entry) : (float)(sh.dbg_t[0] - dbg_a0);
         inf[42] = (float)(dbg_a3 - sh.dbg_t[0]);
         if (SDC_STAMP_A != 0 && SDC_STAMP_B != 0) inf[42] = (float)(sh.dbg_s[1] - sh.dbg_s[0]);
+        inf[SDC_INFO_RESERVED] += (float)(8u * sh.dbg_bits);
+        if (S.debug_flags & 256)     // where the wavefront ran: XCC id << 16 | HW_ID (wave, SIMD, CU, SH, SE)
+          inf[40] = (float)(((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu));
         inf[43] = (S.debug_flags & 16) ? (float)(dbg_a3 & 0xFFFFFull) : (float)(dbg_a3 - dbg_a0);
       }
     }
@@ -1503,16 +1605,16 @@ __device__ __forceinline__ int first_pair_of_block(const int bi, const int nb) {
 #define SDC_SWEEP_BLOCKS (SDC_RQ_MAX / SDC_STEP_WPB)
 #define SDC_CUS 256
 #ifndef SDC_SWEEP_PRIO
-#define SDC_SWEEP_PRIO 0
+#define SDC_SWEEP_PRIO 3
 #endif
 #ifndef SDC_SWEEP_SPREAD
 #define SDC_SWEEP_SPREAD 1
 #endif
 #ifndef SDC_SWEEP_AT
-#define SDC_SWEEP_AT 320
+#define SDC_SWEEP_AT 0
 #endif
 #ifndef SDC_LATE_PRIO
-#define SDC_LATE_PRIO 1
+#define SDC_LATE_PRIO (SDC_BASE_PRIO + 1)
 #endif
 // The kernel arguments (SdcDev by value + the output pointers: ten 64-byte lines) are read by scalar loads wherever the
 // compiler first needs a field -- several dependent batches, each a miss in the scalar cache at the start of a launch.
@@ -1543,12 +1645,14 @@ __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const
   if (j >= cnt) return;
   const SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + j;
   if (rq->step != S.step_no - 1) return;                            // stale (a multi-step launch came in between)
-  // (issue priority SDC_SWEEP_PRIO; measured: above the env pairs' it costs the random-action case, below it changes nothing)
+  // (issue priority SDC_SWEEP_PRIO = 3, above the env pairs': the launch cannot end before its sweeps have, and a sweep
+  // is one wavefront working through 40 KB -- measured with the sweep workgroups first in the grid, us per step: priority 3
+  // 13.13, same as the pairs 13.43, below them 15.3)
   __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
   const int env = rq->env, w = rq->win, n = rq->n;
   QTrack A = {rq->keys[lane], rq->r0, rq->hi};
   const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), rq->patch_slot, rq->patch_x};
-  qt_refill(A, rq->dir, rq->kt, n, R, lane, tl, w == 3 ? KEY_NONE : 0u);
+  qt_refill<10>(A, rq->dir, rq->kt, n, R, lane, tl, w == 3 ? KEY_NONE : 0u);
   SdcRefillRes* rs = S.rs + set * SDC_RQ_MAX + j;
   rs->keys[lane] = A.w;
   if (lane == 0) {
@@ -1561,25 +1665,27 @@ __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const
 
 // One launch of this kernel is one env-step of all N environments.
 template <bool FAST>
-__device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs, const int rel_hint, const int32_t* __restrict__ actions,
+__device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs, double* kt, const int rel_hint, const int32_t* __restrict__ actions,
                                                 float* __restrict__ obs, float* __restrict__ share_obs,
                                                 unsigned char* __restrict__ done, float* __restrict__ info,
                                                 float* __restrict__ final_obs, float* __restrict__ rew) {
-  const KernargTouch kt = kernarg_touch();
+  const KernargTouch ktouch = kernarg_touch();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
   const int lane = threadIdx.x % SDC_WAVE;
-  kernarg_touch_done(kt);
+  kernarg_touch_done(ktouch);
   const int pair_blocks = (int)gridDim.x - SDC_SWEEP_BLOCKS;
   // where the 32 sweep workgroups sit in the grid: after the first SDC_SWEEP_AT pair workgroups (or last, in a small grid)
   const int sweep_first = pair_blocks > SDC_SWEEP_AT ? SDC_SWEEP_AT : pair_blocks;
   const int bx = (int)blockIdx.x;
   if (bx >= sweep_first && bx < sweep_first + SDC_SWEEP_BLOCKS) {
-    // Not first: the env pairs' workgroups must fill the CUs evenly (two rounds of 256 at 4096 envs), and the sweep
-    // workgroups without a request exit at once -- in front they leave 32 CUs one workgroup short until a third round
-    // lands there.  Not last either: as the youngest wavefronts of their SIMDs the sweeps would be served after both env
-    // pairs and end the launch when there are many of them (constant policies: ~100 requests per step).  Early in the
-    // second round (measured at 128 / 256 / 320 / 384 / last: uniform-random actions 15.7 / 15.5 / 15.6 / 15.6 / 15.6 us
-    // per step, all-idle actions 15.4 / 16.6 / 15.8 / 15.8 / 17.2).
+    // WHERE the 32 sweep workgroups sit in the grid decides how the env pairs' workgroups land on the CUs (round 3,
+    // tools/wave_tail.py: every pair wavefront stamps the SIMD it ran on).  Inserted after the first 320 pair workgroups
+    // (round 2) they pushed the dispatcher off its stride: 128 SIMDs received THREE pair wavefronts and 128 only one, and
+    // the last wavefront of every launch (300 of 300) was one of a trio, ~1.2 us behind the rest.  First or last in the
+    // grid every SIMD gets exactly two.  Last, the sweeps -- dispatched last, the youngest wavefronts of their SIMDs --
+    // end the launch (15.4 us per step); FIRST and at raised issue priority they are done while the pairs still run:
+    // 13.1 us per step against 13.6 with the insertion point at 320 (uniform-random actions; all-idle actions, four
+    // times the requests: 14.1 against 15.1).
 #if SDC_SWEEP_SPREAD
     serve_recentring_requests(S, (bx - sweep_first) + wave * SDC_SWEEP_BLOCKS, lane, shs[wave].tl);   // requests 0..31 on 32 different CUs
 #else
@@ -1593,24 +1699,31 @@ __device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs
   // A SIMD issues from its oldest wavefront first: of the two env pairs that share a SIMD at 4096 envs, the one whose
   // workgroup arrived in the second round of 256 (one per CU) would finish ~1.8 us after the other.  Raised priority for
   // the later rounds evens the two out, and the launch ends when the slower one does.
-  if (pb >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
+  if (pb >= SDC_CUS)
+    __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
+  else
+    __builtin_amdgcn_s_setprio(SDC_BASE_PRIO);
   if (!FAST && lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
   pair_step<FAST>(S, shs[wave], env0, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew,
-                  FAST ? nullptr : S.actions_out, S.step_no, true);
+                  FAST ? nullptr : S.actions_out, S.step_no, true, kt, true);
   if (!FAST && lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 1);
 }
+// (three resident wavefronts per SIMD: two env pairs + room for a spare one, <= 168 VGPRs)
+#define SDC_STEP_BOUNDS __launch_bounds__(SDC_WAVE * SDC_STEP_WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 // the general kernel, and the one for the common case (see pair_dynamics; the host picks: sdc_capi.hip fast_case)
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_WPB) void sdc_dynamics_kernel(
+extern "C" __global__ SDC_STEP_BOUNDS void sdc_dynamics_kernel(
     SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
     unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
   __shared__ PairShared shs[SDC_STEP_WPB];
-  dynamics_launch<false>(S, shs, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+  __shared__ double ktab[SDC_K_LDS];
+  dynamics_launch<false>(S, shs, ktab, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
 }
-extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_WPB) void sdc_dynamics_fast_kernel(
+extern "C" __global__ SDC_STEP_BOUNDS void sdc_dynamics_fast_kernel(
     SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
     unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
   __shared__ PairShared shs[SDC_STEP_WPB];
-  dynamics_launch<true>(S, shs, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+  __shared__ double ktab[SDC_K_LDS];
+  dynamics_launch<true>(S, shs, ktab, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
 }
 
 // K env-steps per launch for action sequences that are known up front or chosen by the built-in rule-based policies
@@ -1620,7 +1733,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 12 / SDC_STEP_W
 // obs [K][N][3][26], share_obs [K][N][29] (or null), rew [K][N][3], done [K][N], info [K][N][44] (or null) hold every
 // step's outputs.  The host keeps K within the episode (sdc_rollout).
 template <bool FAST>
-__device__ __forceinline__ void rollout_launch(const SdcDev& S, PairShared* shs, const int K, const int rel_hint,
+__device__ __forceinline__ void rollout_launch(const SdcDev& S, PairShared* shs, double* kt, const int K, const int rel_hint,
                                                const int32_t* __restrict__ actions, float* __restrict__ obs,
                                                float* __restrict__ share_obs, unsigned char* __restrict__ done,
                                                float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
@@ -1642,7 +1755,7 @@ __device__ __forceinline__ void rollout_launch(const SdcDev& S, PairShared* shs,
                     (FAST || actions) ? actions + (size_t)k * N * 3 : nullptr, obs + (size_t)k * N * SDC_OBS_OUT,
                     (FAST || share_obs) ? share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM : nullptr, done + (size_t)k * N,
                     (FAST || info) ? info + (size_t)k * N * SDC_INFO_DIM : nullptr, k == K - 1 ? final_obs : nullptr,
-                    rew + (size_t)k * N * 3, aout ? aout + (size_t)k * N * 3 : nullptr, S.step_no + k, false);
+                    rew + (size_t)k * N * 3, aout ? aout + (size_t)k * N * 3 : nullptr, S.step_no + k, false, kt, k == 0);
     // this wavefront's stores of step k are the loads of its step k + 1: complete them and drop stale lines of the
     // CU's vector L1 (workgroup scope: the L2 behind it is the same for both)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1656,12 +1769,14 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WP
     float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs,
     float* __restrict__ rew) {
   __shared__ PairShared shs[SDC_STEP_WPB];
-  rollout_launch<false>(S, shs, K, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+  __shared__ double ktab[SDC_K_LDS];
+  rollout_launch<false>(S, shs, ktab, K, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
 }
 extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WPB) void sdc_rollout_fast_kernel(
     SdcDev S, const int K, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs,
     float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs,
     float* __restrict__ rew) {
   __shared__ PairShared shs[SDC_STEP_WPB];
-  rollout_launch<true>(S, shs, K, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+  __shared__ double ktab[SDC_K_LDS];
+  rollout_launch<true>(S, shs, ktab, K, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
 }

@@ -9,10 +9,12 @@ SRCS="dc_rl_amd/csrc/sdc_capi.hip dc_rl_amd/csrc/sdc_step.hip dc_rl_amd/csrc/sdc
 NAMES=""
 for v in "$@"; do
   name="${v%%:*}"; flags="${v#*:}"
+  rm -f tools/bin/lib_$name.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $flags -o tools/bin/lib_$name.so $SRCS 2>/dev/null &
   NAMES="$NAMES $name"
 done
 wait
+for n in $NAMES; do [ -f tools/bin/lib_$n.so ] || { echo "variant $n did not compile"; exit 1; }; done
 REMOTE="cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/orig.so; for rep in 1 2; do for n in $NAMES; do cp tools/bin/lib_\$n.so dc_rl_amd/csrc/libsustaindc_hip.so; echo \"== \$n (pass \$rep)\"; $CMD; done; done"
 T=${GTIMEOUT:-900}
 exec timeout $((T + 900)) gpurun --timeout $T -- "$REMOTE"
