@@ -599,12 +599,46 @@ def main():
                     o = (16 + done_steps) % (POOL - Kr)
                     eng.rollout(pool[o:o + k])
                     done_steps += k
+                    if os.environ.get("SDC_BENCH_DEBUG"):
+                        torch.cuda.synchronize(); print("rollout launch k", k, "t", time.perf_counter() - tr, file=sys.stderr)
                 torch.cuda.synchronize()
                 tr = time.perf_counter() - tr
                 out["rollout"] = {"steps_per_launch": Kr, "value": round(N * done_steps / tr, 1), "unit": "env-steps/s",
                                   "ms_per_step": round(tr / done_steps * 1e3, 5)}
             except Exception as e:
                 out["rollout"] = {"error": repr(e)}
+        if world == 1 and not args.no_rollout:
+            # the CLOSED loop: sdc_rollout_actor, 48 env-steps per launch with the three agents' actor networks (the
+            # reference's StochasticPolicy: LayerNorm(26) -> 64 -> 64 -> 3, fp32, happo.yaml hidden_sizes [64, 64]; random
+            # weights) evaluated inside the kernel between the steps -- every env-step includes three network inferences
+            try:
+                rngw = np.random.default_rng(7)
+                for a_ in range(3):
+                    eng.set_actor(a_, {"ln0_gamma": 1 + 0.1 * rngw.standard_normal(26), "ln0_beta": 0.1 * rngw.standard_normal(26),
+                                       "w1": rngw.standard_normal((64, 26)) * 0.3, "b1": 0.1 * rngw.standard_normal(64),
+                                       "ln1_gamma": 1 + 0.1 * rngw.standard_normal(64), "ln1_beta": 0.1 * rngw.standard_normal(64),
+                                       "w2": rngw.standard_normal((64, 64)) * 0.2, "b2": 0.1 * rngw.standard_normal(64),
+                                       "ln2_gamma": 1 + 0.1 * rngw.standard_normal(64), "ln2_beta": 0.1 * rngw.standard_normal(64),
+                                       "w3": rngw.standard_normal((3, 64)) * 0.2, "b3": np.zeros(3), "activation": "tanh"})
+                eng.reset()
+                for i in range(16):
+                    eng.step(pool[i])
+                Kr, done_steps = 48, 0
+                torch.cuda.synchronize()
+                tr = time.perf_counter()
+                while done_steps < 1920:
+                    k = min(Kr, eng.steps_to_episode_end())
+                    _, _, _, _, _, acts_cl, _ = eng.rollout_actor(k, sample=True)
+                    done_steps += k
+                torch.cuda.synchronize()
+                tr = time.perf_counter() - tr
+                hist_a = torch.bincount(acts_cl.reshape(-1).long(), minlength=3).cpu().tolist()
+                out["closed_loop"] = {"steps_per_launch": Kr, "value": round(N * done_steps / tr, 1), "unit": "env-steps/s",
+                                      "ms_per_step": round(tr / done_steps * 1e3, 5),
+                                      "policy": "3 actor networks LayerNorm(26)-64-64-3 (tanh, fp32) evaluated in the kernel every "
+                                                "step, actions sampled from their softmax", "actions_last_launch": hist_a}
+            except Exception as e:
+                out["closed_loop"] = {"error": repr(e)}
         if world == 1 and not args.no_secondary:
             # secondary lines (not `value`): the shape the reference's shipped HARL YAML trains on, and how the rate moves
             # with the number of envs per GPU -- so that the driver's record, not only profiles/, shows both

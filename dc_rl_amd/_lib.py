@@ -18,7 +18,7 @@ INFO_DIM = 44
 TABLE_LEN = 35040
 HDR_DWORDS = 64    # csrc/sdc_device.hpp SdcHdr: 256-byte per-env header
 QWIN = 64          # csrc/sdc_device.hpp SDC_WIN: keys per rank window (4 windows per env: Q1, Q3, upper / lower clip bound)
-ABI_VERSION = 300  # include/sustaindc_hip.h SDC_ABI_VERSION: the struct layouts and argument lists this binding was written for
+ABI_VERSION = 310  # include/sustaindc_hip.h SDC_ABI_VERSION: the struct layouts and argument lists this binding was written for
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
@@ -107,12 +107,24 @@ class SdcResetOverride(C.Structure):
     ]
 
 
+class SdcActorParams(C.Structure):
+    """One agent's actor network in torch's layout (include/sustaindc_hip.h sdc_actor_params)."""
+    _fields_ = [
+        ("ln0_gamma", C.c_float * 26), ("ln0_beta", C.c_float * 26),
+        ("w1", C.c_float * (64 * 26)), ("b1", C.c_float * 64), ("ln1_gamma", C.c_float * 64), ("ln1_beta", C.c_float * 64),
+        ("w2", C.c_float * (64 * 64)), ("b2", C.c_float * 64), ("ln2_gamma", C.c_float * 64), ("ln2_beta", C.c_float * 64),
+        ("w3", C.c_float * (3 * 64)), ("b3", C.c_float * 3),
+        ("use_feature_normalization", C.c_int32), ("activation", C.c_int32),
+    ]
+
+
 EXPORTS = [
     "sdc_last_error", "sdc_version", "sdc_create", "sdc_destroy", "sdc_set_seed", "sdc_weather_window_len", "sdc_set_tables",
     "sdc_set_dc_params", "sdc_assign_envs", "sdc_reset", "sdc_step", "sdc_rollout", "sdc_steps_to_episode_end",
     "sdc_last_done",
     "sdc_get_state", "sdc_set_state",
     "sdc_hist_stride", "sdc_queue_stride", "sdc_profile_enable", "sdc_profile_read",
+    "sdc_set_actor", "sdc_rollout_actor",
 ]
 
 
@@ -166,6 +178,8 @@ def load():
     L.sdc_set_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_profile_enable.argtypes = [vp, C.c_int]
     L.sdc_profile_read.argtypes = [vp, dp, C.c_int]
+    L.sdc_set_actor.argtypes = [vp, C.c_int, C.POINTER(SdcActorParams)]
+    L.sdc_rollout_actor.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, vp, fp, fp, vp, fp, vp]
     for name in EXPORTS:
         getattr(L, name)
     built = L.sdc_version()

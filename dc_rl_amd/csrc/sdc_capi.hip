@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "sdc_device.hpp"
+#include "sdc_actor.hpp"
 
 extern "C" __global__ void sdc_dynamics_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                                unsigned char* done, float* info, float* final_obs, float* rew);
@@ -22,6 +23,11 @@ extern "C" __global__ void sdc_dynamics_fast_kernel(SdcDev S, int rel_hint, cons
                                                     unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_rollout_fast_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs,
                                                    float* share_obs, unsigned char* done, float* info, float* final_obs, float* rew);
+extern "C" __global__ void sdc_rollout_actor_kernel(SdcDev S, int K, int rel_hint, const SdcActorDev* nets, const float* obs_in,
+                                                    int sample, float* obs, float* share_obs, unsigned char* done, float* info,
+                                                    float* final_obs, float* rew, int32_t* actions_out, float* logits_out,
+                                                    float* obs_latch);
+size_t sdc_rollout_actor_lds_bytes();
 extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
 extern "C" __global__ void sdc_features_kernel(SdcDev S);
 extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
@@ -83,6 +89,12 @@ struct sdc_handle {
   int steps_to_terminal = 0;
   std::vector<unsigned char> feat_host;   // host mirror of R_FEAT_OK: the env's episode has valid observation feature rows
   int n_feat_host = 0;                    // how many envs have
+  // closed loop (sdc_set_actor / sdc_rollout_actor): the three actor networks and the library's copy of the latest
+  // observations (what the first actions of a launch are chosen from); allocated when the first actor is set
+  SdcActorDev* actor_dev = nullptr;
+  bool actor_set[3] = {false, false, false};
+  float* obs_latch = nullptr;
+  bool latch_valid = false;
   int racks_cfg0 = 0;                     // racks of data-centre config 0 (the specialised kernels take <= 32: one pass)
   std::vector<unsigned char> last_done;   // which envs finished in the last sdc_step / sdc_rollout call (host mirror)
   int n_last_done = 0;
@@ -199,6 +211,14 @@ bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_o
 int invalidate_trackers(sdc_handle* h) {
   std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
   if (rec_put(h, H_VALID, 1, z.data(), 1)) return -1;
+  return 0;
+}
+
+// keep the library's copy of the latest observations (closed loop only: no actor set, no copy)
+int latch_obs(sdc_handle* h, const float* obs, hipStream_t st) {
+  if (!h->obs_latch || !obs) return 0;
+  HIP_TRY(hipMemcpyAsync(h->obs_latch, obs, sizeof(float) * (size_t)h->cfg.n_envs * SDC_OBS_OUT, hipMemcpyDeviceToDevice, st));
+  h->latch_valid = true;
   return 0;
 }
 
@@ -558,6 +578,7 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
     if (es != hipSuccess) return fail("sdc_reset: injected reset", es);
   }
   HIP_TRY(hipGetLastError());
+  if (latch_obs(h, obs, st)) return -1;
   if (mask_host) HIP_TRY(hipStreamSynchronize(st));  // mask staging buffer is reused by the next call
   sync_mirror(h);
   for (int e = 0; e < N; e++)
@@ -622,6 +643,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
     }
   }
   if (timed) h->prof_used += 1;
+  if (latch_obs(h, obs, st)) return -1;
   return 0;
 }
 
@@ -678,6 +700,101 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
           note_features(h, e);
         }
       recompute_steps_to_terminal(h);
+    }
+  }
+  if (latch_obs(h, obs + (size_t)(n_steps - 1) * N * SDC_OBS_OUT, st)) return -1;
+  return 0;
+}
+
+int sdc_set_actor(sdc_handle* h, int slot, const sdc_actor_params* p) {
+  if (!h || !p) return fail_msg("sdc_set_actor: null argument");
+  if (slot < 0 || slot > 2) return fail_msg("sdc_set_actor: agent_slot must be 0 (ls), 1 (dc) or 2 (bat)");
+  if (p->activation < 0 || p->activation > 1) return fail_msg("sdc_set_actor: activation must be 0 (tanh) or 1 (relu)");
+  HIP_TRY(hipSetDevice(h->device));
+  if (!h->actor_dev) {
+    if (dev_alloc(h, &h->actor_dev, 3) != 0) return -1;
+    if (dev_alloc(h, &h->obs_latch, (size_t)h->cfg.n_envs * SDC_OBS_OUT) != 0) return -1;
+    h->latch_valid = false;      // (filled by the next reset / step / rollout)
+  }
+  // torch's [out][in] rows -> the kernel's k-major, pairwise interleaved layout (sdc_actor.hpp)
+  static SdcActorDev a;
+  std::memset(&a, 0, sizeof(a));
+  for (int k = 0; k < SDC_ACT_IN; k++) {
+    a.ln0_g[k] = p->ln0_gamma[k];
+    a.ln0_b[k] = p->ln0_beta[k];
+  }
+  for (int j = 0; j < SDC_ACT_H; j++) {
+    for (int k = 0; k < SDC_ACT_IN; k++) a.w1[k / 2][j][k & 1] = p->w1[j * SDC_ACT_IN + k];
+    for (int k = 0; k < SDC_ACT_H; k++) a.w2[k / 2][j][k & 1] = p->w2[j * SDC_ACT_H + k];
+    a.b1[j] = p->b1[j]; a.ln1_g[j] = p->ln1_gamma[j]; a.ln1_b[j] = p->ln1_beta[j];
+    a.b2[j] = p->b2[j]; a.ln2_g[j] = p->ln2_gamma[j]; a.ln2_b[j] = p->ln2_beta[j];
+    for (int c = 0; c < SDC_ACT_OUT; c++) a.w3[c][j] = p->w3[c * SDC_ACT_H + j];
+  }
+  for (int c = 0; c < SDC_ACT_OUT; c++) a.b3[c] = p->b3[c];
+  a.flags = (p->use_feature_normalization ? 1 : 0) | (p->activation << 1);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->actor_dev + slot, &a, sizeof(a), hipMemcpyHostToDevice));
+  h->actor_set[slot] = true;
+  return 0;
+}
+
+int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float* share_obs, float* rew, uint8_t* done,
+                      float* info, float* final_obs, int32_t* actions_out, float* logits_out, void* stream) {
+  if (!h || !obs || !share_obs || !rew || !done || !info || !actions_out) return fail_msg("sdc_rollout_actor: null argument");
+  if (!h->actor_set[0] || !h->actor_set[1] || !h->actor_set[2]) return fail_msg("sdc_rollout_actor: sdc_set_actor all three agents first");
+  if (!h->started) return fail_msg("sdc_rollout_actor: sdc_reset must be called first");
+  if (!h->latch_valid) return fail_msg("sdc_rollout_actor: no observations yet (the actors were set after the last reset / step: reset or step once)");
+  if (n_steps <= 0) return fail_msg("sdc_rollout_actor: n_steps must be positive");
+  if (n_steps > h->steps_to_terminal)
+    return fail_msg("sdc_rollout_actor: the rollout would run past the end of an episode (" + std::to_string(h->steps_to_terminal) +
+                    " steps left); split it there");
+  // the common case only: what fast_case checks, with the actions coming from the actors instead of the caller
+  static const int32_t some_actions = 0;
+  if (!fast_case(h, &some_actions, share_obs, info, false) || (h->cfg.debug_flags & 1))
+    return fail_msg("sdc_rollout_actor: needs the common case (lock-step batch with feature rows, one data-centre config of <= 32 "
+                    "racks, external-action slots, default rewards, an even number of envs, no debug flags)");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int N = h->cfg.n_envs;
+  SdcDev d = h->d;
+  d.actions_out = nullptr;
+  h->step_no = next_step_no(h->step_no, 0);
+  d.step_no = h->step_no;
+  h->step_no = next_step_no(h->step_no, n_steps + 3);
+  HIP_TRY(hipMemsetAsync(d.rq_count, 0, sizeof(int) * 4, st));
+  const size_t lds = sdc_rollout_actor_lds_bytes();
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sdc_rollout_actor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  constexpr int AWPB = 8;     // sdc_step.hip SDC_ACTOR_WPB
+  const int blocks = ((N + 1) / 2 + AWPB - 1) / AWPB;
+  hipLaunchKernelGGL(sdc_rollout_actor_kernel, dim3(blocks), dim3(SDC_WAVE * AWPB), lds, st, d, n_steps, h->rel_hint, h->actor_dev,
+                     h->obs_latch, sample ? 1 : 0, obs, share_obs, done, info, final_obs, rew, actions_out, logits_out, h->obs_latch);
+  HIP_TRY(hipGetLastError());
+  h->n_last_done = 0;
+  h->steps_to_terminal -= n_steps;
+  h->pending += n_steps;
+  if (h->rel_hint >= 0) h->rel_hint += n_steps;
+  if (h->steps_to_terminal == 0) {
+    sync_mirror(h);
+    note_done(h);
+    if (h->cfg.auto_reset) {
+      d.reset_mask = nullptr;
+      const size_t last = (size_t)(n_steps - 1) * N;
+      hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
+                         h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs + last * SDC_OBS_OUT,
+                         share_obs + last * SDC_SHARE_OBS_DIM, nullptr, nullptr);
+      launch_features(h, d, st);
+      HIP_TRY(hipGetLastError());
+      for (int e = 0; e < N; e++)
+        if (h->host_t_rel[e] >= h->cfg.episode_steps) {
+          h->host_t_rel[e] = 0;
+          note_features(h, e);
+        }
+      recompute_steps_to_terminal(h);
+      if (latch_obs(h, obs + last * SDC_OBS_OUT, st)) return -1;     // the next launch starts from the reset observations
     }
   }
   return 0;

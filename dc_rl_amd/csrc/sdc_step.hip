@@ -26,6 +26,7 @@
 // Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
 #include "sdc_ringpath.hpp"
 #include "sdc_halfwin.hpp"
+#include "sdc_actor.hpp"
 
 namespace {
 
@@ -1305,13 +1306,16 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
 
 // One env-step of the env pair (env0, env0 + 1) by its wavefront: loads the state, runs the dynamics of both, the rewards
 // and the reward-state upkeep of each, stores the new state and the outputs.
-template <bool FAST>
+// ACTOR: the three actions of this lane's env come in registers (act_reg: the in-kernel neural policy of
+// sdc_rollout_actor_kernel has just computed them) instead of from the caller's array.
+template <bool FAST, bool ACTOR = false>
 __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const int env0, const int lane, const int rel_hint,
                                           const int32_t* __restrict__ actions, float* __restrict__ obs,
                                           float* __restrict__ share_obs, unsigned char* __restrict__ done,
                                           float* __restrict__ info, float* __restrict__ final_obs,
                                           float* __restrict__ rew, int32_t* __restrict__ actions_out, const int step_no,
-                                          const bool defer, double* kt, const bool kt_fill) {
+                                          const bool defer, double* kt, const bool kt_fill, const int act_reg0 = 1,
+                                          const int act_reg1 = 1, const int act_reg2 = 2) {
   const int TL = S.table_len;
   double kt0 = 0.0, kt1 = 0.0;
   if (kt_fill) ktab_fetch(lane, kt0, kt1);      // (the constant table: requested first, stored with the record)
@@ -1326,7 +1330,11 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   // step a second memory round trip.  Memory returns loads in order, so once the record below has arrived these have too.
   typedef int int3v __attribute__((ext_vector_type(3)));
   int3v act_v = {1, 1, 2};
-  if (FAST || actions != nullptr) {
+  if constexpr (ACTOR) {
+    act_v.x = act_reg0;
+    act_v.y = act_reg1;
+    act_v.z = act_reg2;
+  } else if (FAST || actions != nullptr) {
     const int32_t* ap = actions + (size_t)envc * 3;
     asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(act_v) : "v"(ap) : "memory");
   }
@@ -1595,9 +1603,9 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
 // the 8 XCDs, each with its own L2): give every XCD a CONTIGUOUS range of envs, so that output lines shared by
 // neighbouring envs (rew, done, the unaligned obs rows) are assembled in one L2 instead of being written back in pieces
 // from several.
-__device__ __forceinline__ int first_pair_of_block(const int bi, const int nb) {
+__device__ __forceinline__ int first_pair_of_block(const int bi, const int nb, const int wpb = SDC_STEP_WPB) {
   const int vb = (nb % 8 == 0) ? (bi % 8) * (nb / 8) + bi / 8 : bi;
-  return vb * SDC_STEP_WPB;
+  return vb * wpb;
 }
 
 // The spare wavefronts of a step launch (32 workgroups early in the second dispatch round): wavefront j serves re-centring request j of the previous step (see
@@ -1780,3 +1788,106 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WP
   __shared__ double ktab[SDC_K_LDS];
   rollout_launch<true>(S, shs, ktab, K, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CLOSED LOOP in one launch: K env-steps with the three agents' ACTOR NETWORKS (sdc_actor.hpp: the reference's
+// StochasticPolicy, 26 -> 64 -> 64 -> 3, fp32) evaluated inside the kernel between the steps -- observation -> actor ->
+// action -> step never leaves the wavefront that owns the env pair, and there is no launch, no dispatch ramp and no
+// host round trip per step.  The common case only (see pair_dynamics FAST).
+// Workgroup = 8 wavefronts (16 envs) sharing ONE copy of the three networks in LDS (76 KB; with the wavefronts' own
+// 5.5 KB each and the constant table ~122 KB of the CU's 160 KB: one workgroup per CU, two wavefronts per SIMD at 4096
+// envs).  obs_in [N][3][26]: the observations the first actions are chosen from (the engine's latest).  actions_out
+// [K][N][3] receives what the actors chose, logits_out [K][N][3][3] (or null) their logits.
+#define SDC_ACTOR_WPB 8
+struct ActorLds {
+  PairShared shs[SDC_ACTOR_WPB];
+  double ktab[SDC_K_LDS];
+  SdcActorDev net[3];
+  float2 xs[SDC_ACTOR_WPB][SDC_ACT_H];
+};
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_ACTOR_WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
+sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcActorDev* __restrict__ nets,
+                         const float* __restrict__ obs_in, const int sample, float* __restrict__ obs,
+                         float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info,
+                         float* __restrict__ final_obs, float* __restrict__ rew, int32_t* __restrict__ actions_out,
+                         float* __restrict__ logits_out, float* __restrict__ obs_latch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  ActorLds& L = *reinterpret_cast<ActorLds*>(lds_raw);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
+  const int lane = threadIdx.x % SDC_WAVE;
+  // the three networks: global -> LDS, the whole workgroup copying (coalesced uint4), once per launch
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(nets);
+    uint4* dst = reinterpret_cast<uint4*>(L.net);
+    for (int i = (int)threadIdx.x; i < (int)(3 * sizeof(SdcActorDev) / 16); i += SDC_WAVE * SDC_ACTOR_WPB) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int env0 = (first_pair_of_block((int)blockIdx.x, (int)gridDim.x, SDC_ACTOR_WPB) + wave) * EPW;
+  if (env0 >= S.n_envs) return;
+  PairShared& sh = L.shs[wave];
+  const size_t N = (size_t)S.n_envs;
+  const int h = lane >> 5, l = lane & (HL - 1);
+  const int envc = env0 + h;
+  // the observation pool of both envs from the latest observations (inverse of obs_padded_at / share layout:
+  // pool[0..25] = agent_ls, [26] = agent_dc[11], [27] = agent_dc[13], [28] = agent_bat[12])
+  if (l < SDC_POOL_DIM) {
+    const float* o = obs_in + (size_t)envc * SDC_OBS_OUT;
+    sh.pool[h][l] = l < SDC_OBS_PAD ? o[l] : (l == SDC_P_WNEXT ? o[SDC_OBS_PAD + 11] : (l == SDC_P_NTNEXT ? o[SDC_OBS_PAD + 13] : o[2 * SDC_OBS_PAD + 12]));
+  }
+  wave_sync();
+#pragma unroll 1
+  for (int k = 0; k < K; k++) {
+    int env_k = env0, lane_k = lane;
+    asm volatile("" : "+s"(env_k), "+v"(lane_k));
+    // ---- the three actors on the current observations (in the LDS pool) ------------------------------------------------
+    int act[3];
+    const int lk = lane_k & (HL - 1), hk = lane_k >> 5;
+    const int rel_now = rel_hint + k;
+#pragma unroll 1
+    for (int a = 0; a < 3; a++) {
+      const float x = lk < SDC_ACT_IN ? obs_padded_at(sh.pool[hk], a * SDC_OBS_PAD + lk) : 0.0f;
+      float lg[6];
+      sdc_act::forward(L.net[a], x, lane_k, L.xs[wave], lg);
+      float u = 0.0f;
+      if (sample) {   // one uniform per (env, episode step, agent): Philox keyed on the GLOBAL env index, like the resets
+        const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + hk), (unsigned)a, 0xAC70u,
+                                        (unsigned)S.seed, (unsigned)(S.seed >> 32) ^ (unsigned)S.step_no);
+        u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+      }
+      const int ai = sdc_act::pick_action(hk ? lg[3] : lg[0], hk ? lg[4] : lg[1], hk ? lg[5] : lg[2], sample != 0, u);
+      if (a == 0) act[0] = ai;
+      if (a == 1) act[1] = ai;
+      if (a == 2) act[2] = ai;
+      if (logits_out && lk < SDC_ACT_OUT)
+        logits_out[(((size_t)k * N + (size_t)(env_k + hk)) * 3 + a) * 3 + lk] = hk ? (lk == 0 ? lg[3] : lk == 1 ? lg[4] : lg[5]) : (lk == 0 ? lg[0] : lk == 1 ? lg[1] : lg[2]);
+    }
+    if (lk == 0) {
+      int32_t* ao = actions_out + ((size_t)k * N + (size_t)(env_k + hk)) * 3;
+      ao[0] = act[0];
+      ao[1] = act[1];
+      ao[2] = act[2];
+    }
+    // ---- the env step on those actions ------------------------------------------------------------------------------------
+    pair_step<true, true>(S, sh, env_k, lane_k, rel_now, nullptr, obs + (size_t)k * N * SDC_OBS_OUT,
+                          share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM, done + (size_t)k * N, info + (size_t)k * N * SDC_INFO_DIM,
+                          k == K - 1 ? final_obs : nullptr, rew + (size_t)k * N * 3, nullptr, S.step_no + k, false, L.ktab, k == 0,
+                          act[0], act[1], act[2]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_sync();
+  }
+  // the observations the NEXT launch's first actions are chosen from (unless the episode ended: the host then copies the
+  // reset observations in)
+  if (obs_latch) {
+#pragma unroll
+    for (int q = 0; q < (EPW * SDC_OBS_OUT + SDC_WAVE - 1) / SDC_WAVE; q++) {
+      const int idx = q * SDC_WAVE + lane;
+      if (idx < EPW * SDC_OBS_OUT) {
+        const int e = idx >= SDC_OBS_OUT ? 1 : 0, j = idx - e * SDC_OBS_OUT;
+        obs_latch[(size_t)env0 * SDC_OBS_OUT + idx] = obs_padded_at(sh.pool[e], j);
+      }
+    }
+  }
+}
+// (host side: the dynamic LDS the closed-loop kernel is launched with)
+size_t sdc_rollout_actor_lds_bytes() { return sizeof(ActorLds); }

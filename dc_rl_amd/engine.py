@@ -52,6 +52,39 @@ def dc_params_struct(p: dict) -> L.SdcDcParams:
     return s
 
 
+_ACTOR_SD_KEYS = {   # the reference's StochasticPolicy state_dict -> sdc_actor_params fields
+    "ln0_gamma": "base.feature_norm.weight", "ln0_beta": "base.feature_norm.bias",
+    "w1": "base.mlp.fc.0.weight", "b1": "base.mlp.fc.0.bias", "ln1_gamma": "base.mlp.fc.2.weight", "ln1_beta": "base.mlp.fc.2.bias",
+    "w2": "base.mlp.fc.3.weight", "b2": "base.mlp.fc.3.bias", "ln2_gamma": "base.mlp.fc.5.weight", "ln2_beta": "base.mlp.fc.5.bias",
+    "w3": "act.action_out.linear.weight", "b3": "act.action_out.linear.bias",
+}
+_ACTOR_SHAPES = {"ln0_gamma": (26,), "ln0_beta": (26,), "w1": (64, 26), "b1": (64,), "ln1_gamma": (64,), "ln1_beta": (64,),
+                 "w2": (64, 64), "b2": (64,), "ln2_gamma": (64,), "ln2_beta": (64,), "w3": (3, 64), "b3": (3,)}
+
+
+def actor_params(params) -> L.SdcActorParams:
+    """dict (sdc_actor_params field names, or the reference's StochasticPolicy state_dict keys) -> C struct."""
+    p = L.SdcActorParams()
+    feature_norm = True
+    for field, shape in _ACTOR_SHAPES.items():
+        v = params.get(field, params.get(_ACTOR_SD_KEYS[field]))
+        if v is None:
+            if field in ("ln0_gamma", "ln0_beta"):      # use_feature_normalization False: no feature_norm in the state_dict
+                feature_norm = False
+                continue
+            raise KeyError(f"actor parameters: neither {field!r} nor {_ACTOR_SD_KEYS[field]!r} given")
+        a = np.ascontiguousarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)
+        if a.shape != shape:
+            raise ValueError(f"actor parameter {field}: shape {a.shape}, expected {shape} (hidden_sizes [64, 64], 26 inputs, 3 actions)")
+        C.memmove(getattr(p, field), a.ctypes.data, a.nbytes)
+    p.use_feature_normalization = 1 if params.get("use_feature_normalization", feature_norm) else 0
+    act = params.get("activation", "tanh")
+    if act not in ("tanh", "relu", 0, 1):
+        raise NotImplementedError(f"actor activation {act!r}: the kernel runs tanh (happo.yaml) and relu")
+    p.activation = {"tanh": 0, "relu": 1}.get(act, act)
+    return p
+
+
 class SdcEngine:
     def __init__(self, n_envs: int, episode_steps: int = 672, device: int = 0, n_locations: int = 1,
                  n_dc_configs: int = 1, auto_reset: bool = True, seed: int = 0, hist_cap: int = 10000,
@@ -282,6 +315,38 @@ class SdcEngine:
         if want_actions:
             return obs, share, rew, done, info, aout
         return obs, share, rew, done, info
+
+    # ------------------------------------------------------------------ closed loop: the actors inside the kernel
+    def set_actor(self, agent_slot: int, params):
+        """One agent's actor network (slot 0 agent_ls, 1 agent_dc, 2 agent_bat) for rollout_actor().  `params`: a
+        state_dict of the reference's StochasticPolicy (harl/models/policy_models/stochastic_policy.py: keys
+        base.feature_norm.*, base.mlp.fc.{0,2,3,5}.*, act.action_out.linear.*; tensors or arrays) or a dict with the
+        fields of sdc_actor_params; `activation`: "tanh" (happo.yaml) or "relu"."""
+        L.check(self.lib.sdc_set_actor(self._h, int(agent_slot), C.byref(actor_params(params))))
+
+    def rollout_actor(self, n_steps: int, sample: bool = False, want_logits: bool = False):
+        """K env-steps in ONE launch with the three actors (set_actor) choosing every action inside the kernel from the
+        step's own observations -- the closed loop observation -> actor -> action -> step without a launch per step.
+        sample=False: the distributions' mode (the reference's deterministic=True), True: a draw.
+        Returns (obs [K,N,3,26], share_obs [K,N,29], rew [K,N,3], done [K,N], info [K,N,44], actions [K,N,3] int32,
+        logits [K,N,3,3] or None).  K must not run past the end of the episode (steps_to_episode_end())."""
+        t = self.torch
+        K, N = int(n_steps), self.n_envs
+        kw = dict(device=self.device)
+        obs = t.empty((K, N, L.N_AGENTS, L.OBS_PAD), dtype=t.float32, **kw)
+        share = t.empty((K, N, L.SHARE_OBS_DIM), dtype=t.float32, **kw)
+        rew = t.empty((K, N, L.N_AGENTS), dtype=t.float32, **kw)
+        done = t.empty((K, N), dtype=t.uint8, **kw)
+        info = t.empty((K, N, L.INFO_DIM), dtype=t.float32, **kw)
+        acts = t.empty((K, N, 3), dtype=t.int32, **kw)
+        logits = t.empty((K, N, 3, 3), dtype=t.float32, **kw) if want_logits else None
+        p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        with t.cuda.device(self.device):
+            L.check(self.lib.sdc_rollout_actor(self._h, K, 1 if sample else 0, p(obs), p(share), p(rew), p(done), p(info),
+                                               p(self.final_obs), p(acts), p(logits), self._stream()))
+        self.obs.copy_(obs[-1]); self.share_obs.copy_(share[-1]); self.rew.copy_(rew[-1]); self.done.copy_(done[-1])
+        self.info.copy_(info[-1])
+        return obs, share, rew, done, info, acts, logits
 
     # ------------------------------------------------------------------ state access (parity injection / checkpoint)
     def _state_array(self, name):

@@ -203,8 +203,9 @@ const char* sdc_last_error(void);
  * returns the value the library was BUILT with; a caller compares the two before anything else (dc_rl_amd/_lib.py
  * does) -- the .so is shipped out of band, so a stale one must fail loudly, not corrupt silently.
  *   100  round 1        300  sdc_config: env_index_base, policy[3], trim_and_respond_limit; sdc_reset_override: noise,
- *                            roll_days; sdc_rollout: actions_out; debug_flags bit 6 */
-#define SDC_ABI_VERSION 300
+ *                            roll_days; sdc_rollout: actions_out; debug_flags bit 6
+ *   310  sdc_set_actor, sdc_rollout_actor (closed loop with the actor networks inside the kernel); debug_flags bit 7 */
+#define SDC_ABI_VERSION 310
 int sdc_version(void);
 
 int sdc_create(const sdc_config* cfg, sdc_handle** out);
@@ -255,6 +256,31 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
  * actions_out [n_steps][N][3] (device, or NULL) receives the actions every step applied. */
 int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, float* share_obs, float* rew,
                 uint8_t* done, float* info, float* final_obs, int32_t* actions_out, void* stream);
+/* CLOSED LOOP.  replaces: the actor forward pass of the reference's rollout loop (harl/runners/on_policy_base_runner.py
+ * collect -> harl/algorithms/actors/on_policy_base.py get_actions -> StochasticPolicy.forward,
+ * harl/models/policy_models/stochastic_policy.py:11-60) between two env steps: one agent's network
+ *     LayerNorm(26) -> Linear(26, 64) -> act -> LayerNorm(64) -> Linear(64, 64) -> act -> LayerNorm(64) -> Linear(64, 3)
+ * (harl/models/base/mlp.py:8-72, act.py:45-84; hidden_sizes [64, 64], happo.yaml:58) with the weights in torch's layout
+ * ([out][in], row-major), fp32.  sdc_set_actor copies them to the device (host pointers). */
+typedef struct {
+  float ln0_gamma[26], ln0_beta[26];                 /* feature_norm (use_feature_normalization) */
+  float w1[64 * 26], b1[64], ln1_gamma[64], ln1_beta[64];
+  float w2[64 * 64], b2[64], ln2_gamma[64], ln2_beta[64];
+  float w3[3 * 64], b3[3];                           /* act.action_out.linear */
+  int32_t use_feature_normalization;                 /* 1: LayerNorm over the 26 inputs first */
+  int32_t activation;                                /* 0 tanh, 1 relu */
+} sdc_actor_params;
+int sdc_set_actor(sdc_handle* h, int agent_slot, const sdc_actor_params* p);
+/* n_steps env-steps in ONE launch, every step's three actions chosen INSIDE the kernel by the three actors from the
+ * step's own observations (the first from the observations the last sdc_reset / sdc_step / sdc_rollout* call returned,
+ * of which the library keeps a copy once an actor is set): observation -> actor -> action -> step without a launch or a
+ * host round trip per step.  sample = 0: the distributions' mode (deterministic = True in the reference), 1: a draw
+ * (counter-based RNG keyed on seed, global env index, episode step, agent).  Outputs as sdc_rollout (all required but
+ * final_obs); actions_out [n_steps][N][3] receives the actions, logits_out [n_steps][N][3][3] (may be NULL) the actors'
+ * logits.  Only for the common case the specialised kernels serve (lock-step batch with feature rows, one data-centre
+ * config of <= 32 racks, default rewards, an even number of envs); anything else is refused. */
+int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float* share_obs, float* rew, uint8_t* done,
+                      float* info, float* final_obs, int32_t* actions_out, float* logits_out, void* stream);
 /* steps until the first env finishes its episode (0: a reset is due) */
 int sdc_steps_to_episode_end(const sdc_handle* h);
 /* which envs finished their episode in the last sdc_step / sdc_rollout call -- the `done` output, but from the host's

@@ -1,0 +1,144 @@
+"""The closed loop in one launch (sdc_rollout_actor): the three agents' actor networks evaluated INSIDE the rollout kernel.
+
+  * the in-kernel network against a plain PyTorch fp32 restatement of the reference's StochasticPolicy
+    (harl/models/policy_models/stochastic_policy.py:11-60: LayerNorm(26) -> Linear(26,64) -> tanh -> LayerNorm(64) ->
+    Linear(64,64) -> tanh -> LayerNorm(64) -> Linear(64,3) -> Categorical), same weights, evaluated on the very
+    observations the kernel saw: logits within 2e-4 (fp32, different summation order, hardware exp2 / rsq), actions equal
+    wherever the top-two logit gap exceeds that;
+  * the dynamics under those actions against the external-action rollout of a second engine: bit for bit;
+  * sampling: the empirical action frequencies against softmax(logits)."""
+import numpy as np
+import pytest
+
+from dc_rl_amd import _lib as L
+from dc_rl_amd import dc_config, traces
+from dc_rl_amd.engine import SdcEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_actor(seed, activation="tanh"):
+    import torch
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(seed)
+    act = nn.Tanh if activation == "tanh" else nn.ReLU
+
+    class Base(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.feature_norm = nn.LayerNorm(26)
+            self.mlp = nn.Module()
+            self.mlp.fc = nn.Sequential(nn.Linear(26, 64), act(), nn.LayerNorm(64), nn.Linear(64, 64), act(), nn.LayerNorm(64))
+
+    class Policy(nn.Module):      # parameter names as in the reference's StochasticPolicy
+        def __init__(self):
+            super().__init__()
+            self.base = Base()
+            self.act = nn.Module()
+            self.act.action_out = nn.Module()
+            self.act.action_out.linear = nn.Linear(64, 3)
+
+        def forward(self, x):
+            return self.act.action_out.linear(self.base.mlp.fc(self.base.feature_norm(x)))
+
+    m = Policy()
+    with torch.no_grad():        # trained-looking weights: every parameter random, LayerNorm affine included
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.35 if p.dim() == 2 else 0.2) + (1.0 if p.dim() == 1 and p.numel() in (26, 64) and False else 0.0))
+        for ln in (m.base.feature_norm, m.base.mlp.fc[2], m.base.mlp.fc[5]):
+            ln.weight.copy_(1.0 + 0.2 * torch.randn(ln.weight.shape, generator=g))
+    return m
+
+
+def _engine(N, steps, seed=5):
+    tb = traces.synthetic_tables("ny", 0)
+    p = dc_config.size_datacenter("dc_config.json", 1, 30.0)
+    e = SdcEngine(N, episode_steps=steps, auto_reset=True, seed=seed)
+    e.set_tables(0, tb["W"], tb["C"], tb["T"], tb["WB"])
+    e.set_dc_params(0, p)
+    e.assign(0, 0, 174, 188)
+    return e
+
+
+@pytest.mark.parametrize("activation", ["tanh", "relu"])
+def test_in_kernel_actor_matches_torch_and_external_rollout(activation):
+    import torch
+    N, steps, K = 512, 96, 40
+    nets = [_torch_actor(100 + a, activation) for a in range(3)]
+    a_eng, b_eng = _engine(N, steps), _engine(N, steps)
+    for a in range(3):
+        sd = dict(nets[a].state_dict())
+        sd["activation"] = activation
+        a_eng.set_actor(a, sd)
+    obs0, _ = a_eng.reset()
+    obs0 = obs0.clone()
+    b_eng.reset()
+    worst, checked = 0.0, 0
+    prev_obs = obs0
+    for rnd in range(3):          # 3 launches: 40 + 40 + 16 steps, the last one ends the episode (auto-reset inside)
+        k = min(K, a_eng.steps_to_episode_end())
+        obs, share, rew, done, info, acts, logits = a_eng.rollout_actor(k, sample=False, want_logits=True)
+        # the networks, step by step, on the observations the kernel chose from
+        inp = torch.cat([prev_obs[None], obs[:-1]], 0)                       # [k, N, 3, 26]
+        for a in range(3):
+            with torch.no_grad():
+                ref = nets[a](inp[:, :, a, :].cpu()).numpy()                 # [k, N, 3]
+            got = logits[:, :, a, :].cpu().numpy()
+            err = np.abs(got - ref).max()
+            worst = max(worst, float(err))
+            assert err <= 2e-4, (rnd, a, err)
+            top2 = np.sort(ref, axis=-1)
+            clear = (top2[..., 2] - top2[..., 1]) > 1e-3
+            np.testing.assert_array_equal(acts[:, :, a].cpu().numpy()[clear], ref.argmax(-1)[clear])
+            checked += int(clear.sum())
+        # the same actions fed from outside give the same trajectory, bit for bit
+        ob, sb, rb, db, ib = b_eng.rollout(acts)
+        assert torch.equal(obs, ob) and torch.equal(rew, rb) and torch.equal(done, db) and torch.equal(share, sb)
+        ia, ibb = info.clone(), ib.clone()
+        ia[..., L.INFO_IDX["reserved"]] = 0
+        ibb[..., L.INFO_IDX["reserved"]] = 0
+        assert torch.equal(ia, ibb)
+        prev_obs = obs[-1].clone()
+    assert a_eng.steps_to_episode_end() == steps and (a_eng.get_state("episode") == 2).all()
+    np.testing.assert_array_equal(a_eng.get_state("record"), b_eng.get_state("record"))
+    assert (a_eng.info[:, L.INFO_IDX["fault"]] == 0).all()
+    print("in-kernel actor (%s): max |logit error| %.2e over %d action checks" % (activation, worst, checked))
+    a_eng.close()
+    b_eng.close()
+
+
+def test_in_kernel_actor_sampling_follows_the_softmax():
+    import torch
+    N, steps = 2048, 96
+    nets = [_torch_actor(7 + a) for a in range(3)]
+    eng = _engine(N, steps)
+    for a in range(3):
+        eng.set_actor(a, nets[a].state_dict())
+    eng.reset()
+    obs, share, rew, done, info, acts, logits = eng.rollout_actor(48, sample=True, want_logits=True)
+    p = torch.softmax(logits.double(), -1).cpu().numpy()                # [K, N, 3 agents, 3 actions]
+    a = acts.cpu().numpy()
+    assert a.min() >= 0 and a.max() <= 2
+    for ag in range(3):
+        freq = np.stack([(a[..., ag] == c).mean() for c in range(3)])
+        exp = p[:, :, ag, :].mean((0, 1))
+        assert np.abs(freq - exp).max() < 0.01, (ag, freq, exp)          # ~98 000 draws per agent
+    # different steps / envs draw differently; the same launch twice from the same state draws the same (counter-based)
+    assert len(np.unique(a[:, :, 0], axis=0)) > 1
+    eng.close()
+
+
+def test_rollout_actor_refuses_what_it_does_not_serve():
+    eng = _engine(64, 96)
+    eng.reset()
+    with pytest.raises(L.SdcError, match="sdc_set_actor"):
+        eng.rollout_actor(4)
+    for a in range(3):
+        eng.set_actor(a, _torch_actor(a).state_dict())
+    with pytest.raises(L.SdcError, match="no observations yet"):
+        eng.rollout_actor(4)
+    eng.reset()
+    with pytest.raises(L.SdcError, match="past the end"):
+        eng.rollout_actor(97)
+    eng.rollout_actor(4)
+    eng.close()
