@@ -40,6 +40,8 @@ static_assert(sizeof(SdcActorDev) % 16 == 0, "copied to LDS as uint4");
 
 namespace sdc_act {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(const float v) {   // (every row written, no source lane -> 0)
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -59,6 +61,30 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(s[1]) + __uint_as_float(s[0]);
 }
+// N sums at once, stage by stage: a reduction is a chain of seven dependent steps, each a DPP / permlane operation that
+// must wait out the previous one (the compiler pads a lone chain with s_nop); N independent chains fill each other's gaps
+template <int N, bool HALF>
+__device__ __forceinline__ void sums(float (&v)[N]) {
+#define SDC_ACT_STAGE(C)  \
+  _Pragma("unroll") for (int i = 0; i < N; i++) v[i] += dpp_f32<C>(v[i]);
+  SDC_ACT_STAGE(SDC_DPP_XOR1)
+  SDC_ACT_STAGE(SDC_DPP_XOR2)
+  SDC_ACT_STAGE(SDC_DPP_HALF_MIRROR)
+  SDC_ACT_STAGE(SDC_DPP_MIRROR)
+#undef SDC_ACT_STAGE
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+    v[i] = __uint_as_float(s[1]) + __uint_as_float(s[0]);
+  }
+  if constexpr (!HALF) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+      v[i] = __uint_as_float(s[1]) + __uint_as_float(s[0]);
+    }
+  }
+}
 __device__ __forceinline__ float activate(const float x, const int kind) {
   if (kind == 1) return x > 0.0f ? x : 0.0f;
   // tanh x = 1 - 2 / (e^(2x) + 1): hardware exp2 / rcp (~1 ulp each), exact limits at +-inf
@@ -66,12 +92,15 @@ __device__ __forceinline__ float activate(const float x, const int kind) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 // LayerNorm over the 64 lanes (torch: biased variance, eps 1e-5), both envs
+// (one pass: sum and sum of squares of both envs as four interleaved reductions, variance = E[x^2] - mean^2; the inputs
+// are activations in [-1, 1] or a ReLU's outputs of order one: the cancellation costs ~1e-7 of the value)
 __device__ __forceinline__ void layer_norm64(float& a0, float& a1, const float g, const float b) {
-  const float m0 = wave_sum_f32(a0) * (1.0f / SDC_ACT_H), m1 = wave_sum_f32(a1) * (1.0f / SDC_ACT_H);
-  const float d0 = a0 - m0, d1 = a1 - m1;
-  const float v0 = wave_sum_f32(d0 * d0) * (1.0f / SDC_ACT_H), v1 = wave_sum_f32(d1 * d1) * (1.0f / SDC_ACT_H);
-  a0 = d0 * __builtin_amdgcn_rsqf(v0 + 1e-5f) * g + b;
-  a1 = d1 * __builtin_amdgcn_rsqf(v1 + 1e-5f) * g + b;
+  float r[4] = {a0, a1, a0 * a0, a1 * a1};
+  sums<4, false>(r);
+  const float m0 = r[0] * (1.0f / SDC_ACT_H), m1 = r[1] * (1.0f / SDC_ACT_H);
+  const float v0 = fmaxf(r[2] * (1.0f / SDC_ACT_H) - m0 * m0, 0.0f), v1 = fmaxf(r[3] * (1.0f / SDC_ACT_H) - m1 * m1, 0.0f);
+  a0 = (a0 - m0) * __builtin_amdgcn_rsqf(v0 + 1e-5f) * g + b;
+  a1 = (a1 - m1) * __builtin_amdgcn_rsqf(v1 + 1e-5f) * g + b;
 }
 
 // One agent's forward pass for both envs of the wavefront.  x: this lane's input (lane (h, k): entry k < 26 of env h's
@@ -82,48 +111,53 @@ __device__ __forceinline__ void forward(const SdcActorDev& A, const float x, con
   const int kind = (A.flags >> 1) & 3;
   float xn = x;
   if (A.flags & 1) {
-    const float mean = half_sum_f32(x) * (1.0f / SDC_ACT_IN);
-    const float d = k < SDC_ACT_IN ? x - mean : 0.0f;
-    const float var = half_sum_f32(d * d) * (1.0f / SDC_ACT_IN);
-    xn = d * __builtin_amdgcn_rsqf(var + 1e-5f) * A.ln0_g[k] + A.ln0_b[k];
+    // (observation entries are of order one -- normalised by construction -- so the one-pass variance is safe here too)
+    float r[2] = {x, x * x};
+    sums<2, true>(r);
+    const float mean = r[0] * (1.0f / SDC_ACT_IN);
+    const float var = fmaxf(r[1] * (1.0f / SDC_ACT_IN) - mean * mean, 0.0f);
+    xn = (x - mean) * __builtin_amdgcn_rsqf(var + 1e-5f) * A.ln0_g[k] + A.ln0_b[k];
   }
   wave_sync();                                     // (the previous layer's readers are done with xs)
   if (k < SDC_ACT_IN) reinterpret_cast<float*>(xs)[2 * k + h] = xn;
   wave_sync();
-  float a0 = A.b1[lane], a1 = a0;
+  // (both envs in one packed instruction: v_pk_fma_f32 {acc0, acc1} += {w, w} * {x0, x1}, the weight broadcast by op_sel)
+  v2f acc = {A.b1[lane], A.b1[lane]};
 #pragma unroll
   for (int i = 0; i < SDC_ACT_IN / 2; i++) {
     const float4 xx = reinterpret_cast<const float4*>(xs)[i];          // {x0[2i], x1[2i], x0[2i+1], x1[2i+1]}, broadcast
     const float2 w = *reinterpret_cast<const float2*>(A.w1[i][lane]);
-    a0 = __builtin_fmaf(w.x, xx.x, a0);
-    a1 = __builtin_fmaf(w.x, xx.y, a1);
-    a0 = __builtin_fmaf(w.y, xx.z, a0);
-    a1 = __builtin_fmaf(w.y, xx.w, a1);
+    acc = __builtin_elementwise_fma(v2f{w.x, w.x}, v2f{xx.x, xx.y}, acc);
+    acc = __builtin_elementwise_fma(v2f{w.y, w.y}, v2f{xx.z, xx.w}, acc);
   }
-  a0 = activate(a0, kind);
-  a1 = activate(a1, kind);
+  float a0 = activate(acc.x, kind);
+  float a1 = activate(acc.y, kind);
   layer_norm64(a0, a1, A.ln1_g[lane], A.ln1_b[lane]);
   wave_sync();
   xs[lane] = make_float2(a0, a1);
   wave_sync();
-  float c0 = A.b2[lane], c1 = c0;
-#pragma unroll 8
+  v2f acc2 = {A.b2[lane], A.b2[lane]};
+#pragma unroll 16
   for (int i = 0; i < SDC_ACT_H / 2; i++) {
     const float4 xx = reinterpret_cast<const float4*>(xs)[i];
     const float2 w = *reinterpret_cast<const float2*>(A.w2[i][lane]);
-    c0 = __builtin_fmaf(w.x, xx.x, c0);
-    c1 = __builtin_fmaf(w.x, xx.y, c1);
-    c0 = __builtin_fmaf(w.y, xx.z, c0);
-    c1 = __builtin_fmaf(w.y, xx.w, c1);
+    acc2 = __builtin_elementwise_fma(v2f{w.x, w.x}, v2f{xx.x, xx.y}, acc2);
+    acc2 = __builtin_elementwise_fma(v2f{w.y, w.y}, v2f{xx.z, xx.w}, acc2);
   }
-  c0 = activate(c0, kind);
-  c1 = activate(c1, kind);
+  float c0 = activate(acc2.x, kind);
+  float c1 = activate(acc2.y, kind);
   layer_norm64(c0, c1, A.ln2_g[lane], A.ln2_b[lane]);
 #pragma unroll
   for (int c = 0; c < SDC_ACT_OUT; c++) {
     const float w = A.w3[c][lane];
-    lg[c] = wave_sum_f32(w * c0) + A.b3[c];
-    lg[3 + c] = wave_sum_f32(w * c1) + A.b3[c];
+    lg[c] = w * c0;
+    lg[3 + c] = w * c1;
+  }
+  sums<6, false>(lg);
+#pragma unroll
+  for (int c = 0; c < SDC_ACT_OUT; c++) {
+    lg[c] += A.b3[c];
+    lg[3 + c] += A.b3[c];
   }
 }
 

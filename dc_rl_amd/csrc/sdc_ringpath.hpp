@@ -277,6 +277,160 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
 }
 
 // ------------------------------------------------------------------------------------------------
+// THE SAME REFILL BY A WHOLE WORKGROUP (the spare sweep workgroups of a step launch): its NW wavefronts take a quarter of
+// the ring each -- 10 loads per lane, all in flight at once -- keep their lanes' 4 smallest distances and borrow counts
+// as above, and meet in LDS: the counts add up, D is the smallest 4th-smallest of ANY lane of the workgroup, the complete
+// parts of all lists are compacted into one list (~140 keys instead of ~45: four times the lists, each seeing a quarter
+// of the keys), ranked by counting (the entries dealt round the wavefronts) and placed.  One sweep then costs each of
+// the four SIMDs ~0.5 us of issue instead of one SIMD ~2 us plus eight memory round trips -- and the two env-pair
+// wavefronts that share a SIMD with a sweeping wavefront are what ends a step launch (tools/wave_tail.py).
+// Every wavefront of the workgroup calls this with the same arguments (q: the same window in each); all return the same q.
+constexpr int COOP_NW = 4;
+constexpr int COOP_LIST = COOP_NW * 3 * SDC_WAVE + 4;   // every lane's three complete slots, worst case
+struct CoopLds {
+  unsigned list[COOP_LIST];
+  unsigned win[WIN];
+  unsigned cnt[COOP_NW], dmin[COOP_NW], m[COOP_NW];
+};
+__device__ __forceinline__ void qt_refill_coop(QTrack& q, const int dir, const int k, const int n, const RingView& R, const int lane,
+                                               const int wave, CoopLds& C, const unsigned side) {
+  static_assert(RING_VECS % COOP_NW == 0, "the ring splits evenly over the wavefronts");
+  constexpr int PER = RING_VECS / COOP_NW;
+  const unsigned fd = dir == REFILL_DOWN ? KEY_NONE : 0u;
+  const unsigned f = fd ^ side;
+  const int hi = q.hi;
+  unsigned w = q.w;
+  int r0 = q.r0, kk = k;
+  if (fd) {
+    const unsigned rv = (unsigned)__shfl((int)q.w, (hi - 1 - lane) & 63);
+    w = lane < hi ? ~rv : KEY_NONE;
+    r0 = n - (q.r0 + hi);
+    kk = n - 1 - k;
+  }
+  const int n_empty = f ? SDC_HIST_STRIDE - n : 0;
+  int top = r0 + hi;
+  const int s = min(max(kk - WIN / 2 - r0, 0), hi - 1);
+  const int kept = hi - s;
+  unsigned pivot = lane_key(w, hi - 1);
+  if (wave == 0) {
+    C.win[lane] = KEY_NONE;
+    wave_sync();
+    if (lane >= s && lane < hi) C.win[lane - s] = w;
+  }
+  __syncthreads();
+  int filled = kept;
+#pragma unroll 1
+  for (int round = 0; round < 8 && filled < WIN && top < n; round++) {     // (every condition is the same in all wavefronts)
+    const unsigned pp = pivot + 1u;
+    const unsigned smax = KEY_NONE - pp;
+    unsigned c = 0u;
+    unsigned e0 = KEY_NONE, e1 = KEY_NONE, e2 = KEY_NONE, e3 = KEY_NONE;
+    {
+      uint4 v[PER];
+#pragma unroll
+      for (int i = 0; i < PER; i++) v[i] = ring_fetch(R, wave * PER + i, lane);
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        const unsigned xs[4] = {v[i].x ^ f, v[i].y ^ f, v[i].z ^ f, v[i].w ^ f};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          unsigned d;
+          SDC_SUB_COUNT(d, c, xs[j], pp);
+          e3 = umed3(e2, d, e3);
+          e2 = umed3(e1, d, e2);
+          e1 = umed3(e0, d, e1);
+          e0 = min(e0, d);
+        }
+      }
+    }
+    const unsigned cw = wave_sum_u32(c), dw = wave_min_u32(e3);
+    if (lane == 0) {
+      C.cnt[wave] = cw;
+      C.dmin[wave] = dw;
+    }
+    __syncthreads();
+    const int extra = (int)(C.cnt[0] + C.cnt[1] + C.cnt[2] + C.cnt[3]) - n_empty - top;
+    const unsigned D = min(min(min(C.dmin[0], C.dmin[1]), min(C.dmin[2], C.dmin[3])), smax);
+    if (extra < 0) {
+      filled = -1;
+      break;
+    }
+    // the complete part of every lane's list (e3 >= D always), compacted: this wavefront's share behind the others'
+    const unsigned mine3[3] = {e0, e1, e2};
+    unsigned long long mk[3];
+    int mw = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      mk[j] = __ballot(mine3[j] < D);
+      mw += (int)__popcll(mk[j]);
+    }
+    if (lane == 0) C.m[wave] = (unsigned)mw;
+    __syncthreads();
+    int off = 0, m = 0;
+#pragma unroll
+    for (int v = 0; v < COOP_NW; v++) {
+      if (v < wave) off += (int)C.m[v];
+      m += (int)C.m[v];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      if (mine3[j] < D) C.list[off + (int)__popcll(mk[j] & ((1ull << lane) - 1ull))] = mine3[j];
+      off += (int)__popcll(mk[j]);
+    }
+    if (wave == 0 && lane < 4) C.list[m + lane] = KEY_NONE;      // pad to a multiple of 4 (ranks below nothing)
+    if (wave == 0 && lane < extra && filled + lane < WIN) C.win[filled + lane] = pivot;   // copies of the pivot first
+    __syncthreads();
+    // rank = how many caught distances are smaller; the entries are dealt round the wavefronts, 64 per pass
+#pragma unroll 1
+    for (int c0 = wave * SDC_WAVE; c0 < m; c0 += COOP_NW * SDC_WAVE) {
+      const unsigned mine = c0 + lane < m ? C.list[c0 + lane] : 0u;
+      unsigned rank = 0u;
+#pragma unroll 2
+      for (int i = 0; i < m; i += 4) {
+        const uint4 v4 = *reinterpret_cast<const uint4*>(&C.list[i]);
+        unsigned t;
+        SDC_SUB_COUNT(t, rank, v4.x, mine);
+        SDC_SUB_COUNT(t, rank, v4.y, mine);
+        SDC_SUB_COUNT(t, rank, v4.z, mine);
+        SDC_SUB_COUNT(t, rank, v4.w, mine);
+        (void)t;
+      }
+      const int pos = filled + extra + (int)rank;
+      if (c0 + lane < m && pos < WIN) C.win[pos] = pp + mine;
+    }
+    __syncthreads();
+    filled += extra + m;
+    top += extra + m;
+    if (D >= smax) break;
+    if (filled - kept >= 12) break;
+    pivot = pp + D;
+  }
+  if (filled <= kept) {
+    q.hi = 0;
+    return;
+  }
+  const int hi2 = min(WIN, filled);
+  const int r2 = r0 + s;
+  unsigned v = C.win[lane];      // (every wavefront reads the finished window: all return the same q)
+  v = lane < hi2 && v != KEY_NONE ? v : 0u;
+  v = max(v, dpp_u32<0x111, 0xF>(0u, v));
+  v = max(v, dpp_u32<0x112, 0xF>(0u, v));
+  v = max(v, dpp_u32<0x114, 0xF>(0u, v));
+  v = max(v, dpp_u32<0x118, 0xF>(0u, v));
+  v = max(v, dpp_u32<0x142, 0xA>(0u, v));
+  v = max(v, dpp_u32<0x143, 0xC>(0u, v));
+  if (fd) {
+    const unsigned rv = (unsigned)__shfl((int)v, (hi2 - 1 - lane) & 63);
+    q.w = lane < hi2 ? ~rv : KEY_NONE;
+    q.r0 = n - (r2 + hi2);
+  } else {
+    q.w = lane < hi2 ? v : KEY_NONE;
+    q.r0 = r2;
+  }
+  q.hi = hi2;
+}
+
+// ------------------------------------------------------------------------------------------------
 // REBUILD (bootstrap, injected state, a tracker or set that did not cover): everything from the ring, one wavefront.
 
 // exact order statistics at four ranks by bisection on the key space (robust against any number of equal keys)

@@ -1618,6 +1618,9 @@ __device__ __forceinline__ int first_pair_of_block(const int bi, const int nb, c
 #ifndef SDC_SWEEP_SPREAD
 #define SDC_SWEEP_SPREAD 1
 #endif
+#ifndef SDC_SWEEP_COOP
+#define SDC_SWEEP_COOP 1     // a sweep is shared by the four wavefronts of its workgroup (qt_refill_coop)
+#endif
 #ifndef SDC_SWEEP_AT
 #define SDC_SWEEP_AT 0
 #endif
@@ -1671,6 +1674,39 @@ __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const
   }
 }
 
+// The same service by the whole sweep workgroup: workgroup b takes requests b, b + 32, ... one after the other, its four
+// wavefronts sharing each sweep (qt_refill_coop).  Every wavefront of the workgroup must call this (barriers inside).
+__device__ __forceinline__ void serve_recentring_requests_coop(const SdcDev& S, const int wg, const int wave, const int lane,
+                                                               sdc_rw::CoopLds& C) {
+  using namespace sdc_rw;
+  static_assert(SDC_STEP_WPB == COOP_NW, "one quarter of the ring per wavefront of the workgroup");
+  const int set = S.step_no % 3;
+  if (wg == 0 && wave == 0 && lane == 0) S.rq_count[(S.step_no + 2) % 3] = 0;     // the set the NEXT step's requests go to
+  const int cnt = min(S.rq_count[set], SDC_RQ_MAX);
+  if (wg >= cnt) return;
+  __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
+#pragma unroll 1
+  for (int j = wg; j < cnt; j += SDC_SWEEP_BLOCKS) {
+    const SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + j;
+    if (rq->step != S.step_no - 1) continue;                          // stale (a multi-step launch came in between)
+    const int env = rq->env, w = rq->win, n = rq->n;
+    QTrack A = {rq->keys[lane], rq->r0, rq->hi};
+    const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), rq->patch_slot, rq->patch_x};
+    qt_refill_coop(A, rq->dir, rq->kt, n, R, lane, wave, C, w == 3 ? KEY_NONE : 0u);
+    if (wave == 0) {
+      SdcRefillRes* rs = S.rs + set * SDC_RQ_MAX + j;
+      rs->keys[lane] = A.w;
+      if (lane == 0) {
+        rs->r0 = A.r0;
+        rs->hi = A.hi;
+        rs->step = S.step_no;
+        rs->env_win = env * 4 + w;
+      }
+    }
+    __syncthreads();      // (the LDS meeting point is reused by the next request)
+  }
+}
+
 // One launch of this kernel is one env-step of all N environments.
 template <bool FAST>
 __device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs, double* kt, const int rel_hint, const int32_t* __restrict__ actions,
@@ -1694,7 +1730,10 @@ __device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs
     // end the launch (15.4 us per step); FIRST and at raised issue priority they are done while the pairs still run:
     // 13.1 us per step against 13.6 with the insertion point at 320 (uniform-random actions; all-idle actions, four
     // times the requests: 14.1 against 15.1).
-#if SDC_SWEEP_SPREAD
+#if SDC_SWEEP_COOP
+    static_assert(sizeof(sdc_rw::CoopLds) <= sizeof(PairShared) * SDC_STEP_WPB, "the sweep workgroup's LDS");
+    serve_recentring_requests_coop(S, bx - sweep_first, wave, lane, *reinterpret_cast<sdc_rw::CoopLds*>(shs));
+#elif SDC_SWEEP_SPREAD
     serve_recentring_requests(S, (bx - sweep_first) + wave * SDC_SWEEP_BLOCKS, lane, shs[wave].tl);   // requests 0..31 on 32 different CUs
 #else
     serve_recentring_requests(S, (bx - sweep_first) * SDC_STEP_WPB + wave, lane, shs[wave].tl);
@@ -1847,7 +1886,17 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
     for (int a = 0; a < 3; a++) {
       const float x = lk < SDC_ACT_IN ? obs_padded_at(sh.pool[hk], a * SDC_OBS_PAD + lk) : 0.0f;
       float lg[6];
+#ifdef SDC_ACTOR_SKIP
+      {   // (measurement: the kernel without the networks -- pseudo-random actions from a hash)
+        unsigned hsh = (unsigned)(env_k + hk) * 2654435761u + (unsigned)(rel_now * 3 + a) * 40503u;
+        hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+        const int pick = (int)(hsh % 3u);
+        lg[0] = lg[3] = pick == 0 ? 1.f : 0.f; lg[1] = lg[4] = pick == 1 ? 1.f : 0.f; lg[2] = lg[5] = pick == 2 ? 1.f : 0.f;
+        (void)x;
+      }
+#else
       sdc_act::forward(L.net[a], x, lane_k, L.xs[wave], lg);
+#endif
       float u = 0.0f;
       if (sample) {   // one uniform per (env, episode step, agent): Philox keyed on the GLOBAL env index, like the resets
         const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + hk), (unsigned)a, 0xAC70u,
