@@ -1756,7 +1756,10 @@ __device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs
   if (!FAST && lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 1);
 }
 // (three resident wavefronts per SIMD: two env pairs + room for a spare one, <= 168 VGPRs)
-#define SDC_STEP_BOUNDS __launch_bounds__(SDC_WAVE * SDC_STEP_WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
+#ifndef SDC_STEP_WAVES_PER_EU
+#define SDC_STEP_WAVES_PER_EU 3
+#endif
+#define SDC_STEP_BOUNDS __launch_bounds__(SDC_WAVE * SDC_STEP_WPB) __attribute__((amdgpu_waves_per_eu(SDC_STEP_WAVES_PER_EU, SDC_STEP_WAVES_PER_EU)))
 // the general kernel, and the one for the common case (see pair_dynamics; the host picks: sdc_capi.hip fast_case)
 extern "C" __global__ SDC_STEP_BOUNDS void sdc_dynamics_kernel(
     SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
