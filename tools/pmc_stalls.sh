@@ -8,7 +8,7 @@ for d in ("/tmp/p1", "/tmp/p2"):
     vals = collections.defaultdict(list)
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(fn)):
-            if "sdc_dynamics_kernel" in row["Kernel_Name"]:
+            if "sdc_dynamics" in row["Kernel_Name"]:
                 vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in sorted(vals.items()):
         t = v[-32:]

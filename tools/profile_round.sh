@@ -2,13 +2,13 @@
 # One gpurun call that produces everything profiles/ and DESIGN.md quote for a round:  bash tools/profile_round.sh r2
 # (rocprofv3 passes run from /tmp with TMPDIR=/tmp; --pmc passes -- inside bench.py -- use --kernel-trace only)
 set -x
-TAG=${1:-r2}
+TAG=${1:-r3}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the default bench command (without the PMC sub-passes, which are separate processes)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --steps 2000 --no-pmc --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/trace.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --steps 2000 --no-pmc --no-cpu-baseline --no-secondary > $O/bench_under_rocprof.json 2> $O/trace.err
 cd $R
 python tools/trace_summary.py $O/trace --last 1500 --out $O/kernel_trace_steady_state.json 2>&1 | tail -3
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
@@ -20,7 +20,14 @@ timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_s
 timeout 600 python bench.py --mixed-racks --no-cpu-baseline --no-pmc > $O/bench_mixed_racks.json 2>> $O/bench.err
 # 3. side measurements DESIGN.md quotes
 timeout 600 python tools/batch_scan.py > $O/batch_scan.txt 2>&1
+timeout 600 python tools/qb.py > $O/quick_rates.txt 2>&1
+# (the in-kernel clock stamps of the COMMON-CASE kernels need the measurement build: tools/bin/lib_dbg.so, made by
+#  tools/ab.sh ... dbg:'-DSDC_FAST_DEBUG=1'; without it these tools time the general kernels)
+if [ -f tools/bin/lib_dbg.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/prod.so; cp tools/bin/lib_dbg.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
 timeout 600 python tools/wave_phases.py > $O/wave_phases.txt 2>&1
+timeout 600 python tools/wave_timeline.py > $O/wave_timeline.txt 2>&1
+timeout 600 python tools/wave_tail.py > $O/wave_tail.txt 2>&1
+if [ -f /tmp/prod.so ]; then cp /tmp/prod.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
 timeout 600 python tools/rollout_rate.py > $O/rollout_rate.txt 2>&1
 SDC_GROUPS=2 SDC_N=4096 timeout 600 python tools/two_streams.py > $O/two_streams.txt 2>&1
 SDC_GROUPS=2 SDC_N=8192 timeout 600 python tools/two_streams.py >> $O/two_streams.txt 2>&1
@@ -30,8 +37,6 @@ hipcc --offload-arch=gfx950 -O3 tools/launch_floor.hip -o /tmp/launch_floor 2>/d
 hipcc --offload-arch=gfx950 -O3 tools/dispatch_rate.hip -o /tmp/dispatch_rate 2>/dev/null && /tmp/dispatch_rate > $O/dispatch_rate.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/dispatch_rate2.hip -o /tmp/dispatch_rate2 2>/dev/null && /tmp/dispatch_rate2 > $O/dispatch_rate2.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/load_latency.hip -o /tmp/load_latency 2>/dev/null && /tmp/load_latency > $O/load_latency.txt 2>&1
-timeout 600 python tools/slow_waves.py > $O/slow_waves.txt 2>&1
-timeout 600 python tools/wave_timeline.py > $O/wave_timeline.txt 2>&1
 bash tools/pmc_stalls.sh > $O/pmc_stalls.txt 2>&1
 bash tools/pmc_latency.sh > $O/pmc_latency.txt 2>&1
 grep -v amdgpu.ids $O/*.txt | tail -60
