@@ -1608,8 +1608,10 @@ __device__ __forceinline__ int first_pair_of_block(const int bi, const int nb, c
   return vb * wpb;
 }
 
-// The spare wavefronts of a step launch (32 workgroups early in the second dispatch round): wavefront j serves re-centring request j of the previous step (see
-// SdcRefillReq): one sweep over that env's ring as the previous step left it, the re-centred window out as a result.
+// The spare wavefronts of a step launch (32 workgroups, first in the grid): they serve the re-centring requests of the
+// previous step (see SdcRefillReq): one sweep over that env's ring as the previous step left it, the re-centred window out
+// as a result.  serve_recentring_requests: wavefront j serves request j alone (round 2; kept for -DSDC_SWEEP_COOP=0);
+// serve_recentring_requests_coop: the four wavefronts of a workgroup share each sweep (round 3, the default).
 #define SDC_SWEEP_BLOCKS (SDC_RQ_MAX / SDC_STEP_WPB)
 #define SDC_CUS 256
 #ifndef SDC_SWEEP_PRIO
@@ -1718,7 +1720,7 @@ __device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs
   const int lane = threadIdx.x % SDC_WAVE;
   kernarg_touch_done(ktouch);
   const int pair_blocks = (int)gridDim.x - SDC_SWEEP_BLOCKS;
-  // where the 32 sweep workgroups sit in the grid: after the first SDC_SWEEP_AT pair workgroups (or last, in a small grid)
+  // where the 32 sweep workgroups sit in the grid: after the first SDC_SWEEP_AT pair workgroups (0: first; or last, in a small grid)
   const int sweep_first = pair_blocks > SDC_SWEEP_AT ? SDC_SWEEP_AT : pair_blocks;
   const int bx = (int)blockIdx.x;
   if (bx >= sweep_first && bx < sweep_first + SDC_SWEEP_BLOCKS) {
