@@ -11,27 +11,36 @@
 //       -> Linear(64, 3)  -> Categorical(logits): mode() = argmax (deterministic) or sample()
 // one network per agent (agent_ls, agent_dc, agent_bat), fp32 like the reference.
 //
-// Mapping: lane = hidden unit (64 lanes = 64 units), BOTH envs of the wavefront at once (two accumulators per lane share
-// every weight read); the layer input is handed round as float2 {env 0, env 1} through LDS (broadcast reads); the three
-// agents' weights sit in LDS once per workgroup (76 KB), k-major and interleaved in pairs so that a lane reads the two
-// weights of inputs 2i, 2i + 1 with one ds_read_b64.  LayerNorm / logits: DPP reductions.  This is a contraction, but
-// at 2 envs per wavefront an MFMA tile (>= 16 rows) would be 7/8 padding; the fp32 VALU form costs ~470 instructions
-// per agent and pair.
+// Mapping: the two hidden layers are contractions and run on the MATRIX CORES, wavefront-locally -- no barrier, no
+// partner wavefront.  The instruction is v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products, K = 1,
+//     D_b[i][j] += A_b[i] * B_b[j]        b = 0..15, lane 4 b + j holds column j of block b, register i = row i
+// read as ONE 4 x 64 product: rows i = envs (2 of the 4 are real: the wavefront's pair), columns 4 b + j = hidden unit
+// = LANE.  B: lane l supplies W[k][unit l] -- a row of the k-major weight matrix, straight from LDS.  A: with the
+// broadcast modifiers (cbsz = 4: all 16 blocks take block `abid`'s A), lanes 4 m + e of ONE register supply x[env e][k]
+// for the instruction that names abid = m; a register P_v with P_v[4 m + e] = x_e[4 m + v] therefore serves the 16
+// instructions k = 4 m + v, m = 0..15 -- and because the layer's output sits as (lane = unit, register = env), P_v is
+// a quad permutation (DPP) of the activations: the layer-to-layer hand-over never touches LDS.
+// Cost per wavefront and env-step: 3 x (28 + 64) MFMAs of 8 cycles, 69 ds_read_b128 of weights, ~100 VALU.
+// (The first form of this, lane-per-unit packed FMAs with the inputs broadcast through LDS, spent 8.5 us per step on the
+// three networks, LDS-bandwidth bound; the second, 16x16x4 tiles pooling a workgroup's 16 envs between two barriers, 4.3 us
+// plus what a barrier per step costs a workgroup whose wavefronts' step times differ)
 #pragma once
 #include "sdc_device.hpp"
 
 #define SDC_ACT_IN SDC_OBS_PAD     // 26
+#define SDC_ACT_M1 7               // K-quads of layer 1 (26 inputs padded to 28)
 #define SDC_ACT_H 64
+#define SDC_ACT_M2 (SDC_ACT_H / 4)
 #define SDC_ACT_OUT 3
 
 // one agent's actor as the kernel reads it (device memory, then LDS); filled by sdc_set_actor (sdc_capi.hip)
 struct SdcActorDev {
   float ln0_g[32], ln0_b[32];                 // feature LayerNorm over the 26 inputs (entries 26.. unused)
-  float w1[SDC_ACT_IN / 2][SDC_ACT_H][2];     // w1[i][j] = {W1[j][2i], W1[j][2i+1]}   (W as torch stores it: [out][in])
-  float b1[SDC_ACT_H], ln1_g[SDC_ACT_H], ln1_b[SDC_ACT_H];
-  float w2[SDC_ACT_H / 2][SDC_ACT_H][2];
-  float b2[SDC_ACT_H], ln2_g[SDC_ACT_H], ln2_b[SDC_ACT_H];
+  float w1[SDC_ACT_M1][SDC_ACT_H][4];         // w1[m][j][v] = W1[j][4 m + v]   (W as torch stores it: [out][in]; 0 beyond k = 25)
+  float w2[SDC_ACT_M2][SDC_ACT_H][4];         // w2[m][j][v] = W2[j][4 m + v]: one ds_read_b128 per lane = four B operands
   float w3[4][SDC_ACT_H];                     // w3[c][j] = W3[c][j], c < 3
+  float b1[SDC_ACT_H], ln1_g[SDC_ACT_H], ln1_b[SDC_ACT_H];
+  float b2[SDC_ACT_H], ln2_g[SDC_ACT_H], ln2_b[SDC_ACT_H];
   float b3[4];
   int flags;                                  // bit 0: feature LayerNorm on; bits 1-2: activation (0 tanh, 1 relu)
   int pad[3];
@@ -40,32 +49,17 @@ static_assert(sizeof(SdcActorDev) % 16 == 0, "copied to LDS as uint4");
 
 namespace sdc_act {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(const float v) {   // (every row written, no source lane -> 0)
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-// sum over the 32 lanes of each half (every lane gets its half's sum): the tree of half_sum_f64
-__device__ __forceinline__ float half_sum_f32(float v) {
-  v += dpp_f32<SDC_DPP_XOR1>(v);
-  v += dpp_f32<SDC_DPP_XOR2>(v);
-  v += dpp_f32<SDC_DPP_HALF_MIRROR>(v);
-  v += dpp_f32<SDC_DPP_MIRROR>(v);
-  const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(s[1]) + __uint_as_float(s[0]);
-}
-// sum over all 64 lanes, every lane gets it
-__device__ __forceinline__ float wave_sum_f32(float v) {
-  v = half_sum_f32(v);
-  const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(s[1]) + __uint_as_float(s[0]);
-}
-// N sums at once, stage by stage: a reduction is a chain of seven dependent steps, each a DPP / permlane operation that
-// must wait out the previous one (the compiler pads a lone chain with s_nop); N independent chains fill each other's gaps
+// N sums at once, stage by stage, over the 32 lanes of each half (HALF) or all 64: a reduction is a chain of dependent
+// DPP / permlane steps, each waiting out the previous one; N independent chains fill each other's gaps
 template <int N, bool HALF>
 __device__ __forceinline__ void sums(float (&v)[N]) {
-#define SDC_ACT_STAGE(C)  \
+#define SDC_ACT_STAGE(C) \
   _Pragma("unroll") for (int i = 0; i < N; i++) v[i] += dpp_f32<C>(v[i]);
   SDC_ACT_STAGE(SDC_DPP_XOR1)
   SDC_ACT_STAGE(SDC_DPP_XOR2)
@@ -85,80 +79,183 @@ __device__ __forceinline__ void sums(float (&v)[N]) {
     }
   }
 }
-__device__ __forceinline__ float activate(const float x, const int kind) {
-  if (kind == 1) return x > 0.0f ? x : 0.0f;
+template <int KIND>
+__device__ __forceinline__ float activate(const float x) {
+  if constexpr (KIND == 1) return x > 0.0f ? x : 0.0f;
   // tanh x = 1 - 2 / (e^(2x) + 1): hardware exp2 / rcp (~1 ulp each), exact limits at +-inf
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
-// LayerNorm over the 64 lanes (torch: biased variance, eps 1e-5), both envs
-// (one pass: sum and sum of squares of both envs as four interleaved reductions, variance = E[x^2] - mean^2; the inputs
-// are activations in [-1, 1] or a ReLU's outputs of order one: the cancellation costs ~1e-7 of the value)
-__device__ __forceinline__ void layer_norm64(float& a0, float& a1, const float g, const float b) {
-  float r[4] = {a0, a1, a0 * a0, a1 * a1};
-  sums<4, false>(r);
-  const float m0 = r[0] * (1.0f / SDC_ACT_H), m1 = r[1] * (1.0f / SDC_ACT_H);
-  const float v0 = fmaxf(r[2] * (1.0f / SDC_ACT_H) - m0 * m0, 0.0f), v1 = fmaxf(r[3] * (1.0f / SDC_ACT_H) - m1 * m1, 0.0f);
-  a0 = (a0 - m0) * __builtin_amdgcn_rsqf(v0 + 1e-5f) * g + b;
-  a1 = (a1 - m1) * __builtin_amdgcn_rsqf(v1 + 1e-5f) * g + b;
+
+// The A operands of a layer from its input as (lane = entry k, x0 = env 0's value, x1 = env 1's):
+// P[v][lane 4 m + e] = x_e[4 m + v] -- a quad broadcast of x0 and of x1, merged on the lane's parity (lanes 4 m + 2, + 3
+// repeat envs 0, 1: rows 2, 3 of the product, never read).
+template <int V>
+__device__ __forceinline__ float quad_bcast(const float x) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), V * 0x55, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void a_operands(float (&P)[4], const float x0, const float x1, const bool odd) {
+  // (both broadcasts FIRST, by every lane, then the select: written as `odd ? bcast(x1) : bcast(x0)` each DPP ran under half
+  // the exec mask -- its source lanes switched off)
+  const float e0 = quad_bcast<0>(x0), e1 = quad_bcast<1>(x0), e2 = quad_bcast<2>(x0), e3 = quad_bcast<3>(x0);
+  const float o0 = quad_bcast<0>(x1), o1 = quad_bcast<1>(x1), o2 = quad_bcast<2>(x1), o3 = quad_bcast<3>(x1);
+  P[0] = odd ? o0 : e0;
+  P[1] = odd ? o1 : e1;
+  P[2] = odd ? o2 : e2;
+  P[3] = odd ? o3 : e3;
+}
+// bias, activation, LayerNorm(64) of the three agents' layer outputs at once (torch: biased variance, eps 1e-5; one
+// pass -- the inputs are activations in [-1, 1] or a ReLU's outputs of order one: E[x^2] - mean^2 costs ~1e-7 of the
+// value); twelve reductions interleaved.  In: acc[a][e] = env e's pre-activation; out: h[a][e], lane = unit.
+template <int KIND>
+__device__ __forceinline__ void epilogue(const f4 (&acc)[3], const float (&bias)[3], const float (&g)[3], const float (&b)[3],
+                                         float (&h)[3][2]) {
+  float r[12];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const float v = activate<KIND>(acc[a][e] + bias[a]);
+      h[a][e] = v;
+      r[4 * a + e] = v;
+      r[4 * a + 2 + e] = v * v;
+    }
+  sums<12, false>(r);
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const float mean = r[4 * a + e] * (1.0f / SDC_ACT_H);
+      const float var = fmaxf(r[4 * a + 2 + e] * (1.0f / SDC_ACT_H) - mean * mean, 0.0f);
+      h[a][e] = (h[a][e] - mean) * __builtin_amdgcn_rsqf(var + 1e-5f) * g[a] + b[a];
+    }
 }
 
-// One agent's forward pass for both envs of the wavefront.  x: this lane's input (lane (h, k): entry k < 26 of env h's
-// padded observation of this agent, 0 beyond); xs: the wavefront's LDS hand-round buffer, float2[64].
-// Returns the three logits of env 0 in lg[0..2], of env 1 in lg[3..5] (every lane).
-__device__ __forceinline__ void forward(const SdcActorDev& A, const float x, const int lane, float2* xs, float (&lg)[6]) {
-  const int h = lane >> 5, k = lane & 31;
-  const int kind = (A.flags >> 1) & 3;
-  float xn = x;
-  if (A.flags & 1) {
-    // (observation entries are of order one -- normalised by construction -- so the one-pass variance is safe here too)
-    float r[2] = {x, x * x};
-    sums<2, true>(r);
-    const float mean = r[0] * (1.0f / SDC_ACT_IN);
-    const float var = fmaxf(r[1] * (1.0f / SDC_ACT_IN) - mean * mean, 0.0f);
-    xn = (x - mean) * __builtin_amdgcn_rsqf(var + 1e-5f) * A.ln0_g[k] + A.ln0_b[k];
-  }
-  wave_sync();                                     // (the previous layer's readers are done with xs)
-  if (k < SDC_ACT_IN) reinterpret_cast<float*>(xs)[2 * k + h] = xn;
-  wave_sync();
-  // (both envs in one packed instruction: v_pk_fma_f32 {acc0, acc1} += {w, w} * {x0, x1}, the weight broadcast by op_sel)
-  v2f acc = {A.b1[lane], A.b1[lane]};
+// A layer's K-quads in chunks of SDC_ACT_CH, double-buffered: the weights of chunk c + 1 (or, after the last, the first
+// chunk of the NEXT layer: they depend on nothing) are fetched -- ds_read_b128: four B operands per lane -- while chunk c
+// multiplies.  The scheduling barriers keep that order (left alone, the scheduler sinks every fetch next to its use and
+// each group of MFMAs waits out an LDS round trip).
+#define SDC_ACT_CH 2
+struct WBuf { f4 w[2][3][SDC_ACT_CH]; };
+template <int NM>
+__device__ __forceinline__ void fetch3(f4 (&B)[3][SDC_ACT_CH], const SdcActorDev* A, const bool layer2, const int m0, const int lane) {
 #pragma unroll
-  for (int i = 0; i < SDC_ACT_IN / 2; i++) {
-    const float4 xx = reinterpret_cast<const float4*>(xs)[i];          // {x0[2i], x1[2i], x0[2i+1], x1[2i+1]}, broadcast
-    const float2 w = *reinterpret_cast<const float2*>(A.w1[i][lane]);
-    acc = __builtin_elementwise_fma(v2f{w.x, w.x}, v2f{xx.x, xx.y}, acc);
-    acc = __builtin_elementwise_fma(v2f{w.y, w.y}, v2f{xx.z, xx.w}, acc);
-  }
-  float a0 = activate(acc.x, kind);
-  float a1 = activate(acc.y, kind);
-  layer_norm64(a0, a1, A.ln1_g[lane], A.ln1_b[lane]);
-  wave_sync();
-  xs[lane] = make_float2(a0, a1);
-  wave_sync();
-  v2f acc2 = {A.b2[lane], A.b2[lane]};
-#pragma unroll 16
-  for (int i = 0; i < SDC_ACT_H / 2; i++) {
-    const float4 xx = reinterpret_cast<const float4*>(xs)[i];
-    const float2 w = *reinterpret_cast<const float2*>(A.w2[i][lane]);
-    acc2 = __builtin_elementwise_fma(v2f{w.x, w.x}, v2f{xx.x, xx.y}, acc2);
-    acc2 = __builtin_elementwise_fma(v2f{w.y, w.y}, v2f{xx.z, xx.w}, acc2);
-  }
-  float c0 = activate(acc2.x, kind);
-  float c1 = activate(acc2.y, kind);
-  layer_norm64(c0, c1, A.ln2_g[lane], A.ln2_b[lane]);
+  for (int a = 0; a < 3; a++)
 #pragma unroll
-  for (int c = 0; c < SDC_ACT_OUT; c++) {
-    const float w = A.w3[c][lane];
-    lg[c] = w * c0;
-    lg[3 + c] = w * c1;
+    for (int i = 0; i < NM; i++)
+      B[a][i] = layer2 ? *reinterpret_cast<const f4*>(A[a].w2[m0 + i][lane]) : *reinterpret_cast<const f4*>(A[a].w1[m0 + i][lane]);
+}
+template <int M, int MEND>       // the MFMAs of K-quads M .. MEND-1, the three agents interleaved (an accumulator is touched every
+struct KQuads {                  // third instruction: no MFMA waits for the one before it)
+  static __device__ __forceinline__ void run(f4 (&acc)[3], const float (&P)[3][4], const f4 (&B)[3][SDC_ACT_CH]) {
+#define SDC_ACT_MFMA(V) \
+  _Pragma("unroll") for (int a = 0; a < 3; a++) \
+    acc[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[a][V], B[a][M % SDC_ACT_CH][V], acc[a], 4, M, 0);
+    SDC_ACT_MFMA(0) SDC_ACT_MFMA(1) SDC_ACT_MFMA(2) SDC_ACT_MFMA(3)
+#undef SDC_ACT_MFMA
+    if constexpr (M + 1 < MEND) KQuads<M + 1, MEND>::run(acc, P, B);
   }
-  sums<6, false>(lg);
+};
+// chunk C of a layer of MQ K-quads (buffer C % 2 holds it; PAR: the buffer parity the layer started on)
+template <int C, int MQ, bool LAYER2, int PAR>
+struct Chunks {
+  static constexpr int NCH = (MQ + SDC_ACT_CH - 1) / SDC_ACT_CH;
+  static __device__ __forceinline__ void run(f4 (&acc)[3], const float (&P)[3][4], WBuf& W, const SdcActorDev* A, const int lane) {
+    constexpr int M0 = C * SDC_ACT_CH, M1 = M0 + SDC_ACT_CH < MQ ? M0 + SDC_ACT_CH : MQ;
+    if constexpr (C + 1 < NCH) {
+      constexpr int N1 = (M1 + SDC_ACT_CH < MQ ? M1 + SDC_ACT_CH : MQ) - M1;
+      fetch3<N1>(W.w[(PAR + C + 1) & 1], A, LAYER2, M1, lane);
+    } else if constexpr (!LAYER2) {
+      fetch3<SDC_ACT_CH>(W.w[(PAR + C + 1) & 1], A, true, 0, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    KQuads<M0, M1>::run(acc, P, W.w[(PAR + C) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (C + 1 < NCH) Chunks<C + 1, MQ, LAYER2, PAR>::run(acc, P, W, A, lane);
+  }
+};
+// (KQuads indexes a chunk's buffer by M % SDC_ACT_CH: chunks start at multiples of SDC_ACT_CH)
+
+// THE THREE AGENTS' NETWORKS FOR THE WAVEFRONT'S TWO ENVS, interleaved (three independent chains fill each other's
+// latencies).  x[a]: this lane's input of agent a (lane (h, k): entry k < 26 of env h's padded observation of that agent,
+// 0 beyond).  lg[a][0..2] = env 0's logits, lg[a][3..5] = env 1's (every lane).
+template <int KIND>
+__device__ __forceinline__ void forward3_kind(const SdcActorDev* A, const float (&x)[3], const int lane, float (&lg)[3][6]) {
+  const int k = lane & 31;
+  const bool odd = (lane & 1) != 0;
+  WBuf W;
+  fetch3<SDC_ACT_CH>(W.w[0], A, false, 0, lane);
+  // feature LayerNorm (observation entries are of order one -- normalised by construction -- so one pass is safe here too)
+  float xn[3] = {x[0], x[1], x[2]};
+  {
+    float r[6] = {x[0], x[0] * x[0], x[1], x[1] * x[1], x[2], x[2] * x[2]};
+    sums<6, true>(r);
 #pragma unroll
-  for (int c = 0; c < SDC_ACT_OUT; c++) {
-    lg[c] += A.b3[c];
-    lg[3 + c] += A.b3[c];
+    for (int a = 0; a < 3; a++)
+      if (A[a].flags & 1) {
+        const float mean = r[2 * a] * (1.0f / SDC_ACT_IN);
+        const float var = fmaxf(r[2 * a + 1] * (1.0f / SDC_ACT_IN) - mean * mean, 0.0f);
+        xn[a] = (x[a] - mean) * __builtin_amdgcn_rsqf(var + 1e-5f) * A[a].ln0_g[k] + A[a].ln0_b[k];
+      }
   }
+  float P[3][4];
+  f4 acc[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    // env 0's inputs sit in lanes 0..25, env 1's in lanes 32..57: both to lanes 0..25 (the lane = the entry k)
+    const float xa = k < SDC_ACT_IN ? xn[a] : 0.0f;
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(xa), __float_as_uint(xa), false, false);
+    a_operands(P[a], __uint_as_float(s[0]), __uint_as_float(s[1]), odd);
+    acc[a] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  // ---- layer 1: 26 (28) -> 64 ------------------------------------------------------------------------------------------
+  Chunks<0, SDC_ACT_M1, false, 0>::run(acc, P, W, A, lane);
+  constexpr int PAR2 = ((SDC_ACT_M1 + SDC_ACT_CH - 1) / SDC_ACT_CH) & 1;      // (the buffer layer 2's first chunk went to)
+  float h[3][2];
+  {
+    const float bias[3] = {A[0].b1[lane], A[1].b1[lane], A[2].b1[lane]};
+    const float g[3] = {A[0].ln1_g[lane], A[1].ln1_g[lane], A[2].ln1_g[lane]};
+    const float b[3] = {A[0].ln1_b[lane], A[1].ln1_b[lane], A[2].ln1_b[lane]};
+    epilogue<KIND>(acc, bias, g, b, h);
+  }
+  // ---- layer 2: 64 -> 64 -----------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    a_operands(P[a], h[a][0], h[a][1], odd);
+    acc[a] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  Chunks<0, SDC_ACT_M2, true, PAR2>::run(acc, P, W, A, lane);
+  {
+    const float bias[3] = {A[0].b2[lane], A[1].b2[lane], A[2].b2[lane]};
+    const float g[3] = {A[0].ln2_g[lane], A[1].ln2_g[lane], A[2].ln2_g[lane]};
+    const float b[3] = {A[0].ln2_b[lane], A[1].ln2_b[lane], A[2].ln2_b[lane]};
+    epilogue<KIND>(acc, bias, g, b, h);
+  }
+  // ---- the three logits per env: 64 -> 3, a dot product per lane-resident unit and a reduction ----------------------------
+  float r[18];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int c = 0; c < SDC_ACT_OUT; c++) {
+      const float w3 = A[a].w3[c][lane];
+      r[6 * a + c] = w3 * h[a][0];
+      r[6 * a + 3 + c] = w3 * h[a][1];
+    }
+  sums<18, false>(r);
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int c = 0; c < SDC_ACT_OUT; c++) {
+      const float b3 = A[a].b3[c];
+      lg[a][c] = r[6 * a + c] + b3;
+      lg[a][3 + c] = r[6 * a + 3 + c] + b3;
+    }
+}
+// (the activation is a template parameter: chosen per element at run time it became a branch around every exp -> rcp chain;
+// the three agents share it -- sdc_set_actor refuses a mix)
+__device__ __forceinline__ void forward3(const SdcActorDev* A, const float (&x)[3], const int lane, float (&lg)[3][6]) {
+  if (__builtin_amdgcn_readfirstlane((A[0].flags >> 1) & 3) == 1) forward3_kind<1>(A, x, lane, lg);
+  else forward3_kind<0>(A, x, lane, lg);
 }
 
 // the action of one env from its three logits: mode() = first maximum (torch argmax), or a draw from

@@ -93,6 +93,7 @@ struct sdc_handle {
   // observations (what the first actions of a launch are chosen from); allocated when the first actor is set
   SdcActorDev* actor_dev = nullptr;
   bool actor_set[3] = {false, false, false};
+  int actor_activation[3] = {0, 0, 0};
   float* obs_latch = nullptr;
   bool latch_valid = false;
   int racks_cfg0 = 0;                     // racks of data-centre config 0 (the specialised kernels take <= 32: one pass)
@@ -716,7 +717,7 @@ int sdc_set_actor(sdc_handle* h, int slot, const sdc_actor_params* p) {
     if (dev_alloc(h, &h->obs_latch, (size_t)h->cfg.n_envs * SDC_OBS_OUT) != 0) return -1;
     h->latch_valid = false;      // (filled by the next reset / step / rollout)
   }
-  // torch's [out][in] rows -> the kernel's k-major, pairwise interleaved layout (sdc_actor.hpp)
+  // torch's [out][in] rows -> the kernel's k-major layout, four consecutive k per lane (sdc_actor.hpp)
   static SdcActorDev a;
   std::memset(&a, 0, sizeof(a));
   for (int k = 0; k < SDC_ACT_IN; k++) {
@@ -724,8 +725,8 @@ int sdc_set_actor(sdc_handle* h, int slot, const sdc_actor_params* p) {
     a.ln0_b[k] = p->ln0_beta[k];
   }
   for (int j = 0; j < SDC_ACT_H; j++) {
-    for (int k = 0; k < SDC_ACT_IN; k++) a.w1[k / 2][j][k & 1] = p->w1[j * SDC_ACT_IN + k];
-    for (int k = 0; k < SDC_ACT_H; k++) a.w2[k / 2][j][k & 1] = p->w2[j * SDC_ACT_H + k];
+    for (int k = 0; k < SDC_ACT_IN; k++) a.w1[k / 4][j][k & 3] = p->w1[j * SDC_ACT_IN + k];
+    for (int k = 0; k < SDC_ACT_H; k++) a.w2[k / 4][j][k & 3] = p->w2[j * SDC_ACT_H + k];
     a.b1[j] = p->b1[j]; a.ln1_g[j] = p->ln1_gamma[j]; a.ln1_b[j] = p->ln1_beta[j];
     a.b2[j] = p->b2[j]; a.ln2_g[j] = p->ln2_gamma[j]; a.ln2_b[j] = p->ln2_beta[j];
     for (int c = 0; c < SDC_ACT_OUT; c++) a.w3[c][j] = p->w3[c * SDC_ACT_H + j];
@@ -735,6 +736,7 @@ int sdc_set_actor(sdc_handle* h, int slot, const sdc_actor_params* p) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(h->actor_dev + slot, &a, sizeof(a), hipMemcpyHostToDevice));
   h->actor_set[slot] = true;
+  h->actor_activation[slot] = p->activation;
   return 0;
 }
 
@@ -742,6 +744,9 @@ int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float*
                       float* info, float* final_obs, int32_t* actions_out, float* logits_out, void* stream) {
   if (!h || !obs || !share_obs || !rew || !done || !info || !actions_out) return fail_msg("sdc_rollout_actor: null argument");
   if (!h->actor_set[0] || !h->actor_set[1] || !h->actor_set[2]) return fail_msg("sdc_rollout_actor: sdc_set_actor all three agents first");
+  if (h->actor_activation[0] != h->actor_activation[1] || h->actor_activation[0] != h->actor_activation[2])
+    return fail_msg("sdc_rollout_actor: the three actors must share one activation (the reference builds them from one "
+                    "model config: happo.yaml activation_func)");
   if (!h->started) return fail_msg("sdc_rollout_actor: sdc_reset must be called first");
   if (!h->latch_valid) return fail_msg("sdc_rollout_actor: no observations yet (the actors were set after the last reset / step: reset or step once)");
   if (n_steps <= 0) return fail_msg("sdc_rollout_actor: n_steps must be positive");

@@ -1847,8 +1847,8 @@ struct ActorLds {
   PairShared shs[SDC_ACTOR_WPB];
   double ktab[SDC_K_LDS];
   SdcActorDev net[3];
-  float2 xs[SDC_ACTOR_WPB][SDC_ACT_H];
 };
+static_assert(offsetof(ActorLds, net) % 16 == 0, "the weights are read as ds_read_b128");
 extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_ACTOR_WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcActorDev* __restrict__ nets,
                          const float* __restrict__ obs_in, const int sample, float* __restrict__ obs,
@@ -1879,41 +1879,55 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
     sh.pool[h][l] = l < SDC_OBS_PAD ? o[l] : (l == SDC_P_WNEXT ? o[SDC_OBS_PAD + 11] : (l == SDC_P_NTNEXT ? o[SDC_OBS_PAD + 13] : o[2 * SDC_OBS_PAD + 12]));
   }
   wave_sync();
+#ifdef SDC_ACTOR_CLOCK      // (measurement build: shader-clock cycles per phase, summed over the K steps, into info slots 38..40 of the last step)
+  unsigned long long ck[3] = {0, 0, 0}, c0, c1;
+#define SDC_CK(i) c1 = __builtin_amdgcn_s_memtime(); ck[i] += c1 - c0; c0 = c1;
+#else
+#define SDC_CK(i)
+#endif
 #pragma unroll 1
   for (int k = 0; k < K; k++) {
     int env_k = env0, lane_k = lane;
     asm volatile("" : "+s"(env_k), "+v"(lane_k));
+#ifdef SDC_ACTOR_CLOCK
+    c0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- the three actors on the current observations (in the LDS pool) ------------------------------------------------
     int act[3];
     const int lk = lane_k & (HL - 1), hk = lane_k >> 5;
     const int rel_now = rel_hint + k;
-#pragma unroll 1
-    for (int a = 0; a < 3; a++) {
-      const float x = lk < SDC_ACT_IN ? obs_padded_at(sh.pool[hk], a * SDC_OBS_PAD + lk) : 0.0f;
-      float lg[6];
+    float lg[3][6];
+    {
+      float x[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) x[a] = lk < SDC_ACT_IN ? obs_padded_at(sh.pool[hk], a * SDC_OBS_PAD + lk) : 0.0f;
 #ifdef SDC_ACTOR_SKIP
-      {   // (measurement: the kernel without the networks -- pseudo-random actions from a hash)
+      // (measurement: the kernel without the networks -- pseudo-random actions from a hash)
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
         unsigned hsh = (unsigned)(env_k + hk) * 2654435761u + (unsigned)(rel_now * 3 + a) * 40503u;
         hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
         const int pick = (int)(hsh % 3u);
-        lg[0] = lg[3] = pick == 0 ? 1.f : 0.f; lg[1] = lg[4] = pick == 1 ? 1.f : 0.f; lg[2] = lg[5] = pick == 2 ? 1.f : 0.f;
-        (void)x;
+        lg[a][0] = lg[a][3] = pick == 0 ? 1.f : 0.f; lg[a][1] = lg[a][4] = pick == 1 ? 1.f : 0.f; lg[a][2] = lg[a][5] = pick == 2 ? 1.f : 0.f;
       }
+      (void)x;
 #else
-      sdc_act::forward(L.net[a], x, lane_k, L.xs[wave], lg);
+      sdc_act::forward3(L.net, x, lane_k, lg);
 #endif
+    }
+    SDC_CK(0)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
       float u = 0.0f;
       if (sample) {   // one uniform per (env, episode step, agent): Philox keyed on the GLOBAL env index, like the resets
         const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + hk), (unsigned)a, 0xAC70u,
                                         (unsigned)S.seed, (unsigned)(S.seed >> 32) ^ (unsigned)S.step_no);
         u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
       }
-      const int ai = sdc_act::pick_action(hk ? lg[3] : lg[0], hk ? lg[4] : lg[1], hk ? lg[5] : lg[2], sample != 0, u);
-      if (a == 0) act[0] = ai;
-      if (a == 1) act[1] = ai;
-      if (a == 2) act[2] = ai;
+      const float l0 = hk ? lg[a][3] : lg[a][0], l1 = hk ? lg[a][4] : lg[a][1], l2 = hk ? lg[a][5] : lg[a][2];
+      act[a] = sdc_act::pick_action(l0, l1, l2, sample != 0, u);
       if (logits_out && lk < SDC_ACT_OUT)
-        logits_out[(((size_t)k * N + (size_t)(env_k + hk)) * 3 + a) * 3 + lk] = hk ? (lk == 0 ? lg[3] : lk == 1 ? lg[4] : lg[5]) : (lk == 0 ? lg[0] : lk == 1 ? lg[1] : lg[2]);
+        logits_out[(((size_t)k * N + (size_t)(env_k + hk)) * 3 + a) * 3 + lk] = lk == 0 ? l0 : (lk == 1 ? l1 : l2);
     }
     if (lk == 0) {
       int32_t* ao = actions_out + ((size_t)k * N + (size_t)(env_k + hk)) * 3;
@@ -1921,6 +1935,7 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
       ao[1] = act[1];
       ao[2] = act[2];
     }
+    SDC_CK(1)
     // ---- the env step on those actions ------------------------------------------------------------------------------------
     pair_step<true, true>(S, sh, env_k, lane_k, rel_now, nullptr, obs + (size_t)k * N * SDC_OBS_OUT,
                           share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM, done + (size_t)k * N, info + (size_t)k * N * SDC_INFO_DIM,
@@ -1929,7 +1944,12 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wave_sync();
+    SDC_CK(2)
   }
+#ifdef SDC_ACTOR_CLOCK
+  if (lane == 0)
+    for (int i = 0; i < 3; i++) info[((size_t)(K - 1) * N + (size_t)env0) * SDC_INFO_DIM + 38 + i] = (float)ck[i];
+#endif
   // the observations the NEXT launch's first actions are chosen from (unless the episode ended: the host then copies the
   // reset observations in)
   if (obs_latch) {
