@@ -55,10 +55,10 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f32(const float v) {   // (every row written, no source lane -> 0)
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-// N sums at once, stage by stage, over the 32 lanes of each half (HALF) or all 64: a reduction is a chain of dependent
-// DPP / permlane steps, each waiting out the previous one; N independent chains fill each other's gaps
-template <int N, bool HALF>
-__device__ __forceinline__ void sums(float (&v)[N]) {
+// REDUCTIONS over the wavefront.  Within the 16 lanes of a DPP row: four butterfly stages, N chains interleaved (each
+// stage waits out the previous one).
+template <int N>
+__device__ __forceinline__ void row_sums(float (&v)[N]) {
 #define SDC_ACT_STAGE(C) \
   _Pragma("unroll") for (int i = 0; i < N; i++) v[i] += dpp_f32<C>(v[i]);
   SDC_ACT_STAGE(SDC_DPP_XOR1)
@@ -66,18 +66,29 @@ __device__ __forceinline__ void sums(float (&v)[N]) {
   SDC_ACT_STAGE(SDC_DPP_HALF_MIRROR)
   SDC_ACT_STAGE(SDC_DPP_MIRROR)
 #undef SDC_ACT_STAGE
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
-    v[i] = __uint_as_float(s[1]) + __uint_as_float(s[0]);
-  }
-  if constexpr (!HALF) {
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
-      v[i] = __uint_as_float(s[1]) + __uint_as_float(s[0]);
-    }
-  }
+}
+// ACROSS the four rows, two (then four) values per register: v_permlane16_swap exchanges the odd rows of its first
+// operand with the even rows of its second, so swapping two DIFFERENT row-sum registers a, b and adding the results
+// gives rows [a0+a1, b0+b1, a2+a3, b2+b3] -- both pair sums in one register, two instructions, no copies; one
+// v_permlane32_swap + add of two such registers gives rows [A, B, C, D], the four totals.  (Reducing each value on its
+// own -- swap with itself -- took a copy, a swap and an add per value and stage: the networks are VALU-issue bound, and
+// a third of their instructions were these.)
+__device__ __forceinline__ float swap16_sum(const float a, const float b) {
+  const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+__device__ __forceinline__ float swap32_sum(const float r, const float q) {
+  const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(q), false, false);
+  return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+// rows [T0, T1, T2, T3] -> even = [T0, T0, T2, T2], odd = [T1, T1, T3, T3]: each half of the wavefront its own pair
+__device__ __forceinline__ void spread16(const float t, float& even, float& odd) {
+  const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  even = __uint_as_float(s[0]);
+  odd = __uint_as_float(s[1]);
+}
+__device__ __forceinline__ float row_value(const float t, const int row) {      // (wave-uniform: an SGPR)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 16 * row));
 }
 template <int KIND>
 __device__ __forceinline__ float activate(const float x) {
@@ -106,7 +117,7 @@ __device__ __forceinline__ void a_operands(float (&P)[4], const float x0, const 
 }
 // bias, activation, LayerNorm(64) of the three agents' layer outputs at once (torch: biased variance, eps 1e-5; one
 // pass -- the inputs are activations in [-1, 1] or a ReLU's outputs of order one: E[x^2] - mean^2 costs ~1e-7 of the
-// value); twelve reductions interleaved.  In: acc[a][e] = env e's pre-activation; out: h[a][e], lane = unit.
+// value).  In: acc[a][e] = env e's pre-activation; out: h[a][e], lane = unit.
 template <int KIND>
 __device__ __forceinline__ void epilogue(const f4 (&acc)[3], const float (&bias)[3], const float (&g)[3], const float (&b)[3],
                                          float (&h)[3][2]) {
@@ -120,15 +131,18 @@ __device__ __forceinline__ void epilogue(const f4 (&acc)[3], const float (&bias)
       r[4 * a + e] = v;
       r[4 * a + 2 + e] = v * v;
     }
-  sums<12, false>(r);
+  row_sums<12>(r);
 #pragma unroll
-  for (int a = 0; a < 3; a++)
+  for (int a = 0; a < 3; a++) {
+    // rows: [sum v (env 0), sum v (env 1), sum v^2 (env 0), sum v^2 (env 1)]
+    const float t = swap32_sum(swap16_sum(r[4 * a], r[4 * a + 1]), swap16_sum(r[4 * a + 2], r[4 * a + 3]));
 #pragma unroll
     for (int e = 0; e < 2; e++) {
-      const float mean = r[4 * a + e] * (1.0f / SDC_ACT_H);
-      const float var = fmaxf(r[4 * a + 2 + e] * (1.0f / SDC_ACT_H) - mean * mean, 0.0f);
+      const float mean = row_value(t, e) * (1.0f / SDC_ACT_H);
+      const float var = fmaxf(row_value(t, 2 + e) * (1.0f / SDC_ACT_H) - mean * mean, 0.0f);
       h[a][e] = (h[a][e] - mean) * __builtin_amdgcn_rsqf(var + 1e-5f) * g[a] + b[a];
     }
+  }
 }
 
 // A layer's K-quads in chunks of SDC_ACT_CH, double-buffered: the weights of chunk c + 1 (or, after the last, the first
@@ -178,9 +192,9 @@ struct Chunks {
 
 // THE THREE AGENTS' NETWORKS FOR THE WAVEFRONT'S TWO ENVS, interleaved (three independent chains fill each other's
 // latencies).  x[a]: this lane's input of agent a (lane (h, k): entry k < 26 of env h's padded observation of that agent,
-// 0 beyond).  lg[a][0..2] = env 0's logits, lg[a][3..5] = env 1's (every lane).
+// 0 beyond).  lg[a][0..2] = agent a's logits for THE LANE'S OWN env.
 template <int KIND>
-__device__ __forceinline__ void forward3_kind(const SdcActorDev* A, const float (&x)[3], const int lane, float (&lg)[3][6]) {
+__device__ __forceinline__ void forward3_kind(const SdcActorDev* A, const float (&x)[3], const int lane, float (&lg)[3][3]) {
   const int k = lane & 31;
   const bool odd = (lane & 1) != 0;
   WBuf W;
@@ -189,12 +203,15 @@ __device__ __forceinline__ void forward3_kind(const SdcActorDev* A, const float 
   float xn[3] = {x[0], x[1], x[2]};
   {
     float r[6] = {x[0], x[0] * x[0], x[1], x[1] * x[1], x[2], x[2] * x[2]};
-    sums<6, true>(r);
+    row_sums<6>(r);
 #pragma unroll
     for (int a = 0; a < 3; a++)
       if (A[a].flags & 1) {
-        const float mean = r[2 * a] * (1.0f / SDC_ACT_IN);
-        const float var = fmaxf(r[2 * a + 1] * (1.0f / SDC_ACT_IN) - mean * mean, 0.0f);
+        // rows [sum x (env 0), sum x^2 (env 0), sum x (env 1), sum x^2 (env 1)]: an env is a half = two rows
+        float sx, sxx;
+        spread16(swap16_sum(r[2 * a], r[2 * a + 1]), sx, sxx);
+        const float mean = sx * (1.0f / SDC_ACT_IN);
+        const float var = fmaxf(sxx * (1.0f / SDC_ACT_IN) - mean * mean, 0.0f);
         xn[a] = (x[a] - mean) * __builtin_amdgcn_rsqf(var + 1e-5f) * A[a].ln0_g[k] + A[a].ln0_b[k];
       }
   }
@@ -231,29 +248,37 @@ __device__ __forceinline__ void forward3_kind(const SdcActorDev* A, const float 
     const float b[3] = {A[0].ln2_b[lane], A[1].ln2_b[lane], A[2].ln2_b[lane]};
     epilogue<KIND>(acc, bias, g, b, h);
   }
-  // ---- the three logits per env: 64 -> 3, a dot product per lane-resident unit and a reduction ----------------------------
-  float r[18];
+  // ---- the three logits per env: 64 -> 3, a product per lane-resident unit and a reduction; every lane ends with ITS env's ---
+  float p[10][2];                       // [agent a, action c -> 3 a + c][env]; entry 9 pads the pairs
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
     for (int c = 0; c < SDC_ACT_OUT; c++) {
       const float w3 = A[a].w3[c][lane];
-      r[6 * a + c] = w3 * h[a][0];
-      r[6 * a + 3 + c] = w3 * h[a][1];
+      p[3 * a + c][0] = w3 * h[a][0];
+      p[3 * a + c][1] = w3 * h[a][1];
     }
-  sums<18, false>(r);
+  p[9][0] = p[9][1] = 0.0f;
+  {
+    float r[18];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r[2 * i] = p[i][0]; r[2 * i + 1] = p[i][1]; }
+    row_sums<18>(r);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { p[i][0] = r[2 * i]; p[i][1] = r[2 * i + 1]; }
+  }
+  float own[10];
+#pragma unroll
+  for (int i = 0; i < 10; i += 2)       // rows [X (env 0), Y (env 0), X (env 1), Y (env 1)], X = entry i, Y = entry i + 1
+    spread16(swap32_sum(swap16_sum(p[i][0], p[i + 1][0]), swap16_sum(p[i][1], p[i + 1][1])), own[i], own[i + 1]);
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int c = 0; c < SDC_ACT_OUT; c++) {
-      const float b3 = A[a].b3[c];
-      lg[a][c] = r[6 * a + c] + b3;
-      lg[a][3 + c] = r[6 * a + 3 + c] + b3;
-    }
+    for (int c = 0; c < SDC_ACT_OUT; c++) lg[a][c] = own[3 * a + c] + A[a].b3[c];
 }
 // (the activation is a template parameter: chosen per element at run time it became a branch around every exp -> rcp chain;
 // the three agents share it -- sdc_set_actor refuses a mix)
-__device__ __forceinline__ void forward3(const SdcActorDev* A, const float (&x)[3], const int lane, float (&lg)[3][6]) {
+__device__ __forceinline__ void forward3(const SdcActorDev* A, const float (&x)[3], const int lane, float (&lg)[3][3]) {
   if (__builtin_amdgcn_readfirstlane((A[0].flags >> 1) & 3) == 1) forward3_kind<1>(A, x, lane, lg);
   else forward3_kind<0>(A, x, lane, lg);
 }

@@ -1896,7 +1896,7 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
     int act[3];
     const int lk = lane_k & (HL - 1), hk = lane_k >> 5;
     const int rel_now = rel_hint + k;
-    float lg[3][6];
+    float lg[3][3];
     {
       float x[3];
 #pragma unroll
@@ -1908,7 +1908,7 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
         unsigned hsh = (unsigned)(env_k + hk) * 2654435761u + (unsigned)(rel_now * 3 + a) * 40503u;
         hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
         const int pick = (int)(hsh % 3u);
-        lg[a][0] = lg[a][3] = pick == 0 ? 1.f : 0.f; lg[a][1] = lg[a][4] = pick == 1 ? 1.f : 0.f; lg[a][2] = lg[a][5] = pick == 2 ? 1.f : 0.f;
+        lg[a][0] = pick == 0 ? 1.f : 0.f; lg[a][1] = pick == 1 ? 1.f : 0.f; lg[a][2] = pick == 2 ? 1.f : 0.f;
       }
       (void)x;
 #else
@@ -1924,7 +1924,7 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
                                         (unsigned)S.seed, (unsigned)(S.seed >> 32) ^ (unsigned)S.step_no);
         u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
       }
-      const float l0 = hk ? lg[a][3] : lg[a][0], l1 = hk ? lg[a][4] : lg[a][1], l2 = hk ? lg[a][5] : lg[a][2];
+      const float l0 = lg[a][0], l1 = lg[a][1], l2 = lg[a][2];
       act[a] = sdc_act::pick_action(l0, l1, l2, sample != 0, u);
       if (logits_out && lk < SDC_ACT_OUT)
         logits_out[(((size_t)k * N + (size_t)(env_k + hk)) * 3 + a) * 3 + lk] = lk == 0 ? l0 : (lk == 1 ? l1 : l2);
