@@ -1916,14 +1916,19 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
 #endif
     }
     SDC_CK(0)
+    // one uniform per (env, episode step, agent): ONE Philox block per (env, episode step), keyed on the GLOBAL env index like
+    // the resets, its words x, y, z for agent_ls, agent_dc, agent_bat
+    float u3[3] = {0.0f, 0.0f, 0.0f};
+    if (sample) {
+      const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + hk), 0u, 0xAC70u, (unsigned)S.seed,
+                                      (unsigned)(S.seed >> 32) ^ (unsigned)S.step_no);
+      u3[0] = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+      u3[1] = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+      u3[2] = (float)(r.z >> 8) * (1.0f / 16777216.0f);
+    }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      float u = 0.0f;
-      if (sample) {   // one uniform per (env, episode step, agent): Philox keyed on the GLOBAL env index, like the resets
-        const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + hk), (unsigned)a, 0xAC70u,
-                                        (unsigned)S.seed, (unsigned)(S.seed >> 32) ^ (unsigned)S.step_no);
-        u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
-      }
+      const float u = u3[a];
       const float l0 = lg[a][0], l1 = lg[a][1], l2 = lg[a][2];
       act[a] = sdc_act::pick_action(l0, l1, l2, sample != 0, u);
       if (logits_out && lk < SDC_ACT_OUT)
