@@ -278,7 +278,8 @@ int sdc_set_actor(sdc_handle* h, int agent_slot, const sdc_actor_params* p);
  * (counter-based RNG keyed on seed, global env index, episode step, agent).  Outputs as sdc_rollout (all required but
  * final_obs); actions_out [n_steps][N][3] receives the actions, logits_out [n_steps][N][3][3] (may be NULL) the actors'
  * logits.  Only for the common case the specialised kernels serve (lock-step batch with feature rows, one data-centre
- * config of <= 32 racks, default rewards, an even number of envs); anything else is refused. */
+ * config of <= 32 racks, default rewards, an even number of envs) and three actors with the same activation; anything
+ * else is refused. */
 int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float* share_obs, float* rew, uint8_t* done,
                       float* info, float* final_obs, int32_t* actions_out, float* logits_out, void* stream);
 /* steps until the first env finishes its episode (0: a reset is due) */
