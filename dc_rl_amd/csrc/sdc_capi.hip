@@ -21,6 +21,10 @@ extern "C" __global__ void sdc_dynamics_kernel(SdcDev S, int rel_hint, const int
                                                unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_dynamics_fast_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                                     unsigned char* done, float* info, float* final_obs, float* rew);
+extern "C" __global__ void sdc_dynamics_quad_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
+                                                    unsigned char* done, float* info, float* final_obs, float* rew);
+extern "C" __global__ void sdc_rollout_quad_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs,
+                                                   float* share_obs, unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_rollout_fast_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs,
                                                    float* share_obs, unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_rollout_actor_kernel(SdcDev S, int K, int rel_hint, const SdcActorDev* nets, const float* obs_in,
@@ -193,16 +197,27 @@ void note_features(sdc_handle* h, int e) {
 // every env in lock-step with valid feature rows, one data-centre config, the caller's actions on all three slots, the
 // default reward functions, no diagnostics or profiling, an even number of envs, every output array present.
 // debug_flags bit 0 (the verify kernel, a separate launch) and bit 6 (test hook of sdc_create) do not touch the step;
-// bit 7 forces the general kernel (tests compare the two bit for bit).
+// bit 7 forces the general kernel (tests compare the two bit for bit).  The common case runs FOUR envs per wavefront
+// (sdc_*_quad_kernel) when the batch is a multiple of four envs and large enough for that mapping to pay (QUAD_MIN_ENVS:
+// below it a SIMD would hold a single such wavefront, whose waits nothing overlaps); bit 9 keeps it at two envs per
+// wavefront, bit 10 picks four whatever the size (the tests compare all of them bit for bit).
 #ifndef SDC_FAST_DEBUG
 #define SDC_FAST_DEBUG 0
 #endif
 constexpr int FAST_DEBUG_FLAGS = SDC_FAST_DEBUG ? (8 | 16 | 32 | 256) : 0;   // (measurement builds: see sdc_step.hip)
+#ifndef SDC_QUAD_MIN_ENVS
+#define SDC_QUAD_MIN_ENVS 8192
+#endif
+bool quad_case(const sdc_handle* h) {
+  return (h->cfg.n_envs & 3) == 0 && (h->d.debug_flags & (512 | FAST_DEBUG_FLAGS)) == 0 &&
+         (h->cfg.n_envs >= SDC_QUAD_MIN_ENVS || (h->d.debug_flags & 1024));
+}
+int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_obs, const float* info, bool timed) {
   const SdcDev& d = h->d;
   return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs && d.n_cfg == 1 && h->racks_cfg0 > 0 &&
          h->racks_cfg0 <= 32 && actions && share_obs &&
-         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | FAST_DEBUG_FLAGS)) == 0 &&
+         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | 512 | 1024 | FAST_DEBUG_FLAGS)) == 0 &&
          d.policy[0] == SDC_POLICY_EXTERNAL && d.policy[1] == SDC_POLICY_EXTERNAL && d.policy[2] == SDC_POLICY_EXTERNAL &&
          d.reward_method[0] == SDC_REWARD_DEFAULT && d.reward_method[1] == SDC_REWARD_DEFAULT &&
          d.reward_method[2] == SDC_REWARD_DEFAULT;
@@ -610,7 +625,10 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   }
   d.step_no = h->step_no;
   h->step_no = next_step_no(h->step_no, 1);
-  if (fast_case(h, actions, share_obs, info, timed))
+  if (fast_case(h, actions, share_obs, info, timed) && quad_case(h))
+    hipLaunchKernelGGL(sdc_dynamics_quad_kernel, dim3(SWEEP_BLOCKS + quad_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
+                       h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+  else if (fast_case(h, actions, share_obs, info, timed))
     hipLaunchKernelGGL(sdc_dynamics_fast_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
                        h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
   else
@@ -670,7 +688,10 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
     d.step_no = h->step_no;
     h->step_no = next_step_no(h->step_no, n_steps + 3);
     HIP_TRY(hipMemsetAsync(d.rq_count, 0, sizeof(int) * 4, st));
-    if (fast_case(h, actions, share_obs, info, false) && !actions_out)
+    if (fast_case(h, actions, share_obs, info, false) && !actions_out && quad_case(h))
+      hipLaunchKernelGGL(sdc_rollout_quad_kernel, dim3(quad_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, n_steps, h->rel_hint,
+                         actions, obs, share_obs, done, info, final_obs, rew);
+    else if (fast_case(h, actions, share_obs, info, false) && !actions_out)
       hipLaunchKernelGGL(sdc_rollout_fast_kernel, dim3(step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, n_steps, h->rel_hint,
                          actions, obs, share_obs, done, info, final_obs, rew);
     else

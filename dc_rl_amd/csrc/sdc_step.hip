@@ -26,6 +26,7 @@
 // Reference: sustaindc_env.py:533-737 and the sub-environment steps it drives (see per-block citations).
 #include "sdc_ringpath.hpp"
 #include "sdc_halfwin.hpp"
+#include "sdc_quadwin.hpp"
 #include "sdc_actor.hpp"
 
 namespace {
@@ -99,6 +100,9 @@ static_assert(P_COUNT <= HL, "one config scalar per lane of a half");
   } while (0)
 #ifndef SDC_PRIO_DROP
 #define SDC_PRIO_DROP 2
+#endif
+#ifndef SDC_QUAD_LATE_LOADS
+#define SDC_QUAD_LATE_LOADS 1
 #endif
 #ifndef SDC_BASE_PRIO
 #define SDC_BASE_PRIO 0      // issue priority of the env pairs' wavefronts (the late dispatch round: + 1 during the dynamics)
@@ -194,6 +198,44 @@ __device__ __forceinline__ double half_sum_f64(double v) {
 __device__ __forceinline__ unsigned half_ballot(const bool p, const int h) {
   const unsigned long long m = __ballot(p);
   return h ? (unsigned)(m >> 32) : (unsigned)m;
+}
+
+// ---- FOUR ENVS PER WAVEFRONT (the common-case kernels; MapQuad below) ---------------------------------------------------------
+// The same step with a DPP row of 16 lanes per env instead of a half: every per-env instruction is issued once for FOUR
+// envs, a launch needs a quarter of the wavefronts of one-per-env (half of the pair mapping's: half the dispatch ramp, one
+// wavefront per SIMD at 4096 envs), the reductions over an env stay inside a row (no permlane stage), and the rack model
+// takes two passes for configs of more than 16 racks.  pair_dynamics and pair_reward_fast are written once for both
+// mappings (template parameter M); what differs is spelled `if constexpr (M::LPE == 16)` there.
+constexpr int QE = 4;     // envs per wavefront
+constexpr int QL = 16;    // lanes per env
+struct QuadShared {
+  double g[QE][16];                    // gathered step inputs (the slots below G_NC: the common case has feature rows)
+  double prm[HL];                      // config scalars (P_*): ONE config in the common case
+  unsigned rec[QE][SDC_REC_DWORDS];
+  unsigned hdr[QE][SDC_HDR_DWORDS];
+  float pool[QE][32];
+  float info[QE][SDC_INFO_DIM];
+  unsigned long long dbg_t[2];
+  unsigned long long dbg_s[2];
+  unsigned dbg_bits;
+  sdc_rw::TailLds tl;
+};
+struct MapPair {
+  static constexpr int LPE = HL, ENVS = EPW, KPL = 2;
+  using Shared = PairShared;
+  using Win = sdc_hw::HWin;
+};
+struct MapQuad {
+  static constexpr int LPE = QL, ENVS = QE, KPL = 4;
+  using Shared = QuadShared;
+  using Win = sdc_hw::QWin;
+};
+__device__ __forceinline__ const double* prm_of(const PairShared& sh, const int h) { return sh.prm[h]; }
+__device__ __forceinline__ const double* prm_of(const QuadShared& sh, const int) { return sh.prm; }
+template <int LPE>
+__device__ __forceinline__ unsigned env_ballot(const bool p, const int h) {
+  if constexpr (LPE == HL) return half_ballot(p, h);
+  else return sdc_hw::row_ballot(p, h);
 }
 
 // log2 of a positive, normal, finite double: |error| <= 3e-15 absolute (for the rack model's x^y = exp2(y log2 x), nine
@@ -312,18 +354,23 @@ __device__ __forceinline__ double lrec_f64(const unsigned* rp, int idx) { return
 // arrays present.  What the general code decides at run time is then a compile-time constant: the same source, the
 // same arithmetic in the same order (so both kernels give the same bits), minus the tests, the exec-mask bookkeeping
 // around them and the kernel arguments only the other cases read.
-template <bool FAST>
+// M (MapPair / MapQuad): lanes per env.  With 16 a lane carries TWO entries of the feature row (frow = entry 2l, frow_b =
+// 2l + 1) and of the queue table ahead of the oldest task (q_ahead = step head + 2l, q_ahead_b = head + 2l + 1).
+template <bool FAST, class M = MapPair>
 __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc, const int h, const int l, const int a_ls,
                                                 const int a_dc_in, const int a_bat_in, unsigned fault, const bool feat_ok_in,
                                                 const float frow, const uint2 q_ahead, const bool q_ahead_ok,
-                                                int32_t* __restrict__ actions_out_in, PairShared& sh, const double* kt_lds) {
+                                                int32_t* __restrict__ actions_out_in, typename M::Shared& sh, const double* kt_lds,
+                                                const float frow_b = 0.0f, const uint2 q_ahead_b = make_uint2(0u, 0u)) {
+  static_assert(M::LPE == HL || FAST, "four envs per wavefront: the common case only");
+  constexpr int LPE = M::LPE;
   typename KSel<FAST>::type kt{};
   if constexpr (FAST) kt.t = kt_lds;
   const bool feat_ok = FAST ? true : feat_ok_in;
   int32_t* const actions_out = FAST ? nullptr : actions_out_in;
   const unsigned* rp = sh.rec[h];
   const double* g = sh.g[h];
-  const double* pr = sh.prm[h];
+  const double* pr = prm_of(sh, h);
   const int i = lrec_i32(rp, R_CURSOR);
   const int rel = lrec_i32(rp, R_TREL);
   const int day = lrec_i32(rp, R_DAY);
@@ -404,6 +451,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     // were requested with the step's inputs (q_ahead: lane l holds cum / cumT of step head + l) whenever the action can
     // pop tasks; the new head is almost always among them (it moves past <= 90 tasks, and a step's defer adds ~5-15).
     bool need_search = need;
+    if constexpr (LPE == HL) {
     if (q_ahead_ok) {
       const int t = head + l;
       const int c = (t == now) ? cum_now : (int)q_ahead.x;
@@ -420,18 +468,43 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
         }
       }
     }
+    } else {
+    if (q_ahead_ok) {
+      // the same 32 entries, two per lane of the row: entry index 2 l + {0, 1} = step head + that
+      const int t0 = head + 2 * l, t1 = t0 + 1;
+      const int c0 = (t0 == now) ? cum_now : (int)q_ahead.x, c1 = (t1 == now) ? cum_now : (int)q_ahead_b.x;
+      const unsigned m0 = sdc_hw::row_ballot(need && t0 <= now && c0 > popped, h);
+      const unsigned m1 = sdc_hw::row_ballot(need && t1 <= now && c1 > popped, h);
+      const bool found = (m0 | m1) != 0u;
+      const int f0 = m0 != 0u ? 2 * (__ffs((int)m0) - 1) : 64, f1 = m1 != 0u ? 2 * (__ffs((int)m1) - 1) + 1 : 64;
+      const int f = min(f0, f1);
+      const int fm1 = found ? max(f - 1, 0) : 0;
+      const bool od = (fm1 & 1) != 0;                          // (uniform in the row: every lane offers the entry of that parity)
+      const int src = ((h << 4) + (fm1 >> 1)) << 2;
+      const int c_m1 = __builtin_amdgcn_ds_bpermute(src, od ? (int)q_ahead_b.x : (int)q_ahead.x);
+      const int ct_m1 = __builtin_amdgcn_ds_bpermute(src, od ? (int)q_ahead_b.y : (int)q_ahead.y);
+      if (need && found) {
+        need_search = false;
+        if (f > 0) {
+          head += f;
+          cum_hm1 = c_m1;
+          cumT_hm1 = (unsigned)ct_m1;
+        }
+      }
+    }
+    }
     if (__builtin_expect(__ballot(need_search) != 0ull, 0)) {
       SDC_DBG_BIT(FAST, sh, 1u);
       const bool need = need_search;
       int lo = head, hi = now;
-      while (__ballot(need && hi - lo + 1 > HL) != 0ull) {
-        const bool act = need && hi - lo + 1 > HL;
+      while (__ballot(need && hi - lo + 1 > LPE) != 0ull) {
+        const bool act = need && hi - lo + 1 > LPE;
         const int len = hi - lo + 1;
-        const int stride = (len + HL - 1) / HL;
+        const int stride = (len + LPE - 1) / LPE;
         const int t = min(lo + (l + 1) * stride - 1, hi);
         int c = 0;
         if (act) c = (t == now) ? cum_now : (int)qt[t].x;
-        const unsigned m = half_ballot(act && c > popped, h);
+        const unsigned m = env_ballot<LPE>(act && c > popped, h);
         const int f = __ffs((int)m) - 1;  // exists: cum[now] > popped
         if (act) {
           const int nlo = lo + f * stride;
@@ -443,7 +516,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
         const int t = lo + l;
         int c = 0;
         if (need && t <= hi) c = (t == now) ? cum_now : (int)qt[t].x;
-        const unsigned m = half_ballot(need && t <= hi && c > popped, h);
+        const unsigned m = env_ballot<LPE>(need && t <= hi && c > popped, h);
         if (need) head = lo + (__ffs((int)m) - 1);
       }
       if (need) {
@@ -490,9 +563,11 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       for (int b = 0; b < 5; b++) pool[SDC_P_HIST + b] = (float)hist[b];
     }
   } else if (l == 0) {
-    double* o = sh.osc[h];
-    o[5] = normq; o[6] = oldest_norm; o[7] = avg_norm;
-    for (int b = 0; b < 5; b++) o[8 + b] = hist[b];
+    if constexpr (!FAST) {
+      double* o = sh.osc[h];
+      o[5] = normq; o[6] = oldest_norm; o[7] = avg_norm;
+      for (int b = 0; b < 5; b++) o[8 + b] = hist[b];
+    }
   }
   if (l == 0) {
     float* inf = sh.info[h];
@@ -558,6 +633,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   const int R = (int)pr[P_N_RACKS];
   const double load_pct = util * 100;
   double pcpu = 0.0, pfan = 0.0, outlet = 0.0;
+  double outlet_a = 0.0, pw_a = 0.0;       // (16 lanes per env: the first rack pass)
   bool bad_delta = false;
   {
     const double m_cpu = pr[P_M_CPU], c_cpu = pr[P_C_CPU], rs_cpu = pr[P_RS_CPU];
@@ -590,7 +666,15 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       pfan += valid ? pf : 0.0;
       outlet += valid ? out : 0.0;
     };
-    if constexpr (FAST) {
+    if constexpr (FAST && LPE == QL) {
+      // 16 lanes per env: racks 0..15, then 16..31 (the sums of the two passes are reduced apart and added -- rows 1 + 0
+      // of the half-wave tree -- so that both mappings round alike)
+      rack(l, l < R);
+      outlet_a = outlet;
+      pw_a = pcpu + pfan;
+      outlet = 0.0; pcpu = 0.0; pfan = 0.0;
+      rack(l + QL, l + QL < R);
+    } else if constexpr (FAST) {
       // the host has checked that the config has <= 32 racks: ONE pass, every lane of the half computing (lanes without
       // a rack on the table's unused entries: their results are dropped by selects) -- straight-line code.  A loop here
       // makes the compiler fetch all of the body's ~25 constants in front of it and hold them in registers across it.
@@ -604,15 +688,15 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   __builtin_amdgcn_s_setprio(SDC_BASE_PRIO);
 #endif
   SDC_AT(5, sh, lane0);
-  if (half_ballot(bad_delta, h) != 0u) fault |= SDC_FAULT_OUTLET_DELTA;
+  if (env_ballot<LPE>(bad_delta, h) != 0u) fault |= SDC_FAULT_OUTLET_DELTA;
   // (ONE reduction for CPU + fan power: only their total is used.  The reference sums the two lists separately and adds
   // the totals; the difference is a rounding of the last place)
   // CRAC return temperature (datacenter.py:531-541: the mean of return approach + outlet over the racks): the approach
   // temperatures are constants of the config, their sum comes from the host
-  const double sum_outlet = half_sum_f64(outlet);
+  const double sum_outlet = LPE == HL ? half_sum_f64(outlet) : sdc_hw::row_sum_f64(outlet) + sdc_hw::row_sum_f64(outlet_a);
   const double avg_ret = (pr[P_RET_SUM] + sum_outlet) * pr[P_RC_N_RACKS];
   const double mean_outlet = sum_outlet * pr[P_RC_N_RACKS];
-  const double p_it = half_sum_f64(pcpu + pfan);
+  const double p_it = LPE == HL ? half_sum_f64(pcpu + pfan) : sdc_hw::row_sum_f64(pcpu + pfan) + sdc_hw::row_sum_f64(pw_a);
 
   SDC_AT(6, sh, lane0);
   // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 ------------------------------------------
@@ -687,13 +771,20 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     constexpr unsigned TRACE_ONLY = 0x7u | (0x7Fu << SDC_P_CI7) | (1u << SDC_P_W) | (1u << SDC_P_NT) | (1u << SDC_P_TSLOPE) |
                                     (0x1Fu << SDC_P_T5) | (1u << SDC_P_WNEXT) | (1u << SDC_P_NTNEXT);
     float* pool = sh.pool[h];
-    if (l < SDC_POOL_DIM && ((TRACE_ONLY >> l) & 1u)) pool[l] = frow;
+    if constexpr (LPE == HL) {
+      if (l < SDC_POOL_DIM && ((TRACE_ONLY >> l) & 1u)) pool[l] = frow;
+    } else {
+      if (2 * l < SDC_POOL_DIM && ((TRACE_ONLY >> (2 * l)) & 1u)) pool[2 * l] = frow;
+      if (2 * l + 1 < SDC_POOL_DIM && ((TRACE_ONLY >> (2 * l + 1)) & 1u)) pool[2 * l + 1] = frow_b;
+    }
     if (l == 1) pool[SDC_P_SOC] = (float)soc_after;
   } else if (l == 0) {
     // no feature rows for this episode: the wavefront computes the features of this env below (whole-wave, per env)
-    double* o = sh.osc[h];
-    o[0] = g[G_LUT]; o[1] = g[G_LUT2]; o[2] = w_ip; o[3] = w_ip1; o[4] = soc_after;
-    o[13] = ip >= 16 ? 1.0 : 0.0;
+    if constexpr (!FAST) {
+      double* o = sh.osc[h];
+      o[0] = g[G_LUT]; o[1] = g[G_LUT2]; o[2] = w_ip; o[3] = w_ip1; o[4] = soc_after;
+      o[13] = ip >= 16 ? 1.0 : 0.0;
+    }
   }
 
   // ---- history append (utils/reward_creator.py:7-14) --------------------------------------------------------
@@ -998,13 +1089,34 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
 // keys, a non-appending reward configuration) is left untouched and reported in the returned mask: env_reward()
 // then redoes it from its unmodified state.  wa / wb: the lane's keys 2l / 2l + 1 of {Q1, Q3, BU, BL}.
 // Returns the ballot of lanes whose env was completed here.
-template <bool FAST>
+// a window of either mapping from / to its KPL keys per lane
+__device__ __forceinline__ sdc_hw::HWin win_from(const unsigned (&k)[2], const int r0, const int hi) { return sdc_hw::HWin{k[0], k[1], r0, hi}; }
+__device__ __forceinline__ sdc_hw::QWin win_from(const unsigned (&k)[4], const int r0, const int hi) {
+  return sdc_hw::QWin{k[0], k[1], k[2], k[3], r0, hi};
+}
+__device__ __forceinline__ void win_keys(const sdc_hw::HWin& q, unsigned (&k)[2]) { k[0] = q.a; k[1] = q.b; }
+__device__ __forceinline__ void win_keys(const sdc_hw::QWin& q, unsigned (&k)[4]) { k[0] = q.k0; k[1] = q.k1; k[2] = q.k2; k[3] = q.k3; }
+template <int LPE>
+__device__ __forceinline__ double env_sum_f64(const double v) {
+  if constexpr (LPE == HL) return half_sum_f64(v);
+  else return sdc_hw::row_sum_f64(v);
+}
+template <int LPE>
+__device__ __forceinline__ unsigned env_sum_u32(const unsigned v) {
+  if constexpr (LPE == HL) return sdc_hw::half_sum_u32(v);
+  else return sdc_hw::row_sum_u32(v);
+}
+
+// wk[i]: keys KPL l + i of the four windows {Q1, Q3, BU, BL} (one uint4 per key position, as they lie in SdcDev::qwin)
+template <bool FAST, class M = MapPair>
 __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, const int envc, const bool active, const int h,
-                                                               const int l, const uint4 wa, const uint4 wb, const DynOut& d,
-                                                               const unsigned x_old, float* __restrict__ rew, PairShared& sh,
-                                                               const int step_no, const bool defer) {
+                                                               const int l, const uint4 (&wk)[M::KPL], const DynOut& d,
+                                                               const unsigned x_old, float* __restrict__ rew,
+                                                               typename M::Shared& sh, const int step_no, const bool defer) {
   using namespace sdc_rw;
   using namespace sdc_hw;
+  using Win = typename M::Win;
+  constexpr int LPE = M::LPE, KPL = M::KPL;
   const unsigned* hp = sh.hdr[h];
   const bool lane0 = h == 0 && l == 0;
   SDC_AT(11, sh, lane0);
@@ -1014,10 +1126,13 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   const unsigned x_new = d.x_new;
   int k1, k3;
   quartile_ranks(n, k1, k3);
-  HWin q1 = {wa.x, wb.x, (int)hp[H_Q1 + T_R0], (int)hp[H_Q1 + T_HI]};
-  HWin q3 = {wa.y, wb.y, (int)hp[H_Q3 + T_R0], (int)hp[H_Q3 + T_HI]};
-  HWin bu = {wa.z, wb.z, (int)hp[H_BU + T_R0], (int)hp[H_BU + T_HI]};
-  HWin bl = {wa.w, wb.w, (int)hp[H_BL + T_R0], (int)hp[H_BL + T_HI]};
+  unsigned kx[KPL], ky[KPL], kz[KPL], kw[KPL];
+#pragma unroll
+  for (int i = 0; i < KPL; i++) { kx[i] = wk[i].x; ky[i] = wk[i].y; kz[i] = wk[i].z; kw[i] = wk[i].w; }
+  Win q1 = win_from(kx, (int)hp[H_Q1 + T_R0], (int)hp[H_Q1 + T_HI]);
+  Win q3 = win_from(ky, (int)hp[H_Q3 + T_R0], (int)hp[H_Q3 + T_HI]);
+  Win bu = win_from(kz, (int)hp[H_BU + T_R0], (int)hp[H_BU + T_HI]);
+  Win bl = win_from(kw, (int)hp[H_BL + T_R0], (int)hp[H_BL + T_HI]);
   double A1 = lrec_f64(hp, H_A1), A2 = lrec_f64(hp, H_A2);
   bool ok = append && n >= SMALL_N && q1.hi > 0 && q3.hi > 0 && bu.hi > 0 && bl.hi > 0 && (int)hp[H_VALID] == 1;
   // ---- deferred re-centrings (SdcRefillReq / SdcRefillRes): a window requested two steps ago arrives now --------------
@@ -1034,7 +1149,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     // pd = (request step mod 2^22) << 10 | result set << 8 | request index + 1.  All due results are requested first (ONE
     // memory round trip whatever the number of windows), then each is replayed and installed; windows with nothing due
     // in either env are skipped as a whole.
-    struct Arrival { int4 hd; unsigned ka, kb; bool due; unsigned age; };
+    struct Arrival { int4 hd; unsigned k[KPL]; bool due; unsigned age; };
     auto fetch = [&](const unsigned pd) __attribute__((always_inline)) {
       Arrival a;
       const int idx = (int)(pd & 0xFFu) - 1, set = (int)((pd >> 8) & 3u);
@@ -1042,23 +1157,23 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
       a.due = pd != 0u && a.age >= 2u;   // (1: being swept right now; anything else but 2: stale -- a multi-step launch, restored state)
       const SdcRefillRes* rs = S.rs + (set > 2 ? 0 : set) * SDC_RQ_MAX + (idx < 0 ? 0 : idx);
       a.hd = make_int4(0, 0, -1, -1);
-      a.ka = KEY_NONE;
-      a.kb = KEY_NONE;
+#pragma unroll
+      for (int i = 0; i < KPL; i++) a.k[i] = KEY_NONE;
       if (a.due) {
         a.hd = *reinterpret_cast<const int4*>(rs);
-        a.ka = rs->keys[2 * l];
-        a.kb = rs->keys[2 * l + 1];
+#pragma unroll
+        for (int i = 0; i < KPL; i++) a.k[i] = rs->keys[KPL * l + i];
       }
       return a;
     };
-    auto install = [&](const Arrival& a, HWin& q, unsigned& pd, unsigned& wf, unsigned& wl, const int w,
+    auto install = [&](const Arrival& a, Win& q, unsigned& pd, unsigned& wf, unsigned& wl, const int w,
                        const unsigned flip) __attribute__((always_inline)) {
       if (__ballot(a.due) == 0ull) return;
-      HWin r = {a.ka, a.kb, a.hd.x, a.hd.y};
+      Win r = win_from(a.k, a.hd.x, a.hd.y);
       const bool good = a.due && a.age == 2u && a.hd.z == step_no - 1 && a.hd.w == envc * 4 + w && r.hi > 0 && ok;
       // the result describes the ring as the request's step left it: replay the previous step's insertion / eviction
       hw_update(r, lx_new ^ flip, lx_old ^ flip, lx_old != KEY_NONE, l_nprev, good, h, l);
-      const unsigned rf = key_at(r.a, r.b, 0, h << 5), rl = key_at(r.a, r.b, r.hi - 1, h << 5);
+      const unsigned rf = win_first(r, h), rl = win_last(r, h);
       if (good && r.hi > 0) {
         q = r;
         wf = rf;
@@ -1085,7 +1200,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   // either env does have a key inside (or starts / ends the history where the key would land) do the lanes run the
   // general update (hw_update), which also refreshes the cache.
   const int m_hist = has_old ? n_prev - 1 : n_prev;
-  auto outside = [&](const HWin& q, const unsigned first, const unsigned last, const unsigned flip, int& r0n) __attribute__((always_inline)) {
+  auto outside = [&](const Win& q, const unsigned first, const unsigned last, const unsigned flip, int& r0n) __attribute__((always_inline)) {
     const unsigned y = x_old ^ flip, x = x_new ^ flip;
     const bool e_below = has_old && y < first;
     const bool e_ok = !has_old || y > last || e_below;          // (evicted key above the window / below it)
@@ -1100,15 +1215,15 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   const bool out1 = outside(q1, wf0, wl0, 0u, r0n1), out3 = outside(q3, wf1, wl1, 0u, r0n3);
   const bool outu = outside(bu, wf2, wl2, 0u, r0nu), outl = outside(bl, wf3, wl3, KEY_NONE, r0nl);
   // (per window: about one wavefront in ten has a key inside SOME window of one of its envs, almost never inside two)
-  auto update = [&](HWin& q, const bool out, const int r0n, unsigned& wf, unsigned& wl, const unsigned flip) __attribute__((always_inline)) {
+  auto update = [&](Win& q, const bool out, const int r0n, unsigned& wf, unsigned& wl, const unsigned flip) __attribute__((always_inline)) {
     if (__builtin_expect(__ballot(ok && !out) == 0ull, 1)) {
       q.r0 = r0n;
       return false;
     }
     SDC_DBG_BIT(FAST, sh, 2u);
     const bool wd = hw_update(q, x_new ^ flip, x_old ^ flip, has_old, n_prev, ok, h, l);
-    wf = key_at(q.a, q.b, 0, h << 5);
-    wl = key_at(q.a, q.b, q.hi - 1, h << 5);
+    wf = win_first(q, h);
+    wl = win_last(q, h);
     return wd;
   };
   const bool wd1 = update(q1, out1, r0n1, wf0, wl0, 0u), wd3 = update(q3, out3, r0n3, wf1, wl1, 0u);
@@ -1142,22 +1257,26 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   {
     // the keys a bound has crossed: this lane's share over its two keys, then the half's total (rare: skipped as a
     // whole when no lane of the wavefront has one)
-    const bool x0a = ok && kb0 != kbl0 && bu.a >= lo0 && bu.a < hi0, x0b = ok && kb0 != kbl0 && bu.b >= lo0 && bu.b < hi0;
-    const bool x1a = ok && kb1 != kbl1 && bl.a >= lo1 && bl.a < hi1, x1b = ok && kb1 != kbl1 && bl.b >= lo1 && bl.b < hi1;
-    if (__builtin_expect(__ballot(x0a || x0b || x1a || x1b) != 0ull, 0)) SDC_DBG_BIT(FAST, sh, 4u);
-    if (__builtin_expect(__ballot(x0a || x0b) != 0ull, 0)) {
-      const double va = x0a ? key_f64(bu.a) : 0.0, vb = x0b ? key_f64(bu.b) : 0.0;
-      const unsigned c = half_sum_u32((x0a ? 1u : 0u) + (x0b ? 1u : 0u));
-      const double s1 = half_sum_f64(va + vb), s2 = half_sum_f64(va * va + vb * vb);
+    const bool en0 = ok && kb0 != kbl0, en1 = ok && kb1 != kbl1;
+    const bool x0 = en0 && win_any_in(bu, lo0, hi0), x1 = en1 && win_any_in(bl, lo1, hi1);
+    if (__builtin_expect(__ballot(x0 || x1) != 0ull, 0)) SDC_DBG_BIT(FAST, sh, 4u);
+    if (__builtin_expect(__ballot(x0) != 0ull, 0)) {
+      unsigned cl;
+      double s1l, s2l;
+      win_crossed(bu, lo0, hi0, 0u, en0, cl, s1l, s2l);
+      const unsigned c = env_sum_u32<LPE>(cl);
+      const double s1 = env_sum_f64<LPE>(s1l), s2 = env_sum_f64<LPE>(s2l);
       const double sg = kb0 > kbl0 ? -1.0 : 1.0;   // bound moved out: the keys in between leave the tail
       qc0 += (kb0 > kbl0 ? -1 : 1) * (int)c;
       qs1_0 += sg * s1;
       qs2_0 += sg * s2;
     }
-    if (__builtin_expect(__ballot(x1a || x1b) != 0ull, 0)) {
-      const double va = x1a ? key_f64(~bl.a) : 0.0, vb = x1b ? key_f64(~bl.b) : 0.0;
-      const unsigned c = half_sum_u32((x1a ? 1u : 0u) + (x1b ? 1u : 0u));
-      const double s1 = half_sum_f64(va + vb), s2 = half_sum_f64(va * va + vb * vb);
+    if (__builtin_expect(__ballot(x1) != 0ull, 0)) {
+      unsigned cl;
+      double s1l, s2l;
+      win_crossed(bl, lo1, hi1, KEY_NONE, en1, cl, s1l, s2l);
+      const unsigned c = env_sum_u32<LPE>(cl);
+      const double s1 = env_sum_f64<LPE>(s1l), s2 = env_sum_f64<LPE>(s2l);
       const double sg = kb1 > kbl1 ? -1.0 : 1.0;
       qc1 += (kb1 > kbl1 ? -1 : 1) * (int)c;
       qs1_1 += sg * s1;
@@ -1174,7 +1293,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   {
     int k1n, k3n;
     quartile_ranks(n < S.hist_cap ? n + 1 : n, k1n, k3n);
-    auto ahead = [&](const HWin& q, const int k_next, const int m_lo, const int m_hi) __attribute__((always_inline)) {
+    auto ahead = [&](const Win& q, const int k_next, const int m_lo, const int m_hi) __attribute__((always_inline)) {
       const int t = k_next - q.r0;
       return (t > q.hi - m_hi && q.r0 + q.hi < n) || (t < m_lo && q.r0 > 0);
     };
@@ -1191,17 +1310,19 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
         const int slot_next = n < S.hist_cap ? n : (d.slot + 1 == S.hist_cap ? 0 : d.slot + 1);
         unsigned patch_x = KEY_NONE;
         if (ok && (w0 || w1 || w2 || w3)) patch_x = S.hist[(size_t)envc * SDC_HIST_STRIDE + slot_next];
-        auto request = [&](const HWin& q, unsigned& pd, const bool want, const int w, const int kt) __attribute__((always_inline)) {
+        auto request = [&](const Win& q, unsigned& pd, const bool want, const int w, const int kt) __attribute__((always_inline)) {
           int idx = -1;
           if (want && ok && active && l == 0) idx = atomicAdd(&S.rq_count[set], 1);
-          idx = __builtin_amdgcn_ds_bpermute((h << 5) << 2, idx);       // lane 0 of the half tells the others
+          idx = __builtin_amdgcn_ds_bpermute((h * LPE) << 2, idx);       // lane 0 of the env's lanes tells the others
           if (want && ok) {
             if (idx < 0 || idx >= SDC_RQ_MAX) {
               ok = false;                          // no room (or a missing env): re-centre inline on the slow path
             } else {
               SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + idx;
-              rq->keys[2 * l] = q.a;
-              rq->keys[2 * l + 1] = q.b;
+              unsigned qk[KPL];
+              win_keys(q, qk);
+#pragma unroll
+              for (int i = 0; i < KPL; i++) rq->keys[KPL * l + i] = qk[i];
               if (l == 0) {
                 const int t = kt - q.r0;
                 rq->env = envc; rq->win = w;
@@ -1253,9 +1374,11 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   const bool commit = ok && active;
   if (commit) {
     if (wd1 || wd3 || wdu || wdl || wdc) {
-      uint4* qw = reinterpret_cast<uint4*>(S.qwin) + (size_t)envc * SDC_WIN + 2 * l;
-      qw[0] = make_uint4(q1.a, q3.a, bu.a, bl.a);
-      qw[1] = make_uint4(q1.b, q3.b, bu.b, bl.b);
+      uint4* qw = reinterpret_cast<uint4*>(S.qwin) + (size_t)envc * SDC_WIN + KPL * l;
+      unsigned o1[KPL], o3[KPL], ou[KPL], ol[KPL];
+      win_keys(q1, o1); win_keys(q3, o3); win_keys(bu, ou); win_keys(bl, ol);
+#pragma unroll
+      for (int i = 0; i < KPL; i++) qw[i] = make_uint4(o1[i], o3[i], ou[i], ol[i]);
     }
     if (l == 0) {
       unsigned* o = sh.hdr[h];
@@ -1298,8 +1421,12 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     }
   }
   wave_sync();
-  if (commit)
-    (reinterpret_cast<unsigned long long*>(S.hdr + (size_t)envc * SDC_HDR_DWORDS))[l] = reinterpret_cast<const unsigned long long*>(sh.hdr[h])[l];
+  if (commit) {
+    if constexpr (LPE == HL)
+      (reinterpret_cast<unsigned long long*>(S.hdr + (size_t)envc * SDC_HDR_DWORDS))[l] = reinterpret_cast<const unsigned long long*>(sh.hdr[h])[l];
+    else
+      (reinterpret_cast<uint4*>(S.hdr + (size_t)envc * SDC_HDR_DWORDS))[l] = reinterpret_cast<const uint4*>(sh.hdr[h])[l];
+  }
   SDC_AT(18, sh, lane0);
   return __ballot(ok);
 }
@@ -1523,7 +1650,8 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   sh.hdr[0][lane] = hdA;
   sh.hdr[1][lane] = hdB;
   wave_sync();
-  const unsigned long long fast_m = pair_reward_fast<FAST>(S, envc, active, h, l, wka, wkb, d, x_old_l, rew, sh, step_no, defer);
+  const uint4 wk2[2] = {wka, wkb};
+  const unsigned long long fast_m = pair_reward_fast<FAST>(S, envc, active, h, l, wk2, d, x_old_l, rew, sh, step_no, defer);
   // (the loop sits behind its own unlikely test: otherwise the ~50 constants of env_reward, hoisted into the loop's
   // preheader, are materialised on every step)
   const bool all_fast = ((fast_m & 1ull) != 0ull) && (n_here < 2 || ((fast_m >> HL) & 1ull) != 0ull);
@@ -1590,6 +1718,167 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
     }
   }
   if (l == 0 && active) done[envc] = (unsigned char)(terminal ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One env-step of FOUR envs (env0 .. env0 + 3) by their wavefront, a DPP row of 16 lanes each: the common case only (see
+// pair_dynamics FAST; the host also checks that the batch is a multiple of four envs).  Same memory plan as pair_step,
+// the per-lane shares twice as wide: the state record and the header as one dwordx4 per lane, the feature row as one
+// dwordx2, the rank windows as four dwordx4 (keys 4l .. 4l + 3 of the four windows), the queue table ahead of the oldest
+// task as two dwordx2.
+// ACTOR: the three actions of this lane's env come in registers.
+template <bool ACTOR = false>
+__device__ __forceinline__ void quad_step(const SdcDev& S, QuadShared& sh, const int env0, const int lane, const int rel_hint,
+                                          const int32_t* __restrict__ actions, float* __restrict__ obs,
+                                          float* __restrict__ share_obs, unsigned char* __restrict__ done,
+                                          float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew,
+                                          const int step_no, const bool defer, double* kt, const bool kt_fill,
+                                          const int act_reg0 = 1, const int act_reg1 = 1, const int act_reg2 = 2) {
+  const int TL = S.table_len;
+  double kt0 = 0.0, kt1 = 0.0;
+  if (kt_fill) ktab_fetch(lane, kt0, kt1);
+  const int h = lane >> 4, l = lane & (QL - 1);     // h: the env's row
+  const int envc = env0 + h;
+  typedef int int3v __attribute__((ext_vector_type(3)));
+  int3v act_v = {1, 1, 2};
+  if constexpr (ACTOR) {
+    act_v.x = act_reg0;
+    act_v.y = act_reg1;
+    act_v.z = act_reg2;
+  } else {
+    const int32_t* ap = actions + (size_t)envc * 3;
+    asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(act_v) : "v"(ap) : "memory");
+  }
+  // the step's feature row (entries 2l, 2l + 1) and queue-history probes, with the record: one round trip
+  const float2 frow2 = *reinterpret_cast<const float2*>(S.feat + feat_row_offset(S, envc, rel_hint + 1) + 2 * l);
+  double q_pre = 0.0;
+  if (l >= G_Q97 && l <= G_Q96) {
+    const int back = l == G_Q97 ? 97 : 24 * (l - G_Q97);   // 97, 24, 48, 72, 96
+    const int t = rel_hint - back;
+    if (t >= 0) q_pre = *reinterpret_cast<const double*>(S.qtab + (size_t)envc * S.qstride + t);
+  }
+  double prm_pre = 0.0;
+  if (lane < P_COUNT) prm_pre = reinterpret_cast<const double*>(&S.dc[0].p.m_cpu)[lane];
+  uint4* recp = reinterpret_cast<uint4*>(S.rec + (size_t)envc * SDC_REC_DWORDS) + l;
+  const uint4 rr = *recp;
+  {
+    unsigned r0 = rr.x, r1 = rr.y, r2 = rr.z, r3 = rr.w;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(act_v), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+  }
+  int a_ls = act_v.x, a_dc = act_v.y, a_bat = act_v.z;
+  reinterpret_cast<uint4*>(sh.rec[h])[l] = rr;
+  if (kt_fill) ktab_store(kt, lane, kt0, kt1);
+  if (lane < P_COUNT) sh.prm[lane] = prm_pre;
+  wave_sync();
+  const unsigned* rp = sh.rec[h];
+  const int i = lrec_i32(rp, R_CURSOR), rel = lrec_i32(rp, R_TREL);
+  unsigned fault = 0;
+  if (i + 9 > TL - 1) fault |= SDC_FAULT_TABLE_RANGE;
+  if (__builtin_expect((unsigned)a_ls > 2u || (unsigned)a_dc > 2u || (unsigned)a_bat > 2u, 0)) {
+    fault |= SDC_FAULT_ACTION;
+    if ((unsigned)a_ls > 2u) a_ls = 1;
+    if ((unsigned)a_dc > 2u) a_dc = 1;
+    if ((unsigned)a_bat > 2u) a_bat = 2;
+  }
+  const int hl0 = lrec_i32(rp, R_HIST_LEN);
+  const int slot0 = hl0 < S.hist_cap ? hl0 : lrec_i32(rp, R_HIST_POS);
+  {
+    // the row's input slots (doubles W, C, T, WB, NC[i'+1] as float pairs of the row; T[i+1] as a float) and the probes
+    static_assert(SDC_FEAT_W == 10 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 && SDC_FEAT_NCNEXT == 30 &&
+                  SDC_FEAT_T1 == 12 && G_W0 == 0 && G_C0 == 3 && G_T0 == 4 && G_WB0 == 5 && G_NCN == 14, "slot table below");
+    double* gh = sh.g[h];
+    const int slot = l == 5 ? G_W0 : (l == 11 ? G_C0 : (l == 12 ? G_T0 : (l == 14 ? G_WB0 : G_NCN)));
+    if (l == 5 || l == 11 || l == 12 || l == 14 || l == 15) reinterpret_cast<float2*>(gh)[slot] = frow2;
+    if (l >= G_Q97 && l <= G_Q96) gh[l] = q_pre;
+    if (l == 6) gh[G_T1] = (double)frow2.x;
+  }
+  wave_sync();
+
+  // reward-side state, consumed at the end of the step: requested here, behind the staging
+  const bool q_ahead_ok = a_ls == 2;
+  uint2 q_ahead = make_uint2(0u, 0u), q_ahead_b = make_uint2(0u, 0u);
+  if (q_ahead_ok) {
+    const int t = lrec_i32(rp, R_QHEAD) + 2 * l;
+    const uint2* qt = S.qtab + (size_t)envc * S.qstride;
+    if (t < rel) q_ahead = qt[t];
+    if (t + 1 < rel) q_ahead_b = qt[t + 1];
+  }
+  unsigned x_old_l = 0xFFFFFFFFu;
+  if (hl0 >= S.hist_cap) x_old_l = S.hist[(size_t)envc * SDC_HIST_STRIDE + slot0];   // (one address per row)
+#if !SDC_QUAD_LATE_LOADS
+  const uint4 hd4 = reinterpret_cast<const uint4*>(S.hdr + (size_t)envc * SDC_HDR_DWORDS)[l];
+  uint4 wk[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) wk[j] = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 4 * l + j];
+#endif
+  const DynOut d = pair_dynamics<true, MapQuad>(S, envc, h, l, a_ls, a_dc, a_bat, fault, true, frow2.x, q_ahead, q_ahead_ok, nullptr,
+                                                sh, kt, frow2.y, q_ahead_b);
+#if SDC_QUAD_LATE_LOADS
+  // (the reward-side loads AFTER the dynamics: 20 registers fewer across them; their latency is the other resident
+  // wavefronts' time)
+  const uint4 hd4 = reinterpret_cast<const uint4*>(S.hdr + (size_t)envc * SDC_HDR_DWORDS)[l];
+  uint4 wk[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) wk[j] = reinterpret_cast<const uint4*>(S.qwin)[(size_t)envc * SDC_WIN + 4 * l + j];
+#endif
+  wave_sync();
+#if SDC_PRIO_DROP == 2
+  __builtin_amdgcn_s_setprio(SDC_BASE_PRIO);
+#endif
+  reinterpret_cast<uint4*>(sh.hdr[h])[l] = hd4;
+  wave_sync();
+  const unsigned long long fast_m = pair_reward_fast<true, MapQuad>(S, envc, true, h, l, wk, d, x_old_l, rew, sh, step_no, defer);
+  // an env that needs its ring (or anything unusual) is redone whole-wavefront from its untouched state
+  const bool all_fast = ((fast_m & 1ull) != 0ull) && (((fast_m >> QL) & 1ull) != 0ull) && (((fast_m >> (2 * QL)) & 1ull) != 0ull) &&
+                        (((fast_m >> (3 * QL)) & 1ull) != 0ull);
+  if (__builtin_expect(!all_fast, 0))
+#pragma unroll 1
+    for (int e = 0; e < QE; e++) {
+      if (__builtin_expect((fast_m >> (e * QL)) & 1ull, 1)) continue;
+      const unsigned x_old = (unsigned)__builtin_amdgcn_readlane((int)x_old_l, e * QL);
+      const unsigned hd_e = sh.hdr[e][lane];       // (untouched: the O(1) path commits nothing for an env it gives up on)
+      const uint4 qw_e = reinterpret_cast<const uint4*>(S.qwin)[(size_t)(env0 + e) * SDC_WIN + lane];
+      auto pi = [&](const int v) { return __builtin_amdgcn_readlane(v, e * QL); };
+      auto pf = [&](const double v) { return readlane_f64(v, e * QL); };
+      env_reward(S, env0 + e, lane, hd_e, qw_e, pi(d.hl), pi(d.slot), (unsigned)pi((int)d.x_new), x_old, pf(d.e_off), pf(d.energy),
+                 pf(d.norm_ci), pf(d.oldest_norm), pi(d.overdue), pi(d.hourq_n), pf(d.p_it), pf(d.total_kw), pf(d.water), rew,
+                 sh.info[e], sh.tl);
+    }
+  wave_sync();
+
+  // ---- coalesced stores: the four envs' records, obs rows (4 x 78 floats), share_obs (4 x 29), info (4 x 44) are adjacent ----
+  *recp = reinterpret_cast<const uint4*>(sh.rec[h])[l];
+  const int rel_now = lrec_i32(sh.rec[h], R_TREL);     // (patched: rel + 1)
+  const bool terminal = rel_now >= S.episode_steps;
+  const unsigned long long term_m = __ballot(terminal);
+#pragma unroll
+  for (int k = 0; k < (QE * SDC_OBS_OUT + SDC_WAVE - 1) / SDC_WAVE; k++) {
+    const int idx = k * SDC_WAVE + lane;
+    if (idx < QE * SDC_OBS_OUT) {
+      const int e = (idx >= SDC_OBS_OUT ? 1 : 0) + (idx >= 2 * SDC_OBS_OUT ? 1 : 0) + (idx >= 3 * SDC_OBS_OUT ? 1 : 0);
+      const int j = idx - e * SDC_OBS_OUT;
+      const float v = obs_padded_at(sh.pool[e], j);
+      SDC_OUT_STORE(v, &obs[(size_t)env0 * SDC_OBS_OUT + idx]);
+      if (final_obs && ((term_m >> (e * QL)) & 1ull)) final_obs[(size_t)env0 * SDC_OBS_OUT + idx] = v;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (QE * SDC_SHARE_OBS_DIM + SDC_WAVE - 1) / SDC_WAVE; k++) {
+    const int idx = k * SDC_WAVE + lane;
+    if (idx < QE * SDC_SHARE_OBS_DIM) {
+      const int e = (idx >= SDC_SHARE_OBS_DIM ? 1 : 0) + (idx >= 2 * SDC_SHARE_OBS_DIM ? 1 : 0) + (idx >= 3 * SDC_SHARE_OBS_DIM ? 1 : 0);
+      SDC_OUT_STORE(share_obs_at(sh.pool[e], idx - e * SDC_SHARE_OBS_DIM), &share_obs[(size_t)env0 * SDC_SHARE_OBS_DIM + idx]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (QE * SDC_INFO_DIM + SDC_WAVE - 1) / SDC_WAVE; k++) {
+    const int idx = k * SDC_WAVE + lane;
+    if (idx < QE * SDC_INFO_DIM) {
+      const int e = (idx >= SDC_INFO_DIM ? 1 : 0) + (idx >= 2 * SDC_INFO_DIM ? 1 : 0) + (idx >= 3 * SDC_INFO_DIM ? 1 : 0);
+      SDC_OUT_STORE(sh.info[e][idx - e * SDC_INFO_DIM], &info[(size_t)env0 * SDC_INFO_DIM + idx]);
+    }
+  }
+  if (l == 0) done[envc] = (unsigned char)(terminal ? 1 : 0);
 }
 
 }  // namespace
@@ -1778,6 +2067,47 @@ extern "C" __global__ SDC_STEP_BOUNDS void sdc_dynamics_fast_kernel(
   dynamics_launch<true>(S, shs, ktab, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
 }
 
+// the common case, four envs per wavefront (quad_step): workgroup = 4 wavefronts = 16 envs; the sweep workgroups as above
+__device__ __forceinline__ void quad_launch(const SdcDev& S, QuadShared* shs, double* kt, const int rel_hint,
+                                            const int32_t* __restrict__ actions, float* __restrict__ obs,
+                                            float* __restrict__ share_obs, unsigned char* __restrict__ done,
+                                            float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+  const KernargTouch ktouch = kernarg_touch();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
+  const int lane = threadIdx.x % SDC_WAVE;
+  kernarg_touch_done(ktouch);
+  const int env_blocks = (int)gridDim.x - SDC_SWEEP_BLOCKS;
+  const int bx = (int)blockIdx.x;
+  if (bx < SDC_SWEEP_BLOCKS) {     // (the sweep workgroups first in the grid: see dynamics_launch)
+    static_assert(sizeof(sdc_rw::CoopLds) <= sizeof(QuadShared) * SDC_STEP_WPB, "the sweep workgroup's LDS");
+    serve_recentring_requests_coop(S, bx, wave, lane, *reinterpret_cast<sdc_rw::CoopLds*>(shs));
+    return;
+  }
+  const int pb = bx - SDC_SWEEP_BLOCKS;
+  const int env0 = (first_pair_of_block(pb, env_blocks) + wave) * QE;
+  if (env0 >= S.n_envs) return;
+  if (pb >= SDC_CUS)
+    __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
+  else
+    __builtin_amdgcn_s_setprio(SDC_BASE_PRIO);
+  quad_step<false>(S, shs[wave], env0, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew, S.step_no, true, kt, true);
+}
+// (three resident wavefronts per SIMD = 12 envs: with the reward-side loads behind the dynamics -- SDC_QUAD_LATE_LOADS -- the
+// kernel fits 168 VGPRs without spilling; measured at 12 288 envs: 22.6 us per step against 30.4 with two)
+#ifndef SDC_QUAD_WAVES_PER_EU
+#define SDC_QUAD_WAVES_PER_EU 3
+#endif
+#define SDC_QUAD_BOUNDS \
+  __launch_bounds__(SDC_WAVE * SDC_STEP_WPB) __attribute__((amdgpu_waves_per_eu(SDC_QUAD_WAVES_PER_EU, SDC_QUAD_WAVES_PER_EU)))
+
+extern "C" __global__ SDC_QUAD_BOUNDS void sdc_dynamics_quad_kernel(
+    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
+    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+  __shared__ QuadShared shs[SDC_STEP_WPB];
+  __shared__ double ktab[SDC_K_LDS];
+  quad_launch(S, shs, ktab, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+}
+
 // K env-steps per launch for action sequences that are known up front or chosen by the built-in rule-based policies
 // (scripted evaluation, the reference's RBC / do-nothing baselines): every wavefront advances its own two envs K times
 // -- envs do not interact, so there is nothing to wait for between steps; the dispatch ramp, the launch gap and the
@@ -1831,6 +2161,32 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_STEP_WPB, 8 / SDC_STEP_WP
   __shared__ PairShared shs[SDC_STEP_WPB];
   __shared__ double ktab[SDC_K_LDS];
   rollout_launch<true>(S, shs, ktab, K, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+}
+
+// the common case with four envs per wavefront (large batches: see quad_step)
+extern "C" __global__ SDC_QUAD_BOUNDS void sdc_rollout_quad_kernel(
+    SdcDev S, const int K, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs,
+    float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs,
+    float* __restrict__ rew) {
+  __shared__ QuadShared shs[SDC_STEP_WPB];
+  __shared__ double ktab[SDC_K_LDS];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
+  const int env0 = (first_pair_of_block((int)blockIdx.x, (int)gridDim.x) + wave) * QE;
+  const int lane = threadIdx.x % SDC_WAVE;
+  const size_t N = (size_t)S.n_envs;
+  if (env0 >= S.n_envs) return;
+#pragma unroll 1
+  for (int k = 0; k < K; k++) {
+    if ((int)blockIdx.x >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
+    int env_k = env0, lane_k = lane;
+    asm volatile("" : "+s"(env_k), "+v"(lane_k));
+    quad_step<false>(S, shs[wave], env_k, lane_k, rel_hint + k, actions + (size_t)k * N * 3, obs + (size_t)k * N * SDC_OBS_OUT,
+                     share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM, done + (size_t)k * N, info + (size_t)k * N * SDC_INFO_DIM,
+                     k == K - 1 ? final_obs : nullptr, rew + (size_t)k * N * 3, S.step_no + k, false, ktab, k == 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_sync();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -120,7 +120,10 @@ typedef struct {
                               Bit 6 (64): TEST HOOK -- sdc_create reads the environment variable SDC_TEST_STEP_NO and
                               starts the launch counter there (tests of the counter's wrap); ignored otherwise.
                               Bit 7 (128): always launch the GENERAL step / rollout kernels, never the ones specialised
-                              for the common case (same results to the bit: tests compare the two) */
+                              for the common case (same results to the bit: tests compare the two).
+                              Bits 9 / 10 (512 / 1024): the common-case kernels with two / four envs per wavefront
+                              whatever the batch size (by default: four from 8192 envs on, when the batch is a
+                              multiple of four; same results to the bit) */
   int32_t reward_method[3]; /* reward function per agent slot (ls, dc, bat), utils/reward_creator.py:322-334:
                                SDC_REWARD_DEFAULT the slot's own default_*_reward, SDC_REWARD_FOOTPRINT
                                default_dc_reward = default_bat_reward, SDC_REWARD_CUSTOM custom_agent_reward (0),
