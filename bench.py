@@ -39,7 +39,9 @@ the launch + rendezvous + first all-reduce and prints the skeleton line (no devi
 from __future__ import annotations
 
 import argparse
+import contextlib
 import csv
+import gc
 import glob
 import hashlib
 import json
@@ -109,9 +111,34 @@ def build_engine(n_envs, episode_steps, device, seed, dc_files=("dc_config.json"
     return eng, tb, params
 
 
-def secondary_rate(n_envs, episode_steps, location, device, timed_steps, month=None):
+@contextlib.contextmanager
+def no_gc():
+    """A timed region without the interpreter's cyclic garbage collector: a full collection of this process's heap is a
+    35-55 ms host pause (measured: it landed on the second queued sdc_rollout launch of every run without the counter
+    passes and read as 23 us per step instead of 9); the host is not what these regions time."""
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        gc.enable()
+
+
+def actor_weights(seed=7):
+    """random weights of the reference's StochasticPolicy shape (LayerNorm(26)-64-64-3, tanh) for the closed-loop lines"""
+    rngw = np.random.default_rng(seed)
+    return [{"ln0_gamma": 1 + 0.1 * rngw.standard_normal(26), "ln0_beta": 0.1 * rngw.standard_normal(26),
+             "w1": rngw.standard_normal((64, 26)) * 0.3, "b1": 0.1 * rngw.standard_normal(64),
+             "ln1_gamma": 1 + 0.1 * rngw.standard_normal(64), "ln1_beta": 0.1 * rngw.standard_normal(64),
+             "w2": rngw.standard_normal((64, 64)) * 0.2, "b2": 0.1 * rngw.standard_normal(64),
+             "ln2_gamma": 1 + 0.1 * rngw.standard_normal(64), "ln2_beta": 0.1 * rngw.standard_normal(64),
+             "w3": rngw.standard_normal((3, 64)) * 0.2, "b3": np.zeros(3), "activation": "tanh"} for _ in range(3)]
+
+
+def secondary_rate(n_envs, episode_steps, location, device, timed_steps, month=None, loops=False):
     """One secondary line: the step's rate at another batch size / episode length, measured like the headline (all
-    rings filled to 10 000 by real steps, i.i.d. device-resident actions, auto-resets inside the timed region)."""
+    rings filled to 10 000 by real steps, i.i.d. device-resident actions, auto-resets inside the timed region).
+    loops: also sdc_rollout (48 steps per launch) and the closed loop (sdc_rollout_actor) at that batch size."""
     import torch
     eng, _, _ = build_engine(n_envs, episode_steps, device, seed=4321, location=location)
     if month is not None:
@@ -126,20 +153,44 @@ def secondary_rate(n_envs, episode_steps, location, device, timed_steps, month=N
     k = 0
     for _ in range(HIST_CAP + 64):
         eng.step(pool[k % POOL]); k += 1
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(timed_steps):
-        eng.step(pool[k % POOL]); k += 1
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with no_gc():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(timed_steps):
+            eng.step(pool[k % POOL]); k += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     faults = int((eng.info[:, 37] != 0).sum().item())
     hl = int(eng.get_state("hist_len").min())
+    out = {"envs": n_envs, "episode_steps": episode_steps, "location": location, "timed_steps": timed_steps,
+           "us_per_step": round(dt / timed_steps * 1e6, 2), "value": round(n_envs * timed_steps / dt, 1),
+           "unit": "env-steps/s", "history_len": hl, "faults": faults}
+    if loops:
+        for a_, w in enumerate(actor_weights()):
+            eng.set_actor(a_, w)
+        for name in ("rollout", "closed_loop"):
+            eng.reset()
+            for i in range(16):
+                eng.step(pool[i])
+            done_steps = 0
+            with no_gc():
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                while done_steps < 960:
+                    kk = min(48, eng.steps_to_episode_end())
+                    if name == "rollout":
+                        eng.rollout(pool[16:16 + kk])
+                    else:
+                        eng.rollout_actor(kk, sample=True)
+                    done_steps += kk
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t0
+            out[name] = {"steps_per_launch": 48, "us_per_step": round(dt2 / done_steps * 1e6, 2),
+                         "value": round(n_envs * done_steps / dt2, 1)}
     eng.close()
     del pool
     torch.cuda.empty_cache()
-    return {"envs": n_envs, "episode_steps": episode_steps, "location": location, "timed_steps": timed_steps,
-            "us_per_step": round(dt / timed_steps * 1e6, 2), "value": round(n_envs * timed_steps / dt, 1),
-            "unit": "env-steps/s", "history_len": hl, "faults": faults}
+    return out
 
 
 def cpu_baseline(tb, params, episode_steps, budget_s=12.0):
@@ -458,6 +509,8 @@ def main():
     EV_STEPS = 1000
     bpe = max(1, -(-EV_STEPS // K))            # blocks per event interval
     evs = [torch.cuda.Event(enable_timing=True)]
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     evs[0].record()
     for b in range(R):
@@ -470,6 +523,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     nb = [min(bpe, R - j * bpe) for j in range(len(evs) - 1)]            # blocks in each event interval
     block_ms = np.array([evs[j].elapsed_time(evs[j + 1]) / nb[j] for j in range(len(evs) - 1)])   # per block of K steps
     ev_ms = float(sum(evs[j].elapsed_time(evs[j + 1]) for j in range(len(evs) - 1)))
@@ -592,17 +646,16 @@ def main():
                 for i in range(16):
                     eng.step(pool[i])
                 Kr, done_steps = 48, 0
-                torch.cuda.synchronize()
-                tr = time.perf_counter()
-                while done_steps < 1920:
-                    k = min(Kr, eng.steps_to_episode_end())
-                    o = (16 + done_steps) % (POOL - Kr)
-                    eng.rollout(pool[o:o + k])
-                    done_steps += k
-                    if os.environ.get("SDC_BENCH_DEBUG"):
-                        torch.cuda.synchronize(); print("rollout launch k", k, "t", time.perf_counter() - tr, file=sys.stderr)
-                torch.cuda.synchronize()
-                tr = time.perf_counter() - tr
+                with no_gc():
+                    torch.cuda.synchronize()
+                    tr = time.perf_counter()
+                    while done_steps < 1920:
+                        k = min(Kr, eng.steps_to_episode_end())
+                        o = (16 + done_steps) % (POOL - Kr)
+                        eng.rollout(pool[o:o + k])
+                        done_steps += k
+                    torch.cuda.synchronize()
+                    tr = time.perf_counter() - tr
                 out["rollout"] = {"steps_per_launch": Kr, "value": round(N * done_steps / tr, 1), "unit": "env-steps/s",
                                   "ms_per_step": round(tr / done_steps * 1e3, 5)}
             except Exception as e:
@@ -612,26 +665,21 @@ def main():
             # reference's StochasticPolicy: LayerNorm(26) -> 64 -> 64 -> 3, fp32, happo.yaml hidden_sizes [64, 64]; random
             # weights) evaluated inside the kernel between the steps -- every env-step includes three network inferences
             try:
-                rngw = np.random.default_rng(7)
-                for a_ in range(3):
-                    eng.set_actor(a_, {"ln0_gamma": 1 + 0.1 * rngw.standard_normal(26), "ln0_beta": 0.1 * rngw.standard_normal(26),
-                                       "w1": rngw.standard_normal((64, 26)) * 0.3, "b1": 0.1 * rngw.standard_normal(64),
-                                       "ln1_gamma": 1 + 0.1 * rngw.standard_normal(64), "ln1_beta": 0.1 * rngw.standard_normal(64),
-                                       "w2": rngw.standard_normal((64, 64)) * 0.2, "b2": 0.1 * rngw.standard_normal(64),
-                                       "ln2_gamma": 1 + 0.1 * rngw.standard_normal(64), "ln2_beta": 0.1 * rngw.standard_normal(64),
-                                       "w3": rngw.standard_normal((3, 64)) * 0.2, "b3": np.zeros(3), "activation": "tanh"})
+                for a_, w_ in enumerate(actor_weights()):
+                    eng.set_actor(a_, w_)
                 eng.reset()
                 for i in range(16):
                     eng.step(pool[i])
                 Kr, done_steps = 48, 0
-                torch.cuda.synchronize()
-                tr = time.perf_counter()
-                while done_steps < 1920:
-                    k = min(Kr, eng.steps_to_episode_end())
-                    _, _, _, _, _, acts_cl, _ = eng.rollout_actor(k, sample=True)
-                    done_steps += k
-                torch.cuda.synchronize()
-                tr = time.perf_counter() - tr
+                with no_gc():
+                    torch.cuda.synchronize()
+                    tr = time.perf_counter()
+                    while done_steps < 1920:
+                        k = min(Kr, eng.steps_to_episode_end())
+                        _, _, _, _, _, acts_cl, _ = eng.rollout_actor(k, sample=True)
+                        done_steps += k
+                    torch.cuda.synchronize()
+                    tr = time.perf_counter() - tr
                 hist_a = torch.bincount(acts_cl.reshape(-1).long(), minlength=3).cpu().tolist()
                 out["closed_loop"] = {"steps_per_launch": Kr, "value": round(N * done_steps / tr, 1), "unit": "env-steps/s",
                                       "ms_per_step": round(tr / done_steps * 1e3, 5),
@@ -653,7 +701,7 @@ def main():
             scan = []
             for n in (2048, 8192, 16384):
                 try:
-                    r = secondary_rate(n, args.episode_steps, "ny", dev, 2016)
+                    r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=n >= 8192)
                     r["rate_vs_4096_envs"] = round(r["value"] / value, 4)
                     scan.append(r)
                 except Exception as e:

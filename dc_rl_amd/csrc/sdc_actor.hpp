@@ -283,6 +283,136 @@ __device__ __forceinline__ void forward3(const SdcActorDev* A, const float (&x)[
   else forward3_kind<0>(A, x, lane, lg);
 }
 
+// ---- FOUR ENVS PER WAVEFRONT (sdc_rollout_actor_quad_kernel: large batches) -----------------------------------------------
+// The same networks with all four rows of the 4 x 64 product in use: the 276 MFMAs per wavefront-step serve four envs.
+// The A operands are quad broadcasts of FOUR activation registers (lane = entry k, register = env) merged on lane % 4.
+__device__ __forceinline__ void a_operands4(float (&P)[4], const float x0, const float x1, const float x2, const float x3,
+                                            const int lane) {
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+#define SDC_ACT_P(V)                                                                              \
+  {                                                                                               \
+    const float e0 = quad_bcast<V>(x0), e1 = quad_bcast<V>(x1), e2 = quad_bcast<V>(x2), e3 = quad_bcast<V>(x3); \
+    const float lo = b0 ? e1 : e0, hi = b0 ? e3 : e2;                                             \
+    P[V] = b1 ? hi : lo;                                                                          \
+  }
+  SDC_ACT_P(0) SDC_ACT_P(1) SDC_ACT_P(2) SDC_ACT_P(3)
+#undef SDC_ACT_P
+}
+// bias, activation, LayerNorm(64) of the three agents' layer outputs, four envs: acc[a][e] -> h[a][e] (lane = unit).  The
+// 24 sums: four DPP stages inside the rows, then per agent and moment the four envs' row sums merged into one register
+// (rows [env 0, 1, 2, 3] totals) and read back as wave-uniform values.
+template <int KIND>
+__device__ __forceinline__ void epilogue4(const f4 (&acc)[3], const float (&bias)[3], const float (&g)[3], const float (&b)[3],
+                                          float (&h)[3][4]) {
+  float r[24];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float v = activate<KIND>(acc[a][e] + bias[a]);
+      h[a][e] = v;
+      r[8 * a + e] = v;
+      r[8 * a + 4 + e] = v * v;
+    }
+  row_sums<24>(r);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float t1 = swap32_sum(swap16_sum(r[8 * a], r[8 * a + 1]), swap16_sum(r[8 * a + 2], r[8 * a + 3]));
+    const float t2 = swap32_sum(swap16_sum(r[8 * a + 4], r[8 * a + 5]), swap16_sum(r[8 * a + 6], r[8 * a + 7]));
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float mean = row_value(t1, e) * (1.0f / SDC_ACT_H);
+      const float var = fmaxf(row_value(t2, e) * (1.0f / SDC_ACT_H) - mean * mean, 0.0f);
+      h[a][e] = (h[a][e] - mean) * __builtin_amdgcn_rsqf(var + 1e-5f) * g[a] + b[a];
+    }
+  }
+}
+// x[a][j]: lane (half H, k) holds entry k < 26 (0 beyond) of agent a's padded observation of env 2 H + j.
+// lg[a][0..2] = agent a's logits for the env of THE LANE'S ROW (row r of the wavefront = env r).
+template <int KIND>
+__device__ __forceinline__ void forward3_quad_kind(const SdcActorDev* A, const float (&x)[3][2], const int lane, float (&lg)[3][3]) {
+  const int k = lane & 31;
+  WBuf W;
+  fetch3<SDC_ACT_CH>(W.w[0], A, false, 0, lane);
+  // feature LayerNorm: sums over a half (two rows); rows of the merged registers = envs 0..3
+  float xn[3][2];
+  {
+    float r[12];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      r[4 * a] = x[a][0]; r[4 * a + 1] = x[a][1];
+      r[4 * a + 2] = x[a][0] * x[a][0]; r[4 * a + 3] = x[a][1] * x[a][1];
+    }
+    row_sums<12>(r);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      float s0, s1, q0, q1;         // this lane's half: sum x / sum x^2 of its env j = 0 and j = 1
+      spread16(swap16_sum(r[4 * a], r[4 * a + 1]), s0, s1);
+      spread16(swap16_sum(r[4 * a + 2], r[4 * a + 3]), q0, q1);
+      xn[a][0] = x[a][0];
+      xn[a][1] = x[a][1];
+      if (A[a].flags & 1) {
+        const float g0 = A[a].ln0_g[k], b0 = A[a].ln0_b[k];
+        const float m0 = s0 * (1.0f / SDC_ACT_IN), m1 = s1 * (1.0f / SDC_ACT_IN);
+        const float v0 = fmaxf(q0 * (1.0f / SDC_ACT_IN) - m0 * m0, 0.0f), v1 = fmaxf(q1 * (1.0f / SDC_ACT_IN) - m1 * m1, 0.0f);
+        xn[a][0] = (x[a][0] - m0) * __builtin_amdgcn_rsqf(v0 + 1e-5f) * g0 + b0;
+        xn[a][1] = (x[a][1] - m1) * __builtin_amdgcn_rsqf(v1 + 1e-5f) * g0 + b0;
+      }
+    }
+  }
+  float P[3][4];
+  f4 acc[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    // envs 0, 1 sit in lanes 0..25, envs 2, 3 in lanes 32..57: all four to lanes 0..25 (the lane = the entry k)
+    const float xa = k < SDC_ACT_IN ? xn[a][0] : 0.0f, xb = k < SDC_ACT_IN ? xn[a][1] : 0.0f;
+    const auto sa = __builtin_amdgcn_permlane32_swap(__float_as_uint(xa), __float_as_uint(xa), false, false);
+    const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(xb), __float_as_uint(xb), false, false);
+    a_operands4(P[a], __uint_as_float(sa[0]), __uint_as_float(sb[0]), __uint_as_float(sa[1]), __uint_as_float(sb[1]), lane);
+    acc[a] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  Chunks<0, SDC_ACT_M1, false, 0>::run(acc, P, W, A, lane);
+  constexpr int PAR2 = ((SDC_ACT_M1 + SDC_ACT_CH - 1) / SDC_ACT_CH) & 1;
+  float h[3][4];
+  {
+    const float bias[3] = {A[0].b1[lane], A[1].b1[lane], A[2].b1[lane]};
+    const float g[3] = {A[0].ln1_g[lane], A[1].ln1_g[lane], A[2].ln1_g[lane]};
+    const float b[3] = {A[0].ln1_b[lane], A[1].ln1_b[lane], A[2].ln1_b[lane]};
+    epilogue4<KIND>(acc, bias, g, b, h);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    a_operands4(P[a], h[a][0], h[a][1], h[a][2], h[a][3], lane);
+    acc[a] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  Chunks<0, SDC_ACT_M2, true, PAR2>::run(acc, P, W, A, lane);
+  {
+    const float bias[3] = {A[0].b2[lane], A[1].b2[lane], A[2].b2[lane]};
+    const float g[3] = {A[0].ln2_g[lane], A[1].ln2_g[lane], A[2].ln2_g[lane]};
+    const float b[3] = {A[0].ln2_b[lane], A[1].ln2_b[lane], A[2].ln2_b[lane]};
+    epilogue4<KIND>(acc, bias, g, b, h);
+  }
+  // the logits: per (agent, action) the four envs' products reduced into one register whose ROW e holds env e's total
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    float r[12];
+#pragma unroll
+    for (int c = 0; c < SDC_ACT_OUT; c++) {
+      const float w3 = A[a].w3[c][lane];
+#pragma unroll
+      for (int e = 0; e < 4; e++) r[4 * c + e] = w3 * h[a][e];
+    }
+    row_sums<12>(r);
+#pragma unroll
+    for (int c = 0; c < SDC_ACT_OUT; c++)
+      lg[a][c] = swap32_sum(swap16_sum(r[4 * c], r[4 * c + 1]), swap16_sum(r[4 * c + 2], r[4 * c + 3])) + A[a].b3[c];
+  }
+}
+__device__ __forceinline__ void forward3_quad(const SdcActorDev* A, const float (&x)[3][2], const int lane, float (&lg)[3][3]) {
+  if (__builtin_amdgcn_readfirstlane((A[0].flags >> 1) & 3) == 1) forward3_quad_kind<1>(A, x, lane, lg);
+  else forward3_quad_kind<0>(A, x, lane, lg);
+}
+
 // the action of one env from its three logits: mode() = first maximum (torch argmax), or a draw from
 // softmax(logits) by inverse CDF with the uniform u in [0, 1)
 __device__ __forceinline__ int pick_action(const float l0, const float l1, const float l2, const bool sample, const float u) {

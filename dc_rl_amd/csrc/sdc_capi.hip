@@ -32,6 +32,11 @@ extern "C" __global__ void sdc_rollout_actor_kernel(SdcDev S, int K, int rel_hin
                                                     float* final_obs, float* rew, int32_t* actions_out, float* logits_out,
                                                     float* obs_latch);
 size_t sdc_rollout_actor_lds_bytes();
+extern "C" __global__ void sdc_rollout_actor_quad_kernel(SdcDev S, int K, int rel_hint, const SdcActorDev* nets, const float* obs_in,
+                                                         int sample, float* obs, float* share_obs, unsigned char* done, float* info,
+                                                         float* final_obs, float* rew, int32_t* actions_out, float* logits_out,
+                                                         float* obs_latch);
+size_t sdc_rollout_actor_quad_lds_bytes();
 extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
 extern "C" __global__ void sdc_features_kernel(SdcDev S);
 extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
@@ -788,16 +793,26 @@ int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float*
   d.step_no = h->step_no;
   h->step_no = next_step_no(h->step_no, n_steps + 3);
   HIP_TRY(hipMemsetAsync(d.rq_count, 0, sizeof(int) * 4, st));
-  const size_t lds = sdc_rollout_actor_lds_bytes();
+  constexpr int AWPB = 8;     // sdc_step.hip SDC_ACTOR_WPB
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sdc_rollout_actor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sdc_rollout_actor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sdc_rollout_actor_lds_bytes()));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sdc_rollout_actor_quad_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sdc_rollout_actor_quad_lds_bytes()));
     attr_done = true;
   }
-  constexpr int AWPB = 8;     // sdc_step.hip SDC_ACTOR_WPB
-  const int blocks = ((N + 1) / 2 + AWPB - 1) / AWPB;
-  hipLaunchKernelGGL(sdc_rollout_actor_kernel, dim3(blocks), dim3(SDC_WAVE * AWPB), lds, st, d, n_steps, h->rel_hint, h->actor_dev,
-                     h->obs_latch, sample ? 1 : 0, obs, share_obs, done, info, final_obs, rew, actions_out, logits_out, h->obs_latch);
+  if (quad_case(h)) {         // four envs per wavefront (large batches)
+    const int blocks = (N / 4 + AWPB - 1) / AWPB;
+    hipLaunchKernelGGL(sdc_rollout_actor_quad_kernel, dim3(blocks), dim3(SDC_WAVE * AWPB), sdc_rollout_actor_quad_lds_bytes(), st, d,
+                       n_steps, h->rel_hint, h->actor_dev, h->obs_latch, sample ? 1 : 0, obs, share_obs, done, info, final_obs, rew,
+                       actions_out, logits_out, h->obs_latch);
+  } else {
+    const int blocks = ((N + 1) / 2 + AWPB - 1) / AWPB;
+    hipLaunchKernelGGL(sdc_rollout_actor_kernel, dim3(blocks), dim3(SDC_WAVE * AWPB), sdc_rollout_actor_lds_bytes(), st, d, n_steps,
+                       h->rel_hint, h->actor_dev, h->obs_latch, sample ? 1 : 0, obs, share_obs, done, info, final_obs, rew, actions_out,
+                       logits_out, h->obs_latch);
+  }
   HIP_TRY(hipGetLastError());
   h->n_last_done = 0;
   h->steps_to_terminal -= n_steps;

@@ -2326,3 +2326,107 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
 }
 // (host side: the dynamic LDS the closed-loop kernel is launched with)
 size_t sdc_rollout_actor_lds_bytes() { return sizeof(ActorLds); }
+
+// The closed loop with FOUR envs per wavefront (large batches): workgroup = 8 wavefronts = 32 envs sharing the LDS copy of
+// the networks; every MFMA row carries an env (forward3_quad).
+struct ActorQuadLds {
+  QuadShared shs[SDC_ACTOR_WPB];
+  double ktab[SDC_K_LDS];
+  SdcActorDev net[3];
+};
+static_assert(sizeof(ActorQuadLds) <= 160 * 1024, "one workgroup per CU");
+static_assert(offsetof(ActorQuadLds, net) % 16 == 0, "the weights are read as ds_read_b128");
+extern "C" __global__ __launch_bounds__(SDC_WAVE * SDC_ACTOR_WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
+sdc_rollout_actor_quad_kernel(SdcDev S, const int K, const int rel_hint, const SdcActorDev* __restrict__ nets,
+                              const float* __restrict__ obs_in, const int sample, float* __restrict__ obs,
+                              float* __restrict__ share_obs, unsigned char* __restrict__ done, float* __restrict__ info,
+                              float* __restrict__ final_obs, float* __restrict__ rew, int32_t* __restrict__ actions_out,
+                              float* __restrict__ logits_out, float* __restrict__ obs_latch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  ActorQuadLds& L = *reinterpret_cast<ActorQuadLds*>(lds_raw);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
+  const int lane = threadIdx.x % SDC_WAVE;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(nets);
+    uint4* dst = reinterpret_cast<uint4*>(L.net);
+    for (int i = (int)threadIdx.x; i < (int)(3 * sizeof(SdcActorDev) / 16); i += SDC_WAVE * SDC_ACTOR_WPB) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int env0 = (first_pair_of_block((int)blockIdx.x, (int)gridDim.x, SDC_ACTOR_WPB) + wave) * QE;
+  if (env0 >= S.n_envs) return;
+  QuadShared& sh = L.shs[wave];
+  const size_t N = (size_t)S.n_envs;
+  {
+    // the observation pools of the four envs from the latest observations (see sdc_rollout_actor_kernel): two entries per lane
+    const int r = lane >> 4, l = lane & (QL - 1);
+    const float* o = obs_in + (size_t)(env0 + r) * SDC_OBS_OUT;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int j = 2 * l + t;
+      if (j < SDC_POOL_DIM)
+        sh.pool[r][j] = j < SDC_OBS_PAD ? o[j] : (j == SDC_P_WNEXT ? o[SDC_OBS_PAD + 11] : (j == SDC_P_NTNEXT ? o[SDC_OBS_PAD + 13] : o[2 * SDC_OBS_PAD + 12]));
+    }
+  }
+  wave_sync();
+#pragma unroll 1
+  for (int k = 0; k < K; k++) {
+    int env_k = env0, lane_k = lane;
+    asm volatile("" : "+s"(env_k), "+v"(lane_k));
+    const int row = lane_k >> 4, lk = lane_k & (QL - 1);
+    const int half = lane_k >> 5, kk = lane_k & 31;
+    const int rel_now = rel_hint + k;
+    // ---- the three actors on the current observations of the four envs ---------------------------------------------------
+    float lg[3][3];
+    {
+      float x[3][2];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const int pi = obs_pool_index(a * SDC_OBS_PAD + (kk < SDC_ACT_IN ? kk : 0));
+        const float v0 = sh.pool[2 * half][pi < 0 ? 0 : pi], v1 = sh.pool[2 * half + 1][pi < 0 ? 0 : pi];
+        x[a][0] = (kk < SDC_ACT_IN && pi >= 0) ? v0 : 0.0f;
+        x[a][1] = (kk < SDC_ACT_IN && pi >= 0) ? v1 : 0.0f;
+      }
+      sdc_act::forward3_quad(L.net, x, lane_k, lg);
+    }
+    float u3[3] = {0.0f, 0.0f, 0.0f};
+    if (sample) {
+      const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + row), 0u, 0xAC70u, (unsigned)S.seed,
+                                      (unsigned)(S.seed >> 32) ^ (unsigned)S.step_no);
+      u3[0] = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+      u3[1] = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+      u3[2] = (float)(r.z >> 8) * (1.0f / 16777216.0f);
+    }
+    int act[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float l0 = lg[a][0], l1 = lg[a][1], l2 = lg[a][2];
+      act[a] = sdc_act::pick_action(l0, l1, l2, sample != 0, u3[a]);
+      if (logits_out && lk < SDC_ACT_OUT)
+        logits_out[(((size_t)k * N + (size_t)(env_k + row)) * 3 + a) * 3 + lk] = lk == 0 ? l0 : (lk == 1 ? l1 : l2);
+    }
+    if (lk == 0) {
+      int32_t* ao = actions_out + ((size_t)k * N + (size_t)(env_k + row)) * 3;
+      ao[0] = act[0];
+      ao[1] = act[1];
+      ao[2] = act[2];
+    }
+    quad_step<true>(S, sh, env_k, lane_k, rel_now, nullptr, obs + (size_t)k * N * SDC_OBS_OUT,
+                    share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM, done + (size_t)k * N, info + (size_t)k * N * SDC_INFO_DIM,
+                    k == K - 1 ? final_obs : nullptr, rew + (size_t)k * N * 3, S.step_no + k, false, L.ktab, k == 0, act[0], act[1],
+                    act[2]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_sync();
+  }
+  if (obs_latch) {
+#pragma unroll
+    for (int q = 0; q < (QE * SDC_OBS_OUT + SDC_WAVE - 1) / SDC_WAVE; q++) {
+      const int idx = q * SDC_WAVE + lane;
+      if (idx < QE * SDC_OBS_OUT) {
+        const int e = (idx >= SDC_OBS_OUT ? 1 : 0) + (idx >= 2 * SDC_OBS_OUT ? 1 : 0) + (idx >= 3 * SDC_OBS_OUT ? 1 : 0);
+        obs_latch[(size_t)env0 * SDC_OBS_OUT + idx] = obs_padded_at(sh.pool[e], idx - e * SDC_OBS_OUT);
+      }
+    }
+  }
+}
+size_t sdc_rollout_actor_quad_lds_bytes() { return sizeof(ActorQuadLds); }

@@ -50,22 +50,24 @@ def _torch_actor(seed, activation="tanh"):
     return m
 
 
-def _engine(N, steps, seed=5):
+def _engine(N, steps, seed=5, debug_flags=0):
     tb = traces.synthetic_tables("ny", 0)
     p = dc_config.size_datacenter("dc_config.json", 1, 30.0)
-    e = SdcEngine(N, episode_steps=steps, auto_reset=True, seed=seed)
+    e = SdcEngine(N, episode_steps=steps, auto_reset=True, seed=seed, debug_flags=debug_flags)
     e.set_tables(0, tb["W"], tb["C"], tb["T"], tb["WB"])
     e.set_dc_params(0, p)
     e.assign(0, 0, 174, 188)
     return e
 
 
-@pytest.mark.parametrize("activation,N", [("tanh", 512), ("relu", 512), ("tanh", 40)])     # (40 envs: a partly filled workgroup)
-def test_in_kernel_actor_matches_torch_and_external_rollout(activation, N):
+# (40 envs: a partly filled workgroup; debug_flags 1024: four envs per wavefront -- the mapping of large batches -- whatever the size)
+@pytest.mark.parametrize("activation,N,flags", [("tanh", 512, 0), ("relu", 512, 0), ("tanh", 40, 0), ("tanh", 512, 1024),
+                                                ("relu", 40, 1024)])
+def test_in_kernel_actor_matches_torch_and_external_rollout(activation, N, flags):
     import torch
     steps, K = 96, 40
     nets = [_torch_actor(100 + a, activation) for a in range(3)]
-    a_eng, b_eng = _engine(N, steps), _engine(N, steps)
+    a_eng, b_eng = _engine(N, steps, debug_flags=flags), _engine(N, steps)
     for a in range(3):
         sd = dict(nets[a].state_dict())
         sd["activation"] = activation

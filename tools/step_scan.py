@@ -23,6 +23,24 @@ for N in [int(x) for x in os.environ.get("SDC_NS", "4096,8192,12288,16384").spli
             kk = min(48, eng.steps_to_episode_end())
             eng.rollout(pool[:kk]); done += kk
         torch.cuda.synchronize(); tr = (time.perf_counter() - t0) / done * 1e6
-        print("N %6d  %s: %.2f us per step = %.1f M env-steps/s;  sdc_rollout (48 per launch) %.2f us per step = %.1f M" % (
-            N, "two envs per wavefront " if flags == 512 else "four envs per wavefront", best, N / best, tr, N / tr))
+        import numpy as np
+        rngw = np.random.default_rng(7)
+        for a_ in range(3):
+            eng.set_actor(a_, {"ln0_gamma": 1 + 0.1 * rngw.standard_normal(26), "ln0_beta": 0.1 * rngw.standard_normal(26),
+                               "w1": rngw.standard_normal((64, 26)) * 0.3, "b1": 0.1 * rngw.standard_normal(64),
+                               "ln1_gamma": 1 + 0.1 * rngw.standard_normal(64), "ln1_beta": 0.1 * rngw.standard_normal(64),
+                               "w2": rngw.standard_normal((64, 64)) * 0.2, "b2": 0.1 * rngw.standard_normal(64),
+                               "ln2_gamma": 1 + 0.1 * rngw.standard_normal(64), "ln2_beta": 0.1 * rngw.standard_normal(64),
+                               "w3": rngw.standard_normal((3, 64)) * 0.2, "b3": np.zeros(3), "activation": "tanh"})
+        eng.reset()
+        for i in range(16):
+            eng.step(pool[i])
+        done = 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        while done < 480:
+            kk = min(48, eng.steps_to_episode_end())
+            eng.rollout_actor(kk, sample=True); done += kk
+        torch.cuda.synchronize(); tc = (time.perf_counter() - t0) / done * 1e6
+        print("N %6d  %s: %.2f us per step = %.1f M env-steps/s;  sdc_rollout (48 per launch) %.2f us = %.1f M;  closed loop (sampled) %.2f us = %.1f M" % (
+            N, "two envs per wavefront " if flags == 512 else "four envs per wavefront", best, N / best, tr, N / tr, tc, N / tc))
         eng.close()
