@@ -207,7 +207,8 @@ const char* sdc_last_error(void);
  * does) -- the .so is shipped out of band, so a stale one must fail loudly, not corrupt silently.
  *   100  round 1        300  sdc_config: env_index_base, policy[3], trim_and_respond_limit; sdc_reset_override: noise,
  *                            roll_days; sdc_rollout: actions_out; debug_flags bit 6
- *   310  sdc_set_actor, sdc_rollout_actor (closed loop with the actor networks inside the kernel); debug_flags bit 7 */
+ *   310  sdc_set_actor, sdc_rollout_actor (closed loop with the actor networks inside the kernel); debug_flags bit 7
+ *        (debug_flags bits 9 / 10 came later without a bump: no layout or argument list changed) */
 #define SDC_ABI_VERSION 310
 int sdc_version(void);
 
