@@ -244,3 +244,40 @@ def test_common_case_kernels_equal_the_general_kernels():
             np.testing.assert_array_equal(sa[name], sb, err_msg=name + " / " + which)
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("N", [8192, 8200])      # (8200: a partly filled last workgroup, a grid that is not a multiple of 8)
+def test_large_batches_take_the_four_env_mapping(N):
+    """From 8192 envs on the common case runs four envs per wavefront by default (sdc_capi.hip quad_case): same outputs
+    and state, bit for bit, as the two-env mapping (debug_flags bit 9) at those sizes -- steps, a rollout, the closed loop."""
+    import torch
+    from tests.test_gpu_actor import _torch_actor
+    steps = 96
+    tb = traces.synthetic_tables("ny", 0)
+    p = dc_config.size_datacenter("dc_config.json", 1, 30.0)
+    engs = []
+    for flags in (0, 512):
+        e = SdcEngine(N, episode_steps=steps, auto_reset=True, seed=21, debug_flags=flags)
+        e.set_tables(0, tb["W"], tb["C"], tb["T"], tb["WB"])
+        e.set_dc_params(0, p)
+        e.assign(0, 0, 100, 120)
+        for a in range(3):
+            e.set_actor(a, _torch_actor(40 + a, "tanh").state_dict())
+        e.reset()
+        engs.append(e)
+    a, b = engs
+    g = torch.Generator(device="cpu").manual_seed(8)
+    acts = torch.randint(0, 3, (64, N, 3), dtype=torch.int32, generator=g).cuda()
+    for t in range(40):
+        for u, v, nm in zip(a.step(acts[t]), b.step(acts[t]), ("obs", "share_obs", "rew", "done", "info")):
+            assert torch.equal(u, v), (t, nm)
+    for u, v in zip(a.rollout(acts[40:56]), b.rollout(acts[40:56])):
+        assert torch.equal(u, v)
+    ra, rb = a.rollout_actor(24, sample=True), b.rollout_actor(24, sample=True)
+    for u, v in zip(ra[:6], rb[:6]):
+        assert torch.equal(u, v)
+    for name in ("record", "qwin", "hist", "qtab"):
+        np.testing.assert_array_equal(a.get_state(name), b.get_state(name), err_msg=name)
+    assert (a.info[:, L.INFO_IDX["fault"]] == 0).all()
+    for e in engs:
+        e.close()
