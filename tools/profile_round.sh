@@ -37,6 +37,8 @@ hipcc --offload-arch=gfx950 -O3 tools/launch_floor.hip -o /tmp/launch_floor 2>/d
 hipcc --offload-arch=gfx950 -O3 tools/dispatch_rate.hip -o /tmp/dispatch_rate 2>/dev/null && /tmp/dispatch_rate > $O/dispatch_rate.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/dispatch_rate2.hip -o /tmp/dispatch_rate2 2>/dev/null && /tmp/dispatch_rate2 > $O/dispatch_rate2.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/load_latency.hip -o /tmp/load_latency 2>/dev/null && /tmp/load_latency > $O/load_latency.txt 2>&1
+timeout 900 python tools/step_scan.py > $O/step_scan.txt 2>&1
+bash tools/pmc_actor.sh > $O/pmc_actor.txt 2>&1
 bash tools/pmc_stalls.sh > $O/pmc_stalls.txt 2>&1
 bash tools/pmc_latency.sh > $O/pmc_latency.txt 2>&1
 grep -v amdgpu.ids $O/*.txt | tail -60
