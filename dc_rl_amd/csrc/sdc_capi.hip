@@ -203,19 +203,26 @@ void note_features(sdc_handle* h, int e) {
 // default reward functions, no diagnostics or profiling, an even number of envs, every output array present.
 // debug_flags bit 0 (the verify kernel, a separate launch) and bit 6 (test hook of sdc_create) do not touch the step;
 // bit 7 forces the general kernel (tests compare the two bit for bit).  The common case runs FOUR envs per wavefront
-// (sdc_*_quad_kernel) when the batch is a multiple of four envs and large enough for that mapping to pay (QUAD_MIN_ENVS:
-// below it a SIMD would hold a single such wavefront, whose waits nothing overlaps); bit 9 keeps it at two envs per
-// wavefront, bit 10 picks four whatever the size (the tests compare all of them bit for bit).
+// (sdc_*_quad_kernel) when the batch is a multiple of four envs and large enough for that mapping to pay: a SIMD has to hold
+// more than one such wavefront, or nothing overlaps its waits.  Measured (tools/step_scan.py, MI355X: 1024 SIMDs): single
+// steps are faster with four envs per wavefront from ~6 700 envs on (6144: 16.3 us with two, 16.7 with four; 7168: 21.7 /
+// 18.3); the multi-step kernels (sdc_rollout, sdc_rollout_actor), whose two-env form keeps two wavefronts per SIMD and
+// needs a second round above 4096 envs, from any batch above 4096 (5120 envs: rollout 17.7 / 14.0 us per step, closed loop
+// 28.2 / 19.7).  debug_flags bit 9 keeps two envs per wavefront, bit 10 picks four whatever the size (the tests compare
+// all of them bit for bit).
 #ifndef SDC_FAST_DEBUG
 #define SDC_FAST_DEBUG 0
 #endif
 constexpr int FAST_DEBUG_FLAGS = SDC_FAST_DEBUG ? (8 | 16 | 32 | 256) : 0;   // (measurement builds: see sdc_step.hip)
-#ifndef SDC_QUAD_MIN_ENVS
-#define SDC_QUAD_MIN_ENVS 8192
+#ifndef SDC_QUAD_MIN_ENVS_STEP
+#define SDC_QUAD_MIN_ENVS_STEP 6656
 #endif
-bool quad_case(const sdc_handle* h) {
+#ifndef SDC_QUAD_MIN_ENVS_LOOP
+#define SDC_QUAD_MIN_ENVS_LOOP 4100
+#endif
+bool quad_case(const sdc_handle* h, const bool multi_step) {
   return (h->cfg.n_envs & 3) == 0 && (h->d.debug_flags & (512 | FAST_DEBUG_FLAGS)) == 0 &&
-         (h->cfg.n_envs >= SDC_QUAD_MIN_ENVS || (h->d.debug_flags & 1024));
+         (h->cfg.n_envs >= (multi_step ? SDC_QUAD_MIN_ENVS_LOOP : SDC_QUAD_MIN_ENVS_STEP) || (h->d.debug_flags & 1024));
 }
 int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_obs, const float* info, bool timed) {
@@ -630,7 +637,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   }
   d.step_no = h->step_no;
   h->step_no = next_step_no(h->step_no, 1);
-  if (fast_case(h, actions, share_obs, info, timed) && quad_case(h))
+  if (fast_case(h, actions, share_obs, info, timed) && quad_case(h, false))
     hipLaunchKernelGGL(sdc_dynamics_quad_kernel, dim3(SWEEP_BLOCKS + quad_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
                        h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
   else if (fast_case(h, actions, share_obs, info, timed))
@@ -693,7 +700,7 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
     d.step_no = h->step_no;
     h->step_no = next_step_no(h->step_no, n_steps + 3);
     HIP_TRY(hipMemsetAsync(d.rq_count, 0, sizeof(int) * 4, st));
-    if (fast_case(h, actions, share_obs, info, false) && !actions_out && quad_case(h))
+    if (fast_case(h, actions, share_obs, info, false) && !actions_out && quad_case(h, true))
       hipLaunchKernelGGL(sdc_rollout_quad_kernel, dim3(quad_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, n_steps, h->rel_hint,
                          actions, obs, share_obs, done, info, final_obs, rew);
     else if (fast_case(h, actions, share_obs, info, false) && !actions_out)
@@ -802,7 +809,7 @@ int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float*
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sdc_rollout_actor_quad_lds_bytes()));
     attr_done = true;
   }
-  if (quad_case(h)) {         // four envs per wavefront (large batches)
+  if (quad_case(h, true)) {   // four envs per wavefront (batches above 4096 envs)
     const int blocks = (N / 4 + AWPB - 1) / AWPB;
     hipLaunchKernelGGL(sdc_rollout_actor_quad_kernel, dim3(blocks), dim3(SDC_WAVE * AWPB), sdc_rollout_actor_quad_lds_bytes(), st, d,
                        n_steps, h->rel_hint, h->actor_dev, h->obs_latch, sample ? 1 : 0, obs, share_obs, done, info, final_obs, rew,

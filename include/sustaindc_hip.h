@@ -122,8 +122,9 @@ typedef struct {
                               Bit 7 (128): always launch the GENERAL step / rollout kernels, never the ones specialised
                               for the common case (same results to the bit: tests compare the two).
                               Bits 9 / 10 (512 / 1024): the common-case kernels with two / four envs per wavefront
-                              whatever the batch size (by default: four from 8192 envs on, when the batch is a
-                              multiple of four; same results to the bit) */
+                              whatever the batch size (by default four when the batch is a multiple of four and
+                              large: single steps from 6656 envs on, the multi-step entry points above 4096; same
+                              results to the bit) */
   int32_t reward_method[3]; /* reward function per agent slot (ls, dc, bat), utils/reward_creator.py:322-334:
                                SDC_REWARD_DEFAULT the slot's own default_*_reward, SDC_REWARD_FOOTPRINT
                                default_dc_reward = default_bat_reward, SDC_REWARD_CUSTOM custom_agent_reward (0),
