@@ -23,7 +23,11 @@ ABI_VERSION = 310  # include/sustaindc_hip.h SDC_ABI_VERSION: the struct layouts
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
 SOURCES = ["sdc_capi.hip", "sdc_step.hip", "sdc_features.hip", "sdc_verify.hip", "sdc_reset.hip"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# (-amdgpu-sched-strategy=max-ilp: the machine scheduler orders for instruction-level parallelism instead of minimal register
+#  pressure -- the step kernels' occupancy is pinned by amdgpu_waves_per_eu anyway, and their time is dependent-issue latency:
+#  measured 12.09 -> 11.78 us per step of 4096 envs, the large-batch kernels +1-2 %)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 # info column names = the reference's info keys (sustaindc_hip.h enum sdc_info_col)
 INFO_COLS = [
@@ -133,6 +137,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     deps.append(os.path.join(CSRC, "..", "..", "include", "sustaindc_hip.h"))
+    deps.append(os.path.abspath(__file__))      # (the compiler flags live here)
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

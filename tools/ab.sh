@@ -10,7 +10,7 @@ NAMES=""
 for v in "$@"; do
   name="${v%%:*}"; flags="${v#*:}"
   rm -f tools/bin/lib_$name.so
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $flags -o tools/bin/lib_$name.so $SRCS 2>/dev/null &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -amdgpu-sched-strategy=max-ilp $flags -o tools/bin/lib_$name.so $SRCS 2>/dev/null &
   NAMES="$NAMES $name"
 done
 wait

@@ -10,7 +10,7 @@ N=0
 for i in $(seq 1 17); do
   if [ tools/bin/lib_seg$i.so -nt dc_rl_amd/csrc/sdc_step.hip ]; then continue; fi
   j=$((i + 1))
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DSDC_STAMP_A=$i -DSDC_STAMP_B=$j -o tools/bin/lib_seg$i.so $SRCS 2>/dev/null &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -amdgpu-sched-strategy=max-ilp -DSDC_STAMP_A=$i -DSDC_STAMP_B=$j -o tools/bin/lib_seg$i.so $SRCS 2>/dev/null &
   N=$((N + 1))
   if [ $((N % 6)) -eq 0 ]; then wait; fi
 done
