@@ -4,13 +4,15 @@
 set -e
 cd /root/repo
 CMD="$1"; shift
+# the production build's scheduling strategy (dc_rl_amd/_lib.py HIPCC_FLAGS); AB_BASE="" to compare strategies
+BASE="${AB_BASE--mllvm -amdgpu-sched-strategy=max-ilp}"
 mkdir -p tools/bin
 SRCS="dc_rl_amd/csrc/sdc_capi.hip dc_rl_amd/csrc/sdc_step.hip dc_rl_amd/csrc/sdc_features.hip dc_rl_amd/csrc/sdc_verify.hip dc_rl_amd/csrc/sdc_reset.hip"
 NAMES=""
 for v in "$@"; do
   name="${v%%:*}"; flags="${v#*:}"
   rm -f tools/bin/lib_$name.so
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -amdgpu-sched-strategy=max-ilp $flags -o tools/bin/lib_$name.so $SRCS 2>/dev/null &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $BASE $flags -o tools/bin/lib_$name.so $SRCS 2>/dev/null &
   NAMES="$NAMES $name"
 done
 wait
