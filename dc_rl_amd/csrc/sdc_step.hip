@@ -1508,6 +1508,21 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   }
   reinterpret_cast<uint2*>(sh.rec[h])[l] = rr;
   if (kt_fill) ktab_store(kt, lane, kt0, kt1);
+  if constexpr (FAST) {
+    // the common case: nothing of what the dynamics read from LDS depends on the record -- the config scalars, the feature
+    // row's input slots and the queue probes go to LDS with it, behind ONE synchronisation
+    static_assert(SDC_FEAT_W == 10 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 && SDC_FEAT_NCNEXT == 30 &&
+                  G_W0 == 0 && G_C0 == 3 && G_T0 == 4 && G_WB0 == 5 && G_NCN == 14, "slot table below");
+    static_assert(SDC_FEAT_T - 2 * G_T0 == SDC_FEAT_C - 2 * G_C0, "C and T share an offset");
+    if (l < P_COUNT) sh.prm[h][l] = prm_pre;
+    double* gh = sh.g[h];
+    unsigned* g32 = reinterpret_cast<unsigned*>(gh);
+    const int off = l < 12 ? SDC_FEAT_W - 2 * G_W0 : l < 26 ? SDC_FEAT_C - 2 * G_C0 : l < 30 ? SDC_FEAT_WB - 2 * G_WB0
+                                                                                            : SDC_FEAT_NCNEXT - 2 * G_NCN;
+    if ((0xF3C00C00u >> l) & 1u) g32[l - off] = (unsigned)__float_as_int(frow_pre);
+    if (l >= G_Q97 && l <= G_Q96) gh[l] = q_pre;
+    if (l == SDC_FEAT_T1) gh[G_T1] = (double)frow_pre;
+  }
   wave_sync();
   const unsigned* rp = sh.rec[h];
   const int i = lrec_i32(rp, R_CURSOR), rel = lrec_i32(rp, R_TREL);
@@ -1527,7 +1542,8 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   }
   // ---- level 1 ----------------------------------------------------------------------------------------------------------
   // config scalars: lane j of the half fetches scalar j of its env's config (one coalesced 8-byte load), LDS hands them round
-  if (l < P_COUNT) sh.prm[h][l] = one_cfg ? prm_pre : reinterpret_cast<const double*>(&PD->p.m_cpu)[l];
+  if constexpr (!FAST)
+    if (l < P_COUNT) sh.prm[h][l] = one_cfg ? prm_pre : reinterpret_cast<const double*>(&PD->p.m_cpu)[l];
   // the ring slot this step's energy will overwrite: its current key is the evicted value the reward state's
   // order-statistic trackers need (0xFFFFFFFF while the ring is still filling)
   const int hl0 = lrec_i32(rp, R_HIST_LEN);
@@ -1541,7 +1557,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   float frow = frow_pre;
   if (feat_ok && !fast) frow = S.feat[feat_row_offset(S, envc, rel + 1) + l];
   const bool want_c3 = FAST ? false : S.policy[2] == SDC_POLICY_RBC;
-  {
+  if constexpr (!FAST) {
     const double ci_min = lrec_f64(rp, R_CI_MIN), ci_den = lrec_f64(rp, R_CI_DEN);
     const double t_min = lrec_f64(rp, R_T_MIN), t_den = lrec_f64(rp, R_T_DEN);
     auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
@@ -1598,8 +1614,8 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
         gh[HL + l] = gather(HL + l);
       }
     }
+    wave_sync();
   }
-  wave_sync();
 
   unsigned long long dbg_a0 = 0ull;
   if (SDC_DBG_OK(FAST) && __builtin_expect((S.debug_flags & 8) != 0, 0)) dbg_a0 = wall_clock64();
@@ -1769,6 +1785,16 @@ __device__ __forceinline__ void quad_step(const SdcDev& S, QuadShared& sh, const
   reinterpret_cast<uint4*>(sh.rec[h])[l] = rr;
   if (kt_fill) ktab_store(kt, lane, kt0, kt1);
   if (lane < P_COUNT) sh.prm[lane] = prm_pre;
+  {
+    // the row's input slots (doubles W, C, T, WB, NC[i'+1] as float pairs of the row; T[i+1] as a float) and the probes
+    static_assert(SDC_FEAT_W == 10 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 && SDC_FEAT_NCNEXT == 30 &&
+                  SDC_FEAT_T1 == 12 && G_W0 == 0 && G_C0 == 3 && G_T0 == 4 && G_WB0 == 5 && G_NCN == 14, "slot table below");
+    double* gh = sh.g[h];
+    const int slot = l == 5 ? G_W0 : (l == 11 ? G_C0 : (l == 12 ? G_T0 : (l == 14 ? G_WB0 : G_NCN)));
+    if (l == 5 || l == 11 || l == 12 || l == 14 || l == 15) reinterpret_cast<float2*>(gh)[slot] = frow2;
+    if (l >= G_Q97 && l <= G_Q96) gh[l] = q_pre;
+    if (l == 6) gh[G_T1] = (double)frow2.x;
+  }
   wave_sync();
   const unsigned* rp = sh.rec[h];
   const int i = lrec_i32(rp, R_CURSOR), rel = lrec_i32(rp, R_TREL);
@@ -1782,17 +1808,6 @@ __device__ __forceinline__ void quad_step(const SdcDev& S, QuadShared& sh, const
   }
   const int hl0 = lrec_i32(rp, R_HIST_LEN);
   const int slot0 = hl0 < S.hist_cap ? hl0 : lrec_i32(rp, R_HIST_POS);
-  {
-    // the row's input slots (doubles W, C, T, WB, NC[i'+1] as float pairs of the row; T[i+1] as a float) and the probes
-    static_assert(SDC_FEAT_W == 10 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 && SDC_FEAT_NCNEXT == 30 &&
-                  SDC_FEAT_T1 == 12 && G_W0 == 0 && G_C0 == 3 && G_T0 == 4 && G_WB0 == 5 && G_NCN == 14, "slot table below");
-    double* gh = sh.g[h];
-    const int slot = l == 5 ? G_W0 : (l == 11 ? G_C0 : (l == 12 ? G_T0 : (l == 14 ? G_WB0 : G_NCN)));
-    if (l == 5 || l == 11 || l == 12 || l == 14 || l == 15) reinterpret_cast<float2*>(gh)[slot] = frow2;
-    if (l >= G_Q97 && l <= G_Q96) gh[l] = q_pre;
-    if (l == 6) gh[G_T1] = (double)frow2.x;
-  }
-  wave_sync();
 
   // reward-side state, consumed at the end of the step: requested here, behind the staging
   const bool q_ahead_ok = a_ls == 2;
