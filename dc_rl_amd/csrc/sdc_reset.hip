@@ -139,6 +139,12 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
         const double incl = wave_incl_scan_f64(acc, lane);
         const double off = carry + (incl - acc);
         carry += readlane_f64(incl, 63);
+        // does this block of 256 samples reach the window the episode reads?  (wave-uniform: one env per wavefront; the
+        // window is wlen of the year's 35 040 samples -- most of the 137 blocks skip the per-sample index arithmetic)
+        int blk0 = base + shift;                         // rolled position of the block's first sample (np.roll, managers.py:602)
+        if (blk0 >= TL) blk0 -= TL;
+        const int blk1 = blk0 + 4 * SDC_WAVE;            // (may run past TL: the part beyond wraps to [0, blk1 - TL))
+        const bool hit = (blk0 < c0 + wlen && blk1 > c0) || (blk1 > TL && c0 < blk1 - TL);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int j = j0 + k;
@@ -146,11 +152,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
             const double w = off + p[k];
             sum += w;
             sumsq += w * w;
-            // base index j lands at rolled position (j + shift) mod TL (np.roll, managers.py:602)
-            int pos = j + shift;
-            if (pos >= TL) pos -= TL;
-            const int rel = pos - c0;
-            if (rel >= 0 && rel < wlen) walk[rel] = w;
+            if (hit) {
+              // base index j lands at rolled position (j + shift) mod TL
+              int pos = j + shift;
+              if (pos >= TL) pos -= TL;
+              const int rel = pos - c0;
+              if (rel >= 0 && rel < wlen) walk[rel] = w;
+            }
           }
         }
       }
