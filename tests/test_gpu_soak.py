@@ -12,11 +12,13 @@ from tests import parity_util as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("hist_cap,steps_total", [(10000, 2600), (1500, 5200)])
-def test_reward_state_soak(hist_cap, steps_total):
+# (flags 1: verify mode; + 1024: the common-case kernel with four envs per wavefront -- the mapping of large batches -- whatever
+# the batch size)
+@pytest.mark.parametrize("hist_cap,steps_total,flags", [(10000, 2600, 1), (1500, 5200, 1), (1500, 5200, 1 | 1024)])
+def test_reward_state_soak(hist_cap, steps_total, flags):
     import torch
     N, ep = 512, 288
-    rig = P.ParityRig(N, episode_steps=ep, seed=77, hist_cap=hist_cap, with_oracle=False)
+    rig = P.ParityRig(N, episode_steps=ep, seed=77, hist_cap=hist_cap, with_oracle=False, debug_flags=flags)
     eng = rig.eng
     rng = np.random.default_rng(77)
     # start from a nearly full ring so that it wraps within the test; per-env spread, skew and level differ
@@ -69,14 +71,14 @@ def test_reward_state_soak(hist_cap, steps_total):
     eng.close()
 
 
-@pytest.mark.parametrize("hist_cap", [33, 64, 65, 100, 200])
-def test_rank_windows_small_histories(hist_cap):
+@pytest.mark.parametrize("hist_cap,flags", [(33, 1), (64, 1), (65, 1), (100, 1), (200, 1), (64, 1 | 1024), (100, 1 | 1024)])
+def test_rank_windows_small_histories(hist_cap, flags):
     """Histories about as long as a 64-key window, from empty: the windows list the whole history while it is shorter
     than a window, stay anchored at its ends when it is not much longer, and every eviction hits a window.  Random and
     constant policies (the latter: runs of equal keys).  Verify mode checks every window key against its rank."""
     import torch
     N, ep = 128, 96
-    rig = P.ParityRig(N, episode_steps=ep, seed=91 + hist_cap, hist_cap=hist_cap, with_oracle=False)
+    rig = P.ParityRig(N, episode_steps=ep, seed=91 + hist_cap, hist_cap=hist_cap, with_oracle=False, debug_flags=flags)
     eng = rig.eng
     rig.reset_all()
     paths = np.zeros(4, np.int64)
