@@ -1134,7 +1134,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   Win bu = win_from(kz, (int)hp[H_BU + T_R0], (int)hp[H_BU + T_HI]);
   Win bl = win_from(kw, (int)hp[H_BL + T_R0], (int)hp[H_BL + T_HI]);
   double A1 = lrec_f64(hp, H_A1), A2 = lrec_f64(hp, H_A2);
-  bool ok = append && n >= SMALL_N && q1.hi > 0 && q3.hi > 0 && bu.hi > 0 && bl.hi > 0 && (int)hp[H_VALID] == 1;
+  bool ok = append & (n >= SMALL_N) & (q1.hi > 0) & (q3.hi > 0) & (bu.hi > 0) & (bl.hi > 0) & ((int)hp[H_VALID] == 1);
   // ---- deferred re-centrings (SdcRefillReq / SdcRefillRes): a window requested two steps ago arrives now --------------
   unsigned pend0 = hp[H_PEND], pend1 = hp[H_PEND + 1], pend2 = hp[H_PEND + 2], pend3 = hp[H_PEND + 3];
   // cached first / last key of every window (see below)
@@ -1295,10 +1295,12 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     quartile_ranks(n < S.hist_cap ? n + 1 : n, k1n, k3n);
     auto ahead = [&](const Win& q, const int k_next, const int m_lo, const int m_hi) __attribute__((always_inline)) {
       const int t = k_next - q.r0;
-      return (t > q.hi - m_hi && q.r0 + q.hi < n) || (t < m_lo && q.r0 > 0);
+      return ((t > q.hi - m_hi) & (q.r0 + q.hi < n)) | ((t < m_lo) & (q.r0 > 0));
     };
-    const bool w0 = pend0 == 0u && ahead(q1, k1n, 3, 6), w1 = pend1 == 0u && ahead(q3, k3n, 3, 6);
-    const bool w2 = pend2 == 0u && ahead(bu, n - qc0, 10, 10), w3 = pend3 == 0u && ahead(bl, n - qc1, 10, 10);
+    // (`&`, not `&&`: a short-circuit here is a divergent branch per window -- four of them, each with its exec-mask save
+    // and restore, in the middle of the step's straight-line code)
+    const bool w0 = (pend0 == 0u) & ahead(q1, k1n, 3, 6), w1 = (pend1 == 0u) & ahead(q3, k3n, 3, 6);
+    const bool w2 = (pend2 == 0u) & ahead(bu, n - qc0, 10, 10), w3 = (pend3 == 0u) & ahead(bl, n - qc1, 10, 10);
     if (__builtin_expect(__ballot(ok && (w0 || w1 || w2 || w3)) != 0ull, 0)) {
       SDC_DBG_BIT(FAST, sh, 16u);
       if (!defer) {

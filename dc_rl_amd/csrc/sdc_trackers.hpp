@@ -151,8 +151,11 @@ __device__ __forceinline__ Bounds clip_bounds(const int n, unsigned a1, unsigned
   const double fa3 = key_f64(a3), fb3 = key_f64(b3);
   // numpy _lerp: a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5
   const double d1 = fb1 - fa1, d3 = fb3 - fa3;
-  const double qv1 = (t1 == 0.0) ? fa1 : ((t1 >= 0.5) ? fb1 - d1 * (1.0 - t1) : fa1 + d1 * t1);
-  const double qv3 = (t3 == 0.0) ? fa3 : ((t3 >= 0.5) ? fb3 - d3 * (1.0 - t3) : fa3 + d3 * t3);
+  // (both forms evaluated, then selected: written as nested conditionals this was two divergent branches per quartile)
+  const double up1 = fb1 - d1 * (1.0 - t1), lo1 = fa1 + d1 * t1, up3 = fb3 - d3 * (1.0 - t3), lo3 = fa3 + d3 * t3;
+  const double m1 = (t1 >= 0.5) ? up1 : lo1, m3 = (t3 >= 0.5) ? up3 : lo3;
+  const double qv1 = (t1 == 0.0) ? fa1 : m1;
+  const double qv3 = (t3 == 0.0) ? fa3 : m3;
   const double iqr = qv3 - qv1;
   Bounds b;
   b.lb = qv1 - 1.5 * iqr;
