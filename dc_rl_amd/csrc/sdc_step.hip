@@ -1820,6 +1820,7 @@ __device__ __forceinline__ void quad_step(const SdcDev& S, QuadShared& sh, const
     if (t < rel) q_ahead = qt[t];
     if (t + 1 < rel) q_ahead_b = qt[t + 1];
   }
+  // (the evicted ring key must be read BEFORE the dynamics: they store this step's key into that slot)
   unsigned x_old_l = 0xFFFFFFFFu;
   if (hl0 >= S.hist_cap) x_old_l = S.hist[(size_t)envc * SDC_HIST_STRIDE + slot0];   // (one address per row)
 #if !SDC_QUAD_LATE_LOADS
