@@ -251,7 +251,7 @@ PMC_PASSES = (
     ("fetch", ["FETCH_SIZE"]),
     ("write", ["WRITE_SIZE"]),
     ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES",
-            "SQ_INSTS_LDS"]),
+            "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY"]),
     ("grbm", ["GRBM_GUI_ACTIVE"]),
 )
 
@@ -318,6 +318,11 @@ def pmc_summary(c):
         out["waves_per_launch"] = w
     if "SQ_ACTIVE_INST_VALU" in c:
         out["valu_active_simd_cycles_per_launch"] = 4.0 * c["SQ_ACTIVE_INST_VALU"]   # SQ_ACTIVE_INST_* count quad-cycles
+    if "SQ_ACTIVE_INST_ANY" in c:
+        out["issue_active_simd_cycles_per_launch"] = 4.0 * c["SQ_ACTIVE_INST_ANY"]  # any instruction class executing
+        if c.get("SQ_WAVE_CYCLES"):
+            # share of a wavefront's life with one of ITS instructions executing (the rest: parked at s_waitcnt, or waiting to issue)
+            out["wave_issue_frac"] = round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
     return out
 
 
@@ -616,6 +621,11 @@ def main():
             "achieved": round(valu_cyc / 1e6, 3) if valu_cyc else None, "peak": round(simd_cycles / 1e6, 3),
             "unit": "M SIMD-cycles per launch (VALU active / available)",
             "frac": round(valu_busy, 4) if valu_busy else None,
+            # every instruction class (VALU, scalar, LDS, memory, branch) against the same SIMD-cycles: what the two wavefronts
+            # of a SIMD keep its issue port busy with over the whole launch, launch gap and dispatch ramp included
+            "issue_frac": (round(pmc["issue_active_simd_cycles_per_launch"] / simd_cycles, 4)
+                           if pmc and pmc.get("issue_active_simd_cycles_per_launch") else None),
+            "wave_issue_frac": pmc.get("wave_issue_frac") if pmc else None,
             "traffic": traffic,
             "hbm_frac": round(traffic / k_evt / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
             "hbm_achieved_GBps": round(traffic / k_evt / 1e9, 1) if traffic else None, "hbm_peak_GBps": HBM_PEAK_GBPS,
