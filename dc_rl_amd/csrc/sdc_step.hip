@@ -104,6 +104,7 @@ static_assert(P_COUNT <= HL, "one config scalar per lane of a half");
 #ifndef SDC_QUAD_LATE_LOADS
 #define SDC_QUAD_LATE_LOADS 1
 #endif
+
 #ifndef SDC_BASE_PRIO
 #define SDC_BASE_PRIO 0      // issue priority of the env pairs' wavefronts (the late dispatch round: + 1 during the dynamics)
 #endif
@@ -211,6 +212,7 @@ constexpr int QL = 16;    // lanes per env
 struct QuadShared {
   double g[QE][16];                    // gathered step inputs (the slots below G_NC: the common case has feature rows)
   double prm[HL];                      // config scalars (P_*): ONE config in the common case
+  double rk[4][HL];                    // ... and its per-rack parameters {supply, idle, full, n} of racks 0..31
   unsigned rec[QE][SDC_REC_DWORDS];
   unsigned hdr[QE][SDC_HDR_DWORDS];
   float pool[QE][32];
@@ -640,14 +642,25 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     const double m_fan = pr[P_M_FAN], c_fan = pr[P_C_FAN], rs_fan = pr[P_RS_FAN];
     const double cpu_shift = rs_cpu * KDIV(load_pct, 100), fan_shift = rs_fan * KDIV(load_pct, 20);
     auto rack = [&](const int rk, const bool valid) __attribute__((always_inline)) {
-      const double sa = fmax(KC(3.8), fmin(P.rack_supply[rk], KC(5.3)));  // datacenter.py:209-215
+      // (four envs per wavefront: the rack's four parameters come from LDS, where the step's FIRST loads left them -- read
+      // from the config in memory here they are a memory round trip in the middle of the dynamics, which a wavefront
+      // without much company on its SIMD waits out: sdc_rollout at 8 192 envs 15.8 -> 15.1 us per step.  Two envs per
+      // wavefront: left where they are used -- ahead of the dynamics they join a burst of loads, and the step launch of
+      // 4096 envs measured 11.9-12.0 us against 11.75 with the loads in place, same box.)
+      double r_supply, r_idle, r_full, r_n;
+      if constexpr (FAST && LPE != HL) {
+        r_supply = sh.rk[0][rk]; r_idle = sh.rk[1][rk]; r_full = sh.rk[2][rk]; r_n = sh.rk[3][rk];
+      } else {
+        r_supply = P.rack_supply[rk]; r_idle = P.rack_idle[rk]; r_full = P.rack_full[rk]; r_n = P.rack_n[rk];
+      }
+      const double sa = fmax(KC(3.8), fmin(r_supply, KC(5.3)));  // datacenter.py:209-215
       const double inlet = sa + stpt;
       const double ratio = ((m_cpu + KC(0.05)) * inlet + c_cpu) + cpu_shift;
-      const double cpu1 = fmax(P.rack_idle[rk], P.rack_full[rk] * ratio);
+      const double cpu1 = fmax(r_idle, r_full * ratio);
       const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
       const double fan1 = pr[P_ITFAN_REF_P] * (v * pr[P_RC_ITFAN_REF_V_RATIO]);
       const double vf1 = pr[P_IT_FAN_FULL_LOAD_V] * v;
-      const double n = P.rack_n[rk];
+      const double n = r_n;
       const double pc = n * cpu1, pf = n * fan1;
       const double vtot = n * vf1;
       // x^y as exp2(y log2 x): <= 5e-14 relative against the correctly rounded power (the reference's libm pow is
@@ -1777,6 +1790,11 @@ __device__ __forceinline__ void quad_step(const SdcDev& S, QuadShared& sh, const
   }
   double prm_pre = 0.0;
   if (lane < P_COUNT) prm_pre = reinterpret_cast<const double*>(&S.dc[0].p.m_cpu)[lane];
+  // the per-rack parameters of racks 0..31: lanes 0..31 fetch {supply, idle}, lanes 32..63 {full, n} (see pair_step)
+  const sdc_dc_params& P0 = S.dc[0].p;
+  const int rl = lane & 31, rh = lane >> 5;
+  const double rk_pre0 = rh == 0 ? P0.rack_supply[rl] : P0.rack_full[rl];
+  const double rk_pre1 = rh == 0 ? P0.rack_idle[rl] : P0.rack_n[rl];
   uint4* recp = reinterpret_cast<uint4*>(S.rec + (size_t)envc * SDC_REC_DWORDS) + l;
   const uint4 rr = *recp;
   {
@@ -1787,6 +1805,8 @@ __device__ __forceinline__ void quad_step(const SdcDev& S, QuadShared& sh, const
   reinterpret_cast<uint4*>(sh.rec[h])[l] = rr;
   if (kt_fill) ktab_store(kt, lane, kt0, kt1);
   if (lane < P_COUNT) sh.prm[lane] = prm_pre;
+  sh.rk[2 * rh][rl] = rk_pre0;
+  sh.rk[2 * rh + 1][rl] = rk_pre1;
   {
     // the row's input slots (doubles W, C, T, WB, NC[i'+1] as float pairs of the row; T[i+1] as a float) and the probes
     static_assert(SDC_FEAT_W == 10 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 && SDC_FEAT_NCNEXT == 30 &&
