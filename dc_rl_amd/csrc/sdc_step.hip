@@ -786,10 +786,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     float* pool = sh.pool[h];
     if constexpr (LPE == HL) {
       if (l < SDC_POOL_DIM && ((TRACE_ONLY >> l) & 1u)) pool[l] = frow;
-    } else {
-      if (2 * l < SDC_POOL_DIM && ((TRACE_ONLY >> (2 * l)) & 1u)) pool[2 * l] = frow;
-      if (2 * l + 1 < SDC_POOL_DIM && ((TRACE_ONLY >> (2 * l + 1)) & 1u)) pool[2 * l + 1] = frow_b;
-    }
+    }      // (four envs per wavefront: quad_step has put them there with the staging -- two registers fewer across the dynamics)
     if (l == 1) pool[SDC_P_SOC] = (float)soc_after;
   } else if (l == 0) {
     // no feature rows for this episode: the wavefront computes the features of this env below (whole-wave, per env)
@@ -1816,6 +1813,12 @@ __device__ __forceinline__ void quad_step(const SdcDev& S, QuadShared& sh, const
     if (l == 5 || l == 11 || l == 12 || l == 14 || l == 15) reinterpret_cast<float2*>(gh)[slot] = frow2;
     if (l >= G_Q97 && l <= G_Q96) gh[l] = q_pre;
     if (l == 6) gh[G_T1] = (double)frow2.x;
+    // ... and the trace-only entries of the NEXT observation (pair_dynamics: TRACE_ONLY) straight into the pool
+    constexpr unsigned TRACE_ONLY = 0x7u | (0x7Fu << SDC_P_CI7) | (1u << SDC_P_W) | (1u << SDC_P_NT) | (1u << SDC_P_TSLOPE) |
+                                    (0x1Fu << SDC_P_T5) | (1u << SDC_P_WNEXT) | (1u << SDC_P_NTNEXT);
+    float* pool = sh.pool[h];
+    if (2 * l < SDC_POOL_DIM && ((TRACE_ONLY >> (2 * l)) & 1u)) pool[2 * l] = frow2.x;
+    if (2 * l + 1 < SDC_POOL_DIM && ((TRACE_ONLY >> (2 * l + 1)) & 1u)) pool[2 * l + 1] = frow2.y;
   }
   wave_sync();
   const unsigned* rp = sh.rec[h];
