@@ -103,6 +103,7 @@ struct sdc_handle {
   SdcActorDev* actor_dev = nullptr;
   bool actor_set[3] = {false, false, false};
   int actor_activation[3] = {0, 0, 0};
+  bool actor_lds_set = false;   // the closed-loop kernels' dynamic-LDS limit has been raised on this handle's device
   float* obs_latch = nullptr;
   bool latch_valid = false;
   int racks_cfg0 = 0;                     // racks of data-centre config 0 (the specialised kernels take <= 32: one pass)
@@ -801,13 +802,12 @@ int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float*
   h->step_no = next_step_no(h->step_no, n_steps + 3);
   HIP_TRY(hipMemsetAsync(d.rq_count, 0, sizeof(int) * 4, st));
   constexpr int AWPB = 8;     // sdc_step.hip SDC_ACTOR_WPB
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (!h->actor_lds_set) {     // (a per-device attribute: once per handle, not once per process)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sdc_rollout_actor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)sdc_rollout_actor_lds_bytes()));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sdc_rollout_actor_quad_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sdc_rollout_actor_quad_lds_bytes()));
-    attr_done = true;
+    h->actor_lds_set = true;
   }
   if (quad_case(h, true)) {   // four envs per wavefront (batches above 4096 envs)
     const int blocks = (N / 4 + AWPB - 1) / AWPB;
