@@ -135,17 +135,54 @@ EXPORTS = [
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]   # (sdc_infos.c: build_infos)
     deps.append(os.path.join(CSRC, "..", "..", "include", "sustaindc_hip.h"))
     deps.append(os.path.abspath(__file__))      # (the compiler flags live here)
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+        build_infos()
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("SDC_HIPCC_EXTRA", "").split() + ["-o", LIB_PATH] + srcs   # (experiments: -D...)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    build_infos(force)
     return LIB_PATH
+
+
+# ---- the host-side helper behind SustainDCVecEnv's `infos` (csrc/sdc_infos.c: CPython C API, gcc, no GPU code) ----------
+INFOS_SRC = os.path.join(CSRC, "sdc_infos.c")
+INFOS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_sdc_infos.so")
+
+
+def build_infos(force: bool = False) -> str:
+    """Compile dc_rl_amd/_sdc_infos.so (the C types of `infos`) in-tree.  One second of gcc."""
+    import sysconfig
+    if not force and os.path.exists(INFOS_LIB) and os.path.getmtime(INFOS_LIB) >= os.path.getmtime(INFOS_SRC):
+        return INFOS_LIB
+    cc = os.environ.get("CC", "gcc")
+    tmp = INFOS_LIB + f".{os.getpid()}.tmp"      # (several ranks / test workers may build at once: rename is atomic)
+    subprocess.check_call([cc, "-O2", "-Wall", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], INFOS_SRC, "-o", tmp])
+    os.replace(tmp, INFOS_LIB)
+    return INFOS_LIB
+
+
+_infos_mod = None
+
+
+def load_infos():
+    """The `_sdc_infos` extension module (built on first use when it is missing or older than its source)."""
+    global _infos_mod
+    if _infos_mod is None:
+        try:
+            build_infos()
+        except Exception as e:
+            if not os.path.exists(INFOS_LIB):
+                raise RuntimeError(f"dc_rl_amd/_sdc_infos.so is missing and could not be built ({e!r}); run "
+                                   "`python -c 'import __graft_entry__ as g; g.build()'`") from e
+        import importlib
+        _infos_mod = importlib.import_module("dc_rl_amd._sdc_infos")
+    return _infos_mod
 
 
 _lib = None

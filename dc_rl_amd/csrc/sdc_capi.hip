@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "sdc_device.hpp"
@@ -607,7 +608,23 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
     if (es != hipSuccess) return fail("sdc_reset: injected reset", es);
   }
   HIP_TRY(hipGetLastError());
-  if (latch_obs(h, obs, st)) return -1;
+  // the closed loop's copy of the latest observations: a reset without an observation buffer leaves it stale (the next
+  // sdc_rollout_actor refuses until a reset / step has delivered observations), and a MASKED reset only wrote the masked
+  // envs' rows of `obs` -- the other rows of the caller's buffer are whatever it held, so only those rows are taken over
+  if (h->obs_latch && !obs) h->latch_valid = false;
+  if (h->obs_latch && obs && mask_host) {
+    const size_t row = sizeof(float) * SDC_OBS_OUT;
+    for (int e = 0; e < N;) {
+      if (!mask_host[e]) { e++; continue; }
+      int e1 = e;
+      while (e1 < N && mask_host[e1]) e1++;
+      HIP_TRY(hipMemcpyAsync(h->obs_latch + (size_t)e * SDC_OBS_OUT, obs + (size_t)e * SDC_OBS_OUT, row * (size_t)(e1 - e),
+                             hipMemcpyDeviceToDevice, st));
+      e = e1;
+    }
+  } else if (latch_obs(h, obs, st)) {
+    return -1;
+  }
   if (mask_host) HIP_TRY(hipStreamSynchronize(st));  // mask staging buffer is reused by the next call
   sync_mirror(h);
   for (int e = 0; e < N; e++)
@@ -752,7 +769,10 @@ int sdc_set_actor(sdc_handle* h, int slot, const sdc_actor_params* p) {
     h->latch_valid = false;      // (filled by the next reset / step / rollout)
   }
   // torch's [out][in] rows -> the kernel's k-major layout, four consecutive k per lane (sdc_actor.hpp)
-  static SdcActorDev a;
+  // (per call, on the heap: 26 KB is too large for the stack, and a function-static buffer would be shared by engines on
+  // other host threads -- ctypes releases the GIL during this call)
+  std::unique_ptr<SdcActorDev> ap(new SdcActorDev);
+  SdcActorDev& a = *ap;
   std::memset(&a, 0, sizeof(a));
   for (int k = 0; k < SDC_ACT_IN; k++) {
     a.ln0_g[k] = p->ln0_gamma[k];

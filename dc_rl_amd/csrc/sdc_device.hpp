@@ -107,6 +107,13 @@ enum SdcTrack { T_R0 = 0, T_HI = 1, SDC_TRACK_DWORDS = 2 };
 
 // One wavefront = one env: LDS traffic between the lanes of ONE wavefront needs no s_barrier (a wavefront's LDS
 // operations complete in order), only the compiler's view of it ordered.
+// this lane's index, recomputed WHERE IT IS CALLED (a volatile asm is not hoisted): inside the multi-step kernels' step loop a
+// loop-invariant lane id is one more VGPR held -- or spilled -- across the whole step
+__device__ __forceinline__ int lane_fresh() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

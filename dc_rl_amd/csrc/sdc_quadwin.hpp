@@ -67,7 +67,7 @@ __device__ __forceinline__ bool hw_insert(QWin& q, const unsigned x, const int m
       const bool ends = q.r0 + q.hi == m_hist;         // the window lists the history's last key
       if (!(p == q.hi && !ends)) {
         const int s = 4 * l;
-        if (q.hi == WIN && ends) {
+        if (q.hi >= WIN && ends) {   // (not `== WIN`: the compiler then rebuilds {r0, hi} with a hoisted constant 64 -- a register pair held across the multi-step kernels' loop)
           // full, and it must go on ending the history: x enters at p - 1, the keys below it move down, the first drops out
           const int t = p - 1;
           const unsigned a0 = s < t ? q.k1 : (s == t ? x : q.k0), a1 = s + 1 < t ? q.k2 : (s + 1 == t ? x : q.k1);
@@ -79,7 +79,7 @@ __device__ __forceinline__ bool hw_insert(QWin& q, const unsigned x, const int m
           const unsigned a0 = s < p ? q.k0 : (s == p ? x : p3), a1 = s + 1 < p ? q.k1 : (s + 1 == p ? x : q.k0);
           const unsigned a2 = s + 2 < p ? q.k2 : (s + 2 == p ? x : q.k1), a3 = s + 3 < p ? q.k3 : (s + 3 == p ? x : q.k2);
           q.k0 = a0; q.k1 = a1; q.k2 = a2; q.k3 = a3;
-          q.hi = min(WIN, q.hi + 1);
+          q.hi += q.hi < WIN ? 1 : 0;
         }
         ch = true;
       }

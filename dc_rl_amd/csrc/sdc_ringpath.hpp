@@ -168,7 +168,7 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
   unsigned w = q.w;
   int r0 = q.r0, kk = k;
   if (fd) {
-    const unsigned rv = (unsigned)__shfl((int)q.w, (hi - 1 - lane) & 63);
+    const unsigned rv = lane_gather(q.w, (hi - 1 - lane) & 63);
     w = lane < hi ? ~rv : KEY_NONE;
     r0 = n - (q.r0 + hi);
     kk = n - 1 - k;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void qt_refill(QTrack& q, const int dir, const int k,
   v = max(v, dpp_u32<0x142, 0xA>(0u, v));   // row_bcast:15 -> rows 1, 3
   v = max(v, dpp_u32<0x143, 0xC>(0u, v));   // row_bcast:31 -> rows 2, 3
   if (fd) {
-    const unsigned rv = (unsigned)__shfl((int)v, (hi2 - 1 - lane) & 63);
+    const unsigned rv = lane_gather(v, (hi2 - 1 - lane) & 63);
     q.w = lane < hi2 ? ~rv : KEY_NONE;
     q.r0 = n - (r2 + hi2);
   } else {
@@ -302,7 +302,7 @@ __device__ __forceinline__ void qt_refill_coop(QTrack& q, const int dir, const i
   unsigned w = q.w;
   int r0 = q.r0, kk = k;
   if (fd) {
-    const unsigned rv = (unsigned)__shfl((int)q.w, (hi - 1 - lane) & 63);
+    const unsigned rv = lane_gather(q.w, (hi - 1 - lane) & 63);
     w = lane < hi ? ~rv : KEY_NONE;
     r0 = n - (q.r0 + hi);
     kk = n - 1 - k;
@@ -420,7 +420,7 @@ __device__ __forceinline__ void qt_refill_coop(QTrack& q, const int dir, const i
   v = max(v, dpp_u32<0x142, 0xA>(0u, v));
   v = max(v, dpp_u32<0x143, 0xC>(0u, v));
   if (fd) {
-    const unsigned rv = (unsigned)__shfl((int)v, (hi2 - 1 - lane) & 63);
+    const unsigned rv = lane_gather(v, (hi2 - 1 - lane) & 63);
     q.w = lane < hi2 ? ~rv : KEY_NONE;
     q.r0 = n - (r2 + hi2);
   } else {
@@ -642,7 +642,7 @@ __device__ __forceinline__ Rebuilt rebuild_state(const RingView& R, const int la
     if (ph == 1) {
       o.bu = wa;
       // the lower bound's window lives on complemented keys: reverse it, count ranks from the top
-      const unsigned rv = (unsigned)__shfl((int)wb.w, (wb.hi - 1 - lane) & 63);
+      const unsigned rv = lane_gather(wb.w, (wb.hi - 1 - lane) & 63);
       o.bl.w = lane < wb.hi ? ~rv : KEY_NONE;
       o.bl.r0 = n - (wb.r0 + wb.hi);
       o.bl.hi = wb.hi;

@@ -2172,8 +2172,9 @@ __device__ __forceinline__ void rollout_launch(const SdcDev& S, PairShared* shs,
     if ((int)blockIdx.x >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);    // (see sdc_dynamics_kernel)
     // (opaque copies: otherwise every per-env / per-lane address of the step is hoisted out of the loop and held in
     // registers across it)
-    int env_k = env0, lane_k = lane;
-    asm volatile("" : "+s"(env_k), "+v"(lane_k));
+    int env_k = env0;
+    asm volatile("" : "+s"(env_k));
+    const int lane_k = lane_fresh();   // (recomputed every step: two instructions instead of a register held across the loop)
     pair_step<FAST>(S, shs[wave], env_k, lane_k, (FAST || rel_hint >= 0) ? rel_hint + k : -1,
                     (FAST || actions) ? actions + (size_t)k * N * 3 : nullptr, obs + (size_t)k * N * SDC_OBS_OUT,
                     (FAST || share_obs) ? share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM : nullptr, done + (size_t)k * N,
@@ -2219,8 +2220,9 @@ extern "C" __global__ SDC_QUAD_BOUNDS void sdc_rollout_quad_kernel(
 #pragma unroll 1
   for (int k = 0; k < K; k++) {
     if ((int)blockIdx.x >= SDC_CUS) __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
-    int env_k = env0, lane_k = lane;
-    asm volatile("" : "+s"(env_k), "+v"(lane_k));
+    int env_k = env0;
+    asm volatile("" : "+s"(env_k));
+    const int lane_k = lane_fresh();   // (recomputed every step: two instructions instead of a register held across the loop)
     quad_step<false>(S, shs[wave], env_k, lane_k, rel_hint + k, actions + (size_t)k * N * 3, obs + (size_t)k * N * SDC_OBS_OUT,
                      share_obs + (size_t)k * N * SDC_SHARE_OBS_DIM, done + (size_t)k * N, info + (size_t)k * N * SDC_INFO_DIM,
                      k == K - 1 ? final_obs : nullptr, rew + (size_t)k * N * 3, S.step_no + k, false, ktab, k == 0);
@@ -2284,8 +2286,9 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
 #endif
 #pragma unroll 1
   for (int k = 0; k < K; k++) {
-    int env_k = env0, lane_k = lane;
-    asm volatile("" : "+s"(env_k), "+v"(lane_k));
+    int env_k = env0;
+    asm volatile("" : "+s"(env_k));
+    const int lane_k = lane_fresh();   // (recomputed every step: two instructions instead of a register held across the loop)
 #ifdef SDC_ACTOR_CLOCK
     c0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -2411,8 +2414,9 @@ sdc_rollout_actor_quad_kernel(SdcDev S, const int K, const int rel_hint, const S
   wave_sync();
 #pragma unroll 1
   for (int k = 0; k < K; k++) {
-    int env_k = env0, lane_k = lane;
-    asm volatile("" : "+s"(env_k), "+v"(lane_k));
+    int env_k = env0;
+    asm volatile("" : "+s"(env_k));
+    const int lane_k = lane_fresh();   // (recomputed every step: two instructions instead of a register held across the loop)
     const int row = lane_k >> 4, lk = lane_k & (QL - 1);
     const int half = lane_k >> 5, kk = lane_k & 31;
     const int rel_now = rel_hint + k;

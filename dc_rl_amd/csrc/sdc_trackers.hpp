@@ -42,6 +42,17 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
+// lane `src`'s value of v (any lane pattern: ds_bpermute).  Not __shfl: that adds the caller's own lane id (for widths below
+// 64), and inside the multi-step kernels that loop-invariant lane id was hoisted out of the step loop and SPILLED (round 4).
+__device__ __forceinline__ unsigned lane_gather(unsigned v, int src) { return (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)v); }
+// A double constant of a COLD path, materialised where it is used: a plain literal is hoisted out of the multi-step kernels'
+// step loop (two VGPRs held -- or spilled -- across the whole hot path for a branch almost never taken).
+template <unsigned HI, unsigned LO>
+__device__ __forceinline__ double cold_f64() {
+  unsigned lo, hi;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(lo), "=v"(hi) : "i"(LO), "i"(HI));
+  return __hiloint2double((int)hi, (int)lo);
+}
 __device__ __forceinline__ unsigned lane_key(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)sfl((unsigned)l)); }
 
 // ------------------------------------------------------------------------------------------------
@@ -266,7 +277,7 @@ __device__ __forceinline__ double tou_price(const int h) {   // reward_creator.p
 __device__ __forceinline__ Rewards step_rewards(const RewardIn& in, const int (&method)[3], const unsigned hd0) {
   const double foot = -1.0 * (in.norm_ci_next * in.z / 0.50);
   const double overdue_pen = -0.3 * sqrt_count(in.overdue) + 0.3;
-  const double age_pen = -0.1 * in.oldest_norm;
+  const double age_pen = cold_f64<0xBFB99999u, 0x9999999Au>() * in.oldest_norm;   // -0.1 (this is the whole-wavefront fallback: cold)
   double rls = foot + overdue_pen + age_pen;
   rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
   Rewards o;
@@ -279,7 +290,7 @@ __device__ __forceinline__ Rewards step_rewards(const RewardIn& in, const int (&
       case SDC_REWARD_TOU: r = -1.0 * in.energy_kwh * tou_price((int)in.hour % 24); break;
       case SDC_REWARD_ENERGY_EFFICIENCY: r = in.ite_kw / in.total_kw; break;
       case SDC_REWARD_PUE: r = -fabs((in.ite_kw != 0 ? in.total_kw / in.ite_kw : (double)INFINITY) - 1); break;
-      case SDC_REWARD_WATER: r = -0.01 * in.water; break;
+      case SDC_REWARD_WATER: r = cold_f64<0xBF847AE1u, 0x47AE147Bu>() * in.water; break;   // -0.01
       default: r = 0.0;   // SDC_REWARD_CUSTOM: custom_agent_reward returns 0
     }
     o.r[a] = r;

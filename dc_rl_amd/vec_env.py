@@ -92,53 +92,14 @@ class ShareVecEnv(ABC):
         return self
 
 
-class _InfoDict(Mapping):
-    """One agent's info dict of one env, read lazily from the step's info row."""
-
-    def __init__(self, owner: "LazyInfos", env: int, agent: int):
-        self._o, self._e, self._a = owner, env, agent
-
-    def _extra(self):
-        return self._o.extra.get((self._e, self._a), {})
-
-    def __getitem__(self, key):
-        ex = self._extra()
-        if key in ex:
-            return ex[key]
-        o = self._o
-        if key in L.INFO_IDX:
-            return float(o.rows()[self._e, L.INFO_IDX[key]])
-        if key == "ls_task_age_histogram":
-            j = L.INFO_IDX["ls_task_age_hist0"]
-            return np.array(o.rows()[self._e, j:j + 5], dtype=np.float64)
-        if key in o.const[self._e]:
-            return o.const[self._e][key]
-        if key == "ls_action":
-            return int(o.applied_actions()[self._e, 0])
-        if key == "bat_a_t":
-            return ("charge", "discharge", "idle")[int(o.rows()[self._e, L.INFO_IDX["bat_action"]])]
-        if key == "isterminal":
-            return bool(o.done[self._e])
-        raise KeyError(key)
-
-    def __iter__(self):
-        yield from L.INFO_COLS
-        yield "ls_task_age_histogram"
-        yield from self._o.const[self._e]
-        yield from ("ls_action", "bat_a_t", "isterminal")
-        yield from self._extra()
-
-    def __len__(self):
-        return sum(1 for _ in self)
-
-
 class _FinalObs:
     """The `original_obs / original_state / original_avail_actions` entries of the envs that finished in a step
     (env_wrappers.py:176-190 puts them into agent 0's info), built per env on first access from one host copy of the
     step's pre-reset observations."""
 
-    def __init__(self, final_obs: np.ndarray, done: np.ndarray, agent_idx, n_agents: int, concat: bool = False):
-        self._fo, self._done, self._idx, self._k, self._concat = final_obs, done, agent_idx, n_agents, concat
+    def __init__(self, final_obs: np.ndarray, done: np.ndarray, agent_idx, n_agents: int, concat: bool = False,
+                 width: int = L.OBS_PAD):
+        self._fo, self._done, self._idx, self._k, self._concat, self._w = final_obs, done, agent_idx, n_agents, concat, width
         self._made = {}
 
     def get(self, key, default=None):
@@ -150,19 +111,38 @@ class _FinalObs:
             fo = self._fo[e]
             # states[2][-1] of the PADDED obs: agent_bat's zero padding (harlsustaindc_env.py:25-26, :80)
             if self._concat:    # harlsustaindc_env.py:83-85: the trained agents' padded observations, concatenated
-                raw = fo[self._idx].reshape(-1)
+                raw = fo[self._idx][:, :self._w].reshape(-1)
             else:
                 raw = np.concatenate([fo[0, :26], fo[1, 11:12], fo[1, 13:14], fo[2, 25:26]])
-            d = self._made[e] = {"original_obs": fo[self._idx].copy(),
+            d = self._made[e] = {"original_obs": fo[self._idx][:, :self._w].copy(),
                                  "original_state": np.repeat(raw[None, :], self._k, axis=0),
                                  "original_avail_actions": np.ones((self._k, 3), dtype=np.float32)}
         return d
 
 
-class LazyInfos(Sequence):
-    """`infos` of a step: tuple[N] of list[3] of dict in the reference; here views over one [N, K] array."""
+_INFOS = L.load_infos()        # csrc/sdc_infos.c: InfoSeq (`infos`), InfoView (`infos[i][a]`) -- C types, see there
+Mapping.register(_INFOS.InfoView)
+_DERIVED_KEYS = ("ls_action", "bat_a_t", "isterminal")
+_KEY_TEMPLATES = {}
 
-    def __init__(self, info_tensor, actions, done, const, extra, owner=None, valid_for=0, n_agents=3):
+
+def _base_keys(const_keys):
+    """The keys of an info dict without extra entries, in iteration order, as ONE shared dict_keys object (a C-level `in`)."""
+    t = _KEY_TEMPLATES.get(const_keys)
+    if t is None:
+        t = _KEY_TEMPLATES[const_keys] = dict.fromkeys(list(L.INFO_COLS) + ["ls_task_age_histogram"] + list(const_keys) +
+                                                       list(_DERIVED_KEYS))
+    return t.keys()
+
+
+class _InfoSource:
+    """What the views of one step read from: the step's [N, K] info block (fetched once, guarded), and the entries that are
+    not a column of it.  Referenced by the C side (InfoCore); holds no reference back to the `infos` object."""
+
+    __slots__ = ("_t", "_rows", "actions", "_act_version", "_act_host", "done", "const", "extra", "_owner", "_gen", "_valid_for",
+                 "_keys")
+
+    def __init__(self, info_tensor, actions, done, const, extra, owner, valid_for, keys):
         self._t = info_tensor
         self._rows = None
         self.actions = actions
@@ -173,8 +153,8 @@ class LazyInfos(Sequence):
         self.done = done
         self.const = const
         self.extra = extra
-        self._n_agents = n_agents
         self._owner, self._gen, self._valid_for = owner, (owner._gen if owner is not None else 0), valid_for
+        self._keys = keys
 
     def applied_actions(self):
         """[N, 3] host copy of the actions this step applied (read once, on first access)."""
@@ -187,26 +167,71 @@ class LazyInfos(Sequence):
         return self._act_host
 
     def rows(self):
+        """The step's info block as ONE float32 [N, K] host array: one bulk conversion on first access."""
         if self._rows is None:
             # the block this object reads from is reused by later steps: never hand out another step's values
             if self._owner is not None and self._owner._gen - self._gen > self._valid_for:
                 raise RuntimeError("these infos belong to an earlier step whose info block has been overwritten; read them "
                                    "before stepping again or construct the env with snapshot_infos=True")
             # (a copy: the pinned host buffers are reused two steps later)
-            self._rows = self._t.detach().cpu().numpy().copy() if hasattr(self._t, "detach") else np.array(self._t)
+            r = self._t.detach().cpu().numpy() if hasattr(self._t, "detach") else np.asarray(self._t)
+            self._rows = np.array(r, dtype=np.float32, order="C", copy=True)
+            self._owner = None
         return self._rows
 
-    def __len__(self):
-        return len(self.done)
+    # ---- entries that are not a column of the block or a per-env constant (the C side asks for these) ----
+    def _slow_get(self, env, agent, key):
+        ex = self.extra.get((env, agent))
+        if ex and key in ex:
+            return ex[key]
+        if key == "ls_task_age_histogram":
+            j = L.INFO_IDX["ls_task_age_hist0"]
+            return np.array(self.rows()[env, j:j + 5], dtype=np.float64)
+        if key == "ls_action":
+            return int(self.applied_actions()[env, 0])
+        if key == "bat_a_t":
+            return ("charge", "discharge", "idle")[int(self.rows()[env, L.INFO_IDX["bat_action"]])]
+        if key == "isterminal":
+            return bool(self.done[env])
+        raise KeyError(key)
 
-    def __getitem__(self, i):
-        if isinstance(i, slice):
-            return [self[j] for j in range(*i.indices(len(self)))]
-        if i < 0:
-            i += len(self)
-        # one dict per TRAINED agent, in the reference's order (harlsustaindc_env.py:118-123); position 0 carries the
-        # `original_*` entries of a finished env
-        return [_InfoDict(self, i, a) for a in range(self._n_agents)]
+    def _has_extra(self, env, agent):
+        return bool(self.extra.get((env, agent)))
+
+    def _full_keys(self, env, agent):
+        return list(self._keys) + list(self.extra.get((env, agent)) or ())
+
+
+class LazyInfos(_INFOS.InfoSeq):
+    """`infos` of a step: tuple[N] of list[3] of dict in the reference (env_wrappers.py:262-273); here a C sequence over one
+    [N, K] array (csrc/sdc_infos.c): `infos[i]` is the cached list of the env's per-agent views, `infos[i][a]` a read-only
+    mapping whose `get` / `[]` / `in` / `keys()` run in C -- so the access pattern of an unchanged HARL runner
+    (`infos[i][0].get(key, 0)` for 10 keys per env in sustaindc_logger.py:87-101, `"bad_transition" in info[0].keys()` per
+    env in on_policy_base_runner.py:459-471) costs what it costs on plain dicts, without building N x 3 dicts per step."""
+
+    def __init__(self, info_tensor, actions, done, const, extra, owner=None, valid_for=0, n_agents=3):
+        const = const if isinstance(const, list) else list(const)
+        keys = _base_keys(tuple(const[0].keys()) if const else ())
+        src = _InfoSource(info_tensor, actions, done, const, extra, owner, valid_for, keys)
+        super().__init__(len(done), n_agents, L.INFO_IDX, keys, const, src, bool(extra))
+        self._src = src
+
+    actions = property(lambda self: self._src.actions)
+    done = property(lambda self: self._src.done)
+    const = property(lambda self: self._src.const)
+    extra = property(lambda self: self._src.extra)
+
+    def applied_actions(self):
+        return self._src.applied_actions()
+
+    def rows(self):
+        return self._src.rows()
+
+
+Sequence.register(LazyInfos)
+
+
+_WARNED_SHARE_DEFAULT = False
 
 
 def _merge_args(env_args: Optional[dict]) -> dict:
@@ -219,11 +244,18 @@ def _merge_args(env_args: Optional[dict]) -> dict:
     # CONCATENATED shared observation (3 x 26 floats, :83-85), True (the shipped YAML) the 29-float layout (:78-80).
     # (sustaindc_ptzoo.py:29 subscripts the key, so the reference itself raises KeyError when it is absent; the HARL
     # layer's default is the one taken here.)
+    if "nonoverlapping_shared_obs_space" not in a:
+        global _WARNED_SHARE_DEFAULT
+        if not _WARNED_SHARE_DEFAULT:
+            _WARNED_SHARE_DEFAULT = True
+            import warnings
+            warnings.warn("env_args has no 'nonoverlapping_shared_obs_space': taking the HARL layer's .get default (False = the "
+                          "trained agents' padded observations concatenated, 78 floats for three agents); the reference's shipped "
+                          "sustaindc.yaml sets True (the 29-float layout)", stacklevel=3)
     a["nonoverlapping_shared_obs_space"] = bool(a.get("nonoverlapping_shared_obs_space", False))
     if not a.get("partial_obs", True):
         raise NotImplementedError("Fully observable states are no longer supported. Please set 'partial_obs' to True.")
-    if a.get("actions_are_logits", False):
-        raise NotImplementedError("actions_are_logits=True: the device takes discrete actions {0,1,2}")
+    # actions_are_logits: the reference stores the flag and never reads it (sustaindc_env.py:204-205): accepted, ignored
     unknown = [x for x in a["agents"] if x not in AGENTS]
     if unknown:
         raise ValueError(f"unknown agents {unknown}; the environment has {AGENTS}")
@@ -316,11 +348,13 @@ class SustainDCVecEnv(ShareVecEnv):
                 "bat_max_bat_cap": e.sized["bat_capacity"], "bat_dcload_min": e.power_lb_kW / 4,
                 "bat_dcload_max": e.power_ub_kW / 4,
             })
-        # HARL pads every agent to the widest space (harlsustaindc_env.py:25-26, :30-33)
-        obs_space = [Box(low=-2.0, high=2.0, shape=(L.OBS_PAD,), dtype=np.float32) for _ in self.agents]
+        # HARL pads every agent to the widest space OF THE TRAINED AGENTS (harlsustaindc_env.py:25-26, :30-33: 26 whenever
+        # agent_ls is trained, 14 for dc + bat, 13 for bat alone)
+        self.obs_width = L.OBS_PAD if full else max(OBS_DIMS[i] for i in self._agent_idx)
+        obs_space = [Box(low=-2.0, high=2.0, shape=(self.obs_width,), dtype=np.float32) for _ in self.agents]
         if self.share_concat:
             # sustaindc_ptzoo.py:32-44: max observation width x number of agents, Box(0, 1)
-            self.share_dim = L.OBS_PAD * len(self.agents)
+            self.share_dim = self.obs_width * len(self.agents)
             share_space = [Box(low=np.float32(0), high=np.float32(1), shape=(self.share_dim,), dtype=np.float32) for _ in self.agents]
         else:
             self.share_dim = L.SHARE_OBS_DIM
@@ -353,13 +387,18 @@ class SustainDCVecEnv(ShareVecEnv):
         # kernel writes, or -- nonoverlapping_shared_obs_space False -- the concatenation of the trained agents' padded
         # observations (:83-85), which is a VIEW of the step's obs block (contiguous [N, 3, 26] -> [N, 78])
         if self.share_concat:
-            o = self._sel(obs)
+            o = self._sel_obs(obs)
             share = o.reshape(o.shape[0], self.share_dim)
         return share.unsqueeze(1).expand(-1, self.n_agents, -1)
 
     def _sel(self, x):
         # the trained agents' rows of a [N, 3, ...] array (all of them in the usual three-agent case)
         return x if self.n_agents == 3 else x[:, self._agent_idx]
+
+    def _sel_obs(self, obs):
+        # ... of the [N, 3, 26] observation block, cut to the widest trained agent's width
+        o = self._sel(obs)
+        return o if self.obs_width == L.OBS_PAD else o[:, :, :self.obs_width]
 
     def seed(self, seed: int):
         self.engine.set_seed(seed)
@@ -368,7 +407,7 @@ class SustainDCVecEnv(ShareVecEnv):
     def reset(self):
         obs, share = self.engine.reset()
         self._need_reset = False
-        return self._out(self._sel(obs)), self._out(self._share3(share, obs)), (self._avail if self.return_torch else self._avail_np)
+        return self._out(self._sel_obs(obs)), self._out(self._share3(share, obs)), (self._avail if self.return_torch else self._avail_np)
 
     def step_async(self, actions):
         t = self._torch
@@ -420,7 +459,8 @@ class SustainDCVecEnv(ShareVecEnv):
             done_h = hb["done"].numpy().astype(bool)
         extra = {}
         if done_h.any():    # ONE host copy of the pre-reset observations; the per-env entries are built when read
-            extra = _FinalObs(self.engine.final_obs.cpu().numpy(), done_h, self._agent_idx, self.n_agents, self.share_concat)
+            extra = _FinalObs(self.engine.final_obs.cpu().numpy(), done_h, self._agent_idx, self.n_agents, self.share_concat,
+                              self.obs_width)
         # `infos` (lazy): reads the step's [N, 44] info block on first access -- from the pinned host copy made with the
         # other outputs (NumPy mode: valid for one more step), from the device otherwise.  An access after the block has
         # been overwritten RAISES instead of returning a later step's values; `snapshot_infos=True` makes every infos
@@ -442,19 +482,23 @@ class SustainDCVecEnv(ShareVecEnv):
         k = self.n_agents
         if self.return_torch:
             # the engine's output tensors are persistent, so the shaped views are too (uint8 0/1 -> bool is a reinterpret)
+            # (an agent SUBSET selects rows by index -- a copy, not a view: obs, rew and the concatenated shared observation
+            # are then rebuilt every step)
             v = self._torch_views
             if v is None:
-                v = (self._share3(share, obs), done.view(t.bool).unsqueeze(1).expand(-1, k),
+                share_is_view = (not self.share_concat) or k == 3
+                v = (self._share3(share, obs) if share_is_view else None, done.view(t.bool).unsqueeze(1).expand(-1, k),
                      (obs, rew.unsqueeze(-1)) if k == 3 else None)
                 self._torch_views = v
-            o, r = v[2] if v[2] is not None else (self._sel(obs), self._sel(rew).unsqueeze(-1))
-            return o, v[0], r, v[1], infos, self._avail
+            o, r = v[2] if v[2] is not None else (self._sel_obs(obs), self._sel(rew).unsqueeze(-1))
+            sh = v[0] if v[0] is not None else self._share3(share, obs)
+            return o, sh, r, v[1], infos, self._avail
         if self.share_concat:
-            sh = self._sel(hb["obs"].numpy()).reshape(self.num_envs, self.share_dim)
+            sh = self._sel_obs(hb["obs"].numpy()).reshape(self.num_envs, self.share_dim)
         else:
             sh = hb["share"].numpy()
         share3 = np.broadcast_to(sh[:, None, :], (self.num_envs, k, sh.shape[1]))
-        return (self._sel(hb["obs"].numpy()), share3, self._sel(hb["rew"].numpy())[..., None],
+        return (self._sel_obs(hb["obs"].numpy()), share3, self._sel(hb["rew"].numpy())[..., None],
                 np.repeat(done_h[:, None], k, axis=1), infos, self._avail_np)
 
     def _host_buffers(self):

@@ -238,7 +238,10 @@ int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id,
 
 /* replaces: SustainDC.reset (sustaindc_env.py:436-531) / ShareVecEnv.reset (env_wrappers.py:275-280).
  * mask_host: NULL = all envs, else [N] bytes (host).  ovr: NULL = draw on device.
- * obs [N][3][26] f32, share_obs [N][29] f32 (device; may be NULL). */
+ * obs [N][3][26] f32, share_obs [N][29] f32 (device; may be NULL).  A masked reset writes the masked envs' rows only.
+ * Closed loop (sdc_set_actor): the library keeps its own copy of the latest observations; a reset with obs == NULL
+ * invalidates it (sdc_rollout_actor then refuses until a reset / step has delivered observations), a masked reset
+ * takes over the masked rows only (the other rows of the caller's buffer are not read). */
 int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override* ovr, float* obs, float* share_obs,
               void* stream);
 

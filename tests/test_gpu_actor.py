@@ -144,3 +144,43 @@ def test_rollout_actor_refuses_what_it_does_not_serve():
         eng.rollout_actor(97)
     eng.rollout_actor(4)
     eng.close()
+
+
+def test_reset_keeps_the_closed_loops_observation_latch_consistent():
+    """sdc_reset and the library's copy of the latest observations (what the first actions of sdc_rollout_actor are chosen
+    from): a reset WITHOUT an observation buffer invalidates it (the closed loop refuses instead of acting on
+    pre-reset observations), and a MASKED reset into a caller's scratch buffer takes over the masked envs' rows only."""
+    import ctypes as C
+    import torch
+    N, steps = 64, 96
+    a_eng, b_eng = _engine(N, steps, seed=9), _engine(N, steps, seed=9)
+    for e in (a_eng, b_eng):
+        for a in range(3):
+            e.set_actor(a, _torch_actor(20 + a).state_dict())
+        e.reset()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    acts = torch.randint(0, 3, (8, N, 3), dtype=torch.int32, generator=g).cuda()
+    for t in range(8):
+        a_eng.step(acts[t])
+        b_eng.step(acts[t])
+    mask = (np.arange(N) % 3 == 0).astype(np.uint8)
+    b_eng.reset(mask=mask)                                    # the engine's own persistent buffer: the reference behaviour
+    scratch = torch.full((N, 3, 26), 123.0, device="cuda")    # a C caller's scratch buffer: garbage in the unmasked rows
+    share = torch.zeros((N, 29), device="cuda")
+    with torch.cuda.device(a_eng.device):
+        L.check(a_eng.lib.sdc_reset(a_eng._h, mask.ctypes.data_as(C.POINTER(C.c_uint8)), None, C.c_void_p(scratch.data_ptr()),
+                                    C.c_void_p(share.data_ptr()), a_eng._stream()))
+    assert (scratch[torch.from_numpy(mask == 0).cuda()] == 123.0).all()     # (the kernel wrote the masked rows only)
+    ra = a_eng.rollout_actor(12, sample=False)
+    rb = b_eng.rollout_actor(12, sample=False)
+    for u, v, nm in zip(ra[:6], rb[:6], ("obs", "share", "rew", "done", "info", "actions")):
+        assert torch.equal(u, v), nm
+    # no observation buffer: the latch is stale, the closed loop refuses until a reset / step has delivered observations
+    with torch.cuda.device(a_eng.device):
+        L.check(a_eng.lib.sdc_reset(a_eng._h, None, None, None, None, a_eng._stream()))
+    with pytest.raises(L.SdcError, match="no observations yet"):
+        a_eng.rollout_actor(4)
+    a_eng.reset()
+    a_eng.rollout_actor(4)
+    a_eng.close()
+    b_eng.close()

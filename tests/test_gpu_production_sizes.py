@@ -1,0 +1,108 @@
+"""Oracle parity in the production configuration at the sizes / kernels the bench line quotes rates for:
+
+  * the four-envs-per-wavefront step kernel (`sdc_dynamics_quad_kernel`: the default from 6 656 envs on) at 12 288 envs
+    (three whole occupancy rounds) and 16 384 envs (a fourth wavefront per SIMD that runs alone), against the ORACLE --
+    until now it was only compared with the two-env kernels, and never above 8 200 envs;
+  * BASELINE configs[3] at its own size: 4096 envs x 16 / 20 / 25 racks x three locations on the GENERAL kernel with
+    `debug_flags = 0`, full rings and deferred re-centring under the full request load;
+  * `sdc_rollout` (48 steps in one launch) and the closed loop `sdc_rollout_actor` at 16 384 envs with full rings (the
+    four-env multi-step kernels): sampled envs against the oracle, the closed loop under the actions its actors chose.
+
+The recipe is tests/production_rig.py (shared with test_timed_configuration_4096_envs_vs_oracle).
+Reference: sustaindc_env.py:533-621, utils/reward_creator.py:16-45."""
+import numpy as np
+import pytest
+
+from dc_rl_amd import _lib as L
+from tests.production_rig import ProductionRig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N", [12288, 16384])
+def test_quad_step_kernel_production_vs_oracle(N):
+    """Four envs per wavefront by default (debug_flags = 0) at 12 288 / 16 384 envs: 330 single steps over two auto-resets,
+    all four rows of the first / last wavefronts and both sides of every occupancy round sampled, every reward-state path."""
+    rig = ProductionRig(N, debug_flags=0, episode_steps=120, seed=1000 + N, envs_per_wave=4)
+    assert len(rig.sample) >= 72
+    obs, _ = rig.eng.reset()
+    rig.begin_all(obs)
+    rig.single_steps(330)
+    print(f"quad step kernel, {N} envs:", rig.worst, "reward-state paths:", rig.paths[:4], "auto-resets:", rig.resets,
+          "sampled envs:", len(rig.sample))
+    assert rig.resets >= 2
+    rig.assert_ok()
+    rig.assert_all_reward_state_paths_seen()
+    rig.eng.close()
+
+
+def test_config3_mixed_racks_4096_production():
+    """BASELINE configs[3]: 4096 envs, rack count 20 / 16 / 25 by env_id % 3, three locations, debug_flags = 0 (the general
+    kernel: several configs are not the common case), full rings, 330 steps over two auto-resets vs the oracle."""
+    rig = ProductionRig(4096, debug_flags=0, mixed=True, episode_steps=120, seed=303, envs_per_wave=2)
+    # every (location, rack count) combination is in the sample
+    combos = {(int(rig.loc_id[i]), int(rig.cfg_id[i])) for i in rig.sample}
+    assert len(combos) == 9, combos
+    obs, _ = rig.eng.reset()
+    rig.begin_all(obs)
+    rig.single_steps(330)
+    print("mixed racks, 4096 envs:", rig.worst, "reward-state paths:", rig.paths[:4], "auto-resets:", rig.resets)
+    assert rig.resets >= 2
+    rig.assert_ok()
+    rig.assert_all_reward_state_paths_seen()
+    rig.eng.close()
+
+
+def test_rollout_16384_envs_full_rings_vs_oracle():
+    """`sdc_rollout` at 16 384 envs (sdc_rollout_quad_kernel), rings full: 10 single steps (their deferred requests are still in
+    flight when the multi-step launch starts), then 48 + 48 + the episode's last 14 steps in three launches, across an
+    auto-reset, vs the oracle."""
+    import torch
+    N = 16384
+    rig = ProductionRig(N, debug_flags=0, episode_steps=120, seed=555, envs_per_wave=4)
+    eng = rig.eng
+    obs, _ = eng.reset()
+    rig.begin_all(obs)
+    rig.single_steps(10)
+    g = torch.Generator(device="cpu").manual_seed(91)
+    while rig.resets < 1:
+        k = min(48, eng.steps_to_episode_end())
+        acts = torch.randint(0, 3, (k, N, 3), dtype=torch.int32, generator=g).cuda()
+        out = eng.rollout(acts)
+        rig.check_rollout(acts, out)
+        if eng.steps_to_episode_end() == rig.steps:
+            rig.resets += 1
+            rig.begin_all(out[0][-1])
+    k = 24
+    acts = torch.randint(0, 3, (k, N, 3), dtype=torch.int32, generator=g).cuda()
+    rig.check_rollout(acts, eng.rollout(acts))
+    print("sdc_rollout, 16384 envs:", rig.worst, "reward-state paths:", rig.paths[:4])
+    rig.assert_ok()
+    rig.eng.close()
+
+
+def test_rollout_actor_16384_envs_full_rings_vs_oracle():
+    """The closed loop at 16 384 envs (sdc_rollout_actor_quad_kernel), rings full: two 48-step launches with sampled actions;
+    the oracle steps the sampled envs under the actions the in-kernel actors chose (`actions_out`)."""
+    from tests.test_gpu_actor import _torch_actor
+    N = 16384
+    rig = ProductionRig(N, debug_flags=0, episode_steps=120, seed=556, envs_per_wave=4)
+    eng = rig.eng
+    for a in range(3):
+        eng.set_actor(a, _torch_actor(60 + a, "tanh").state_dict())
+    obs, _ = eng.reset()
+    rig.begin_all(obs)
+    rig.single_steps(6)
+    seen = np.zeros(3, np.int64)
+    for sample in (True, False):
+        out = eng.rollout_actor(48, sample=sample)
+        acts = out[5]
+        a = acts.cpu().numpy()
+        assert a.min() >= 0 and a.max() <= 2
+        seen += np.bincount(a.reshape(-1), minlength=3)
+        rig.check_rollout(acts, out)
+    assert (seen > 0).all(), seen       # the networks do use all three actions (the oracle saw every branch)
+    print("sdc_rollout_actor, 16384 envs:", rig.worst, "actions chosen:", seen.tolist())
+    rig.assert_ok()
+    assert (eng.info[:, L.INFO_IDX["fault"]] == 0).all()
+    rig.eng.close()

@@ -315,3 +315,40 @@ def test_last_done_host_mirror_matches_device_done():
     o, s, r, dn, i = eng.rollout(acts[:k].contiguous())
     np.testing.assert_array_equal(eng.last_done(), dn[-1].cpu().numpy().astype(bool))
     eng.close()
+
+
+@pytest.mark.parametrize("agents,width", [(["agent_ls", "agent_bat"], 26), (["agent_dc", "agent_bat"], 14)])
+def test_agent_subset_concat_share_obs_on_the_torch_path(agents, width):
+    """An agent SUBSET with the HARL layer's concatenated shared observation (nonoverlapping_shared_obs_space False) and
+    device-resident outputs: `share_obs` is the trained agents' padded observations of THIS step, every step (round 3 cached
+    the first step's copy: ADVICE r3), padded to the widest TRAINED agent like ss.pad_observations_v0
+    (harlsustaindc_env.py:25-26; sustaindc_ptzoo.py:32-44: dc + bat -> 2 x 14)."""
+    import torch
+    from dc_rl_amd import SustainDCVecEnv
+    N = 16
+    args = dict(ENV_ARGS, agents=agents, nonoverlapping_shared_obs_space=False)
+    env = SustainDCVecEnv(args, n_envs=N, seed=3, months=[6] * N, return_torch=True)
+    ref = SustainDCVecEnv(args, n_envs=N, seed=3, months=[6] * N)                      # NumPy outputs, same seed
+    k = len(agents)
+    assert env.observation_space[0].shape == (width,) and env.share_observation_space[0].shape == (width * k,)
+    o, s, _ = env.reset()
+    on, sn, _ = ref.reset()
+    assert o.shape == (N, k, width) and s.shape == (N, k, width * k)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    prev = None
+    for t in range(100):                                   # one auto-reset inside (96-step episodes)
+        a = torch.randint(0, 3, (N, k, 1), generator=g)
+        o, s, r, d, infos, _ = env.step(a.cuda())
+        on, sn, rn, dn, infn, _ = ref.step(a.numpy())
+        assert torch.equal(s[:, 0], o.reshape(N, -1)) and torch.equal(s[:, 0], s[:, k - 1]), t
+        np.testing.assert_array_equal(o.cpu().numpy(), on)
+        np.testing.assert_array_equal(s.cpu().numpy(), sn)
+        if prev is not None:
+            assert not torch.equal(prev, s), t             # (it moves: not the first step's values)
+        prev = s.clone()
+        if dn.all():
+            fo = infn[3][0]["original_obs"]
+            assert fo.shape == (k, width) and infn[3][0]["original_state"].shape == (k, width * k)
+            np.testing.assert_array_equal(infos[3][0]["original_obs"], fo)
+    env.close()
+    ref.close()

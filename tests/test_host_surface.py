@@ -53,11 +53,15 @@ def test_env_config_defaults_match_reference_keys():
         _merge_args({"dc_reward": "default_ls_reward"})
     # the shared-observation option defaults like the reference's HARL layer (harlsustaindc_env.py:53: absent -> False,
     # the 3 x 26 concatenation); the shipped YAML sets True (the 29-float layout)
-    assert _merge_args({})["nonoverlapping_shared_obs_space"] is False
+    with pytest.warns(UserWarning, match="nonoverlapping_shared_obs_space"):     # (said once per process)
+        import dc_rl_amd.vec_env as V
+        V._WARNED_SHARE_DEFAULT = False
+        assert _merge_args({})["nonoverlapping_shared_obs_space"] is False
     assert _merge_args({"nonoverlapping_shared_obs_space": True})["nonoverlapping_shared_obs_space"] is True
-    for bad in ({"partial_obs": False}, {"actions_are_logits": True}):
-        with pytest.raises(NotImplementedError):  # options that change what a runner receives are never silently ignored
-            _merge_args(bad)
+    with pytest.raises(NotImplementedError):  # options that change what a runner receives are never silently ignored
+        _merge_args({"partial_obs": False})
+    # actions_are_logits: the reference stores the flag and never reads it (sustaindc_env.py:204-205) -- accepted, ignored
+    assert _merge_args({"actions_are_logits": True, "nonoverlapping_shared_obs_space": True})["actions_are_logits"] is True
     # a subset of agents is accepted (the other slots are played by the base agents on the device); none is not
     assert _merge_args({"agents": ["agent_ls", "agent_dc"]})["agents"] == ["agent_ls", "agent_dc"]
     with pytest.raises(ValueError):
@@ -141,3 +145,54 @@ def test_lazy_infos_views():
         assert k in infos[0][0], k
     with pytest.raises(KeyError):
         infos[0][0]["nope"]
+
+
+def test_lazy_infos_under_the_unchanged_runner_access_pattern():
+    """The access pattern of the reference's single-process runner, restated loop for loop: the logger's
+    `infos[i][0].get(key, 0)` over its ten keys (harl/envs/sustaindc/sustaindc_logger.py:87-101) and the buffer insert's
+    `"bad_transition" in info[0].keys()` (harl/runners/on_policy_base_runner.py:459-471), on the C-backed `infos`
+    (csrc/sdc_infos.c) -- against plain dicts holding the same rows."""
+    from collections.abc import Mapping, Sequence
+    rng = np.random.default_rng(0)
+    N = 257
+    rows = rng.random((N, L.INFO_DIM)).astype(np.float32)
+    const = [{"ls_queue_max_len": 1000, "ls_unasigned_day_load_left": 0, "dc_power_lb_kW": 100.0 + (i % 3)} for i in range(N)]
+    done = np.zeros(N, bool)
+    done[5] = True
+    extra = {(5, 0): {"original_obs": np.ones((3, 26)), "original_state": np.ones((3, 29))}}
+    infos = LazyInfos(rows, rng.integers(0, 3, (N, 3)), done, const, extra)
+    assert isinstance(infos, Sequence) and isinstance(infos[0][0], Mapping) and isinstance(infos[0], list)
+    plain = [[{**{k: float(rows[i, j]) for k, j in L.INFO_IDX.items()}, **const[i]}] * 3 for i in range(N)]
+
+    def logger(inf):
+        m = {k: 0.0 for k in LOGGER_KEYS}
+        on = []
+        for i in range(len(inf)):
+            for k in LOGGER_KEYS:
+                m[k] += inf[i][0].get(k, 0)
+            if inf[i][0].get("dc_HVAC_total_power_kW", 0) > 0:
+                on.append(inf[i][0].get("dc_HVAC_total_power_kW", 0))
+        bad = np.array([[0.0] if "bad_transition" in info[0].keys() and info[0]["bad_transition"] == True else [1.0]
+                        for info in inf])
+        return m, on, bad
+
+    (ma, oa, ba), (mb, ob, bb) = logger(infos), logger(plain)
+    assert ma == mb and oa == ob and (ba == bb).all() and ba.shape == (N, 1)
+    # the rest of the mapping / sequence surface
+    assert infos[-1][0]["dc_power_lb_kW"] == const[-1]["dc_power_lb_kW"] and infos[N - 1] is infos[-1]
+    assert len(infos[2:9:3]) == 3 and infos[2:9:3][1] is infos[5]
+    with pytest.raises(IndexError):
+        infos[N]
+    d = dict(infos[3][1])
+    assert d["dc_water_usage"] == float(rows[3, L.INFO_IDX["dc_water_usage"]]) and d["isterminal"] is False
+    assert set(d) == set(infos[3][1].keys()) and len(infos[3][1]) == len(d)
+    assert "original_obs" in infos[5][0].keys() and "original_obs" not in infos[5][1].keys() and "original_obs" not in infos[4][0]
+    assert len(infos[5][0]) == len(d) + 2 and dict(infos[5][0].items())["original_state"].shape == (3, 29)
+    assert infos[5][0].get("isterminal") is True and infos[5][0].get("nope") is None and infos[5][0].get("nope", 7) == 7
+    assert [v for v in infos[3][1].values()][0] == d[next(iter(d))]
+    # a view that outlives its `infos` keeps the step's block alive
+    v = infos[7][2]
+    del infos
+    import gc
+    gc.collect()
+    assert v["bat_SOC"] == float(rows[7, L.INFO_IDX["bat_SOC"]])
