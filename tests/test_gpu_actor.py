@@ -158,11 +158,8 @@ def test_reset_keeps_the_closed_loops_observation_latch_consistent():
         for a in range(3):
             e.set_actor(a, _torch_actor(20 + a).state_dict())
         e.reset()
-    g = torch.Generator(device="cpu").manual_seed(4)
-    acts = torch.randint(0, 3, (8, N, 3), dtype=torch.int32, generator=g).cuda()
-    for t in range(8):
-        a_eng.step(acts[t])
-        b_eng.step(acts[t])
+    # (a masked reset right after a full one: every env is at episode step 0, so the batch stays in lock-step -- the closed
+    # loop serves lock-step batches only -- while the masked envs start a NEW episode with other draws and observations)
     mask = (np.arange(N) % 3 == 0).astype(np.uint8)
     b_eng.reset(mask=mask)                                    # the engine's own persistent buffer: the reference behaviour
     scratch = torch.full((N, 3, 26), 123.0, device="cuda")    # a C caller's scratch buffer: garbage in the unmasked rows
