@@ -26,8 +26,13 @@ SOURCES = ["sdc_capi.hip", "sdc_step.hip", "sdc_features.hip", "sdc_verify.hip",
 # (-amdgpu-sched-strategy=max-ilp: the machine scheduler orders for instruction-level parallelism instead of minimal register
 #  pressure -- the step kernels' occupancy is pinned by amdgpu_waves_per_eu anyway, and their time is dependent-issue latency:
 #  measured 12.09 -> 11.78 us per step of 4096 envs, the large-batch kernels +1-2 %)
+# (-disable-machine-licm, round 4: the multi-step kernels run the whole step inside a loop, and the machine-level
+#  loop-invariant code motion hoists every constant materialisation of the step -- LDS offsets, fp64 literal halves, cold-path
+#  constants -- in front of it, holding 20-50 VGPRs across the loop: sdc_rollout_kernel 218 -> 167 VGPRs, the closed-loop
+#  kernels 177 / 185 -> 151 / 159, and sdc_rollout_quad_kernel's 32 bytes of scratch are gone (tests/test_isa_guard.py);
+#  measured: single step unchanged, sdc_rollout 8.55 -> 8.46 us per step at 4096 envs, 25.7 -> 23.8 at 16 384)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+               "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-licm"]
 
 # info column names = the reference's info keys (sustaindc_hip.h enum sdc_info_col)
 INFO_COLS = [

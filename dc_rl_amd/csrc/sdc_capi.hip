@@ -319,6 +319,8 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   d.queue_max = cfg->queue_max_len;
   d.rc_queue_max = 1.0 / (double)cfg->queue_max_len;
   d.rc_hist_cap = 1.0 / (double)cfg->hist_cap;
+  d.queue_max_d = (double)cfg->queue_max_len;
+  d.hist_cap_d = (double)cfg->hist_cap;
   d.table_len = SDC_TABLE_LEN;
   d.lw = cfg->episode_steps + 18;
   d.qstride = (cfg->episode_steps + 63) / 64 * 64;

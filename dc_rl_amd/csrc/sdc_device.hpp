@@ -173,6 +173,8 @@ struct SdcDev {
   const SdcDcDev* dc;   // [n_cfg]
   int n_cfg;
   double rc_queue_max, rc_hist_cap;   // reciprocals of queue_max / hist_cap (see SdcDcDev)
+  double queue_max_d, hist_cap_d;     // ... and the two as doubles (a uniform int -> double conversion inside the multi-step kernels' loop
+                                      // is hoisted out of it and held in two VGPRs across the whole step; these stay scalar)
   const double* hour_lut;   // [96][2] = cos, sin (utils/managers.py:66-88)
   // per-env state
   unsigned* rec;     // [N][SDC_REC_DWORDS] state records (see SdcRec)

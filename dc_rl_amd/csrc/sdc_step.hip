@@ -552,7 +552,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       cumT_hm1 = cumT_now;
     }
   }
-  const double normq = sdc_div_const((double)total, (double)S.queue_max, S.rc_queue_max);
+  const double normq = sdc_div_const((double)total, S.queue_max_d, S.rc_queue_max);
   const double oldest_norm = KDIV(oldest, 24), avg_norm = KDIV(avg, 24);
   // the load-shifting entries of the observation pool and of the info block leave for LDS here (lane 1 / lane 0 of the
   // half), so that none of them stays in registers across the rack model below
@@ -991,7 +991,7 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
   // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
           const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
           const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
-          clipped_moments(n, b, A1, A2, t1, t2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap);
+          clipped_moments(n, b, A1, A2, t1, t2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap, S.hist_cap_d);
           done_eval = true;
         } else {
           why = cov0 ? 7 : 6;
@@ -1298,7 +1298,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
   const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
   double mean, sd, inv_sd;
-  clipped_moments(n, b, A1, A2, t1, t2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap);
+  clipped_moments(n, b, A1, A2, t1, t2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap, S.hist_cap_d);
   // a window that the next step could exhaust is re-centred by the slow path (which then redoes this step)
   {
     int k1n, k3n;

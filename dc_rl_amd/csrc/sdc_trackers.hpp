@@ -197,12 +197,12 @@ __device__ __forceinline__ double sqrt_count(const double n) { return (double)__
 // divisions take the 3-instruction form).  inv_sd = 1 / sd, or 1 when sd is 0 (the z-score's divisor, reward_creator.py:44)
 __device__ __forceinline__ void clipped_moments(const int n, const Bounds& b, const double A1, const double A2, const double T1,
                                                 const double T2, double& mean, double& sd, double& inv_sd, const int n_full = 0,
-                                                const double rc_full = 0.0) {
+                                                const double rc_full = 0.0, const double n_full_d = 0.0) {
   const double C1 = A1 - T1, C2 = A2 - T2;
   double m2;
   if (n == n_full) {
-    mean = sdc_div_const(C1, (double)n, rc_full);
-    m2 = sdc_div_const(C2, (double)n, rc_full);
+    mean = sdc_div_const(C1, n_full_d, rc_full);      // (n_full_d == (double)n here, handed in as a scalar)
+    m2 = sdc_div_const(C2, n_full_d, rc_full);
   } else {
     mean = C1 / (double)n;
     m2 = C2 / (double)n;

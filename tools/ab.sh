@@ -5,7 +5,7 @@ set -e
 cd /root/repo
 CMD="$1"; shift
 # the production build's scheduling strategy (dc_rl_amd/_lib.py HIPCC_FLAGS); AB_BASE="" to compare strategies
-BASE="${AB_BASE--mllvm -amdgpu-sched-strategy=max-ilp}"
+BASE="${AB_BASE--mllvm -amdgpu-sched-strategy=max-ilp -mllvm -disable-machine-licm}"
 mkdir -p tools/bin
 SRCS="dc_rl_amd/csrc/sdc_capi.hip dc_rl_amd/csrc/sdc_step.hip dc_rl_amd/csrc/sdc_features.hip dc_rl_amd/csrc/sdc_verify.hip dc_rl_amd/csrc/sdc_reset.hip"
 NAMES=""
