@@ -135,16 +135,16 @@ def actor_weights(seed=7):
              "w3": rngw.standard_normal((3, 64)) * 0.2, "b3": np.zeros(3), "activation": "tanh"} for _ in range(3)]
 
 
-def secondary_rate(n_envs, episode_steps, location, device, timed_steps, month=None, loops=False):
+def secondary_rate(n_envs, episode_steps, location, device, timed_steps, month=None, loops=False, dc_files=("dc_config.json",)):
     """One secondary line: the step's rate at another batch size / episode length, measured like the headline (all
     rings filled to 10 000 by real steps, i.i.d. device-resident actions, auto-resets inside the timed region).
     loops: also sdc_rollout (48 steps per launch) and the closed loop (sdc_rollout_actor) at that batch size."""
     import torch
-    eng, _, _ = build_engine(n_envs, episode_steps, device, seed=4321, location=location)
+    eng, _, _ = build_engine(n_envs, episode_steps, device, seed=4321, location=location, dc_files=dc_files)
     if month is not None:
         from dc_rl_amd import traces
         d0 = traces.get_init_day(int(month))
-        eng.assign(0, 0, max(0, d0 - 7), min(364, d0 + 7))
+        eng.assign(0, np.arange(n_envs) % len(dc_files), max(0, d0 - 7), min(364, d0 + 7))
     cdev = torch.device("cuda", device)
     POOL = 512
     g = torch.Generator(device=cdev).manual_seed(99)
@@ -349,6 +349,95 @@ def self_launch(n_ranks):
     return subprocess.call(cmd, env=env)
 
 
+def main_single_process(args):
+    """`--gpus N --single-process`: N shards of 4096 envs, one C-ABI handle and one HIP stream per device, all driven by this one
+    process -- every device gets its launch before any is waited for; the return statistics are added up on the host (no
+    collective).  Same workload, fill, warm-up and timing rules as the one-process-per-GPU form; prints the same ONE line."""
+    import torch
+    D = args.gpus
+    devs = [int(x) for x in args.devices.split(",")] if args.devices else list(range(D))
+    if len(devs) != D:
+        print(f"bench.py: --devices names {len(devs)} devices, --gpus is {D}", file=sys.stderr)
+        sys.exit(4)
+    nd = torch.cuda.device_count()
+    if any(not 0 <= d < nd for d in devs):
+        print(f"bench.py: --single-process --gpus {D} needs devices {devs}, {nd} visible", file=sys.stderr)
+        sys.exit(3)
+    N = args.envs_per_gpu
+    dc_files = ("dc_config.json", "dc_config_r16.json", "dc_config_r25.json") if args.mixed_racks else ("dc_config.json",)
+    POOL = 1024
+    engs, pools, streams = [], [], []
+    for r, d in enumerate(devs):
+        with torch.cuda.device(d):
+            st = torch.cuda.Stream(device=d)
+            eng, tb, params = build_engine(N, args.episode_steps, d, seed=1234, dc_files=dc_files, env_index_base=r * N)
+            eng.use_stream(st)
+            g = torch.Generator(device="cpu").manual_seed(1234 + r)
+            pools.append(torch.randint(0, 3, (POOL, N, 3), dtype=torch.int32, generator=g).to(torch.device("cuda", d)))
+            engs.append(eng)
+            streams.append(st)
+    for e in engs:
+        e.reset()
+    ret = np.zeros(7)
+    step_no, in_ep = 0, 0
+
+    def sync():
+        for st in streams:
+            st.synchronize()
+
+    def one_step():
+        nonlocal step_no, in_ep
+        k = step_no % POOL
+        for e, p in zip(engs, pools):          # every device gets its launch ...
+            e.step(p[k])
+        step_no += 1
+        in_ep += 1
+        if in_ep == args.episode_steps:        # ... and only an episode end reads anything back (7 doubles per shard)
+            in_ep = 0
+            for e, st in zip(engs, streams):
+                with torch.cuda.device(e.device), torch.cuda.stream(st):
+                    r = e.info[:, 40:43].double()
+                    ret[:] += torch.cat([r.sum(0), (r * r).sum(0), torch.tensor([float(N)], dtype=torch.float64, device=r.device)]).cpu().numpy()
+
+    fill = 0 if args.no_fill else HIST_CAP
+    for _ in range(fill + args.warmup):
+        one_step()
+    hlen = min(int(e.get_state("hist_len").min()) for e in engs)
+    K = args.steps
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(64):
+        one_step()
+    sync()
+    est = (time.perf_counter() - t0) / 64
+    R = args.repeats if args.repeats > 0 else min(4096, max(1, int(np.ceil(MIN_REGION_S / max(1e-9, est * K)))))
+    with no_gc():
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(R * K):
+            one_step()
+        sync()
+        dt = time.perf_counter() - t0
+    timed = R * K
+    faults = sum(int((e.info[:, 37] != 0).sum().item()) for e in engs)
+    out = {"metric": "coupled env-steps/s", "value": round(N * D * timed / dt, 1), "unit": "env-steps/s", "n_gpus": D,
+           "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / timed * 1e3, 5), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64 dynamics / f32 history ring + outputs", "data": "synthetic",
+           "repeats": R, "timed_steps": timed, "ranks_seen": 1, "dist_backend": None, "single_process": True,
+           "config": {"workload": (f"BASELINE configs[4] form: {N * D} envs over {D} handles ({N} each) in ONE process, devices {devs}"
+                                   if D > 1 else "BASELINE configs[2]: 4096 parallel envs, dc_config.json (20 racks), 1xMI355X"),
+                      "envs_per_gpu": N, "episode_steps": args.episode_steps, "history_len": hlen, "history_fill_steps": fill,
+                      "auto_reset": True, "actions": "i.i.d. uniform {0,1,2}, device-resident pool of 1024 steps per device",
+                      "parallelism": f"env-shard x{D}, one process, one stream per device", "faults": faults,
+                      "distinct_devices": len(set(devs))},
+           "return_stats": {"episodes": int(ret[6]), "mean_return": [round(float(x), 3) for x in ret[0:3] / max(1.0, ret[6])],
+                            "reduced": "on the host, no collective"},
+           "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out))
+    for e in engs:
+        e.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,9 +456,16 @@ def main():
     ap.add_argument("--launch-check", action="store_true",
                     help="only launch the ranks, rendezvous, all-reduce once and print the skeleton line (no device needed)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (HARL YAML shape, batch scan, closed loop)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N devices driven from THIS process (one handle + one stream per device, no torch.distributed): "
+                         "the form a single-process HARL runner uses (dc_rl_amd.multi_device)")
+    ap.add_argument("--devices", type=str, default=None,
+                    help="--single-process: comma-separated device ids, one per shard (default 0..N-1; '0,0' puts two handles on one GPU)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.single_process:
+        return main_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))     # no launcher around us: start the ranks ourselves
 
@@ -708,6 +804,25 @@ def main():
                 sec["harl_yaml_shape"]["vs_headline"] = round(sec["harl_yaml_shape"]["value"] / value, 4)
             except Exception as e:
                 sec["harl_yaml_shape"] = {"error": repr(e)}
+            try:
+                # BASELINE configs[3]: 4096 envs x 16 / 20 / 25-rack configs by env_id % 3 -- the GENERAL kernel (several
+                # configs are not the common case); parity at this size: tests/test_gpu_production_sizes.py
+                sec["mixed_racks"] = secondary_rate(N, args.episode_steps, "ny", dev, 2016,
+                                                    dc_files=("dc_config.json", "dc_config_r16.json", "dc_config_r25.json"))
+                sec["mixed_racks"]["workload"] = "BASELINE configs[3]: 4096 envs x mixed 16/20/25-rack dc configs"
+                sec["mixed_racks"]["vs_headline"] = round(sec["mixed_racks"]["value"] / value, 4)
+            except Exception as e:
+                sec["mixed_racks"] = {"error": repr(e)}
+            try:
+                # what an UNCHANGED single-process HARL runner gets: its per-step walk over `infos` and its buffer inserts
+                # restated around envs.step (tools/harl_loop_rate.py), NumPy in / out; env_side_share = the part of the
+                # loop that is not the runner's own Python
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import harl_loop_rate
+                sec["harl_unchanged_loop"] = [harl_loop_rate.measure(n, steps=(40 if n >= 2048 else 100), device=dev)
+                                              for n in (48, 512, 4096)]
+            except Exception as e:
+                sec["harl_unchanged_loop"] = {"error": repr(e)}
             scan = []
             for n in (2048, 8192, 16384):
                 try:

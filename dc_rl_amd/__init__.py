@@ -5,6 +5,7 @@ Public surface (mirrors the reference's names for this path):
   * `make_ls_env`, `make_dc_pyeplus_env`, `make_bat_fwd_env` -- utils/make_envs_pyenv.py:19, :75, :45
   * `SustainDCVecEnv` (a `ShareVecEnv`), `make_train_env`, `make_eval_env`
                                                    -- harl/envs/env_wrappers.py:53, harl/utils/envs_tools.py:49
+  * `SustainDCMultiDeviceVecEnv` / `make_train_env(..., devices=[...])` -- the same ShareVecEnv over several GPUs in one process
   * `SdcEngine`                                    -- thin ctypes wrapper over the C-ABI (include/sustaindc_hip.h)
 
 The compute path is the HIP extension `csrc/libsustaindc_hip.so` (hand-written gfx950 kernels).  There is
@@ -18,6 +19,7 @@ _LAZY = {
     "EnvConfig": ("sustaindc_env", "EnvConfig"),
     "SustainDCVecEnv": ("vec_env", "SustainDCVecEnv"),
     "ShareVecEnv": ("vec_env", "ShareVecEnv"),
+    "SustainDCMultiDeviceVecEnv": ("multi_device", "SustainDCMultiDeviceVecEnv"),
     "make_train_env": ("envs_tools", "make_train_env"),
     "make_eval_env": ("envs_tools", "make_eval_env"),
     "make_ls_env": ("make_envs_pyenv", "make_ls_env"),

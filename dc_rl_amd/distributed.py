@@ -62,8 +62,14 @@ class ReturnStats:
         """Sum over ranks (RCCL / gloo); returns a new ReturnStats with the job-wide totals."""
         import torch.distributed as dist
         t = self.sums.clone()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(t)
+        if dist.is_available() and dist.is_initialized():     # (a world of one still goes through the backend: RCCL / gloo)
+            if dist.get_backend() == "nccl" and not t.is_cuda:
+                import torch
+                t = t.to(torch.device("cuda", torch.cuda.current_device()))
+                dist.all_reduce(t)
+                t = t.to(self.sums.device)
+            else:
+                dist.all_reduce(t)
         return ReturnStats(t)
 
     def mean_std(self):

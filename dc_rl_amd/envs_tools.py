@@ -27,12 +27,19 @@ def months_for_ranks(n: int, env_args: dict, rank_offset: int = 0) -> List[int]:
 
 
 def make_train_env(env_name, seed, n_threads, env_args, device: int = 0, return_torch: bool = False,
-                   rank_offset: int = 0):
+                   rank_offset: int = 0, devices=None):
     """Counterpart of harl/utils/envs_tools.py:49.  `rank_offset` = index of this shard's first env when the
-    batch is one shard of a multi-GPU job (see dc_rl_amd.distributed)."""
+    batch is one shard of a multi-GPU job (see dc_rl_amd.distributed).  `devices=[0, 1, ...]`: ONE vector env over several
+    GPUs in this process (dc_rl_amd.multi_device: one handle and one stream per device, contiguous env ranges) -- what a
+    single-process HARL runner uses to drive more than one MI355X."""
     if env_name != "sustaindc":
         print("Can not support the " + env_name + "environment.")
         raise NotImplementedError
+    if devices is not None:
+        from .multi_device import SustainDCMultiDeviceVecEnv
+        return SustainDCMultiDeviceVecEnv(env_args, n_envs=n_threads, seed=seed,
+                                          months=months_for_ranks(n_threads, env_args, rank_offset), devices=devices,
+                                          return_torch=return_torch, env_index_base=rank_offset)
     return SustainDCVecEnv(env_args, n_envs=n_threads, seed=seed,
                            months=months_for_ranks(n_threads, env_args, rank_offset), device=device,
                            return_torch=return_torch, env_index_base=rank_offset)

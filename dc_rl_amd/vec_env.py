@@ -501,6 +501,26 @@ class SustainDCVecEnv(ShareVecEnv):
         return (self._sel_obs(hb["obs"].numpy()), share3, self._sel(hb["rew"].numpy())[..., None],
                 np.repeat(done_h[:, None], k, axis=1), infos, self._avail_np)
 
+    def _launch_into(self, host):
+        """One step enqueued, its outputs on their way into the caller's pinned host tensors (`host`: obs / share / rew / info
+        / done slices of a larger block) -- nothing waited for.  For SustainDCMultiDeviceVecEnv: every device is given its
+        work before any is waited on."""
+        if self._need_reset:
+            raise RuntimeError("call reset() before step()")
+        a = self._actions
+        self._actions = None
+        e = self.engine
+        e.step(a)
+        host["obs"].copy_(e.obs, non_blocking=True)
+        host["share"].copy_(e.share_obs, non_blocking=True)
+        host["rew"].copy_(e.rew, non_blocking=True)
+        host["info"].copy_(e.info, non_blocking=True)
+        host["done"].copy_(e.done, non_blocking=True)
+        if self._logger_acc is not None:
+            self._logger_acc.add_(e.info[:, self._logger_idx].sum(0, dtype=self._torch.float64))
+            self._logger_steps += 1
+        return a
+
     def _host_buffers(self):
         t = self._torch
         if self._host is None:

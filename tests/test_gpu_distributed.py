@@ -161,3 +161,49 @@ def test_shard_is_the_same_environments_as_the_unsharded_job():
     assert (whole.get_state("episode") == 2).all()
     whole.close()
     shard.close()
+
+
+_RCCL_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from dc_rl_amd.distributed import ReturnStats, init_process_group
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r},
+                  HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dev = torch.device("cuda", 0)
+# the path's one collective (SURVEY.md section 8(e)): the 7-double return-statistics all-reduce, on RCCL
+st = ReturnStats.zeros(dev)
+st.add_episode_returns(torch.tensor([[1.0, 2.0, 3.0], [3.0, 2.0, 1.0]]))
+tot = st.all_reduce()
+mean, std, n = tot.mean_std()
+# ... the host-resident form (the multi-device env adds its shards up on the host) through the same backend
+host = ReturnStats.zeros()
+host.add_episode_returns([[4.0, 4.0, 4.0]])
+hn = int(host.all_reduce().sums[6])
+# ... and what bench.py reduces around its timed region (MAX over ranks)
+tmax = torch.tensor([1.25], dtype=torch.float64, device=dev)
+dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+print(json.dumps(dict(backend=dist.get_backend(), n=n, mean=mean.tolist(), std=std.tolist(), host_n=hn, tmax=float(tmax.item()),
+                      rccl=str(torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None)))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_world_size_1():
+    """RCCL itself, on the leased GPU: backend "nccl" with a world of ONE rank -- library load, communicator init, the path's
+    7-double all-reduce through ReturnStats.all_reduce, a MAX reduction and a barrier.  (A world of N needs a device per rank:
+    that is the driver's 8-GPU run; everything up to the transport is exercised here.)"""
+    p = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(root=ROOT, port=str(_free_port()))], cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    print("RCCL world of one:", out)
+    assert out["backend"] == "nccl" and out["n"] == 2 and out["host_n"] == 1 and out["tmax"] == 1.25
+    np.testing.assert_allclose(out["mean"], [2, 2, 2])
+    np.testing.assert_allclose(out["std"], [1, 0, 1])

@@ -196,3 +196,15 @@ def test_lazy_infos_under_the_unchanged_runner_access_pattern():
     import gc
     gc.collect()
     assert v["bat_SOC"] == float(rows[7, L.INFO_IDX["bat_SOC"]])
+
+
+def test_multi_device_env_ranges():
+    """dc_rl_amd/multi_device.py: contiguous ranges with even boundaries that cover the job; more devices than env pairs."""
+    from dc_rl_amd.multi_device import shard_ranges
+    for n, d in ((4096, 8), (50, 3), (24, 2), (7, 2), (3, 8), (32768, 8), (1, 1), (2, 4)):
+        r = shard_ranges(n, d)
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert all(lo % 2 == 0 and hi > lo for lo, hi in r) and len(r) <= d
+        sizes = [hi - lo for lo, hi in r]
+        assert max(sizes) - min(sizes) <= 2 or len(r) < d, (n, d, r)
+    assert shard_ranges(32768, 8) == [(4096 * i, 4096 * (i + 1)) for i in range(8)]
