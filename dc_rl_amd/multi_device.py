@@ -144,10 +144,28 @@ class SustainDCMultiDeviceVecEnv(ShareVecEnv):
                 with self._on(d):
                     obs, share = outs[d]
                     res.append((sh._sel_obs(obs), sh._share3(share, obs), sh._avail))
+            self._publish()
             return tuple(r[0] for r in res), tuple(r[1] for r in res), tuple(r[2] for r in res)
-        obs = np.concatenate([o.cpu().numpy() for o, _ in outs], axis=0)
-        share = np.concatenate([s.cpu().numpy() for _, s in outs], axis=0)
+        host = []
+        for d in range(len(self.shards)):           # (read back ON the shard's stream: it is not ordered against any other)
+            with self._on(d):
+                host.append((outs[d][0].cpu().numpy(), outs[d][1].cpu().numpy()))
+        obs = np.concatenate([o for o, _ in host], axis=0)
+        share = np.concatenate([s for _, s in host], axis=0)
         return self._sel_obs(obs), self._share3_np(share, obs), self._avail_np
+
+    def _publish(self):
+        """Device-resident outputs are produced on the shards' own streams: make each device's CURRENT stream (where the
+        caller's policy runs) wait for them -- a device-side dependency, no host synchronisation."""
+        t = self._torch
+        for dev, st in zip(self.devices, self.streams):
+            t.cuda.current_stream(dev).wait_stream(st)
+
+    def _subscribe(self):
+        """... and the shards' streams wait for what the caller's streams have produced so far (its action tensors)."""
+        t = self._torch
+        for dev, st in zip(self.devices, self.streams):
+            st.wait_stream(t.cuda.current_stream(dev))
 
     def _share3_np(self, share, obs):
         if self.share_concat:
@@ -163,6 +181,8 @@ class SustainDCMultiDeviceVecEnv(ShareVecEnv):
             a = actions.reshape(self.num_envs, self.n_agents) if hasattr(actions, "reshape") else \
                 np.asarray(actions).reshape(self.num_envs, self.n_agents)
             parts = [a[lo:hi] for lo, hi in self.ranges]
+        if any(hasattr(p, "is_cuda") and p.is_cuda for p in parts):
+            self._subscribe()
         for d, sh in enumerate(self.shards):
             with self._on(d):
                 sh.step_async(parts[d])
@@ -179,6 +199,7 @@ class SustainDCMultiDeviceVecEnv(ShareVecEnv):
             for d, sh in enumerate(self.shards):
                 with self._on(d):
                     res.append(sh.step_wait())
+            self._publish()
             return tuple(tuple(r[j] for r in res) for j in range(6))
         hs = self._host_sets()
         applied = []

@@ -122,6 +122,7 @@ class _FinalObs:
 
 _INFOS = L.load_infos()        # csrc/sdc_infos.c: InfoSeq (`infos`), InfoView (`infos[i][a]`) -- C types, see there
 Mapping.register(_INFOS.InfoView)
+Sequence.register(_INFOS.InfoRow)
 _DERIVED_KEYS = ("ls_action", "bat_a_t", "isterminal")
 _KEY_TEMPLATES = {}
 
@@ -204,7 +205,7 @@ class _InfoSource:
 
 class LazyInfos(_INFOS.InfoSeq):
     """`infos` of a step: tuple[N] of list[3] of dict in the reference (env_wrappers.py:262-273); here a C sequence over one
-    [N, K] array (csrc/sdc_infos.c): `infos[i]` is the cached list of the env's per-agent views, `infos[i][a]` a read-only
+    [N, K] array (csrc/sdc_infos.c): `infos[i]` is the env's cached row of per-agent views (a read-only sequence), `infos[i][a]` a read-only
     mapping whose `get` / `[]` / `in` / `keys()` run in C -- so the access pattern of an unchanged HARL runner
     (`infos[i][0].get(key, 0)` for 10 keys per env in sustaindc_logger.py:87-101, `"bad_transition" in info[0].keys()` per
     env in on_policy_base_runner.py:459-471) costs what it costs on plain dicts, without building N x 3 dicts per step."""

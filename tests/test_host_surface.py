@@ -161,7 +161,8 @@ def test_lazy_infos_under_the_unchanged_runner_access_pattern():
     done[5] = True
     extra = {(5, 0): {"original_obs": np.ones((3, 26)), "original_state": np.ones((3, 29))}}
     infos = LazyInfos(rows, rng.integers(0, 3, (N, 3)), done, const, extra)
-    assert isinstance(infos, Sequence) and isinstance(infos[0][0], Mapping) and isinstance(infos[0], list)
+    assert isinstance(infos, Sequence) and isinstance(infos[0][0], Mapping) and isinstance(infos[0], Sequence)
+    assert len(infos[0]) == 3 and infos[0][-1] is infos[0][2] and [v.agent for v in infos[0]] == [0, 1, 2] and len(infos[0][1:]) == 2
     plain = [[{**{k: float(rows[i, j]) for k, j in L.INFO_IDX.items()}, **const[i]}] * 3 for i in range(N)]
 
     def logger(inf):
