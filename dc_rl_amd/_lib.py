@@ -18,7 +18,7 @@ INFO_DIM = 44
 TABLE_LEN = 35040
 HDR_DWORDS = 64    # csrc/sdc_device.hpp SdcHdr: 256-byte per-env header
 QWIN = 64          # csrc/sdc_device.hpp SDC_WIN: keys per rank window (4 windows per env: Q1, Q3, upper / lower clip bound)
-ABI_VERSION = 320  # include/sustaindc_hip.h SDC_ABI_VERSION: the struct layouts and argument lists this binding was written for
+ABI_VERSION = 310  # include/sustaindc_hip.h SDC_ABI_VERSION: the struct layouts and argument lists this binding was written for
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
@@ -133,7 +133,7 @@ EXPORTS = [
     "sdc_last_done",
     "sdc_get_state", "sdc_set_state",
     "sdc_hist_stride", "sdc_queue_stride", "sdc_profile_enable", "sdc_profile_read",
-    "sdc_set_actor", "sdc_rollout_actor", "sdc_episode_boundary_stats",
+    "sdc_set_actor", "sdc_rollout_actor",
 ]
 
 
@@ -225,7 +225,6 @@ def load():
     L.sdc_set_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_profile_enable.argtypes = [vp, C.c_int]
     L.sdc_profile_read.argtypes = [vp, dp, C.c_int]
-    L.sdc_episode_boundary_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.sdc_set_actor.argtypes = [vp, C.c_int, C.POINTER(SdcActorParams)]
     L.sdc_rollout_actor.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, vp, fp, fp, vp, fp, vp]
     for name in EXPORTS:

@@ -39,16 +39,14 @@ extern "C" __global__ void sdc_rollout_actor_quad_kernel(SdcDev S, int K, int re
                                                          float* obs_latch);
 size_t sdc_rollout_actor_quad_lds_bytes();
 extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
-extern "C" __global__ void sdc_features_kernel(SdcDev S, int env0);
+extern "C" __global__ void sdc_features_kernel(SdcDev S);
 extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                               unsigned char* done, float* info, float* final_obs, float* rew);
 
 extern "C" __global__ void sdc_reset_kernel(SdcDev S, int use_override, const int* ovr_day, const int* ovr_hour,
                                             const double* ovr_ci_min, const double* ovr_ci_max, const double* ovr_t_min,
                                             const double* ovr_t_max, int only_done, float* obs, float* share_obs,
-                                            const double* inj_noise, const int* inj_roll, int env0);
-extern "C" __global__ void sdc_reset_commit_kernel(SdcDev S, const unsigned* shadow_rec, const float* prep_obs,
-                                                   const float* prep_share, float* obs, float* share_obs);
+                                            const double* inj_noise, const int* inj_roll);
 
 namespace {
 
@@ -121,20 +119,6 @@ struct sdc_handle {
   std::vector<unsigned char> prof_has_reset;
   double wall_clock_khz = 100000.0;
   double acc_ms[5] = {0, 0, 0, 0, 0};      // dynamics, reward, reset, steps, resets
-  // PREPARE-AHEAD of the next episode (see prep_arm): alternate window / feature-row buffers, a shadow of the records the
-  // reset kernels run against, the prepared reset observations, a second stream and the two events that order it
-  struct {
-    bool tried = false, enabled = false;   // buffers exist
-    bool armed = false;                    // a prepare for the coming boundary is enqueued and still describes it
-    int chunk = 1024;                      // envs per prepare launch (how many reset wavefronts run beside the steps at a time)
-    double *t_win = nullptr, *wb_win = nullptr, *walk_tmp = nullptr;
-    float* feat = nullptr;
-    unsigned *rec = nullptr, *hdr = nullptr;
-    float *obs = nullptr, *share = nullptr;
-    hipStream_t side = nullptr;
-    hipEvent_t boundary_done = nullptr, ready = nullptr;
-    long commits = 0, sync_boundaries = 0;
-  } prep;
 };
 
 namespace {
@@ -180,10 +164,10 @@ void sync_mirror(sdc_handle* h) {
 // one field of every env's record (256-byte state record, or 256-byte header) <-> a dense host array
 // the episode's observation feature rows of the envs a reset kernel has just reset (sdc_features.hip); episodes too long
 // for the kernel's LDS windows go without (the step then computes the features itself)
-void launch_features(sdc_handle* h, const SdcDev& d, hipStream_t st, int env0 = 0, int n = -1) {
+void launch_features(sdc_handle* h, const SdcDev& d, hipStream_t st) {
   if (!d.feat) return;
   const size_t lds = sizeof(double) * (size_t)(d.episode_steps + 25 + d.lw) + sizeof(float) * SDC_WAVE * (SDC_FEAT_ROW + 1);
-  hipLaunchKernelGGL(sdc_features_kernel, dim3(n < 0 ? d.n_envs : n), dim3(SDC_WAVE), lds, st, d, env0);
+  hipLaunchKernelGGL(sdc_features_kernel, dim3(d.n_envs), dim3(SDC_WAVE), lds, st, d);
   (void)h;
 }
 
@@ -204,7 +188,6 @@ int rec_get(sdc_handle* h, int idx, int dwords, void* host, int in_hdr = 0) {
 
 // the episode's precomputed observation rows follow the traces, the env's location and its weather windows
 int invalidate_features(sdc_handle* h) {
-  h->prep.armed = false;     // (whatever the host has written, a prepared next episode may no longer describe it)
   std::vector<unsigned> z((size_t)h->cfg.n_envs, 0u);
   h->feat_host.assign((size_t)h->cfg.n_envs, 0);
   h->n_feat_host = 0;
@@ -248,120 +231,10 @@ bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_o
   const SdcDev& d = h->d;
   return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs && d.n_cfg == 1 && h->racks_cfg0 > 0 &&
          h->racks_cfg0 <= 32 && actions && share_obs &&
-         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | 512 | 1024 | 2048 | FAST_DEBUG_FLAGS)) == 0 &&
+         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | 512 | 1024 | FAST_DEBUG_FLAGS)) == 0 &&
          d.policy[0] == SDC_POLICY_EXTERNAL && d.policy[1] == SDC_POLICY_EXTERNAL && d.policy[2] == SDC_POLICY_EXTERNAL &&
          d.reward_method[0] == SDC_REWARD_DEFAULT && d.reward_method[1] == SDC_REWARD_DEFAULT &&
          d.reward_method[2] == SDC_REWARD_DEFAULT;
-}
-
-// ---- PREPARE-AHEAD of the next episode ----------------------------------------------------------------------------------
-// An episode boundary is sdc_reset_kernel + sdc_features_kernel for every env: 0.57 ms at 4096 envs, during which nothing
-// steps -- 0.85 us per step amortised over 672-step episodes, 7 % of the step.  None of that work depends on how the running
-// episode goes: the draws are counter-based (seed, global env index, episode number), the windows and feature rows follow
-// from the draws and the trace tables.  So right after a boundary the NEXT episode is prepared on a second stream while
-// the current one is being stepped: the same two kernels, run against a SHADOW copy of the records (they only need the
-// fields steps never change: location, start-day range, episode number) and writing the ALTERNATE window / feature-row
-// buffers and a prepared-observation buffer.  At the boundary the main stream waits for the prepare's event (long past),
-// sdc_reset_commit_kernel takes the reset-owned record fields over and hands out the observations (~10 us), and the
-// buffers swap roles.  `chunk` envs per launch keep the prepare to a few wavefronts per SIMD beside the steps' (all 4096
-// at once take every register file and the steps wait: measured, tools/overlap_probe.py).
-// Ordering: the prepare of episode k+1 starts behind event `boundary_done` (recorded on the caller's stream after boundary
-// k), so it never writes a buffer the steps of episode k-1 could still read; the boundary waits for event `ready`.  Anything
-// the host does to the env state in between (sdc_reset, sdc_set_state, sdc_set_seed, sdc_assign_envs, tables / configs)
-// clears `armed`: that boundary runs the synchronous path -- the same kernels on the live records -- and re-arms behind it.
-// Same kernels, same inputs: the two paths give the same bits (tests/test_gpu_prepare_ahead.py).
-void recompute_steps_to_terminal(sdc_handle* h);
-bool prep_allowed(const sdc_handle* h) {
-  return h->cfg.auto_reset && !(h->cfg.debug_flags & 2048) && h->d.feat != nullptr;
-}
-int prep_enable(sdc_handle* h) {
-  auto& P = h->prep;
-  if (P.tried) return 0;
-  P.tried = true;
-  if (const char* c = std::getenv("SDC_PREP_CHUNK")) P.chunk = std::max(64, std::atoi(c));
-  if (const char* c = std::getenv("SDC_NO_PREPARE_AHEAD")) { if (std::atoi(c)) return 0; }
-  const SdcDev& d = h->d;
-  const size_t N = (size_t)h->cfg.n_envs;
-  const size_t w = (size_t)(d.lw > SDC_NORM_WINDOW ? d.lw : SDC_NORM_WINDOW);
-  // (a job too large for a second set of feature rows simply keeps the synchronous boundary)
-  if (dev_alloc(h, &P.t_win, N * d.lw) || dev_alloc(h, &P.wb_win, N * d.lw) || dev_alloc(h, &P.walk_tmp, N * w) ||
-      dev_alloc(h, &P.feat, N * (size_t)(h->cfg.episode_steps + 1) * SDC_FEAT_ROW, false) ||
-      dev_alloc(h, &P.rec, N * SDC_REC_DWORDS) || dev_alloc(h, &P.hdr, N * SDC_HDR_DWORDS) ||
-      dev_alloc(h, &P.obs, N * SDC_OBS_OUT) || dev_alloc(h, &P.share, N * SDC_SHARE_OBS_DIM)) {
-    g_err.clear();
-    (void)hipGetLastError();
-    return 0;
-  }
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // (lo: the numerically largest = the least urgent)
-  if (hipStreamCreateWithPriority(&P.side, hipStreamNonBlocking, lo) != hipSuccess ||
-      hipEventCreateWithFlags(&P.boundary_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&P.ready, hipEventDisableTiming) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  P.enabled = true;
-  return 0;
-}
-// behind a boundary on stream `st`: enqueue the prepare of the NEXT episode on the side stream
-int prep_arm(sdc_handle* h, hipStream_t st) {
-  auto& P = h->prep;
-  if (!prep_allowed(h)) return 0;
-  if (prep_enable(h)) return -1;
-  if (!P.enabled) return 0;
-  const int N = h->cfg.n_envs;
-  HIP_TRY(hipEventRecord(P.boundary_done, st));
-  HIP_TRY(hipStreamWaitEvent(P.side, P.boundary_done, 0));
-  // the shadow records: location, start-day range and episode number are what the reset reads -- fields no step changes
-  // (the copy may catch a record half-way through a step's store: those fields hold the same value before and after)
-  HIP_TRY(hipMemcpyAsync(P.rec, h->d.rec, sizeof(unsigned) * (size_t)N * SDC_REC_DWORDS, hipMemcpyDeviceToDevice, P.side));
-  SdcDev dp = h->d;
-  dp.rec = P.rec; dp.hdr = P.hdr; dp.t_win = P.t_win; dp.wb_win = P.wb_win; dp.walk_tmp = P.walk_tmp; dp.feat = P.feat;
-  dp.reset_mask = nullptr; dp.prof_ts = nullptr; dp.actions_out = nullptr;
-  for (int e0 = 0; e0 < N; e0 += P.chunk) {
-    const int n = std::min(P.chunk, N - e0);
-    hipLaunchKernelGGL(sdc_reset_kernel, dim3(n), dim3(SDC_WAVE), 0, P.side, dp, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
-                       h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 0, P.obs, P.share, nullptr, nullptr, e0);
-    launch_features(h, dp, P.side, e0, n);
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(P.ready, P.side));
-  P.armed = true;
-  return 0;
-}
-// The auto-reset of the envs that have just finished (harl/envs/env_wrappers.py:176-190: inside the same step call, the
-// reset observations returned), for sdc_step / sdc_rollout / sdc_rollout_actor.  `d`: the launch's copy of the device block.
-int auto_reset_boundary(sdc_handle* h, SdcDev& d, hipStream_t st, float* obs, float* share_obs, bool* ran_reset_kernel) {
-  const int N = h->cfg.n_envs;
-  auto& P = h->prep;
-  bool all = true;
-  for (int e = 0; e < N && all; e++) all = h->host_t_rel[e] >= h->cfg.episode_steps;
-  d.reset_mask = nullptr;
-  if (all && P.armed && prep_allowed(h)) {
-    HIP_TRY(hipStreamWaitEvent(st, P.ready, 0));
-    hipLaunchKernelGGL(sdc_reset_commit_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, P.rec, P.obs, P.share, obs, share_obs);
-    std::swap(h->d.t_win, P.t_win); std::swap(h->d.wb_win, P.wb_win); std::swap(h->d.feat, P.feat);
-    d.t_win = h->d.t_win; d.wb_win = h->d.wb_win; d.feat = h->d.feat;
-    P.armed = false;
-    P.commits += 1;
-    if (ran_reset_kernel) *ran_reset_kernel = false;
-  } else {
-    P.armed = false;
-    P.sync_boundaries += 1;
-    hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
-                       h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs, share_obs, nullptr, nullptr, 0);
-    launch_features(h, d, st);
-    if (ran_reset_kernel) *ran_reset_kernel = true;
-  }
-  HIP_TRY(hipGetLastError());
-  for (int e = 0; e < N; e++)
-    if (h->host_t_rel[e] >= h->cfg.episode_steps) {
-      h->host_t_rel[e] = 0;
-      note_features(h, e);
-    }
-  recompute_steps_to_terminal(h);
-  if (all) return prep_arm(h, st);
-  return 0;
 }
 
 // the reward state (rank windows, running sums) describes the ring contents: drop it when the ring is injected
@@ -573,12 +446,6 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
 int sdc_destroy(sdc_handle* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
-  if (h->prep.side) {
-    (void)hipStreamSynchronize(h->prep.side);     // (a prepare may still be writing the buffers freed below)
-    (void)hipStreamDestroy(h->prep.side);
-  }
-  if (h->prep.boundary_done) (void)hipEventDestroy(h->prep.boundary_done);
-  if (h->prep.ready) (void)hipEventDestroy(h->prep.ready);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return 0;
@@ -588,7 +455,6 @@ int sdc_set_seed(sdc_handle* h, uint64_t seed) {
   if (!h) return fail_msg("sdc_set_seed: null handle");
   h->cfg.seed = seed;
   h->d.seed = seed;
-  h->prep.armed = false;      // (a prepared next episode was drawn under the old seed)
   return 0;
 }
 
@@ -672,7 +538,6 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int N = h->cfg.n_envs;
-  h->prep.armed = false;      // (a prepared next episode counted on the episode numbers as they were)
   SdcDev d = h->d;
   if (mask_host) {
     HIP_TRY(hipMemcpyAsync(d.reset_mask, mask_host, (size_t)N, hipMemcpyHostToDevice, st));
@@ -736,7 +601,7 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
   }
   hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, inject_noise ? 2 : (ovr ? 1 : 0), h->ovr_day,
                      h->ovr_hour, h->ovr_ci_min, h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 0, obs, share_obs, inj_noise,
-                     inj_roll, 0);
+                     inj_roll);
   launch_features(h, d, st);
   if (inject_noise) {
     const hipError_t es = hipStreamSynchronize(st);
@@ -771,7 +636,6 @@ int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override*
     }
   recompute_steps_to_terminal(h);
   h->started = true;
-  if (!mask_host) return prep_arm(h, st);      // every env starts an episode: the one after it can be prepared from here on
   return 0;
 }
 
@@ -815,9 +679,18 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
     note_done(h);
     if (h->cfg.auto_reset) {
       // harl/envs/env_wrappers.py:176-190: reset inside the same step call and return the reset obs
-      bool ran = true;
-      if (auto_reset_boundary(h, d, st, obs, share_obs, &ran)) return -1;
-      if (timed) h->prof_has_reset[h->prof_used] = ran ? 1 : 0;
+      d.reset_mask = nullptr;
+      if (timed) h->prof_has_reset[h->prof_used] = 1;
+      hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
+                         h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs, share_obs, nullptr, nullptr);
+      launch_features(h, d, st);
+      HIP_TRY(hipGetLastError());
+      for (int e = 0; e < N; e++)
+        if (h->host_t_rel[e] >= h->cfg.episode_steps) {
+          h->host_t_rel[e] = 0;
+          note_features(h, e);
+        }
+      recompute_steps_to_terminal(h);
     }
   }
   if (timed) h->prof_used += 1;
@@ -868,9 +741,19 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
     if (h->cfg.auto_reset) {
       // as in sdc_step: the finished envs are reset inside the call; the LAST step's obs / share_obs slices receive
       // the reset observation, final_obs the pre-reset one
+      d.reset_mask = nullptr;
       const size_t last = (size_t)(n_steps - 1) * N;
-      if (auto_reset_boundary(h, d, st, obs + last * SDC_OBS_OUT, share_obs ? share_obs + last * SDC_SHARE_OBS_DIM : nullptr, nullptr))
-        return -1;
+      hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
+                         h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs + last * SDC_OBS_OUT,
+                         share_obs ? share_obs + last * SDC_SHARE_OBS_DIM : nullptr, nullptr, nullptr);
+      launch_features(h, d, st);
+      HIP_TRY(hipGetLastError());
+      for (int e = 0; e < N; e++)
+        if (h->host_t_rel[e] >= h->cfg.episode_steps) {
+          h->host_t_rel[e] = 0;
+          note_features(h, e);
+        }
+      recompute_steps_to_terminal(h);
     }
   }
   if (latch_obs(h, obs + (size_t)(n_steps - 1) * N * SDC_OBS_OUT, st)) return -1;
@@ -968,8 +851,19 @@ int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float*
     sync_mirror(h);
     note_done(h);
     if (h->cfg.auto_reset) {
+      d.reset_mask = nullptr;
       const size_t last = (size_t)(n_steps - 1) * N;
-      if (auto_reset_boundary(h, d, st, obs + last * SDC_OBS_OUT, share_obs + last * SDC_SHARE_OBS_DIM, nullptr)) return -1;
+      hipLaunchKernelGGL(sdc_reset_kernel, dim3(N), dim3(SDC_WAVE), 0, st, d, 0, h->ovr_day, h->ovr_hour, h->ovr_ci_min,
+                         h->ovr_ci_max, h->ovr_t_min, h->ovr_t_max, 1, obs + last * SDC_OBS_OUT,
+                         share_obs + last * SDC_SHARE_OBS_DIM, nullptr, nullptr);
+      launch_features(h, d, st);
+      HIP_TRY(hipGetLastError());
+      for (int e = 0; e < N; e++)
+        if (h->host_t_rel[e] >= h->cfg.episode_steps) {
+          h->host_t_rel[e] = 0;
+          note_features(h, e);
+        }
+      recompute_steps_to_terminal(h);
       if (latch_obs(h, obs + last * SDC_OBS_OUT, st)) return -1;     // the next launch starts from the reset observations
     }
   }
@@ -977,14 +871,6 @@ int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float*
 }
 
 int sdc_steps_to_episode_end(const sdc_handle* h) { return h ? h->steps_to_terminal : -1; }
-
-int sdc_episode_boundary_stats(const sdc_handle* h, int64_t* out) {
-  if (!h || !out) return fail_msg("sdc_episode_boundary_stats: null argument");
-  out[0] = (int64_t)h->prep.commits;
-  out[1] = (int64_t)h->prep.sync_boundaries;
-  out[2] = h->prep.armed ? 1 : 0;
-  return 0;
-}
 
 int sdc_last_done(const sdc_handle* h, uint8_t* done_host) {
   if (!h) return -1;

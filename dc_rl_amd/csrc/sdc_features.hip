@@ -77,9 +77,9 @@ __device__ __forceinline__ void extract_features(const double cur, const double 
 
 // One wavefront per env that has just been reset (record: episode step 0, no feature rows yet).  Dynamic LDS:
 // (steps + 25) + lw doubles -- the episode's normalised carbon-intensity and temperature windows.
-extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDev S, const int env0) {
+extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDev S) {
   extern __shared__ double lds[];
-  const int env = env0 + (int)blockIdx.x;   // (env0: the launch covers envs [env0, env0 + gridDim.x) -- see sdc_capi.hip prepare-ahead)
+  const int env = blockIdx.x;
   const int lane = threadIdx.x;
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
   const unsigned r = recp[lane];

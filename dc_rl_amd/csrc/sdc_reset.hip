@@ -65,9 +65,9 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
                                                                           int only_done, float* __restrict__ obs,
                                                                           float* __restrict__ share_obs,
                                                                           const double* __restrict__ inj_noise,
-                                                                          const int* __restrict__ inj_roll, const int env0) {
+                                                                          const int* __restrict__ inj_roll) {
   __shared__ ResetShared sh;
-  const int env = env0 + (int)blockIdx.x;   // (the launch covers envs [env0, env0 + gridDim.x))
+  const int env = blockIdx.x;
   const int lane = threadIdx.x;
   if (lane == 0) {   // measurement: workgroups that return early still bracket the launch
     prof_stamp(S, SDC_PROF_RESET, env, 0);
@@ -266,35 +266,4 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
   }
   if (share_obs && lane < SDC_SHARE_OBS_DIM) share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = share_obs_at(sh.obs, lane);
   if (lane == 0) prof_stamp(S, SDC_PROF_RESET, env, 1);
-}
-
-
-// The boundary of a PREPARED episode (sdc_capi.hip "prepare-ahead"): sdc_reset_kernel + sdc_features_kernel have already run
-// for the coming episode -- on a second stream, while the previous episode was being stepped -- against a SHADOW copy of the
-// records and the alternate window / feature-row buffers.  What is left at the boundary itself is this: take the fields a
-// reset owns over from the shadow record (the rest of the live record -- set-point, history cursor, policy counters -- is
-// what the episode's last step left), clear the running returns, hand out the reset observations.  One wavefront per env.
-extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_commit_kernel(SdcDev S, const unsigned* __restrict__ shadow_rec,
-                                                                                 const float* __restrict__ prep_obs,
-                                                                                 const float* __restrict__ prep_share,
-                                                                                 float* __restrict__ obs,
-                                                                                 float* __restrict__ share_obs) {
-  const int env = blockIdx.x, lane = threadIdx.x;
-  constexpr unsigned long long OWNED =
-      (1ull << R_CURSOR) | (1ull << R_TREL) | (1ull << R_DAY) | (1ull << R_HOURQ) | (1ull << R_QPOPPED) | (1ull << R_QCUM) |
-      (1ull << R_QCUMT) | (1ull << R_QHEAD) | (1ull << R_QCUM_HM1) | (1ull << R_QCUMT_HM1) | (1ull << R_LAST_DELTA) |
-      (1ull << R_CONSEC) | (1ull << R_SCALE) | (1ull << R_EPISODE) | (3ull << R_BAT) | (3ull << R_CI_MIN) | (3ull << R_CI_DEN) |
-      (3ull << R_T_MIN) | (3ull << R_T_DEN) | (1ull << R_FEAT_OK);
-  unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
-  const unsigned live = recp[lane], sh = shadow_rec[(size_t)env * SDC_REC_DWORDS + lane];
-  unsigned out = ((OWNED >> lane) & 1ull) ? sh : live;
-  if (lane == R_FAULT) out = live | sh;     // (sticky: what either side has flagged)
-  recp[lane] = out;
-  if (lane < 6) S.hdr[(size_t)env * SDC_HDR_DWORDS + H_RET + lane] = 0u;   // the three running returns (f64)
-  if (obs) {
-    obs[(size_t)env * SDC_OBS_OUT + lane] = prep_obs[(size_t)env * SDC_OBS_OUT + lane];
-    if (lane < SDC_OBS_OUT - 64) obs[(size_t)env * SDC_OBS_OUT + 64 + lane] = prep_obs[(size_t)env * SDC_OBS_OUT + 64 + lane];
-  }
-  if (share_obs && lane < SDC_SHARE_OBS_DIM)
-    share_obs[(size_t)env * SDC_SHARE_OBS_DIM + lane] = prep_share[(size_t)env * SDC_SHARE_OBS_DIM + lane];
 }

@@ -272,13 +272,6 @@ class SdcEngine:
     def steps_to_episode_end(self) -> int:
         return int(self.lib.sdc_steps_to_episode_end(self._h))
 
-    def boundary_stats(self) -> dict:
-        """How the auto-reset boundaries were served: from an episode prepared ahead on the library's second stream, or
-        synchronously (include/sustaindc_hip.h sdc_episode_boundary_stats)."""
-        out = (C.c_int64 * 3)()
-        L.check(self.lib.sdc_episode_boundary_stats(self._h, out))
-        return {"prepared": int(out[0]), "synchronous": int(out[1]), "pending": bool(out[2])}
-
     def rollout_policy(self, n_steps: int, actions=None, want_info: bool = True):
         """`rollout` for engines whose agent slots (some or all) are played by built-in policies (`policy=`): closed-loop
         episodes at rollout speed.  actions: None when every slot has a policy, else [K, N, 3] (slots with a policy

@@ -124,9 +124,7 @@ typedef struct {
                               Bits 9 / 10 (512 / 1024): the common-case kernels with two / four envs per wavefront
                               whatever the batch size (by default four when the batch is a multiple of four and
                               large: single steps from 6656 envs on, the multi-step entry points above 4096; same
-                              results to the bit).
-                              Bit 11 (2048): every auto-reset boundary synchronous (no episode prepared ahead on the
-                              library's second stream: see sdc_episode_boundary_stats; same results to the bit) */
+                              results to the bit) */
   int32_t reward_method[3]; /* reward function per agent slot (ls, dc, bat), utils/reward_creator.py:322-334:
                                SDC_REWARD_DEFAULT the slot's own default_*_reward, SDC_REWARD_FOOTPRINT
                                default_dc_reward = default_bat_reward, SDC_REWARD_CUSTOM custom_agent_reward (0),
@@ -211,9 +209,8 @@ const char* sdc_last_error(void);
  *   100  round 1        300  sdc_config: env_index_base, policy[3], trim_and_respond_limit; sdc_reset_override: noise,
  *                            roll_days; sdc_rollout: actions_out; debug_flags bit 6
  *   310  sdc_set_actor, sdc_rollout_actor (closed loop with the actor networks inside the kernel); debug_flags bit 7
- *        (debug_flags bits 9 / 10 came later without a bump: no layout or argument list changed)
- *   320  round 4: sdc_episode_boundary_stats (episodes prepared ahead on a second stream); debug_flags bit 11 */
-#define SDC_ABI_VERSION 320
+ *        (debug_flags bits 9 / 10 came later without a bump: no layout or argument list changed) */
+#define SDC_ABI_VERSION 310
 int sdc_version(void);
 
 int sdc_create(const sdc_config* cfg, sdc_handle** out);
@@ -295,14 +292,6 @@ int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float*
                       float* info, float* final_obs, int32_t* actions_out, float* logits_out, void* stream);
 /* steps until the first env finishes its episode (0: a reset is due) */
 int sdc_steps_to_episode_end(const sdc_handle* h);
-
-/* How the auto-reset boundaries of this handle were served so far: out[0] = by taking over an episode PREPARED AHEAD (the
- * reset + feature-row kernels run on the library's second stream while the previous episode is stepped; the boundary
- * itself is a ~10 us commit), out[1] = synchronously (the same kernels on the caller's stream: the first boundary, and any
- * boundary after the host touched the env state -- sdc_reset, sdc_set_state, sdc_set_seed, sdc_assign_envs),
- * out[2] = 1 while a prepared episode is pending.  Both paths give the same bits.  sdc_config.debug_flags bit 11 (2048)
- * or SDC_NO_PREPARE_AHEAD=1 in the environment keep every boundary synchronous. */
-int sdc_episode_boundary_stats(const sdc_handle* h, int64_t* out);
 /* which envs finished their episode in the last sdc_step / sdc_rollout call -- the `done` output, but from the host's
  * mirror of the step counters (episodes have a fixed length), so a caller that keeps everything on the device learns
  * about episode boundaries (harl/envs/env_wrappers.py:176-190: "original_obs" bookkeeping) without a device->host
