@@ -108,6 +108,14 @@ struct sdc_handle {
   float* obs_latch = nullptr;
   bool latch_valid = false;
   int racks_cfg0 = 0;                     // racks of data-centre config 0 (the specialised kernels take <= 32: one pass)
+  // several data-centre configs: host copies of the configs and of the assignment, from which every env's own copy of its
+  // config's scalars is built (SdcDev::prm_env) -- the common-case kernels then serve the batch as they serve one config
+  std::vector<SdcDcDev> dc_host;
+  std::vector<int> cfg_host;
+  std::vector<unsigned char> dc_set;
+  double* prm_env_dev = nullptr;
+  bool prm_env_ok = false;
+  int racks_max = 0;
   std::vector<unsigned char> last_done;   // which envs finished in the last sdc_step / sdc_rollout call (host mirror)
   int n_last_done = 0;
   bool tables_set = false, assigned = false, started = false;
@@ -223,18 +231,43 @@ constexpr int FAST_DEBUG_FLAGS = SDC_FAST_DEBUG ? (8 | 16 | 32 | 256) : 0;   // 
 #define SDC_QUAD_MIN_ENVS_LOOP 4100
 #endif
 bool quad_case(const sdc_handle* h, const bool multi_step) {
-  return (h->cfg.n_envs & 3) == 0 && (h->d.debug_flags & (512 | FAST_DEBUG_FLAGS)) == 0 &&
+  return (h->cfg.n_envs & 3) == 0 && h->d.n_cfg == 1 && (h->d.debug_flags & (512 | FAST_DEBUG_FLAGS)) == 0 &&
          (h->cfg.n_envs >= (multi_step ? SDC_QUAD_MIN_ENVS_LOOP : SDC_QUAD_MIN_ENVS_STEP) || (h->d.debug_flags & 1024));
 }
 int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_obs, const float* info, bool timed) {
   const SdcDev& d = h->d;
-  return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs && d.n_cfg == 1 && h->racks_cfg0 > 0 &&
-         h->racks_cfg0 <= 32 && actions && share_obs &&
+  return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs &&
+         (d.n_cfg == 1 ? (h->racks_cfg0 > 0 && h->racks_cfg0 <= 32) : (h->prm_env_ok && h->racks_max <= 32)) && actions && share_obs &&
          info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | 512 | 1024 | FAST_DEBUG_FLAGS)) == 0 &&
          d.policy[0] == SDC_POLICY_EXTERNAL && d.policy[1] == SDC_POLICY_EXTERNAL && d.policy[2] == SDC_POLICY_EXTERNAL &&
          d.reward_method[0] == SDC_REWARD_DEFAULT && d.reward_method[1] == SDC_REWARD_DEFAULT &&
          d.reward_method[2] == SDC_REWARD_DEFAULT;
+}
+
+// several configs: (re)build every env's copy of its config's scalars once all configs and the assignment are known
+int rebuild_prm_env(sdc_handle* h) {
+  h->prm_env_ok = false;
+  h->d.prm_env = nullptr;
+  const int N = h->cfg.n_envs, C = h->cfg.n_dc_configs;
+  if (C <= 1 || (int)h->cfg_host.size() != N) return 0;
+  for (int c = 0; c < C; c++)
+    if (!h->dc_set[c]) return 0;
+  // (the config's scalars lie contiguously from sdc_dc_params::m_cpu to SdcDcDev::ret_sum: sdc_step.hip's P_* enum, asserted there)
+  constexpr size_t P_COUNT_HOST = (offsetof(SdcDcDev, ret_sum) - offsetof(SdcDcDev, p.m_cpu)) / sizeof(double) + 1;
+  static_assert(P_COUNT_HOST <= 32, "prm_env rows are 32 doubles");
+  std::vector<double> tab((size_t)N * 32, 0.0);
+  h->racks_max = 0;
+  for (int e = 0; e < N; e++) {
+    const SdcDcDev& c = h->dc_host[h->cfg_host[e]];
+    std::memcpy(&tab[(size_t)e * 32], &c.p.m_cpu, sizeof(double) * P_COUNT_HOST);
+    h->racks_max = std::max(h->racks_max, c.p.n_racks);
+  }
+  if (!h->prm_env_dev && dev_alloc(h, &h->prm_env_dev, (size_t)N * 32) != 0) return -1;
+  HIP_TRY(hipMemcpy(h->prm_env_dev, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+  h->d.prm_env = h->prm_env_dev;
+  h->prm_env_ok = true;
+  return 0;
 }
 
 // the reward state (rank windows, running sums) describes the ring contents: drop it when the ring is injected
@@ -500,9 +533,14 @@ int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
   e.n_racks_f = (double)p->n_racks;
   e.ret_sum = 0.0;
   for (int r = 0; r < p->n_racks; r++) e.ret_sum += p->rack_return[r];
+  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(const_cast<SdcDcDev*>(h->d.dc) + cfg_id, &e, sizeof(e), hipMemcpyHostToDevice));
   if (cfg_id == 0) h->racks_cfg0 = p->n_racks;
-  return 0;
+  h->dc_host.resize((size_t)h->cfg.n_dc_configs);
+  h->dc_set.resize((size_t)h->cfg.n_dc_configs, 0);
+  h->dc_host[cfg_id] = e;
+  h->dc_set[cfg_id] = 1;
+  return rebuild_prm_env(h);
 }
 
 int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id, const int32_t* day_lo,
@@ -528,7 +566,9 @@ int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id,
     if (rec_put(h, R_STPT, 2, st.data())) return -1;
   }
   h->assigned = true;
-  return 0;
+  h->cfg_host.assign(cfg_id, cfg_id + N);
+  h->dc_set.resize((size_t)h->cfg.n_dc_configs, 0);
+  return rebuild_prm_env(h);
 }
 
 int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override* ovr, float* obs, float* share_obs,
@@ -971,6 +1011,22 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
     HIP_TRY(hipMemcpy(*f->ptr, k.data(), need, hipMemcpyHostToDevice));
   } else {
     HIP_TRY(hipMemcpy(*f->ptr, host_buf, need, hipMemcpyHostToDevice));
+  }
+  if (h->cfg.n_dc_configs > 1) {             // the envs' own copies of their configs' scalars follow the assignment
+    if (std::strcmp(field, "cfg_id") == 0) {
+      const int* c = static_cast<const int*>(host_buf);
+      for (int e = 0; e < h->cfg.n_envs; e++)
+        if (c[e] < 0 || c[e] >= h->cfg.n_dc_configs) return fail_msg("sdc_set_state: cfg_id out of range");
+      h->cfg_host.assign(c, c + h->cfg.n_envs);
+      if (rebuild_prm_env(h)) return -1;
+    } else if (std::strcmp(field, "record") == 0) {
+      const unsigned* r = static_cast<const unsigned*>(host_buf);
+      h->cfg_host.resize((size_t)h->cfg.n_envs);
+      for (int e = 0; e < h->cfg.n_envs; e++) h->cfg_host[e] = (int)r[(size_t)e * SDC_REC_DWORDS + R_CFG];
+      for (int e = 0; e < h->cfg.n_envs; e++)
+        if (h->cfg_host[e] < 0 || h->cfg_host[e] >= h->cfg.n_dc_configs) return fail_msg("sdc_set_state: record with a cfg_id out of range");
+      if (rebuild_prm_env(h)) return -1;
+    }
   }
   if (invalidate_features(h)) return -1;   // whatever was written, the precomputed observation rows may no longer match it
   // Deferred window re-centrings in flight belong to the state that has just been overwritten: a restored header may

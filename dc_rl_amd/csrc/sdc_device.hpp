@@ -172,6 +172,8 @@ struct SdcDev {
   const double* tabWB;  // pre-noise wet bulb
   const SdcDcDev* dc;   // [n_cfg]
   int n_cfg;
+  const double* prm_env;   // [N][32] (several configs only, else null): every env's own copy of its config's scalars (P_*), so
+                           // that the common-case kernels can request them WITH the record -- the config id is inside it
   double rc_queue_max, rc_hist_cap;   // reciprocals of queue_max / hist_cap (see SdcDcDev)
   double queue_max_d, hist_cap_d;     // ... and the two as doubles (a uniform int -> double conversion inside the multi-step kernels' loop
                                       // is hoisted out of it and held in two VGPRs across the whole step; these stay scalar)

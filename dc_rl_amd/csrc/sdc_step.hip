@@ -631,7 +631,8 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
 
   SDC_AT(4, sh, lane0);
   // ---- rack model, lane = rack inside the half: envs/datacenter.py:250-317, :157-181 ------------------
-  const sdc_dc_params& P = S.dc[FAST ? 0 : lrec_i32(rp, R_CFG)].p;
+  // (the common case with four envs per wavefront is one config; with two it may be several: the config id is in the record)
+  const sdc_dc_params& P = S.dc[((FAST && LPE != HL) || (FAST && S.n_cfg == 1)) ? 0 : lrec_i32(rp, R_CFG)].p;
   const int R = (int)pr[P_N_RACKS];
   const double load_pct = util * 100;
   double pcpu = 0.0, pfan = 0.0, outlet = 0.0;
@@ -1494,7 +1495,9 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
   // with a single data-centre configuration (the usual job) its scalars do not wait for the record either
   const bool one_cfg = FAST ? true : S.n_cfg == 1;
   double prm_pre = 0.0;
-  if (one_cfg && l < P_COUNT) prm_pre = reinterpret_cast<const double*>(&S.dc[0].p.m_cpu)[l];
+  if (one_cfg && l < P_COUNT)
+    prm_pre = (!FAST || S.n_cfg == 1) ? reinterpret_cast<const double*>(&S.dc[0].p.m_cpu)[l]
+                                      : S.prm_env[(size_t)envc * 32 + l];   // (several configs: the env's own copy, see SdcDev)
   const unsigned long long dbg_entry = (SDC_DBG_OK(FAST) && (S.debug_flags & 16)) ? wall_clock64() : 0ull;
   if (SDC_DBG_OK(FAST) && (S.debug_flags & 8) && lane == 0) sh.dbg_bits = 0u;
 

@@ -237,3 +237,65 @@ def test_four_env_mapping_other_rack_counts(cfg):
     assert (a.info[:, L.INFO_IDX["fault"]] == 0).all()
     for e in engs:
         e.close()
+
+
+def test_common_case_kernels_serve_several_configs():
+    """BASELINE configs[3] (16 / 20 / 25 racks by env_id % 3, three locations) on the kernels specialised for the common case
+    (round 4: every env carries its own copy of its config's scalars, SdcDev::prm_env, so that they arrive with the record)
+    against the general kernels (debug_flags bit 7): every output and the whole state bit for bit over single steps, two
+    auto-resets and a rollout, rings full -- and after the host re-assigns the configs."""
+    import torch
+    from tests.production_rig import MIXED_FILES, MIXED_LOCATIONS
+    N, steps, cap = 1026, 96, 10000       # (1026: a partly filled last workgroup)
+    tabs = [traces.synthetic_tables(loc, 0) for loc in MIXED_LOCATIONS]
+    combos = [(li, f) for li in range(3) for f in MIXED_FILES]
+    params = [dc_config.size_datacenter(f, 1, traces.max_ambient_for_sizing(traces.obtain_paths(MIXED_LOCATIONS[li])[0]))
+              for li, f in combos]
+    e_idx = np.arange(N)
+    loc_id = ((e_idx // 3) % 3).astype(np.int32)
+    cfg_id = (loc_id * 3 + e_idx % 3).astype(np.int32)
+    rng = np.random.default_rng(4)
+    hist = np.full((N, 10240), np.nan, np.float32)
+    hist[:, :cap] = (331 + 70 * rng.standard_normal((N, cap))).clip(150, 650).astype(np.float32)
+    pos = rng.integers(0, cap, N).astype(np.int32)
+    engs = []
+    for flags in (0, 128):
+        e = SdcEngine(N, episode_steps=steps, auto_reset=True, seed=14, debug_flags=flags, n_locations=3, n_dc_configs=9)
+        for li, tb in enumerate(tabs):
+            e.set_tables(li, tb["W"], tb["C"], tb["T"], tb["WB"])
+        for ci, p in enumerate(params):
+            e.set_dc_params(ci, p)
+        e.assign(loc_id, cfg_id, 174, 188)
+        e.set_state("hist", hist)
+        e.set_state("hist_len", np.full(N, cap, np.int32))
+        e.set_state("hist_pos", pos)
+        e.reset()
+        engs.append(e)
+    a, b = engs
+    g = torch.Generator(device="cpu").manual_seed(6)
+    acts = torch.randint(0, 3, (300, N, 3), dtype=torch.int32, generator=g).cuda()
+
+    def same_steps(t0, t1):
+        for t in range(t0, t1):
+            for u, v, nm in zip(a.step(acts[t]), b.step(acts[t]), ("obs", "share_obs", "rew", "done", "info")):
+                assert torch.equal(u, v), (t, nm, (u != v).nonzero()[:4].tolist())
+
+    same_steps(0, 200)                                # two auto-resets
+    k = min(40, a.steps_to_episode_end())
+    for u, v in zip(a.rollout(acts[200:200 + k]), b.rollout(acts[200:200 + k])):
+        assert torch.equal(u, v)
+    # the host moves every env to another rack count: the envs' copies of the scalars follow (sdc_set_state "cfg_id")
+    cfg2 = (loc_id * 3 + (e_idx + 1) % 3).astype(np.int32)
+    for e in engs:
+        e.set_state("cfg_id", cfg2)
+        e.reset()
+    same_steps(240, 290)
+    for name in ("record", "header", "qwin", "hist", "qtab"):
+        x, y = a.get_state(name), b.get_state(name)
+        if name == "header":
+            x[:, 34:38] &= ~np.uint32(0xFF)
+            y[:, 34:38] &= ~np.uint32(0xFF)
+        np.testing.assert_array_equal(x, y, err_msg=name)
+    assert (a.info[:, L.INFO_IDX["fault"]] == 0).all()
+    for e in engs:
+        e.close()
