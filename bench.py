@@ -67,6 +67,11 @@ ALG_BYTES_FIXED = 1540      # B(H) = 4*H + 1540 bytes pe
 STEP_KERNEL = "sdc_dynamics_fast_kernel"   # the step kernel specialised for the common case, which is what this workload is
 STEP_KERNEL_PREFIX = "sdc_dynamics"            # (the general kernel sdc_dynamics_kernel serves every other case)
 MIN_REGION_S = 0.2
+try:
+    import socket as _socket
+    HOSTNAME = _socket.gethostname()
+except Exception:
+    HOSTNAME = None
 
 
 def alg_bytes_per_env_step(h):
@@ -323,6 +328,35 @@ def pmc_summary(c):
         if c.get("SQ_WAVE_CYCLES"):
             # share of a wavefront's life with one of ITS instructions executing (the rest: parked at s_waitcnt, or waiting to issue)
             out["wave_issue_frac"] = round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
+    return out
+
+
+def scan_roofline(n_envs, episode_steps, us_per_step, args):
+    """The counter passes of `pmc_collect` at another batch size (the four-envs-per-wavefront kernel from 6656 envs on):
+    the same physical figures as the headline's `roofline`, against the wall-clock time per step of that batch."""
+    import argparse as _ap
+    a2 = _ap.Namespace(**vars(args))
+    a2.envs_per_gpu, a2.episode_steps, a2.mixed_racks = n_envs, episode_steps, False
+    c, err = pmc_collect(a2, timeout_s=150)
+    if c is None:
+        return {"error": err}
+    pm = pmc_summary(c)
+    t = us_per_step * 1e-6
+    simd_cycles = N_SIMD * t * MAX_CLOCK_GHZ * 1e9
+    traffic = pm.get("hbm_bytes_per_launch")
+    valu = pm.get("valu_active_simd_cycles_per_launch")
+    out = {"bound": "valu", "kernel": "sdc_dynamics_quad_kernel" if n_envs >= 6656 and n_envs % 4 == 0 else STEP_KERNEL,
+           "frac": round(valu / simd_cycles, 4) if valu else None,
+           "issue_frac": (round(pm["issue_active_simd_cycles_per_launch"] / simd_cycles, 4)
+                          if pm.get("issue_active_simd_cycles_per_launch") else None),
+           "wave_issue_frac": pm.get("wave_issue_frac"), "traffic": traffic,
+           "hbm_frac": round(traffic / t / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+           "alg_bytes_per_launch_without_history_term": ALG_BYTES_FIXED * n_envs,
+           "traffic_over_alg_bytes_without_history_term": round(traffic / (ALG_BYTES_FIXED * n_envs), 3) if traffic else None,
+           "instructions_per_wavefront": pm.get("per_wave"), "wavefronts_per_launch": pm.get("waves_per_launch"),
+           "us_per_step": us_per_step, "raw": pm.get("raw")}
+    if err:
+        out["pmc_error"] = err[:300]
     return out
 
 
@@ -699,6 +733,7 @@ def main():
             if c is not None:
                 pmc, pmc_src = pmc_summary(c), "this run (rocprofv3 --pmc passes over bench.py --pmc-inner)"
                 pmc["csrc_sha"] = here
+                pmc["host"] = HOSTNAME
         if pmc is None and os.path.exists(latest):
             try:
                 pmc = json.load(open(latest))
@@ -734,6 +769,9 @@ def main():
             "effective_hbm_GBps": round(eff, 1), "effective_hbm_frac": round(eff / HBM_PEAK_GBPS, 4),
             "effective_hbm_frac_without_history_term": round(ALG_BYTES_FIXED * N / k_evt / 1e9 / HBM_PEAK_GBPS, 5),
             "pmc_source": pmc_src, "pmc_current": bool(pmc and pmc.get("csrc_sha") == here), "csrc_sha": here,
+            # where the counter passes ran against where the timed region ran (boxes of the pool differ by 1-3 %: a kernel
+            # figure from one box next to a wall clock from another can differ by that much in either direction)
+            "timed_on_host": HOSTNAME, "pmc_on_host": (pmc.get("host") if pmc else None),
             "note": "frac = VALU-busy fraction (physical, <= 1); hbm_frac = PMC bytes / kernel time / 8 TB/s (physical); "
                     "effective_hbm_* price the REFERENCE algorithm's bytes (whole history window read every step), "
                     "which this kernel does not move -- not a physical bandwidth (DESIGN.md section 4)",
@@ -828,6 +866,8 @@ def main():
                 try:
                     r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=n >= 8192)
                     r["rate_vs_4096_envs"] = round(r["value"] / value, 4)
+                    if n >= 8192 and not args.no_pmc:
+                        r["roofline"] = scan_roofline(n, args.episode_steps, r["us_per_step"], args)
                     scan.append(r)
                 except Exception as e:
                     scan.append({"envs": n, "error": repr(e)})

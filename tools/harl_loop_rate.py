@@ -98,8 +98,13 @@ class RunnerSide:
 
 
 def measure(n_envs, steps=40, device=0, warmup=8, env_args=None, devices=None, history_warm_steps=300):
+    import gc
     from dc_rl_amd import make_train_env
     from dc_rl_amd import _lib as L
+    # (what is already on the heap -- torch, the caller's own objects -- out of the collector's way, as in a fresh runner process:
+    # inside bench.py a full collection of that heap is a 35-55 ms pause that lands on whichever loop allocates)
+    gc.collect()
+    gc.freeze()
     args = {"location": "ny", "days_per_episode": 7, "partial_obs": True, "nonoverlapping_shared_obs_space": True}
     args.update(env_args or {})
     envs = make_train_env("sustaindc", seed=1, n_threads=n_envs, env_args=args, device=device, devices=devices)
@@ -150,6 +155,7 @@ def measure(n_envs, steps=40, device=0, warmup=8, env_args=None, devices=None, h
         t_plain += (time.perf_counter() - t0) - (t2 - t1)
     t_plain /= reps
     envs.close()
+    gc.unfreeze()
     per = t_all / steps
     return {"envs": N, "steps": steps, "us_per_runner_step": round(per * 1e6, 1), "value": round(N / per, 1), "unit": "env-steps/s",
             "envs_step_us": round(t_env / steps * 1e6, 1), "runner_own_python_us": round(t_plain * 1e6, 1),
