@@ -67,11 +67,17 @@ ALG_BYTES_FIXED = 1540      # B(H) = 4*H + 1540 bytes pe
 STEP_KERNEL = "sdc_dynamics_fast_kernel"   # the step kernel specialised for the common case, which is what this workload is
 STEP_KERNEL_PREFIX = "sdc_dynamics"            # (the general kernel sdc_dynamics_kernel serves every other case)
 MIN_REGION_S = 0.2
-try:
-    import socket as _socket
-    HOSTNAME = _socket.gethostname()
-except Exception:
-    HOSTNAME = None
+HOSTNAME = None     # set in main(): host name + the GPU's UUID (the boxes of the pool share a container host name)
+
+
+def box_stamp():
+    try:
+        import socket
+        import torch
+        u = getattr(torch.cuda.get_device_properties(0), "uuid", None)
+        return f"{socket.gethostname()}/{u}" if u is not None else socket.gethostname()
+    except Exception:
+        return None
 
 
 def alg_bytes_per_env_step(h):
@@ -572,6 +578,8 @@ def main():
                 print(f"bench.py: {ranks_seen} ranks answered the all-reduce, expected {world}", file=sys.stderr)
             sys.exit(5)
 
+    global HOSTNAME
+    HOSTNAME = box_stamp()
     N = args.envs_per_gpu
     dc_files = ("dc_config.json", "dc_config_r16.json", "dc_config_r25.json") if args.mixed_racks else ("dc_config.json",)
     # one job seed; the reset RNG is keyed on the GLOBAL env index, so the job is the same set of environments

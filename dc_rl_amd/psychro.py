@@ -8,9 +8,12 @@ reference tree and is not installed in this image, so this module restates its
 *published* algorithm (ASHRAE Handbook - Fundamentals 2017, ch. 1: eqns 5, 6,
 22, 33, 35 and the bisection / Newton-Raphson solvers PsychroLib documents).
 
-PARITY UNPINNED: no PsychroLib output or reference test vector exists for this
-routine.  It only feeds the `WB` *input table* of the step (water usage,
-`/root/reference/envs/datacenter.py:343`), so step parity does not depend on it.
+Pinned to PUBLISHED values, not to captured outputs: PsychroLib cannot be run here, so there is no output of the
+reference's own call to compare with; the routine is checked against every public known answer instead --
+PsychroLib 2.5.0's own SI test values (incl. the sub-zero branch and the 1e-7 humidity-ratio clamp) and the ASHRAE
+2017 tables / worked example they quote, within the tolerances stated there
+(`tests/test_weather_fixture.py::test_wet_bulb_known_answers`).  It only feeds the `WB` *input table* of the step
+(water usage, `/root/reference/envs/datacenter.py:343`), so step parity does not depend on it.
 """
 from __future__ import annotations
 
