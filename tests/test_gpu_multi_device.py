@@ -81,3 +81,30 @@ def test_device_resident_outputs_per_device():
         assert im[1][3][0]["bat_SOC"] == iw[multi.ranges[1][0] + 3][0]["bat_SOC"]
     multi.close()
     whole.close()
+
+
+def test_bench_single_process_two_handles_on_one_gpu():
+    """`bench.py --gpus 2 --single-process --devices 0,0`: the one-process form of the multi-GPU bench (two handles, two
+    streams, no torch.distributed) prints the contract's ONE line; its return statistics count both shards' episodes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--devices", "0,0",
+                        "--steps", "40", "--warmup", "8", "--envs-per-gpu", "256", "--episode-steps", "96", "--repeats", "6"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["single_process"] is True and d["metric"] == "coupled env-steps/s" and d["value"] > 0
+    assert d["config"]["history_len"] == 10000 and d["config"]["faults"] == 0 and d["config"]["distinct_devices"] == 1
+    assert d["timed_steps"] == 240 and d["return_stats"]["episodes"] % 512 == 0 and d["return_stats"]["episodes"] > 0
+    # refuses what it was not given
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--devices", "0"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert q.returncode == 4

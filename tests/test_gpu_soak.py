@@ -14,11 +14,15 @@ pytestmark = pytest.mark.gpu
 
 # (flags 1: verify mode; + 1024: the common-case kernel with four envs per wavefront -- the mapping of large batches -- whatever
 # the batch size)
-@pytest.mark.parametrize("hist_cap,steps_total,flags", [(10000, 2600, 1), (1500, 5200, 1), (1500, 5200, 1 | 1024)])
-def test_reward_state_soak(hist_cap, steps_total, flags):
+# (mixed: BASELINE configs[3] -- 16 / 20 / 25 racks x three locations -- on the common-case kernels, every env with its own copy
+# of its config's scalars: round 4)
+@pytest.mark.parametrize("hist_cap,steps_total,flags,mixed", [(10000, 2600, 1, False), (1500, 5200, 1, False),
+                                                              (1500, 5200, 1 | 1024, False), (1500, 2600, 1, True)])
+def test_reward_state_soak(hist_cap, steps_total, flags, mixed):
     import torch
     N, ep = 512, 288
-    rig = P.ParityRig(N, episode_steps=ep, seed=77, hist_cap=hist_cap, with_oracle=False, debug_flags=flags)
+    kw = dict(locations=("ny", "az", "wa"), dc_files=("dc_config.json", "dc_config_r16.json", "dc_config_r25.json")) if mixed else {}
+    rig = P.ParityRig(N, episode_steps=ep, seed=77, hist_cap=hist_cap, with_oracle=False, debug_flags=flags, **kw)
     eng = rig.eng
     rng = np.random.default_rng(77)
     # start from a nearly full ring so that it wraps within the test; per-env spread, skew and level differ
