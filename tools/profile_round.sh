@@ -2,7 +2,7 @@
 # One gpurun call that produces everything profiles/ and DESIGN.md quote for a round:  bash tools/profile_round.sh r2
 # (rocprofv3 passes run from /tmp with TMPDIR=/tmp; --pmc passes -- inside bench.py -- use --kernel-trace only)
 set -x
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -41,6 +41,10 @@ timeout 900 python tools/step_scan.py > $O/step_scan.txt 2>&1
 bash tools/pmc_actor.sh > $O/pmc_actor.txt 2>&1
 bash tools/pmc_stalls.sh > $O/pmc_stalls.txt 2>&1
 bash tools/pmc_latency.sh > $O/pmc_latency.txt 2>&1
+# round 4: what an unchanged single-process HARL runner gets, the one-process multi-device bench, the boundary's two kernels
+timeout 600 python tools/harl_loop_rate.py 48 512 4096 > $O/harl_loop_rate.txt 2>&1
+timeout 600 python bench.py --gpus 2 --single-process --devices 0,0 --steps 200 --warmup 20 > $O/bench_single_process.txt 2>&1
+bash tools/reset_prof2.sh > $O/reset_kernels.txt 2>&1
 grep -v amdgpu.ids $O/*.txt | tail -60
 cut -c1-600 $O/bench.json
 ls $O
