@@ -317,6 +317,23 @@ __device__ __forceinline__ size_t feat_row_offset(const SdcDev& S, const int env
 #define SDC_FEAT_T 24
 #define SDC_FEAT_WB 28
 
+// SEQUENTIAL segmented sum, in lane order: lanes [0,16), [16,32) and [32,64) are three independent groups; lanes that carry no
+// point hold 0.0 (adding it changes nothing).  The order of sdc_features.hip slope_of -- one lane walking its points first to
+// last -- so that an observation's three least-squares slopes are the same BITS whether they come from the episode's
+// precomputed rows or from this whole-wavefront path (round 4: with the butterfly order below the two differed in the last
+// place of fp64, visible after the fp32 cast when a slope is ~1e-20 -- a temperature window clipped flat; 2 of 58 000
+// observations per seed, tools/scratch_feat.py).  ~300 instructions, on a path taken at resets and after host writes only.
+__device__ __forceinline__ double seg3_seq_sum_f64(const double v, const int lane) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    s0 += readlane_f64(v, i);
+    s1 += readlane_f64(v, 16 + i);
+  }
+#pragma unroll
+  for (int i = 0; i < 17; i++) s2 += readlane_f64(v, 32 + i);     // (the temperature slope has 17 points)
+  return lane < 16 ? s0 : (lane < 32 ? s1 : s2);
+}
 // segmented butterfly sum: lanes [0,16), [16,32) and [32,64) are three independent groups
 __device__ __forceinline__ double seg3_sum_f64(double v, int lane) {
   v += dpp_f64<SDC_DPP_XOR1>(v);
@@ -367,9 +384,9 @@ __device__ __forceinline__ void build_obs_pool(const double* nc, const double* n
   const double xm = 0.5 * (double)(n - 1);
   // n is 6, 14 (4 without a past window) or 17 by lane group: division by a per-group constant
   const double nd = (double)n, rn = n == 6 ? 1.0 / 6.0 : (n == 14 ? 1.0 / 14.0 : (n == 4 ? 0.25 : 1.0 / 17.0));
-  const double ym = sdc_div_const(seg3_sum_f64(y, lane), nd, rn);
+  const double ym = sdc_div_const(seg3_seq_sum_f64(y, lane), nd, rn);
   const double dx = act ? (double)xi - xm : 0.0;
-  const double sxy = seg3_sum_f64(act ? dx * (y - ym) : 0.0, lane);
+  const double sxy = seg3_seq_sum_f64(act ? dx * (y - ym) : 0.0, lane);
   const double sxx = seg3_sum_f64(dx * dx, lane);
   const double slope = sxy / sxx;
   if (lane == 0) pool[SDC_P_CI7 + 0] = (float)slope;

@@ -152,17 +152,20 @@ static int seq_init(InfoSeq* s, PyObject* args, PyObject* kw) {
   Py_INCREF(source); c->source = source;
   c->rows_obj = NULL; c->have_rows = 0; c->has_extras = has_extras;
   PyObject_GC_Track(c);
-  PyObject* items = PyList_New(n);
-  if (!items) { Py_DECREF(c); return -1; }
-  for (Py_ssize_t i = 0; i < n; i++) { Py_INCREF(Py_None); PyList_SET_ITEM(items, i, Py_None); }
   Py_XSETREF(s->core, c);     /* (a second __init__ replaces the first one's state; the instance __dict__ stays) */
-  Py_XSETREF(s->items, items);
+  Py_CLEAR(s->items);         /* the row cache is made on first access: a step whose infos nobody reads pays for none of it */
   return 0;
 }
 static Py_ssize_t seq_length(InfoSeq* s) { return s->core ? s->core->n_envs : 0; }
 static PyObject* seq_item(InfoSeq* s, Py_ssize_t i) {
   if (!s->core) { PyErr_SetString(PyExc_RuntimeError, "InfoSeq.__init__ was not called"); return NULL; }
   if (i < 0 || i >= s->core->n_envs) { PyErr_SetString(PyExc_IndexError, "infos index out of range"); return NULL; }
+  if (!s->items) {
+    const Py_ssize_t n = s->core->n_envs;
+    s->items = PyList_New(n);
+    if (!s->items) return NULL;
+    for (Py_ssize_t j = 0; j < n; j++) { Py_INCREF(Py_None); PyList_SET_ITEM(s->items, j, Py_None); }
+  }
   PyObject* it = PyList_GET_ITEM(s->items, i);
   if (it == Py_None) {
     /* one entry per TRAINED agent, in the reference's order (harlsustaindc_env.py:118-123) */
@@ -424,7 +427,7 @@ PyMODINIT_FUNC PyInit__sdc_infos(void) {
   Py_INCREF(&InfoView_Type);
   Py_INCREF(&InfoRow_Type);
   if (PyModule_AddObject(m, "InfoRow", (PyObject*)&InfoRow_Type) < 0 || PyModule_AddObject(m, "InfoSeq", (PyObject*)&InfoSeq_Type) < 0 || PyModule_AddObject(m, "InfoView", (PyObject*)&InfoView_Type) < 0 ||
-      PyModule_AddIntConstant(m, "VERSION", 3) < 0) {
+      PyModule_AddIntConstant(m, "VERSION", 4) < 0) {
     Py_DECREF(m);
     return NULL;
   }

@@ -219,7 +219,7 @@ class SustainDCMultiDeviceVecEnv(ShareVecEnv):
         extra = _ShardedExtra(self.ranges, extras) if any(e is not None for e in extras) else {}
         self._gen += 1
         acts = _ShardedActions(applied)
-        infos = LazyInfos(hs["info"], acts, done_h, self._const, extra, self, 1, k)
+        infos = LazyInfos(hs["info"], acts, done_h, self._const, extra, self, 1, k, self.shards[0]._info_keys)
         if self.snapshot_infos:
             infos.rows()
         obs = hs["obs"].numpy()

@@ -210,9 +210,10 @@ class LazyInfos(_INFOS.InfoSeq):
     (`infos[i][0].get(key, 0)` for 10 keys per env in sustaindc_logger.py:87-101, `"bad_transition" in info[0].keys()` per
     env in on_policy_base_runner.py:459-471) costs what it costs on plain dicts, without building N x 3 dicts per step."""
 
-    def __init__(self, info_tensor, actions, done, const, extra, owner=None, valid_for=0, n_agents=3):
+    def __init__(self, info_tensor, actions, done, const, extra, owner=None, valid_for=0, n_agents=3, keys=None):
         const = const if isinstance(const, list) else list(const)
-        keys = _base_keys(tuple(const[0].keys()) if const else ())
+        if keys is None:      # (the envs hand their own in: one lookup per env object, not per step)
+            keys = _base_keys(tuple(const[0].keys()) if const else ())
         src = _InfoSource(info_tensor, actions, done, const, extra, owner, valid_for, keys)
         super().__init__(len(done), n_agents, L.INFO_IDX, keys, const, src, bool(extra))
         self._src = src
@@ -349,6 +350,7 @@ class SustainDCVecEnv(ShareVecEnv):
                 "bat_max_bat_cap": e.sized["bat_capacity"], "bat_dcload_min": e.power_lb_kW / 4,
                 "bat_dcload_max": e.power_ub_kW / 4,
             })
+        self._info_keys = _base_keys(tuple(self._const[0].keys()))
         # HARL pads every agent to the widest space OF THE TRAINED AGENTS (harlsustaindc_env.py:25-26, :30-33: 26 whenever
         # agent_ls is trained, 14 for dc + bat, 13 for bat alone)
         self.obs_width = L.OBS_PAD if full else max(OBS_DIMS[i] for i in self._agent_idx)
@@ -472,9 +474,9 @@ class SustainDCVecEnv(ShareVecEnv):
             # runners read the final step's infos after the auto-reset); else a guarded view of the engine's buffer
             snap = self.snapshot_infos or bool(extra)
             infos = LazyInfos(info.clone() if snap else info, a, done_h, self._const, extra, None if snap else self, 0,
-                              self.n_agents)
+                              self.n_agents, self._info_keys)
         else:
-            infos = LazyInfos(hb["info"], a, done_h, self._const, extra, self, 1, self.n_agents)   # pinned double buffer: one more step
+            infos = LazyInfos(hb["info"], a, done_h, self._const, extra, self, 1, self.n_agents, self._info_keys)   # pinned double buffer: one more step
             if self.snapshot_infos:
                 infos.rows()
         if self._logger_acc is not None:      # device-side logger sums: one small reduction per step, no read-back

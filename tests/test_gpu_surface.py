@@ -170,16 +170,20 @@ def test_env_groups_on_separate_streams_match_sequential_stepping():
                 np.testing.assert_array_equal(xa, xb)
 
 
-def test_precomputed_observation_rows_match_per_step_features():
+@pytest.mark.parametrize("seed", [321, 302, 310, 327])
+def test_precomputed_observation_rows_match_per_step_features(seed):
     """The trace-only observation entries come from rows computed once per episode (sdc_features.hip, one lane per
     step); after a host write to the env's state the step computes them itself (all lanes of the wavefront on one
-    step).  Both follow the reference's arithmetic: same observations, to the bit, over episodes that include the
-    start-of-year cursor edge (no past CI window) and device-side auto-resets."""
+    step).  Both follow the reference's arithmetic IN THE SAME ORDER: same observations, to the bit, over episodes that
+    include the start-of-year cursor edge (no past CI window) and device-side auto-resets.  (Seeds 302, 310, 327: weather draws
+    under which a temperature window is clipped flat and its least-squares slope is ~1e-20 -- there the whole-wavefront
+    path's butterfly sums of rounds 1-3 showed in the fp32 observation; round 4 sums in lane order, sdc_device.hpp
+    seg3_seq_sum_f64.)"""
     import torch
     import bench
 
     def run(fallback):
-        eng = bench.build_engine(192, 96, 0, seed=321)[0]
+        eng = bench.build_engine(192, 96, 0, seed=seed)[0]
         gen = torch.Generator(device="cpu").manual_seed(11)
         acts = torch.randint(0, 3, (64, 192, 3), dtype=torch.int32, generator=gen).to("cuda:0")
         eng.reset()

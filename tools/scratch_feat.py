@@ -1,0 +1,25 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, bench
+def run(fallback, seed):
+    eng = bench.build_engine(192, 96, 0, seed=seed)[0]
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    acts = torch.randint(0, 3, (64, 192, 3), dtype=torch.int32, generator=gen).to("cuda:0")
+    eng.reset()
+    snaps = []
+    for t in range(300):
+        if fallback and t % 96 == 0:
+            eng.set_state("episode", eng.get_state("episode"))
+        obs, share, rew, done, info = eng.step(acts[t % 64])
+        snaps.append(obs.cpu().numpy().copy())
+    eng.close()
+    return np.stack(snaps)
+for seed in range(300, 330):
+    a, b = run(False, seed), run(True, seed)
+    d = (a != b)
+    if d.any():
+        idx = np.argwhere(d)
+        print("seed", seed, "mismatches", len(idx), "first", idx[:5].tolist(), "max abs", np.abs(a - b).max(),
+              "cols", sorted({(int(i[2]), int(i[3])) for i in idx})[:12])
+    else:
+        print("seed", seed, "ok")
