@@ -3,8 +3,10 @@
   * the four-envs-per-wavefront step kernel (`sdc_dynamics_quad_kernel`: the default from 6 656 envs on) at 12 288 envs
     (three whole occupancy rounds) and 16 384 envs (a fourth wavefront per SIMD that runs alone), against the ORACLE --
     until now it was only compared with the two-env kernels, and never above 8 200 envs;
-  * BASELINE configs[3] at its own size: 4096 envs x 16 / 20 / 25 racks x three locations on the GENERAL kernel with
-    `debug_flags = 0`, full rings and deferred re-centring under the full request load;
+  * BASELINE configs[3] at its own size: 4096 envs x 16 / 20 / 25 racks x three locations with `debug_flags = 0`, full rings
+    and deferred re-centring under the full request load (round 4: served by the common-case kernels, every env carrying
+    its own copy of its config's scalars; their bit-equality with the general kernels on such a batch:
+    tests/test_gpu_timed_config.py::test_common_case_kernels_serve_several_configs);
   * `sdc_rollout` (48 steps in one launch) and the closed loop `sdc_rollout_actor` at 16 384 envs with full rings (the
     four-env multi-step kernels): sampled envs against the oracle, the closed loop under the actions its actors chose.
 
@@ -37,8 +39,8 @@ def test_quad_step_kernel_production_vs_oracle(N):
 
 
 def test_config3_mixed_racks_4096_production():
-    """BASELINE configs[3]: 4096 envs, rack count 20 / 16 / 25 by env_id % 3, three locations, debug_flags = 0 (the general
-    kernel: several configs are not the common case), full rings, 330 steps over two auto-resets vs the oracle."""
+    """BASELINE configs[3]: 4096 envs, rack count 20 / 16 / 25 by env_id % 3, three locations, debug_flags = 0 (what the bench's
+    `secondary.mixed_racks` times), full rings, 330 steps over two auto-resets vs the oracle."""
     rig = ProductionRig(4096, debug_flags=0, mixed=True, episode_steps=120, seed=303, envs_per_wave=2)
     # every (location, rack count) combination is in the sample
     combos = {(int(rig.loc_id[i]), int(rig.cfg_id[i])) for i in rig.sample}
@@ -105,4 +107,20 @@ def test_rollout_actor_16384_envs_full_rings_vs_oracle():
     print("sdc_rollout_actor, 16384 envs:", rig.worst, "actions chosen:", seen.tolist())
     rig.assert_ok()
     assert (eng.info[:, L.INFO_IDX["fault"]] == 0).all()
+    rig.eng.close()
+
+
+def test_real_episode_length_4096_production_vs_oracle():
+    """The bench's own episode shape -- 4096 envs, 672-step (7-day) episodes, debug_flags 0, rings full -- over two whole
+    episodes and into a third (1400 steps, two auto-resets 672 steps apart): the long horizon the 120-step rigs do not reach
+    (a rank window re-centred ~every 600 steps per env: every sampled env goes through several deferred take-overs)."""
+    rig = ProductionRig(4096, debug_flags=0, episode_steps=672, seed=909, envs_per_wave=2, n_random=40)
+    obs, _ = rig.eng.reset()
+    rig.begin_all(obs)
+    rig.single_steps(1400)
+    print("672-step episodes, 4096 envs:", rig.worst, "reward-state paths:", rig.paths[:4], "auto-resets:", rig.resets)
+    assert rig.resets == 2
+    rig.assert_ok()
+    rig.assert_all_reward_state_paths_seen()
+    assert rig.paths[2] > 10 * len(rig.sample) // 72     # deferred take-overs did happen, many times over
     rig.eng.close()
