@@ -322,7 +322,7 @@ __device__ __forceinline__ size_t feat_row_offset(const SdcDev& S, const int env
 // last -- so that an observation's three least-squares slopes are the same BITS whether they come from the episode's
 // precomputed rows or from this whole-wavefront path (round 4: with the butterfly order below the two differed in the last
 // place of fp64, visible after the fp32 cast when a slope is ~1e-20 -- a temperature window clipped flat; 2 of 58 000
-// observations per seed, tools/scratch_feat.py).  ~300 instructions, on a path taken at resets and after host writes only.
+// observations per seed, tools/feature_paths_scan.py).  ~300 instructions, on a path taken at resets and after host writes only.
 __device__ __forceinline__ double seg3_seq_sum_f64(const double v, const int lane) {
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll

@@ -1,3 +1,7 @@
+"""The two ways an observation's trace-only entries are computed -- the per-episode rows of sdc_features.hip and the
+whole-wavefront path a step takes after a host write -- compared bit for bit over many reset seeds (192 envs x 300 steps each):
+prints the seeds, steps, envs and entries at which they differ.  (Round 4: 18 of 30 seeds differed in the temperature slope of a
+flat window until both summed in the same order.)  usage: python tools/feature_paths_scan.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
