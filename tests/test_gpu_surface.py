@@ -356,3 +356,36 @@ def test_agent_subset_concat_share_obs_on_the_torch_path(agents, width):
             np.testing.assert_array_equal(infos[3][0]["original_obs"], fo)
     env.close()
     ref.close()
+
+
+def test_eval_dump_keys_of_the_reference_runner():
+    """The evaluation dump of the reference's runner reads 34 keys per env and step through `eval_infos[i][j].get(key, None)`
+    (harl/runners/on_policy_base_runner.py:617-638: 9 for agent 1, 16 for agent 2, 9 for agent 3): every one of them is served
+    (none falls back to the `None` default), with the values of the step's info block / the env's constants."""
+    from dc_rl_amd import make_eval_env
+    keys = {0: ['ls_original_workload', 'ls_shifted_workload', 'ls_action', 'ls_norm_load_left', 'ls_unasigned_day_load_left',
+                'ls_penalty_flag', 'ls_tasks_in_queue', 'ls_tasks_dropped', 'ls_current_hour'],
+            1: ['dc_ITE_total_power_kW', 'dc_HVAC_total_power_kW', 'dc_total_power_kW', 'dc_power_lb_kW', 'dc_power_ub_kW',
+                'dc_crac_setpoint_delta', 'dc_crac_setpoint', 'dc_cpu_workload_fraction', 'dc_int_temperature',
+                'dc_CW_pump_power_kW', 'dc_CT_pump_power_kW', 'dc_water_usage', 'dc_exterior_ambient_temp', 'outside_temp', 'day',
+                'hour'],
+            2: ['bat_action', 'bat_SOC', 'bat_CO2_footprint', 'bat_avg_CI', 'bat_total_energy_without_battery_KWh',
+                'bat_total_energy_with_battery_KWh', 'bat_max_bat_cap', 'bat_dcload_min', 'bat_dcload_max']}
+    assert sum(len(v) for v in keys.values()) == 34
+    N = 6
+    envs = make_eval_env("sustaindc", seed=2, n_threads=N, env_args=dict(ENV_ARGS))
+    envs.reset()
+    rng = np.random.default_rng(0)
+    for t in range(5):
+        a = rng.integers(0, 3, size=(N, 3, 1))
+        _, _, _, _, infos, _ = envs.step(a)
+        rows = infos.rows()
+        for i in range(N):
+            for j in range(3):
+                got = {k: infos[i][j].get(k, None) for k in keys[j]}
+                assert all(v is not None for v in got.values()), (i, j, [k for k, v in got.items() if v is None])
+            assert infos[i][0].get('ls_action') == int(a[i, 0, 0]) and infos[i][2].get('bat_action') == float(a[i, 2, 0])
+            assert infos[i][1].get('dc_total_power_kW') == float(rows[i, L.INFO_IDX['dc_total_power_kW']]) > 0
+            assert infos[i][1].get('dc_power_ub_kW') > infos[i][1].get('dc_power_lb_kW') > 0
+            assert infos[i][2].get('bat_dcload_max') == infos[i][1].get('dc_power_ub_kW') / 4
+    envs.close()
