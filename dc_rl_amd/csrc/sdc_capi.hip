@@ -1028,6 +1028,7 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
       if (rebuild_prm_env(h)) return -1;
     }
   }
+  h->latch_valid = false;                  // (closed loop: the library's copy of the latest observations describes the state before this write)
   if (invalidate_features(h)) return -1;   // whatever was written, the precomputed observation rows may no longer match it
   // Deferred window re-centrings in flight belong to the state that has just been overwritten: a restored header may
   // carry request stamps (H_PEND) that the NEXT step would find "two steps old" again and take a swept window over --

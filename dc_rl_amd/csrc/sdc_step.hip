@@ -2280,6 +2280,10 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
     const float* o = obs_in + (size_t)envc * SDC_OBS_OUT;
     sh.pool[h][l] = l < SDC_OBS_PAD ? o[l] : (l == SDC_P_WNEXT ? o[SDC_OBS_PAD + 11] : (l == SDC_P_NTNEXT ? o[SDC_OBS_PAD + 13] : o[2 * SDC_OBS_PAD + 12]));
   }
+  // the sampler's key: (seed, global env index, EPISODE NUMBER, episode step) -- all of it env state or configuration, so that a
+  // checkpoint restored later, or the same steps asked for in launches of other lengths, draw the same actions (rounds 3 keyed
+  // on the library's launch counter).  A launch never crosses an episode end: one load per launch.
+  const unsigned ep_key = S.rec[(size_t)envc * SDC_REC_DWORDS + R_EPISODE];
   wave_sync();
 #ifdef SDC_ACTOR_CLOCK      // (measurement build: shader-clock cycles per phase, summed over the K steps, into info slots 38..40 of the last step)
   unsigned long long ck[3] = {0, 0, 0}, c0, c1;
@@ -2323,8 +2327,8 @@ sdc_rollout_actor_kernel(SdcDev S, const int K, const int rel_hint, const SdcAct
     // the resets, its words x, y, z for agent_ls, agent_dc, agent_bat
     float u3[3] = {0.0f, 0.0f, 0.0f};
     if (sample) {
-      const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + hk), 0u, 0xAC70u, (unsigned)S.seed,
-                                      (unsigned)(S.seed >> 32) ^ (unsigned)S.step_no);
+      const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + hk), ep_key, 0xAC70u, (unsigned)S.seed,
+                                      (unsigned)(S.seed >> 32));
       u3[0] = (float)(r.x >> 8) * (1.0f / 16777216.0f);
       u3[1] = (float)(r.y >> 8) * (1.0f / 16777216.0f);
       u3[2] = (float)(r.z >> 8) * (1.0f / 16777216.0f);
@@ -2414,6 +2418,7 @@ sdc_rollout_actor_quad_kernel(SdcDev S, const int K, const int rel_hint, const S
         sh.pool[r][j] = j < SDC_OBS_PAD ? o[j] : (j == SDC_P_WNEXT ? o[SDC_OBS_PAD + 11] : (j == SDC_P_NTNEXT ? o[SDC_OBS_PAD + 13] : o[2 * SDC_OBS_PAD + 12]));
     }
   }
+  const unsigned ep_key = S.rec[(size_t)(env0 + (lane >> 4)) * SDC_REC_DWORDS + R_EPISODE];   // (see sdc_rollout_actor_kernel)
   wave_sync();
 #pragma unroll 1
   for (int k = 0; k < K; k++) {
@@ -2438,8 +2443,8 @@ sdc_rollout_actor_quad_kernel(SdcDev S, const int K, const int rel_hint, const S
     }
     float u3[3] = {0.0f, 0.0f, 0.0f};
     if (sample) {
-      const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + row), 0u, 0xAC70u, (unsigned)S.seed,
-                                      (unsigned)(S.seed >> 32) ^ (unsigned)S.step_no);
+      const Philox4 r = philox4x32_10((unsigned)rel_now, (unsigned)(S.env_base + env_k + row), ep_key, 0xAC70u, (unsigned)S.seed,
+                                      (unsigned)(S.seed >> 32));
       u3[0] = (float)(r.x >> 8) * (1.0f / 16777216.0f);
       u3[1] = (float)(r.y >> 8) * (1.0f / 16777216.0f);
       u3[2] = (float)(r.z >> 8) * (1.0f / 16777216.0f);
