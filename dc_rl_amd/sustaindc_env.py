@@ -34,7 +34,10 @@ class SustainDC(Env):
         self.timezone_shift = env_config["timezone_shift"]
         self.days_per_episode = env_config["days_per_episode"]
         self.month = env_config.get("month") if env_config.get("month") is not None else 0
-        self._vec = SustainDCVecEnv(dict(env_config, _allow_agent_subset=True), n_envs=1, seed=seed,
+        # (the shared-observation option belongs to the HARL layer above this class: whichever, no warning about its absence here)
+        vec_args = dict(env_config, _allow_agent_subset=True)
+        vec_args.setdefault("nonoverlapping_shared_obs_space", True)
+        self._vec = SustainDCVecEnv(vec_args, n_envs=1, seed=seed,
                                     months=[self.month], device=device, auto_reset=False)
         self.ls_env, self.dc_env, self.bat_env = self._vec.ls_env, self._vec.dc_env, self._vec.bat_env
         # spaces of the trained agents only; the others are played by base agents (sustaindc_env.py:172-191)
