@@ -451,7 +451,7 @@ __device__ __forceinline__ void build_obs_pool(const double* nc, const double* n
 //   agent_dc (14): sustaindc_env.py:386-393   agent_bat (13): sustaindc_env.py:426-432
 // Branch-free: the pool index of entry j (0..77) of the padded [3][26] block, or -1 for a padding zero -- a switch here
 // compiles into a tree of exec-mask branches per output lane group (~100 instructions per 64 outputs).
-__device__ __forceinline__ int obs_pool_index(const int j) {
+__host__ __device__ constexpr inline int obs_pool_index(const int j) {
   static_assert(SDC_P_W == 13 && SDC_P_NT == 14 && SDC_P_WNEXT == 26 && SDC_P_NTNEXT == 27 && SDC_P_SOC == 28, "byte tables below");
   const int a = (j >= SDC_OBS_PAD ? 1 : 0) + (j >= 2 * SDC_OBS_PAD ? 1 : 0), k = j - SDC_OBS_PAD * a, t = k - 10;
   // entries 10.. of agent_dc: {W, W next, NT, NT next}; of agent_bat: {W, NT, SoC} (one byte each, low byte first)
@@ -465,6 +465,14 @@ __device__ __forceinline__ float obs_padded_at(const float* pool, int idx) {
   const int s = obs_pool_index(idx);
   const float v = pool[s < 0 ? 0 : s];
   return s < 0 ? 0.0f : v;
+}
+// ... the same through a 78-byte table in LDS (entry j = pool index of padded entry j, 0xFF for a padding zero: the step kernels
+// keep it behind their constant table, sdc_step.hip SDC_K_OBS_SRC): one byte read instead of ~12 compares and selects per
+// output element (the step writes 78 of them per env)
+__device__ __forceinline__ float obs_padded_lut(const float* pool, const unsigned char* osrc, int idx) {
+  const unsigned s = osrc[idx];
+  const float v = pool[s == 0xFFu ? 0u : s];
+  return s == 0xFFu ? 0.0f : v;
 }
 // HARL shared observation (harlsustaindc_env.py:78-80): ls state [0..25], states[1][11] = next workload, states[1][13]
 // = next outside temperature, states[2][-1].  The states are the PADDED 26-vectors (ss.pad_observations_v0 runs before

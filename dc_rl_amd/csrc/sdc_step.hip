@@ -130,7 +130,29 @@ constexpr double SDC_KVALS[] = {SDC_KVALS_LIST};
 constexpr int SDC_K_COUNT = (int)(sizeof(SDC_KVALS) / sizeof(double));
 constexpr int SDC_K_LDS = 128;     // table entries in LDS (two per lane)
 static_assert(SDC_K_COUNT <= SDC_K_LDS, "grow the LDS constant table");
-__device__ const double SDC_KTAB[SDC_K_LDS] = {SDC_KVALS_LIST};
+// ... and behind the constants, in the table's last ten entries, 78 BYTES: the pool index of every entry of the padded [3][26]
+// observation block (obs_pool_index; 0xFF = a padding zero), read by the output code (obs_padded_lut)
+constexpr int SDC_K_OBS_SRC = SDC_K_LDS - 10;
+static_assert(SDC_K_COUNT <= SDC_K_OBS_SRC && SDC_OBS_OUT <= 80, "the observation-source bytes sit behind the constants");
+struct SdcKTabInit {
+  double v[SDC_K_LDS];
+};
+constexpr SdcKTabInit sdc_make_ktab() {
+  SdcKTabInit t{};
+  for (int i = 0; i < SDC_K_COUNT; i++) t.v[i] = SDC_KVALS[i];
+  for (int w = 0; w < 10; w++) {
+    unsigned long long bits = 0ull;
+    for (int b = 0; b < 8; b++) {
+      const int j = 8 * w + b;
+      const int src = j < SDC_OBS_OUT ? obs_pool_index(j) : -1;
+      bits |= (unsigned long long)(src < 0 ? 0xFF : src) << (8 * b);
+    }
+    t.v[SDC_K_OBS_SRC + w] = __builtin_bit_cast(double, bits);
+  }
+  return t;
+}
+__device__ const SdcKTabInit SDC_KTAB_S = sdc_make_ktab();
+#define SDC_KTAB SDC_KTAB_S.v
 constexpr int sdc_kfind(const double v) {
   for (int i = 0; i < SDC_K_COUNT; i++)
     if (SDC_KVALS[i] == v) return i;
@@ -1729,7 +1751,7 @@ __device__ __forceinline__ void pair_step(const SdcDev& S, PairShared& sh, const
     const int idx = k * SDC_WAVE + lane;
     if (idx < n_here * SDC_OBS_OUT) {
       const int e = idx >= SDC_OBS_OUT ? 1 : 0, j = idx - e * SDC_OBS_OUT;
-      const float v = obs_padded_at(sh.pool[e], j);
+      const float v = obs_padded_lut(sh.pool[e], reinterpret_cast<const unsigned char*>(kt + SDC_K_OBS_SRC), j);
       SDC_OUT_STORE(v, &obs[(size_t)env0 * SDC_OBS_OUT + idx]);
       if (final_obs && ((term_m >> (e * HL)) & 1ull)) final_obs[(size_t)env0 * SDC_OBS_OUT + idx] = v;
     }
@@ -1901,7 +1923,7 @@ __device__ __forceinline__ void quad_step(const SdcDev& S, QuadShared& sh, const
     if (idx < QE * SDC_OBS_OUT) {
       const int e = (idx >= SDC_OBS_OUT ? 1 : 0) + (idx >= 2 * SDC_OBS_OUT ? 1 : 0) + (idx >= 3 * SDC_OBS_OUT ? 1 : 0);
       const int j = idx - e * SDC_OBS_OUT;
-      const float v = obs_padded_at(sh.pool[e], j);
+      const float v = obs_padded_lut(sh.pool[e], reinterpret_cast<const unsigned char*>(kt + SDC_K_OBS_SRC), j);
       SDC_OUT_STORE(v, &obs[(size_t)env0 * SDC_OBS_OUT + idx]);
       if (final_obs && ((term_m >> (e * QL)) & 1ull)) final_obs[(size_t)env0 * SDC_OBS_OUT + idx] = v;
     }
