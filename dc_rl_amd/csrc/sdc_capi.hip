@@ -355,6 +355,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   d.queue_max_d = (double)cfg->queue_max_len;
   d.hist_cap_d = (double)cfg->hist_cap;
   d.table_len = SDC_TABLE_LEN;
+  static_assert(SDC_TABLE_LEN % 8 == 0, "sdc_reset_kernel: a lane's 8 samples of the year's walk are all inside the table or all outside");
   d.lw = cfg->episode_steps + 18;
   d.qstride = (cfg->episode_steps + 63) / 64 * 64;
   d.max_roll_days = cfg->max_roll_days;
@@ -403,10 +404,6 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   A(d.qtab, (size_t)N * d.qstride);
   A(d.t_win, (size_t)N * d.lw);
   A(d.wb_win, (size_t)N * d.lw);
-  {
-    const size_t w = (size_t)(d.lw > SDC_NORM_WINDOW ? d.lw : SDC_NORM_WINDOW);
-    A(d.walk_tmp, (size_t)N * w);
-  }
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
   if (hipMemset(d.hist, 0xFF, sizeof(unsigned) * (size_t)N * SDC_HIST_STRIDE) != hipSuccess) {  // every slot empty
     sdc_destroy(h);

@@ -183,7 +183,6 @@ struct SdcDev {
   uint2* qtab;       // [N][qstride] {cum, cumT} per enqueue step of the episode
   double* t_win;     // [N][lw] dry bulb after noise + roll + clip, from the episode's first cursor
   double* wb_win;    // [N][lw] wet bulb likewise
-  double* walk_tmp;  // [N][max(SDC_NORM_WINDOW, lw)] scratch of the device-side reset
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
   unsigned* hdr;     // [N][SDC_HDR_DWORDS] per-env header: step hand-off + reward-side state (see SdcHdr)
   float* feat;       // [episode_steps + 1][N][SDC_FEAT_ROW] the trace-only observation entries of every step of the
@@ -497,15 +496,19 @@ __device__ __forceinline__ void stage_windows(const SdcDev& S, int loc, int ip, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// counter-based RNG for device-side resets: Philox4x32-10 (Salmon et al., SC'11)
+// counter-based RNG for device-side resets: Philox4x32-R (Salmon et al., SC'11; Random123's known-answer vectors for
+// R = 7 and R = 10 pin the NumPy restatement, tests/test_reset_ref.py, and the restatement pins this code,
+// tests/test_gpu_reset_pin.py).  R = 10 for the per-episode draws and the actor's sampler; R = 7 -- the paper's
+// Crush-resistant minimum with a safety margin -- for the 35 040 normals of a reset's weather walk, whose cost is the
+// 2 R quarter-rate 32 x 32 -> 64-bit products per block.
 
 struct Philox4 {
   unsigned x, y, z, w;
 };
-__device__ __forceinline__ Philox4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
-                                                 unsigned k1) {
+template <int R>
+__device__ __forceinline__ Philox4 philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
+  for (int r = 0; r < R; r++) {
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
     const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
     const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
@@ -517,6 +520,10 @@ __device__ __forceinline__ Philox4 philox4x32_10(unsigned c0, unsigned c1, unsig
     k1 += 0xBB67AE85u;
   }
   return Philox4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                                 unsigned k1) {
+  return philox4x32<10>(c0, c1, c2, c3, k0, k1);
 }
 // uniform in (0, 1) from 2 x 32 bits (53-bit mantissa)
 __device__ __forceinline__ double u01(unsigned hi, unsigned lo) {

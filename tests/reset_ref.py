@@ -5,9 +5,9 @@ product):
     coherent noise to dry / wet bulb, np.roll by whole days, clip to [0, 45], 30-day min / max from the cursor.  Pinned
     against the reference itself by tests/golden/weather_resets.npz (tests/test_weather_fixture.py).
   * `coherent_noise_legacy` -- `CoherentNoise.generate` (managers.py:35-48) on NumPy's legacy global MT19937 stream.
-  * `device_reset_expected` -- the DEVICE's draw scheme restated value for value (csrc/sdc_reset.hip): Philox4x32-10
+  * `device_reset_expected` -- the DEVICE's draw scheme restated operation for operation (csrc/sdc_reset.hip): Philox4x32-10
     keyed on (seed, global env index, episode), multiply-shift ranges for day / hour / roll, four fp32 Box-Muller normals
-    per Philox block, fp64 random walk, population std -> the same arithmetic as above.
+    per Philox4x32-7 block, fp64 random walk, population std -> the same arithmetic as above.
 """
 from __future__ import annotations
 
@@ -19,11 +19,12 @@ W0, W1 = 0x9E3779B9, 0xBB67AE85
 MASK = np.uint64(0xFFFFFFFF)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Philox4x32-10 (Salmon et al., SC'11) on uint32 arrays (broadcast); returns 4 uint32 arrays."""
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=10):
+    """Philox4x32-R (Salmon et al., SC'11) on uint32 arrays (broadcast); returns 4 uint32 arrays.  Pinned by Random123's
+    known-answer vectors for R = 7 and R = 10 (tests/test_reset_ref.py)."""
     c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint64) & MASK for x in np.broadcast_arrays(c0, c1, c2, c3))
     k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = M0 * c0
         p1 = M1 * c2
         n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
@@ -34,6 +35,10 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
         k0 = (k0 + W0) & 0xFFFFFFFF
         k1 = (k1 + W1) & 0xFFFFFFFF
     return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    return philox4x32(c0, c1, c2, c3, k0, k1, 10)
 
 
 def coherent_noise_legacy(seed, weight=0.02, desired_std=0.75, n=TL):
@@ -65,9 +70,9 @@ def device_draws(seed, env_global, episode, day_lo, day_hi, max_roll_days=14):
 
 
 def device_normals(seed, env_global, episode, n=TL):
-    """The n standard normals of one (env, episode): block c -> samples 4c .. 4c+3, fp32 Box-Muller."""
+    """The n standard normals of one (env, episode): Philox4x32-7 block c -> samples 4c .. 4c+3, fp32 Box-Muller."""
     nb = (n + 3) // 4
-    x, y, z, w = philox4x32_10(np.arange(nb, dtype=np.uint64), env_global, episode, 0x7E47, seed & 0xFFFFFFFF, seed >> 32)
+    x, y, z, w = philox4x32(np.arange(nb, dtype=np.uint64), env_global, episode, 0x7E47, seed & 0xFFFFFFFF, seed >> 32, 7)
     k24 = np.float32(1.0 / 16777216.0)
     half = np.float32(0.5)
     u1, u2, u3, u4 = (((v >> np.uint32(8)).astype(np.float32) + half) * k24 for v in (x, y, z, w))
@@ -95,7 +100,9 @@ def device_reset_expected(tables, seed, env_global, episode, day_lo, day_hi, epi
     c0 = day * 96 + hour * 4
     nz = device_normals(seed, env_global, episode).astype(np.float64)
     walk = np.cumsum(noise_weight * nz)
-    noise = (walk / np.sqrt(np.mean(walk * walk) - np.mean(walk) ** 2)) * noise_std if noise_std > 0 else np.zeros(TL)
+    # the device scales by noise_std / std (one division per reset) and accumulates the walk with fused multiply-adds:
+    # the same values to within fp64 rounding (~1e-15), far inside the 2e-6 C of its fp32 transcendentals
+    noise = walk * (noise_std / np.sqrt(np.mean(walk * walk) - np.mean(walk) ** 2)) if noise_std > 0 else np.zeros(TL)
     lw = episode_steps + 18
     r = reference_weather_reset(tables["T"], tables["WB"], noise, roll, c0, lw)
     Cseg = tables["C"][c0:c0 + 2880]
