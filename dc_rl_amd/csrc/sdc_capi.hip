@@ -174,8 +174,9 @@ void sync_mirror(sdc_handle* h) {
 // for the kernel's LDS windows go without (the step then computes the features itself)
 void launch_features(sdc_handle* h, const SdcDev& d, hipStream_t st) {
   if (!d.feat) return;
-  const size_t lds = sizeof(double) * (size_t)(d.episode_steps + 25 + d.lw) + sizeof(float) * SDC_WAVE * (SDC_FEAT_ROW + 1);
-  hipLaunchKernelGGL(sdc_features_kernel, dim3(d.n_envs), dim3(SDC_WAVE), lds, st, d);
+  const size_t win = sizeof(double) * (size_t)(d.episode_steps + 25 + d.lw), tile = sizeof(float) * SDC_WAVE * (SDC_FEAT_ROW + 1);
+  const int waves = win + 4 * tile <= 64 * 1024 ? 4 : 1;   // four wavefronts share an env's windows where four tiles fit beside them
+  hipLaunchKernelGGL(sdc_features_kernel, dim3(d.n_envs), dim3(SDC_WAVE * waves), win + waves * tile, st, d);
   (void)h;
 }
 
@@ -412,7 +413,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   A(d.hdr, (size_t)N * SDC_HDR_DWORDS);
   A(d.qwin, (size_t)N * (4 * SDC_WIN));
   d.feat = nullptr;
-  if (sizeof(double) * (size_t)(cfg->episode_steps + 25 + d.lw) <= 50 * 1024)   // the features kernel's LDS windows (+ 8.4 KB tile)
+  if (sizeof(double) * (size_t)(cfg->episode_steps + 25 + d.lw) <= 50 * 1024)   // the features kernel's LDS windows (+ 8.4 KB tile per wavefront)
     A(d.feat, (size_t)N * (size_t)(cfg->episode_steps + 1) * SDC_FEAT_ROW);
   A(d.rq_count, 4);
   A(d.rq, 3 * SDC_RQ_MAX);

@@ -75,12 +75,16 @@ __device__ __forceinline__ void extract_features(const double cur, const double 
 
 }  // namespace
 
-// One wavefront per env that has just been reset (record: episode step 0, no feature rows yet).  Dynamic LDS:
-// (steps + 25) + lw doubles -- the episode's normalised carbon-intensity and temperature windows.
-extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDev S) {
+// One workgroup of W wavefronts (W = blockDim.x / 64: 4, or 1 when the episode's windows leave no room for four tiles) per
+// env that has just been reset (record: episode step 0, no feature rows yet); the wavefronts share the windows and deal the
+// episode's 64-row passes round.  Dynamic LDS: (steps + 25) + lw doubles -- the episode's normalised carbon-intensity and
+// temperature windows -- + one 8.4 KB row tile per wavefront.  (One wavefront per env, rounds 2-4: 19.5 KB each = two per
+// SIMD, and the kernel's compute half is the latency of a wavefront's dependent fp64 chains: it scales with residency.)
+extern "C" __global__ __launch_bounds__(4 * SDC_WAVE) void sdc_features_kernel(SdcDev S) {
   extern __shared__ double lds[];
   const int env = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (SDC_WAVE - 1);
+  const int wv = threadIdx.x / SDC_WAVE, n_wv = blockDim.x / SDC_WAVE;
   unsigned* recp = S.rec + (size_t)env * SDC_REC_DWORDS;
   const unsigned r = recp[lane];
   if (rec_i32(r, R_TREL) != 0 || rec_i32(r, R_FEAT_OK) != 0) return;
@@ -92,16 +96,16 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDe
   double* ntw = lds + (steps + 25);   // ntw[k] = NT[c0 + k],      k in [0, lw)
   // a pass's 64 rows are assembled in LDS (row stride 33 floats: conflict-free for one lane per row) and go out as
   // whole 128-byte rows, two per store instruction
-  float* tile = reinterpret_cast<float*>(ntw + S.lw);
   constexpr int TS = SDC_FEAT_ROW + 1;
+  float* tile = reinterpret_cast<float*>(ntw + S.lw) + wv * (SDC_WAVE * TS);
   const double* tC = S.tabC + (size_t)loc * TL;
   const double* tW = S.tabW + (size_t)loc * TL;
   const double* tw = S.t_win + (size_t)env * S.lw;
   auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
-  for (int j = lane; j < steps + 25; j += SDC_WAVE) ncw[j] = (tC[tix(c0 - 16 + j)] - ci_min) / ci_den;   // managers.py:437
-  for (int k = lane; k < S.lw; k += SDC_WAVE) ntw[k] = (tw[k] - t_min) / t_den;                           // managers.py:608
+  for (int j = threadIdx.x; j < steps + 25; j += blockDim.x) ncw[j] = (tC[tix(c0 - 16 + j)] - ci_min) / ci_den;   // managers.py:437
+  for (int k = threadIdx.x; k < S.lw; k += blockDim.x) ntw[k] = (tw[k] - t_min) / t_den;                           // managers.py:608
   __syncthreads();
-  for (int s0 = 0; s0 <= steps; s0 += SDC_WAVE) {
+  for (int s0 = wv * SDC_WAVE; s0 <= steps; s0 += n_wv * SDC_WAVE) {   // (the tile is the wavefront's own: wave-level syncs)
    const int s = s0 + lane;                         // row s: the observation at i' = c0 + s
    if (s <= steps) {
     const int ip = c0 + s;
@@ -161,14 +165,14 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_features_kernel(SdcDe
     put_f64(SDC_FEAT_WB, S.wb_win[(size_t)env * S.lw + sp]);
     o[SDC_FEAT_T1] = (float)tw[sp + 1];
    }
-   __syncthreads();
+   wave_sync();
    const int n_rows = min(SDC_WAVE, steps + 1 - s0);
 #pragma unroll 4
    for (int j = 0; j < SDC_WAVE / 2; j++) {
      const int rr = 2 * j + (lane >> 5), k = lane & 31;
      if (rr < n_rows) S.feat[feat_row_offset(S, env, s0 + rr) + k] = tile[rr * TS + k];
    }
-   __syncthreads();
+   wave_sync();
   }
-  if (lane == R_FEAT_OK) recp[lane] = 1u;
+  if (threadIdx.x == R_FEAT_OK) recp[lane] = 1u;
 }
