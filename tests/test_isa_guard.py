@@ -8,7 +8,10 @@ A compiler bump or an innocent edit regresses these silently -- the kernels stay
   * the env's three actions are requested by ONE hand-issued `global_load_dwordx3` inside the first burst of loads (before
     any wait for memory: no second round trip), and nothing reads its destination before an `s_waitcnt vmcnt(0)`
     (the inline asm is invisible to the compiler's wait-count insertion: sdc_step.hip "requested FIRST and by hand").
-The file is compiled once, with the production flags of dc_rl_amd/_lib.py."""
+  * the episode boundary's two kernels keep their residency: `sdc_reset_kernel` <= 128 VGPRs (four wavefronts per SIMD = all
+    4096 resets of the timed configuration in flight at once: the kernel is VALU-issue bound and ends with its last wavefront)
+    and `sdc_features_kernel` <= 168 (three per SIMD; its LDS windows are shared by the four wavefronts of an env), no scratch.
+sdc_step.hip is compiled once, with the production flags of dc_rl_amd/_lib.py."""
 import os
 import re
 import subprocess
@@ -48,6 +51,31 @@ def compiled():
         if m and name:
             usage[name][m.group(1).strip()] = int(m.group(2))
     return asm, usage
+
+
+def _usage_of(src):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    flags = [f for f in L.HIPCC_FLAGS if f != "-shared"]
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([hipcc] + flags + ["-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", src, "-o", os.path.join(td, "o.o")],
+                           cwd=L.CSRC, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    u = {}
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m:
+            u[m.group(1).strip()] = int(m.group(2))
+    return u
+
+
+@pytest.mark.parametrize("src,vgprs,waves", [("sdc_reset.hip", 128, 4), ("sdc_features.hip", 168, 3)])
+def test_episode_boundary_kernels_keep_their_residency(src, vgprs, waves):
+    u = _usage_of(src)
+    assert u["ScratchSize"] == 0 and u["VGPRs Spill"] == 0, (src, u)
+    assert u["VGPRs"] <= vgprs and u["Occupancy"] >= waves, (src, u)
+    print(src, u["VGPRs"], u["Occupancy"], u.get("LDS Size"))
 
 
 def test_no_scratch_and_register_budget(compiled):
