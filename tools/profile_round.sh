@@ -44,7 +44,11 @@ bash tools/pmc_latency.sh > $O/pmc_latency.txt 2>&1
 # round 4: what an unchanged single-process HARL runner gets, the one-process multi-device bench, the boundary's two kernels
 timeout 600 python tools/harl_loop_rate.py 48 512 4096 > $O/harl_loop_rate.txt 2>&1
 timeout 600 python bench.py --gpus 2 --single-process --devices 0,0 --steps 200 --warmup 20 > $O/bench_single_process.txt 2>&1
-bash tools/reset_prof2.sh > $O/reset_kernels.txt 2>&1
+bash tools/reset_time.sh > $O/reset_kernels.txt 2>&1
+bash tools/reset_pmc.sh > $O/reset_pmc.txt 2>&1
+# (phase stamps of sdc_reset_kernel: the measurement build tools/bin/lib_rt.so = the production sources with -DSDC_RT)
+if [ -f tools/bin/lib_rt.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/prod.so; cp tools/bin/lib_rt.so dc_rl_amd/csrc/libsustaindc_hip.so; for n in 1024 2048 4096; do timeout 200 python tools/reset_phases.py $n; done > $O/reset_phases.txt 2>&1; cp /tmp/prod.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
+hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o /tmp/valu_rates 2>/dev/null && timeout 200 /tmp/valu_rates > $O/valu_rates.txt 2>&1
 grep -v amdgpu.ids $O/*.txt | tail -60
 cut -c1-600 $O/bench.json
 ls $O
