@@ -39,7 +39,7 @@ extern "C" __global__ void sdc_rollout_actor_quad_kernel(SdcDev S, int K, int re
                                                          float* obs_latch);
 size_t sdc_rollout_actor_quad_lds_bytes();
 extern "C" __global__ void sdc_reward_verify_kernel(SdcDev S, float* info);
-extern "C" __global__ void sdc_features_kernel(SdcDev S);
+extern "C" __global__ void sdc_features_kernel(SdcDev S, int use_sma);
 extern "C" __global__ void sdc_rollout_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                               unsigned char* done, float* info, float* final_obs, float* rew);
 
@@ -174,9 +174,12 @@ void sync_mirror(sdc_handle* h) {
 // for the kernel's LDS windows go without (the step then computes the features itself)
 void launch_features(sdc_handle* h, const SdcDev& d, hipStream_t st) {
   if (!d.feat) return;
-  const size_t win = sizeof(double) * (size_t)(d.episode_steps + 25 + d.lw), tile = sizeof(float) * SDC_WAVE * (SDC_FEAT_ROW + 1);
-  const int waves = win + 4 * tile <= 64 * 1024 ? 4 : 1;   // four wavefronts share an env's windows where four tiles fit beside them
-  hipLaunchKernelGGL(sdc_features_kernel, dim3(d.n_envs), dim3(SDC_WAVE * waves), win + waves * tile, st, d);
+  const size_t win = sizeof(double) * (size_t)(d.episode_steps + 25 + d.lw), sma = sizeof(double) * (size_t)(d.episode_steps + 22);
+  const size_t tile = sizeof(float) * SDC_WAVE * (SDC_FEAT_ROW + 1), cap = 64 * 1024;
+  // four wavefronts share an env's windows (and the window's moving averages, computed once) where four tiles fit beside them
+  const int waves = win + sma + 4 * tile <= cap ? 4 : 1;
+  const int use_sma = win + sma + waves * tile <= cap ? 1 : 0;
+  hipLaunchKernelGGL(sdc_features_kernel, dim3(d.n_envs), dim3(SDC_WAVE * waves), win + (use_sma ? sma : 0) + waves * tile, st, d, use_sma);
   (void)h;
 }
 

@@ -78,9 +78,9 @@ __device__ __forceinline__ void extract_features(const double cur, const double 
 // One workgroup of W wavefronts (W = blockDim.x / 64: 4, or 1 when the episode's windows leave no room for four tiles) per
 // env that has just been reset (record: episode step 0, no feature rows yet); the wavefronts share the windows and deal the
 // episode's 64-row passes round.  Dynamic LDS: (steps + 25) + lw doubles -- the episode's normalised carbon-intensity and
-// temperature windows -- + one 8.4 KB row tile per wavefront.  (One wavefront per env, rounds 2-4: 19.5 KB each = two per
+// temperature windows and the carbon-intensity window's four-tap moving averages -- + one 8.4 KB row tile per wavefront.  (One wavefront per env, rounds 2-4: 19.5 KB each = two per
 // SIMD, and the kernel's compute half is the latency of a wavefront's dependent fp64 chains: it scales with residency.)
-extern "C" __global__ __launch_bounds__(4 * SDC_WAVE) void sdc_features_kernel(SdcDev S) {
+extern "C" __global__ __launch_bounds__(4 * SDC_WAVE) void sdc_features_kernel(SdcDev S, const int use_sma) {
   extern __shared__ double lds[];
   const int env = blockIdx.x;
   const int lane = threadIdx.x & (SDC_WAVE - 1);
@@ -94,16 +94,24 @@ extern "C" __global__ __launch_bounds__(4 * SDC_WAVE) void sdc_features_kernel(S
   const double t_min = rec_f64(r, R_T_MIN), t_den = rec_f64(r, R_T_DEN);
   double* ncw = lds;                  // ncw[j] = NC[c0 - 16 + j], j in [0, steps + 25)
   double* ntw = lds + (steps + 25);   // ntw[k] = NT[c0 + k],      k in [0, lw)
+  // sma[m] = (((ncw[m] + ncw[m+1]) + ncw[m+2]) + ncw[m+3]) / 4, m in [0, steps + 22): the four-tap moving average of
+  // sustaindc_env.py:313-317, the same expression a row used to evaluate 20 times over (6 future + 14 past points; the window
+  // of row s+1 is the window of row s moved by one) -- once per position, by the whole workgroup
+  // (use_sma = 0: episodes whose windows leave no room for it -- 30-day ones -- evaluate the expression per row as before)
+  double* sma = ntw + S.lw;
+  const int n_sma = use_sma ? steps + 22 : 0;
   // a pass's 64 rows are assembled in LDS (row stride 33 floats: conflict-free for one lane per row) and go out as
   // whole 128-byte rows, two per store instruction
   constexpr int TS = SDC_FEAT_ROW + 1;
-  float* tile = reinterpret_cast<float*>(ntw + S.lw) + wv * (SDC_WAVE * TS);
+  float* tile = reinterpret_cast<float*>(sma + n_sma) + wv * (SDC_WAVE * TS);
   const double* tC = S.tabC + (size_t)loc * TL;
   const double* tW = S.tabW + (size_t)loc * TL;
   const double* tw = S.t_win + (size_t)env * S.lw;
   auto tix = [&](int idx) { return idx < 0 ? 0 : (idx > TL - 1 ? TL - 1 : idx); };
   for (int j = threadIdx.x; j < steps + 25; j += blockDim.x) ncw[j] = (tC[tix(c0 - 16 + j)] - ci_min) / ci_den;   // managers.py:437
   for (int k = threadIdx.x; k < S.lw; k += blockDim.x) ntw[k] = (tw[k] - t_min) / t_den;                           // managers.py:608
+  __syncthreads();
+  for (int m = threadIdx.x; m < n_sma; m += blockDim.x) sma[m] = (((ncw[m] + ncw[m + 1]) + ncw[m + 2]) + ncw[m + 3]) / 4;
   __syncthreads();
   for (int s0 = wv * SDC_WAVE; s0 <= steps; s0 += n_wv * SDC_WAVE) {   // (the tile is the wavefront's own: wave-level syncs)
    const int s = s0 + lane;                         // row s: the observation at i' = c0 + s
@@ -124,13 +132,13 @@ extern "C" __global__ __launch_bounds__(4 * SDC_WAVE) void sdc_features_kernel(S
     {  // future: 4-tap moving average of [NC[i'], NC[i'+1..i'+8]]: 9 -> 6 points (sustaindc_env.py:313, 317)
       double sm[6];
 #pragma unroll
-      for (int j = 0; j < 6; j++) sm[j] = (((nc[16 + j] + nc[17 + j]) + nc[18 + j]) + nc[19 + j]) / 4;
+      for (int j = 0; j < 6; j++) sm[j] = use_sma ? sma[s + 16 + j] : (((nc[16 + j] + nc[17 + j]) + nc[18 + j]) + nc[19 + j]) / 4;
       o[SDC_P_CI7 + 0] = (float)slope_of(sm);
     }
     if (ip >= 16) {  // past: [NC[i'-16..i'-1], NC[i']]: 17 -> 14 points
       double sm[14];
 #pragma unroll
-      for (int j = 0; j < 14; j++) sm[j] = (((nc[j] + nc[j + 1]) + nc[j + 2]) + nc[j + 3]) / 4;
+      for (int j = 0; j < 14; j++) sm[j] = use_sma ? sma[s + j] : (((nc[j] + nc[j + 1]) + nc[j + 2]) + nc[j + 3]) / 4;
       o[SDC_P_CI7 + 1] = (float)slope_of(sm);
     } else {         // EMPTY past slice (utils/managers.py:482-483): np.convolve then yields 4 copies of NC[i'] / 4
       const double sm[4] = {nc[16] / 4, nc[16] / 4, nc[16] / 4, nc[16] / 4};

@@ -43,13 +43,15 @@ __device__ __forceinline__ double wave_incl_scan_f64(double v, int) {
 
 // four standard normals per Philox4x32-7 block: two Box-Muller pairs in fp32 (hardware log2 / sqrt / sin / cos); the
 // random walk itself is accumulated in fp64.  Block c of (env, episode) yields the normals of samples 4c .. 4c+3.
-// ((x >> 8) + 0.5) * 2^-24 as ONE fused multiply-add: x * 2^-24 is exact, so the single rounding is the same one.
+// uniform = (fp32(x) + 0.5) * 2^-32 as ONE fused multiply-add on the 32-bit word converted as it is (v_cvt_f32_u32 rounds to
+// nearest even at 24 bits; fp32(x) * 2^-32 is exact, so there is one more rounding: in (0, 1], 1.0 for the top 128 words --
+// a radius of 0 / an angle of one whole revolution, both fine).
 __device__ __forceinline__ void normals4(const SdcDev& S, int env, int episode, int c, float* nz) {
   const Philox4 r = philox4x32<7>((unsigned)c, (unsigned)(S.env_base + env), (unsigned)episode, 0x7E47u, (unsigned)S.seed,
                                   (unsigned)(S.seed >> 32));
-  const float k24 = 1.0f / 16777216.0f, k25 = 1.0f / 33554432.0f;
-  const float u1 = __builtin_fmaf((float)(r.x >> 8), k24, k25), u2 = __builtin_fmaf((float)(r.y >> 8), k24, k25);   // (0, 1)
-  const float u3 = __builtin_fmaf((float)(r.z >> 8), k24, k25), u4 = __builtin_fmaf((float)(r.w >> 8), k24, k25);
+  const float k32 = 1.0f / 4294967296.0f, k33 = 1.0f / 8589934592.0f;
+  const float u1 = __builtin_fmaf((float)r.x, k32, k33), u2 = __builtin_fmaf((float)r.y, k32, k33);
+  const float u3 = __builtin_fmaf((float)r.z, k32, k33), u4 = __builtin_fmaf((float)r.w, k32, k33);
   // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u): v_log_f32 and v_sqrt_f32 as they are (1 ulp; the argument is in [0, 35], no
   // denormal / special-case handling needed -- the IEEE expansion of sqrtf is 13 more instructions per root)
   const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
@@ -199,7 +201,17 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
       };
       double carry = 0.0, sum = 0.0, sumsq = 0.0;
       int n_hit = 0;
+      // the SIMD's four resident wavefronts take turns at the issue priorities, block by block: the arbiter serves the OLDEST
+      // wavefront first, so without this they finish the walk one after the other and the last one walks alone at a lone
+      // wavefront's pace (157 -> 152 us per reset of 4096 envs)
+      const int slot = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u);   // HW_ID.wave_id: the wavefront's slot on its SIMD
       for (int base = 0; base < TL; base += BLK) {
+        switch ((slot + (base >> 9)) & 3) {
+          case 0: __builtin_amdgcn_s_setprio(0); break;
+          case 1: __builtin_amdgcn_s_setprio(1); break;
+          case 2: __builtin_amdgcn_s_setprio(2); break;
+          default: __builtin_amdgcn_s_setprio(3); break;
+        }
         if (reaches_window(base)) {
           if (lane == 0 && n_hit < ResetShared::MAX_HIT) {
             sh.hit_base[n_hit] = base;
@@ -218,6 +230,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) void sdc_reset_kernel(SdcDev S
           }
         }
       }
+      __builtin_amdgcn_s_setprio(0);
       RT_STAMP(2);
       sum = wave_sum_f64(sum);
       sumsq = wave_sum_f64(sumsq);

@@ -73,9 +73,8 @@ def device_normals(seed, env_global, episode, n=TL):
     """The n standard normals of one (env, episode): Philox4x32-7 block c -> samples 4c .. 4c+3, fp32 Box-Muller."""
     nb = (n + 3) // 4
     x, y, z, w = philox4x32(np.arange(nb, dtype=np.uint64), env_global, episode, 0x7E47, seed & 0xFFFFFFFF, seed >> 32, 7)
-    k24 = np.float32(1.0 / 16777216.0)
-    half = np.float32(0.5)
-    u1, u2, u3, u4 = (((v >> np.uint32(8)).astype(np.float32) + half) * k24 for v in (x, y, z, w))
+    # (fp32(word) + 0.5) * 2^-32 with ONE rounding after the conversion's own (a fused multiply-add on the device): exact in fp64
+    u1, u2, u3, u4 = ((v.astype(np.float32).astype(np.float64) * 2.0 ** -32 + 2.0 ** -33).astype(np.float32) for v in (x, y, z, w))
     c = np.float32(-1.3862943611198906)
     r1 = np.sqrt(c * np.log2(u1), dtype=np.float32)
     r2 = np.sqrt(c * np.log2(u3), dtype=np.float32)
