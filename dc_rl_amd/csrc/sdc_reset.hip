@@ -29,7 +29,7 @@ struct ResetShared {
   double hit_carry[MAX_HIT];
 };
 
-// inclusive prefix sum over the 64 lanes on the DPP data path (no LDS round trips: this scan runs 137 times per reset):
+// inclusive prefix sum over the 64 lanes on the DPP data path (no LDS round trips: this scan runs once per 512 samples of the year, ~76 times per reset):
 // row_shr 1, 2, 4, 8 scan each row of 16, row_bcast15 / row_bcast31 carry the row totals upwards
 __device__ __forceinline__ double wave_incl_scan_f64(double v, int) {
   v += dpp_f64<0x111>(v);

@@ -6,7 +6,7 @@
    roll direction and normalisation window included (one engine runs 30-day episodes, so the whole 2880-sample
    window is inside t_win).
 2. Against a NumPy restatement of the device's own draw scheme (tests/reset_ref.py: Philox4x32-10, multiply-shift
-   ranges, fp32 Box-Muller, fp64 walk / std 0.75): day / hour / roll exactly, windows and bounds to 2e-6 C
+   ranges; Philox4x32-7, fp32 Box-Muller, fp64 walk / std 0.75): day / hour / roll exactly, windows and bounds to 2e-6 C
    (the device's v_log_f32 / v_sin_f32 / v_cos_f32 are hardware approximations of the fp32 functions NumPy evaluates)."""
 import numpy as np
 import pytest
