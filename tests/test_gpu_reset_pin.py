@@ -105,3 +105,24 @@ def test_device_draws_match_the_numpy_restatement(steps, n_envs):
     print("device reset vs NumPy restatement: max |dT| =", worst)
     assert worst <= 2e-6      # measured 8.4e-7
     eng.close()
+
+
+def test_device_reset_without_weather_noise_is_exact():
+    """`weather_noise_std = 0`: the device draws day / hour / roll, and the windows are the table rolled and clipped -- no
+    transcendental anywhere, so every value equals the NumPy restatement's exactly (the kernel's other branch: the walk and
+    the second visit of its window blocks are skipped, the batched add / roll / clip pass runs instead)."""
+    tb = traces.synthetic_tables("ny", 0)
+    seed, base, steps, n = 77, 5000, 672, 96
+    eng = _engine(n, steps, [tb], seed=seed, env_index_base=base, weather_noise_std=0.0)
+    lo, hi = np.full(n, 3), np.full(n, 361)          # the whole year: cursors near both ends, rolls that wrap
+    eng.assign(0, 0, lo, hi)
+    eng.reset()
+    day, hq, cur = eng.get_state("day"), eng.get_state("hourq"), eng.get_state("cursor")
+    tw, wb = eng.get_state("t_win"), eng.get_state("wb_win")
+    tmin, tden = eng.get_state("t_min"), eng.get_state("t_den")
+    for i in range(n):
+        x = RR.device_reset_expected(tb, seed, base + i, 1, int(lo[i]), int(hi[i]), steps, noise_std=0.0)
+        assert (day[i], hq[i] // 4, cur[i]) == (x["day"], x["hour"], x["c0"]), i
+        assert np.array_equal(tw[i], x["t_win"]) and np.array_equal(wb[i], x["wb_win"]), i
+        assert tmin[i] == x["t_min"] and tden[i] == x["t_den"], i
+    eng.close()
