@@ -115,9 +115,10 @@ __device__ __forceinline__ void a_operands(float (&P)[4], const float x0, const 
   P[2] = odd ? o2 : e2;
   P[3] = odd ? o3 : e3;
 }
-// bias, activation, LayerNorm(64) of the three agents' layer outputs at once (torch: biased variance, eps 1e-5; one
-// pass -- the inputs are activations in [-1, 1] or a ReLU's outputs of order one: E[x^2] - mean^2 costs ~1e-7 of the
-// value).  In: acc[a][e] = env e's pre-activation; out: h[a][e], lane = unit.
+// bias, activation, LayerNorm(64) of the three agents' layer outputs at once (torch: biased variance, eps 1e-5).  One pass over
+// SHIFTED values d = v - v[unit 0]: E[d^2] - E[d]^2 is the same variance, and with a ReLU's unbounded outputs (activations of
+// ~30 with a small spread) the unshifted form's cancellation error passed eps; shifted, it is the spread that is squared.
+// In: acc[a][e] = env e's pre-activation; out: h[a][e], lane = unit.
 template <int KIND>
 __device__ __forceinline__ void epilogue(const f4 (&acc)[3], const float (&bias)[3], const float (&g)[3], const float (&b)[3],
                                          float (&h)[3][2]) {
@@ -127,9 +128,10 @@ __device__ __forceinline__ void epilogue(const f4 (&acc)[3], const float (&bias)
 #pragma unroll
     for (int e = 0; e < 2; e++) {
       const float v = activate<KIND>(acc[a][e] + bias[a]);
-      h[a][e] = v;
-      r[4 * a + e] = v;
-      r[4 * a + 2 + e] = v * v;
+      const float d = v - __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+      h[a][e] = d;
+      r[4 * a + e] = d;
+      r[4 * a + 2 + e] = d * d;
     }
   row_sums<12>(r);
 #pragma unroll
@@ -310,9 +312,10 @@ __device__ __forceinline__ void epilogue4(const f4 (&acc)[3], const float (&bias
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const float v = activate<KIND>(acc[a][e] + bias[a]);
-      h[a][e] = v;
-      r[8 * a + e] = v;
-      r[8 * a + 4 + e] = v * v;
+      const float d = v - __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));   // (shifted moments: see epilogue)
+      h[a][e] = d;
+      r[8 * a + e] = d;
+      r[8 * a + 4 + e] = d * d;
     }
   row_sums<24>(r);
 #pragma unroll

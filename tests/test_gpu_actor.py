@@ -109,6 +109,41 @@ def test_in_kernel_actor_matches_torch_and_external_rollout(activation, N, flags
     b_eng.close()
 
 
+@pytest.mark.parametrize("flags", [0, 1024])
+def test_layernorm_of_large_relu_activations(flags):
+    """ReLU outputs of ~30 with a spread of ~0.5 (large biases, small weights): the hidden LayerNorms' one-pass variance must not
+    lose the spread to cancellation (advisor finding of round 3: E[x^2] - mean^2 in fp32 is ~1e-4 off at this magnitude, ten times
+    eps; the moments are taken of values shifted by the first unit's)."""
+    import torch
+    N, K = 64, 8
+    nets = [_torch_actor(300 + a, "relu") for a in range(3)]
+    with torch.no_grad():
+        for m in nets:
+            fc = m.base.mlp.fc
+            fc[0].weight.mul_(0.15); fc[0].bias.add_(30.0)
+            fc[3].weight.mul_(0.15); fc[3].bias.add_(40.0)
+    eng = _engine(N, 96, debug_flags=flags)
+    for a in range(3):
+        sd = dict(nets[a].state_dict())
+        sd["activation"] = "relu"
+        eng.set_actor(a, sd)
+    obs0, _ = eng.reset()
+    obs0 = obs0.clone()
+    obs, share, rew, done, info, acts, logits = eng.rollout_actor(K, sample=False, want_logits=True)
+    inp = torch.cat([obs0[None], obs[:-1]], 0)
+    worst = 0.0
+    for a in range(3):
+        with torch.no_grad():
+            x = inp[:, :, a, :].cpu()
+            h1 = nets[a].base.mlp.fc[1](nets[a].base.mlp.fc[0](nets[a].base.feature_norm(x)))
+            assert h1.mean() > 20 and h1.std(-1).mean() < 3        # the regime the finding is about
+            ref = nets[a](x).numpy()
+        worst = max(worst, float(np.abs(logits[:, :, a, :].cpu().numpy() - ref).max()))
+    print("large ReLU activations: max |logit error| %.2e" % worst)
+    assert worst <= 5e-4, worst
+    eng.close()
+
+
 def test_in_kernel_actor_sampling_follows_the_softmax():
     import torch
     N, steps = 2048, 96
