@@ -1,6 +1,7 @@
 """Oracle parity in the production configuration at the sizes / kernels the bench line quotes rates for:
 
-  * the four-envs-per-wavefront step kernel (`sdc_dynamics_quad_kernel`: the default from 6 656 envs on) at 12 288 envs
+  * the four-envs-per-wavefront step kernel (`sdc_dynamics_quad_kernel`: the default from 6 656 envs on) at 12 288 envs, 32 768
+    envs (round 4: eight wavefronts per SIMD, the largest batch a rate is quoted for),
     (three whole occupancy rounds) and 16 384 envs (a fourth wavefront per SIMD that runs alone), against the ORACLE --
     until now it was only compared with the two-env kernels, and never above 8 200 envs;
   * BASELINE configs[3] at its own size: 4096 envs x 16 / 20 / 25 racks x three locations with `debug_flags = 0`, full rings
@@ -21,9 +22,10 @@ from tests.production_rig import ProductionRig
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N", [12288, 16384])
+@pytest.mark.parametrize("N", [12288, 16384, 32768])
 def test_quad_step_kernel_production_vs_oracle(N):
-    """Four envs per wavefront by default (debug_flags = 0) at 12 288 / 16 384 envs: 330 single steps over two auto-resets,
+    """Four envs per wavefront by default (debug_flags = 0) at 12 288 / 16 384 / 32 768 envs (the largest batch a rate is quoted
+    for: eight wavefronts per SIMD, three resident): 330 single steps over two auto-resets,
     all four rows of the first / last wavefronts and both sides of every occupancy round sampled, every reward-state path."""
     rig = ProductionRig(N, debug_flags=0, episode_steps=120, seed=1000 + N, envs_per_wave=4)
     assert len(rig.sample) >= 72
