@@ -1,8 +1,8 @@
 """Oracle parity in the production configuration at the sizes / kernels the bench line quotes rates for:
 
-  * the four-envs-per-wavefront step kernel (`sdc_dynamics_quad_kernel`: the default from 6 656 envs on) at 12 288 envs, 32 768
-    envs (round 4: eight wavefronts per SIMD, the largest batch a rate is quoted for),
-    (three whole occupancy rounds) and 16 384 envs (a fourth wavefront per SIMD that runs alone), against the ORACLE --
+  * the four-envs-per-wavefront step kernel (`sdc_dynamics_quad_kernel`: the default from 6 656 envs on) at 12 288 envs
+    (three whole occupancy rounds), 16 384 envs (a fourth wavefront per SIMD) and 32 768 envs (eight per SIMD, three resident:
+    the largest batch a rate is quoted for), against the ORACLE --
     until now it was only compared with the two-env kernels, and never above 8 200 envs;
   * BASELINE configs[3] at its own size: 4096 envs x 16 / 20 / 25 racks x three locations with `debug_flags = 0`, full rings
     and deferred re-centring under the full request load (round 4: served by the common-case kernels, every env carrying
