@@ -870,11 +870,11 @@ def main():
             except Exception as e:
                 sec["harl_unchanged_loop"] = {"error": repr(e)}
             scan = []
-            for n in (2048, 8192, 16384):
+            for n in (2048, 8192, 16384, 32768):   # (32 768: where one GPU's rate still grows -- eight four-env wavefronts per SIMD)
                 try:
-                    r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=n >= 8192)
+                    r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=8192 <= n <= 16384)
                     r["rate_vs_4096_envs"] = round(r["value"] / value, 4)
-                    if n >= 8192 and not args.no_pmc:
+                    if 8192 <= n <= 16384 and not args.no_pmc:
                         r["roofline"] = scan_roofline(n, args.episode_steps, r["us_per_step"], args)
                     scan.append(r)
                 except Exception as e:
