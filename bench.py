@@ -338,7 +338,7 @@ def pmc_summary(c):
 
 
 def scan_roofline(n_envs, episode_steps, us_per_step, args):
-    """The counter passes of `pmc_collect` at another batch size (the four-envs-per-wavefront kernel from 6656 envs on):
+    """The counter passes of `pmc_collect` at another batch size (the four-envs-per-wavefront kernel above 5632 envs):
     the same physical figures as the headline's `roofline`, against the wall-clock time per step of that batch."""
     import argparse as _ap
     a2 = _ap.Namespace(**vars(args))
@@ -351,7 +351,7 @@ def scan_roofline(n_envs, episode_steps, us_per_step, args):
     simd_cycles = N_SIMD * t * MAX_CLOCK_GHZ * 1e9
     traffic = pm.get("hbm_bytes_per_launch")
     valu = pm.get("valu_active_simd_cycles_per_launch")
-    out = {"bound": "valu", "kernel": "sdc_dynamics_quad_kernel" if n_envs >= 6656 and n_envs % 4 == 0 else STEP_KERNEL,
+    out = {"bound": "valu", "kernel": "sdc_dynamics_quad_kernel" if n_envs >= 5636 and n_envs % 4 == 0 else STEP_KERNEL,
            "frac": round(valu / simd_cycles, 4) if valu else None,
            "issue_frac": (round(pm["issue_active_simd_cycles_per_launch"] / simd_cycles, 4)
                           if pm.get("issue_active_simd_cycles_per_launch") else None),

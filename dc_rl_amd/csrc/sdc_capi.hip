@@ -229,7 +229,10 @@ void note_features(sdc_handle* h, int e) {
 #endif
 constexpr int FAST_DEBUG_FLAGS = SDC_FAST_DEBUG ? (8 | 16 | 32 | 256) : 0;   // (measurement builds: see sdc_step.hip)
 #ifndef SDC_QUAD_MIN_ENVS_STEP
-#define SDC_QUAD_MIN_ENVS_STEP 6656
+// (round 4: 5 632 envs = 704 env-pair workgroups = 2.75 dispatch rounds is the last size at which two envs per wavefront win --
+// 12.6 against 13.1 us per step; 6 144 envs: 16.5 against 13.3, the third round full and the spare sweep wavefronts pushing 128 env
+// wavefronts into a fourth)
+#define SDC_QUAD_MIN_ENVS_STEP 5636
 #endif
 #ifndef SDC_QUAD_MIN_ENVS_LOOP
 #define SDC_QUAD_MIN_ENVS_LOOP 4100

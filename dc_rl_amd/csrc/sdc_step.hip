@@ -2064,6 +2064,25 @@ __device__ __forceinline__ void serve_recentring_requests_coop(const SdcDev& S, 
   }
 }
 
+// Issue priority of an env workgroup by the dispatch round it arrives in (a round = 256 workgroups, one per CU: one more wavefront
+// on every SIMD).  A SIMD issues from its OLDEST wavefront first, so of the wavefronts that share a SIMD the one from a later round
+// would finish last by as much as the others took: up to ~2.75 rounds (all resident: three wavefronts per SIMD at most) the later
+// rounds run the dynamics at raised priority, which evens them out (4096 envs: 1.8 us).  Beyond three rounds the wavefronts of the
+// fourth, fifth ... round start when an older one ENDS: there the older ones should end early, and only the LAST round -- the
+// wavefronts that end the launch -- is raised (round 4, four-env kernel: 16 384 envs 26.4 -> 24.9 us, 13 312 envs 23.9 -> 22.2,
+// 24 576 envs 36.2 -> 34.1); with exactly three full rounds (12 288 envs: the spare sweep wavefronts push 128 env wavefronts into
+// a fourth round of their own) no raise is best (22.4 -> 21.5).
+__device__ __forceinline__ void set_round_priority(const int pb, const int n_blocks) {
+  bool late;
+  if (4 * n_blocks <= 11 * SDC_CUS) late = pb >= SDC_CUS;
+  else if (n_blocks <= 3 * SDC_CUS) late = false;
+  else late = pb >= ((n_blocks - 1) / SDC_CUS) * SDC_CUS;
+  if (late)
+    __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
+  else
+    __builtin_amdgcn_s_setprio(SDC_BASE_PRIO);
+}
+
 // One launch of this kernel is one env-step of all N environments.
 template <bool FAST>
 __device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs, double* kt, const int rel_hint, const int32_t* __restrict__ actions,
@@ -2100,13 +2119,9 @@ __device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs
   const int pb = bx < sweep_first ? bx : bx - SDC_SWEEP_BLOCKS;          // index among the pair workgroups
   const int env0 = (first_pair_of_block(pb, pair_blocks) + wave) * EPW;
   if (env0 >= S.n_envs) return;
-  // A SIMD issues from its oldest wavefront first: of the two env pairs that share a SIMD at 4096 envs, the one whose
-  // workgroup arrived in the second round of 256 (one per CU) would finish ~1.8 us after the other.  Raised priority for
-  // the later rounds evens the two out, and the launch ends when the slower one does.
-  if (pb >= SDC_CUS)
-    __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
-  else
-    __builtin_amdgcn_s_setprio(SDC_BASE_PRIO);
+  // (of the two env pairs that share a SIMD at 4096 envs, the one whose workgroup arrived in the second round of 256 -- one per
+  // CU -- would finish ~1.8 us after the other: set_round_priority)
+  set_round_priority(pb, pair_blocks);
   if (!FAST && lane == 0) prof_stamp(S, SDC_PROF_DYNAMICS, env0, 0);
   pair_step<FAST>(S, shs[wave], env0, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew,
                   FAST ? nullptr : S.actions_out, S.step_no, true, kt, true);
@@ -2152,10 +2167,7 @@ __device__ __forceinline__ void quad_launch(const SdcDev& S, QuadShared* shs, do
   const int pb = bx - SDC_SWEEP_BLOCKS;
   const int env0 = (first_pair_of_block(pb, env_blocks) + wave) * QE;
   if (env0 >= S.n_envs) return;
-  if (pb >= SDC_CUS)
-    __builtin_amdgcn_s_setprio(SDC_LATE_PRIO);
-  else
-    __builtin_amdgcn_s_setprio(SDC_BASE_PRIO);
+  set_round_priority(pb, env_blocks);
   quad_step<false>(S, shs[wave], env0, lane, rel_hint, actions, obs, share_obs, done, info, final_obs, rew, S.step_no, true, kt, true);
 }
 // (three resident wavefronts per SIMD = 12 envs: with the reward-side loads behind the dynamics -- SDC_QUAD_LATE_LOADS -- the

@@ -123,7 +123,7 @@ typedef struct {
                               for the common case (same results to the bit: tests compare the two).
                               Bits 9 / 10 (512 / 1024): the common-case kernels with two / four envs per wavefront
                               whatever the batch size (by default four when the batch is a multiple of four and
-                              large: single steps from 6656 envs on, the multi-step entry points above 4096; same
+                              large: single steps above 5632 envs, the multi-step entry points above 4096; same
                               results to the bit) */
   int32_t reward_method[3]; /* reward function per agent slot (ls, dc, bat), utils/reward_creator.py:322-334:
                                SDC_REWARD_DEFAULT the slot's own default_*_reward, SDC_REWARD_FOOTPRINT

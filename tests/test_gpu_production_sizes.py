@@ -1,6 +1,6 @@
 """Oracle parity in the production configuration at the sizes / kernels the bench line quotes rates for:
 
-  * the four-envs-per-wavefront step kernel (`sdc_dynamics_quad_kernel`: the default from 6 656 envs on) at 12 288 envs
+  * the four-envs-per-wavefront step kernel (`sdc_dynamics_quad_kernel`: the default above 5 632 envs) at 12 288 envs
     (three whole occupancy rounds), 16 384 envs (a fourth wavefront per SIMD) and 32 768 envs (eight per SIMD, three resident:
     the largest batch a rate is quoted for), against the ORACLE --
     until now it was only compared with the two-env kernels, and never above 8 200 envs;

@@ -7,7 +7,7 @@ from tests.production_rig import ProductionRig
 episodes = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 t0 = time.time()
-rig = ProductionRig(N, debug_flags=0, episode_steps=672, seed=2024, envs_per_wave=4 if N >= 6656 else 2, n_random=40)
+rig = ProductionRig(N, debug_flags=0, episode_steps=672, seed=2024, envs_per_wave=4 if N >= 5636 else 2, n_random=40)
 obs, _ = rig.eng.reset()
 rig.begin_all(obs)
 rig.single_steps(672 * episodes + 5)

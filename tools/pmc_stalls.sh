@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 E=${SDC_PMC_ENVS:-4096}
-export SDC_PMC_WAVES=$(( E >= 6656 ? E / 4 + 128 : E / 2 + 128 ))
+export SDC_PMC_WAVES=$(( E >= 5636 ? E / 4 + 128 : E / 2 + 128 ))
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d /tmp/p1 -- python $R/bench.py --pmc-inner --steps 48 --warmup 16 --envs-per-gpu $E > /dev/null 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SENDMSG --kernel-trace --output-format csv -d /tmp/p2 -- python $R/bench.py --pmc-inner --steps 48 --warmup 16 --envs-per-gpu $E > /dev/null 2>&1
 python - <<'PY'
