@@ -135,7 +135,6 @@ constexpr int PROF_SLOTS = 256;
 #ifndef SDC_STEP_WPB
 #define SDC_STEP_WPB 4
 #endif
-constexpr int SWEEP_BLOCKS = SDC_RQ_MAX / SDC_STEP_WPB;   // csrc/sdc_step.hip: one spare wavefront per possible re-centring request
 constexpr int STEP_WPB = SDC_STEP_WPB;   // csrc/sdc_step.hip SDC_STEP_WPB: env pairs (wavefronts) per workgroup of the step kernel
 int step_blocks(int n_envs) { return ((n_envs + 1) / 2 + STEP_WPB - 1) / STEP_WPB; }
 // The step counter that stamps re-centring requests wraps at 3 * 2^22: a multiple of the 3 rotating request sets and of
@@ -422,8 +421,11 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   if (sizeof(double) * (size_t)(cfg->episode_steps + 25 + d.lw) <= 50 * 1024)   // the features kernel's LDS windows (+ 8.4 KB tile per wavefront)
     A(d.feat, (size_t)N * (size_t)(cfg->episode_steps + 1) * SDC_FEAT_ROW);
   A(d.rq_count, 4);
-  A(d.rq, 3 * SDC_RQ_MAX);
-  A(d.rs, 3 * SDC_RQ_MAX);
+  // deferred re-centring capacity by batch size (sdc_device.hpp): ~26 requests per step and 4096 envs on average
+  d.rq_max = std::min((int)SDC_RQ_LIMIT, std::max((int)SDC_RQ_MIN, (N / 32 + 127) / 128 * 128));
+  d.sweep_blocks = std::min(128, std::max(32, N / 128));   // four wavefronts each; a workgroup serves requests b, b + sweep_blocks, ...
+  A(d.rq, 3 * (size_t)d.rq_max);
+  A(d.rs, 3 * (size_t)d.rq_max);
   A(d.reset_mask, N);
   A(h->ovr_day, N); A(h->ovr_hour, N);
   A(h->ovr_ci_min, N); A(h->ovr_ci_max, N); A(h->ovr_t_min, N); A(h->ovr_t_max, N);
@@ -702,13 +704,13 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   d.step_no = h->step_no;
   h->step_no = next_step_no(h->step_no, 1);
   if (fast_case(h, actions, share_obs, info, timed) && quad_case(h, false))
-    hipLaunchKernelGGL(sdc_dynamics_quad_kernel, dim3(SWEEP_BLOCKS + quad_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
+    hipLaunchKernelGGL(sdc_dynamics_quad_kernel, dim3(d.sweep_blocks + quad_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
                        h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
   else if (fast_case(h, actions, share_obs, info, timed))
-    hipLaunchKernelGGL(sdc_dynamics_fast_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
+    hipLaunchKernelGGL(sdc_dynamics_fast_kernel, dim3(d.sweep_blocks + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
                        h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
   else
-    hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(SWEEP_BLOCKS + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, h->rel_hint,
+    hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(d.sweep_blocks + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, h->rel_hint,
                        actions, obs, share_obs, done, info, final_obs, rew);
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
   HIP_TRY(hipGetLastError());

@@ -88,7 +88,7 @@ enum SdcHdr {
   H_WFIRST = 22,  // [4] first key of each rank window {Q1, Q3, BU, BL} (in the window's own key space) ...
   H_WLAST = 52,   // [4] ... and its last valid key: a step whose appended / evicted keys lie outside [first, last] of a
                   // window only moves that window's ranks -- decided from these two numbers, without touching its lanes
-  H_PEND = 34,    // [4] per rank window: a deferred re-centring in flight (0: none): request step mod 2^22 << 10 | result set << 8 | request index + 1
+  H_PEND = 34,    // [4] per rank window: a deferred re-centring in flight (0: none): request step mod 2^19 << 13 | result set << 11 | request index + 1
   H_LAST_XNEW = 38,   // the previous step's appended key, evicted key (KEY_NONE: none) and history length before it:
   H_LAST_XOLD = 39,   // what a re-centred window that describes the ring one step back has to catch up with
   H_LAST_NPREV = 40,
@@ -139,7 +139,11 @@ struct SdcDcDev {
 // re-centred window as a RESULT; the env's own wavefront picks it up at step t + 2, replays step t + 1's one
 // insertion / eviction on it (remembered in the header) and carries on.  The old window stays valid through step
 // t + 1 (that is what "ahead of need" guarantees).  Three request / result sets rotate with the step number.
-#define SDC_RQ_MAX 128
+// Requests per set: S.rq_max (and S.sweep_blocks four-wavefront sweep workgroups per launch), sized by the host with the batch --
+// ~26 windows per 4096 envs ask per step, and a request that finds no room is re-centred INLINE by its env's wavefront (a 5 us
+// straggler).  Rounds 2-3 had 128 / 32 whatever the batch: at 16 384 envs 42 % of the re-centrings ran inline.
+#define SDC_RQ_MIN 128        // (4096 envs and below)
+#define SDC_RQ_LIMIT 2047     // (the request index + 1 has 11 bits in the header's stamp)
 struct SdcRefillReq {
   int env, win, dir, kt, n, r0, hi, patch_slot;
   unsigned patch_x;
@@ -161,8 +165,9 @@ struct SdcDev {
   int32_t* actions_out;   // [N][3] the actions the step applied, or nullptr (sdc_step); sdc_rollout passes its own
   int step_no;            // steps launched so far (host counter): stamps the deferred re-centring requests / results
   int* rq_count;          // [3] requests filed into each set
-  SdcRefillReq* rq;       // [3][SDC_RQ_MAX]
-  SdcRefillRes* rs;       // [3][SDC_RQ_MAX]
+  SdcRefillReq* rq;       // [3][rq_max]
+  SdcRefillRes* rs;       // [3][rq_max]
+  int rq_max, sweep_blocks;   // request slots per set; sweep workgroups at the front of a single-step launch's grid
   unsigned long long seed;
   double noise_std, noise_weight;
   // shared, read-only

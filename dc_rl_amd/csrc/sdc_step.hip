@@ -1179,16 +1179,16 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
     SDC_DBG_BIT(FAST, sh, 8u);
     const unsigned lx_new = hp[H_LAST_XNEW], lx_old = hp[H_LAST_XOLD];
     const int l_nprev = (int)hp[H_LAST_NPREV];
-    // pd = (request step mod 2^22) << 10 | result set << 8 | request index + 1.  All due results are requested first (ONE
+    // pd = (request step mod 2^19) << 13 | result set << 11 | request index + 1.  All due results are requested first (ONE
     // memory round trip whatever the number of windows), then each is replayed and installed; windows with nothing due
     // in either env are skipped as a whole.
     struct Arrival { int4 hd; unsigned k[KPL]; bool due; unsigned age; };
     auto fetch = [&](const unsigned pd) __attribute__((always_inline)) {
       Arrival a;
-      const int idx = (int)(pd & 0xFFu) - 1, set = (int)((pd >> 8) & 3u);
-      a.age = ((unsigned)step_no - (pd >> 10)) & 0x3FFFFFu;      // steps since the request (mod 2^22)
+      const int idx = (int)(pd & 0x7FFu) - 1, set = (int)((pd >> 11) & 3u);
+      a.age = ((unsigned)step_no - (pd >> 13)) & 0x7FFFFu;      // steps since the request (mod 2^19)
       a.due = pd != 0u && a.age >= 2u;   // (1: being swept right now; anything else but 2: stale -- a multi-step launch, restored state)
-      const SdcRefillRes* rs = S.rs + (set > 2 ? 0 : set) * SDC_RQ_MAX + (idx < 0 ? 0 : idx);
+      const SdcRefillRes* rs = S.rs + (set > 2 ? 0 : set) * S.rq_max + (idx < 0 ? 0 : idx);
       a.hd = make_int4(0, 0, -1, -1);
 #pragma unroll
       for (int i = 0; i < KPL; i++) a.k[i] = KEY_NONE;
@@ -1350,10 +1350,10 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
           if (want && ok && active && l == 0) idx = atomicAdd(&S.rq_count[set], 1);
           idx = __builtin_amdgcn_ds_bpermute((h * LPE) << 2, idx);       // lane 0 of the env's lanes tells the others
           if (want && ok) {
-            if (idx < 0 || idx >= SDC_RQ_MAX) {
+            if (idx < 0 || idx >= S.rq_max) {
               ok = false;                          // no room (or a missing env): re-centre inline on the slow path
             } else {
-              SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + idx;
+              SdcRefillReq* rq = S.rq + set * S.rq_max + idx;
               unsigned qk[KPL];
               win_keys(q, qk);
 #pragma unroll
@@ -1365,7 +1365,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
                 rq->kt = kt; rq->n = n; rq->r0 = q.r0; rq->hi = q.hi;
                 rq->patch_slot = slot_next; rq->patch_x = patch_x; rq->step = step_no;
               }
-              pd = (((unsigned)step_no & 0x3FFFFFu) << 10) | ((unsigned)set << 8) | (unsigned)(idx + 1);
+              pd = (((unsigned)step_no & 0x7FFFFu) << 13) | ((unsigned)set << 11) | (unsigned)(idx + 1);
               filed = true;
             }
           }
@@ -1967,7 +1967,6 @@ __device__ __forceinline__ int first_pair_of_block(const int bi, const int nb, c
 // previous step (see SdcRefillReq): one sweep over that env's ring as the previous step left it, the re-centred window out
 // as a result.  serve_recentring_requests: wavefront j serves request j alone (round 2; kept for -DSDC_SWEEP_COOP=0);
 // serve_recentring_requests_coop: the four wavefronts of a workgroup share each sweep (round 3, the default).
-#define SDC_SWEEP_BLOCKS (SDC_RQ_MAX / SDC_STEP_WPB)
 #define SDC_CUS 256
 #ifndef SDC_SWEEP_PRIO
 #define SDC_SWEEP_PRIO 3
@@ -2009,9 +2008,9 @@ __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const
   using namespace sdc_rw;
   const int set = S.step_no % 3;
   if (j == 0 && lane == 0) S.rq_count[(S.step_no + 2) % 3] = 0;     // the set the NEXT step's requests go to
-  const int cnt = min(S.rq_count[set], SDC_RQ_MAX);
+  const int cnt = min(S.rq_count[set], S.rq_max);
   if (j >= cnt) return;
-  const SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + j;
+  const SdcRefillReq* rq = S.rq + set * S.rq_max + j;
   if (rq->step != S.step_no - 1) return;                            // stale (a multi-step launch came in between)
   // (issue priority SDC_SWEEP_PRIO = 3, above the env pairs': the launch cannot end before its sweeps have, and a sweep
   // is one wavefront working through 40 KB -- measured with the sweep workgroups first in the grid, us per step: priority 3
@@ -2021,7 +2020,7 @@ __device__ __forceinline__ void serve_recentring_requests(const SdcDev& S, const
   QTrack A = {rq->keys[lane], rq->r0, rq->hi};
   const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), rq->patch_slot, rq->patch_x};
   qt_refill<10>(A, rq->dir, rq->kt, n, R, lane, tl, w == 3 ? KEY_NONE : 0u);
-  SdcRefillRes* rs = S.rs + set * SDC_RQ_MAX + j;
+  SdcRefillRes* rs = S.rs + set * S.rq_max + j;
   rs->keys[lane] = A.w;
   if (lane == 0) {
     rs->r0 = A.r0;
@@ -2039,19 +2038,19 @@ __device__ __forceinline__ void serve_recentring_requests_coop(const SdcDev& S, 
   static_assert(SDC_STEP_WPB == COOP_NW, "one quarter of the ring per wavefront of the workgroup");
   const int set = S.step_no % 3;
   if (wg == 0 && wave == 0 && lane == 0) S.rq_count[(S.step_no + 2) % 3] = 0;     // the set the NEXT step's requests go to
-  const int cnt = min(S.rq_count[set], SDC_RQ_MAX);
+  const int cnt = min(S.rq_count[set], S.rq_max);
   if (wg >= cnt) return;
   __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
 #pragma unroll 1
-  for (int j = wg; j < cnt; j += SDC_SWEEP_BLOCKS) {
-    const SdcRefillReq* rq = S.rq + set * SDC_RQ_MAX + j;
+  for (int j = wg; j < cnt; j += S.sweep_blocks) {
+    const SdcRefillReq* rq = S.rq + set * S.rq_max + j;
     if (rq->step != S.step_no - 1) continue;                          // stale (a multi-step launch came in between)
     const int env = rq->env, w = rq->win, n = rq->n;
     QTrack A = {rq->keys[lane], rq->r0, rq->hi};
     const RingView R = {reinterpret_cast<const uint4*>(S.hist + (size_t)env * SDC_HIST_STRIDE), rq->patch_slot, rq->patch_x};
     qt_refill_coop(A, rq->dir, rq->kt, n, R, lane, wave, C, w == 3 ? KEY_NONE : 0u);
     if (wave == 0) {
-      SdcRefillRes* rs = S.rs + set * SDC_RQ_MAX + j;
+      SdcRefillRes* rs = S.rs + set * S.rq_max + j;
       rs->keys[lane] = A.w;
       if (lane == 0) {
         rs->r0 = A.r0;
@@ -2093,11 +2092,11 @@ __device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));   // wave-uniform, in an SGPR
   const int lane = threadIdx.x % SDC_WAVE;
   kernarg_touch_done(ktouch);
-  const int pair_blocks = (int)gridDim.x - SDC_SWEEP_BLOCKS;
+  const int pair_blocks = (int)gridDim.x - S.sweep_blocks;
   // where the 32 sweep workgroups sit in the grid: after the first SDC_SWEEP_AT pair workgroups (0: first; or last, in a small grid)
   const int sweep_first = pair_blocks > SDC_SWEEP_AT ? SDC_SWEEP_AT : pair_blocks;
   const int bx = (int)blockIdx.x;
-  if (bx >= sweep_first && bx < sweep_first + SDC_SWEEP_BLOCKS) {
+  if (bx >= sweep_first && bx < sweep_first + S.sweep_blocks) {
     // WHERE the 32 sweep workgroups sit in the grid decides how the env pairs' workgroups land on the CUs (round 3,
     // tools/wave_tail.py: every pair wavefront stamps the SIMD it ran on).  Inserted after the first 320 pair workgroups
     // (round 2) they pushed the dispatcher off its stride: 128 SIMDs received THREE pair wavefronts and 128 only one, and
@@ -2110,13 +2109,13 @@ __device__ __forceinline__ void dynamics_launch(const SdcDev& S, PairShared* shs
     static_assert(sizeof(sdc_rw::CoopLds) <= sizeof(PairShared) * SDC_STEP_WPB, "the sweep workgroup's LDS");
     serve_recentring_requests_coop(S, bx - sweep_first, wave, lane, *reinterpret_cast<sdc_rw::CoopLds*>(shs));
 #elif SDC_SWEEP_SPREAD
-    serve_recentring_requests(S, (bx - sweep_first) + wave * SDC_SWEEP_BLOCKS, lane, shs[wave].tl);   // requests 0..31 on 32 different CUs
+    serve_recentring_requests(S, (bx - sweep_first) + wave * S.sweep_blocks, lane, shs[wave].tl);   // requests 0..31 on 32 different CUs
 #else
     serve_recentring_requests(S, (bx - sweep_first) * SDC_STEP_WPB + wave, lane, shs[wave].tl);
 #endif
     return;
   }
-  const int pb = bx < sweep_first ? bx : bx - SDC_SWEEP_BLOCKS;          // index among the pair workgroups
+  const int pb = bx < sweep_first ? bx : bx - S.sweep_blocks;          // index among the pair workgroups
   const int env0 = (first_pair_of_block(pb, pair_blocks) + wave) * EPW;
   if (env0 >= S.n_envs) return;
   // (of the two env pairs that share a SIMD at 4096 envs, the one whose workgroup arrived in the second round of 256 -- one per
@@ -2157,14 +2156,14 @@ __device__ __forceinline__ void quad_launch(const SdcDev& S, QuadShared* shs, do
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
   const int lane = threadIdx.x % SDC_WAVE;
   kernarg_touch_done(ktouch);
-  const int env_blocks = (int)gridDim.x - SDC_SWEEP_BLOCKS;
+  const int env_blocks = (int)gridDim.x - S.sweep_blocks;
   const int bx = (int)blockIdx.x;
-  if (bx < SDC_SWEEP_BLOCKS) {     // (the sweep workgroups first in the grid: see dynamics_launch)
+  if (bx < S.sweep_blocks) {     // (the sweep workgroups first in the grid: see dynamics_launch)
     static_assert(sizeof(sdc_rw::CoopLds) <= sizeof(QuadShared) * SDC_STEP_WPB, "the sweep workgroup's LDS");
     serve_recentring_requests_coop(S, bx, wave, lane, *reinterpret_cast<sdc_rw::CoopLds*>(shs));
     return;
   }
-  const int pb = bx - SDC_SWEEP_BLOCKS;
+  const int pb = bx - S.sweep_blocks;
   const int env0 = (first_pair_of_block(pb, env_blocks) + wave) * QE;
   if (env0 >= S.n_envs) return;
   set_round_priority(pb, env_blocks);
