@@ -178,7 +178,8 @@ extern "C" __global__ __launch_bounds__(4 * SDC_WAVE) void sdc_features_kernel(S
 #pragma unroll 4
    for (int j = 0; j < SDC_WAVE / 2; j++) {
      const int rr = 2 * j + (lane >> 5), k = lane & 31;
-     if (rr < n_rows) S.feat[feat_row_offset(S, env, s0 + rr) + k] = tile[rr * TS + k];
+     // (non-temporal: 353 MB that nothing reads before the episode's steps do, one row per step -- 138 -> 131 us)
+     if (rr < n_rows) __builtin_nontemporal_store(tile[rr * TS + k], &S.feat[feat_row_offset(S, env, s0 + rr) + k]);
    }
    wave_sync();
   }
