@@ -17,7 +17,7 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
 # fixtures with their own layout and their own tests (not single-env episode fixtures)
-OTHER_FIXTURES = {"weather_resets", "harl_ny_n4", "harl_ny_n2_concat", "rbc_ny_m7"}
+OTHER_FIXTURES = {"weather_resets", "harl_ny_n4", "harl_ny_n2_concat", "rbc_ny_m7", "tou_prices"}
 
 
 def golden_names():

@@ -536,6 +536,19 @@ def gen_rbc_episode(location="ny", month=7, seed=31, episodes=2, tr_limit=None):
     return out
 
 
+def gen_tou_prices():
+    """utils/reward_creator.py:154-198 called DIRECTLY on whole-hour parameters: the 24 prices of its table (energy 1 kWh) and the
+    reward at three energies per hour.  An episode cannot pin this function: the env hands it `hour` as a float with quarter
+    hours (sustaindc_env.py:679), which the table's integer keys only match on the full hour (KeyError otherwise)."""
+    from utils import reward_creator
+    hours = np.arange(24)
+    energies = np.array([1.0, 331.25, 612.5])
+    rew = np.array([[reward_creator.tou_reward({"bat_total_energy_with_battery_KWh": float(e), "energy_usage": float(e),
+                                                 "hour": int(h)}) for h in hours] for e in energies])
+    assert reward_creator.get_reward_method("tou_reward") is reward_creator.tou_reward
+    return {"hours": hours, "energies": energies, "reward": rew, "price": -rew[0]}
+
+
 def _find_early_seed():
     """Seed for which (day 0, hour < 4) -> cursor < 16; uses python `random` exactly like reset()."""
     for s in range(1000):
@@ -554,6 +567,7 @@ def main():
     args = ap.parse_args()
     _install_shims()
     extra = {"weather_resets": gen_weather_resets, "harl_ny_n4": gen_harl_layer, "rbc_ny_m7": gen_rbc_episode,
+             "tou_prices": gen_tou_prices,
              "harl_ny_n2_concat": lambda: gen_harl_layer(n_envs=2, n_steps=120, seed=23, nonoverlapping=False)}
     for name, fn in extra.items():
         if args.only == name or (args.only is None and args.extras):

@@ -43,7 +43,8 @@ class ParityRig:
     """N envs on the engine + N scalar oracle envs fed the same inputs."""
 
     def __init__(self, n_envs, episode_steps=672, seed=0, locations=("ny",), dc_files=("dc_config.json",),
-                 capacity_mw=1.0, months=None, hist_cap=10000, with_oracle=True, oracle_envs=None, debug_flags=1):
+                 capacity_mw=1.0, months=None, hist_cap=10000, with_oracle=True, oracle_envs=None, debug_flags=1,
+                 reward_method=(0, 0, 0)):
         self.N = n_envs
         self.steps = episode_steps
         self.rng = np.random.default_rng(seed)
@@ -54,7 +55,8 @@ class ParityRig:
             ci_loc, _ = traces.obtain_paths(locations[li])
             self.params.append(dc_config.size_datacenter(f, capacity_mw, traces.max_ambient_for_sizing(ci_loc)))
         self.eng = SdcEngine(n_envs, episode_steps=episode_steps, auto_reset=False, n_locations=len(locations),
-                             n_dc_configs=len(combos), seed=seed, hist_cap=hist_cap, debug_flags=debug_flags)
+                             n_dc_configs=len(combos), seed=seed, hist_cap=hist_cap, debug_flags=debug_flags,
+                             reward_method=tuple(reward_method))
         for li, tb in enumerate(self.tables):
             self.eng.set_tables(li, tb["W"], tb["C"], tb["T"], tb["WB"])
         for ci, p in enumerate(self.params):
@@ -72,7 +74,8 @@ class ParityRig:
         self.oracles = {}
         if with_oracle:
             for i in self.oracle_envs:
-                self.oracles[i] = po.OracleEnv(G.oracle_params_from_dict(self.params[self.cfg_id[i]]))
+                self.oracles[i] = po.OracleEnv(G.oracle_params_from_dict(dict(self.params[self.cfg_id[i]],
+                                                                              reward_method=tuple(reward_method))))
                 self.oracles[i].e.stpt = float(self.params[self.cfg_id[i]]["init_setpoint"])
 
     def reset_all(self):

@@ -72,3 +72,31 @@ def test_oracle_matches_reference_episode(name):
 def test_oracle_matches_reference_long(name):
     w = _run(name)
     print(name, w)
+
+
+def test_oracle_tou_reward_uses_the_references_price_table():
+    """utils/reward_creator.py:154-198 tou_reward: the oracle's case 3 against the 24 prices captured from the reference's
+    function itself (tests/golden/tou_prices.npz, gen_golden.py gen_tou_prices).  On full hours the oracle's reward IS the
+    reference's function of (energy, hour); between them the reference raises KeyError and the oracle keeps the hour's price."""
+    tp = np.load(os.path.join(GOLDEN_DIR, "tou_prices.npz"))
+    price = tp["price"]
+    np.testing.assert_array_equal(tp["reward"], -tp["energies"][:, None] * price[None, :])
+    d = np.load(os.path.join(GOLDEN_DIR, "ny_m6_random.npz"))
+    scal = {k[len("static_"):]: d[k] for k in d.files if k.startswith("static_") and d[k].ndim == 0}
+    scal["reward_method"] = (3, 3, 3)
+    p = po.make_params(d["static_rack_n"], d["static_rack_full"], d["static_rack_idle"], d["static_rack_supply"],
+                       d["static_rack_return"], scal)
+    env = po.OracleEnv(p)
+    env.e.stpt = float(d["init_stpt"])
+    env.begin(d["ep0_W"], d["ep0_C"], d["ep0_NC"], d["ep0_T"], d["ep0_WB"], d["ep0_NT"], int(d["ep0_win_lo"]),
+              int(d["ep0_init_day"]), int(d["ep0_init_hour"]), int(d["meta_steps"]))
+    seen = set()
+    for t in range(200):
+        _, rew, _, info = env.step(d["ep0_actions"][t])
+        hour = info[po.INFO_IDX["hour"]]
+        e = info[po.INFO_IDX["bat_total_energy_with_battery_KWh"]]
+        h = int(hour) % 24
+        seen.add(h)
+        np.testing.assert_array_equal(rew, np.full(3, -1.0 * e * price[h]))
+        assert env.e.hist_len == 0          # only default_ls_reward appends to the energy history (reward_creator.py:63)
+    assert seen == set(range(24))
