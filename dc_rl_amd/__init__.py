@@ -3,8 +3,9 @@
 Public surface (mirrors the reference's names for this path):
   * `SustainDC`, `EnvConfig`                      -- sustaindc_env.py:34, :90
   * `make_ls_env`, `make_dc_pyeplus_env`, `make_bat_fwd_env` -- utils/make_envs_pyenv.py:19, :75, :45
-  * `SustainDCVecEnv` (a `ShareVecEnv`), `make_train_env`, `make_eval_env`
-                                                   -- harl/envs/env_wrappers.py:53, harl/utils/envs_tools.py:49
+  * `SustainDCVecEnv` (a `ShareVecEnv`), `make_train_env`, `make_eval_env`, `make_render_env`
+                                                   -- harl/envs/env_wrappers.py:53, harl/utils/envs_tools.py:49, :77, :106
+  * `install_into_harl()`                          -- rebinds those factories inside an UNCHANGED HARL tree (zero edits)
   * `SustainDCMultiDeviceVecEnv` / `make_train_env(..., devices=[...])` -- the same ShareVecEnv over several GPUs in one process
   * `SdcEngine`                                    -- thin ctypes wrapper over the C-ABI (include/sustaindc_hip.h)
 
@@ -22,6 +23,8 @@ _LAZY = {
     "SustainDCMultiDeviceVecEnv": ("multi_device", "SustainDCMultiDeviceVecEnv"),
     "make_train_env": ("envs_tools", "make_train_env"),
     "make_eval_env": ("envs_tools", "make_eval_env"),
+    "make_render_env": ("envs_tools", "make_render_env"),
+    "install_into_harl": ("envs_tools", "install_into_harl"),
     "make_ls_env": ("make_envs_pyenv", "make_ls_env"),
     "make_dc_pyeplus_env": ("make_envs_pyenv", "make_dc_pyeplus_env"),
     "make_bat_fwd_env": ("make_envs_pyenv", "make_bat_fwd_env"),
