@@ -160,7 +160,10 @@ def measure(n_envs, steps=40, device=0, warmup=8, env_args=None, devices=None, h
     return {"envs": N, "steps": steps, "us_per_runner_step": round(per * 1e6, 1), "value": round(N / per, 1), "unit": "env-steps/s",
             "envs_step_us": round(t_env / steps * 1e6, 1), "runner_own_python_us": round(t_plain * 1e6, 1),
             "env_side_share": round(max(0.0, per - t_plain) / per, 4),
-            "note": "NumPy actions in / NumPy outputs (PCIe inclusive); logger walk + buffer insert restated from the reference; "
+            "note": "NumPy actions in / NumPy outputs (PCIe inclusive); logger walk + buffer insert RESTATED from the reference (the "
+                    "reference cannot travel to the GPU box); the reference's own SustainDCLogger.per_step + OnPolicyBaseRunner.insert, "
+                    "timed beside this restatement on the same inputs in the build container, take 3-11 % longer "
+                    "(profiles/r5_harl_reference_loop.txt, tools/harl_reference_loop.py): this rate is an upper bound by that much; "
                     "actor networks not included (they would lower the share)"}
 
 
