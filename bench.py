@@ -16,15 +16,19 @@ so a short `--steps 20` run measures the same steady state as a long one instead
 an idle GPU.  `value` = envs x K x R / wall time of the region (MAX over ranks); HIP events at the block
 boundaries give the per-block times (`block_ms_median` etc.) without extra synchronisation.
 
-Roofline: the step is ONE kernel and it is NOT HBM bound -- it keeps the reward normalisation's order statistics
-incrementally instead of streaming the 40 KB history, so it is bound by VALU issue and dependent-instruction
-latency of wave-uniform fp64 physics.  `roofline.frac` is therefore the measured VALU-busy fraction (PMC
-SQ_ACTIVE_INST_VALU against the SIMD-cycles of the launch), `hbm_frac` = PMC bytes / kernel time / 8 TB/s, both
-physical and <= 1.  The bytes the REFERENCE algorithm would move (4*H + 1540 per env-step) over
-the kernel time is reported separately as `effective_hbm_frac` and may exceed 1.  The PMC counters are collected
-in this very run (rank 0, N = 1) by short `rocprofv3 --pmc ... --kernel-trace` passes over `bench.py --pmc-inner`;
-if rocprofv3 is not usable the numbers fall back to profiles/pmc_latest.json, which carries the hash of the
-kernel sources it was measured at (`pmc_source`, `pmc_current`).
+Roofline (`roofline`): SURVEY.md 8(d) bounds the path by HBM (8 TB/s) and prices an env-step at B(H) = 4*H + 1540 bytes, asking
+for the fraction with AND without the history term because an incremental implementation does not move the 4*H bytes.  This
+step is ONE kernel that keeps the reward normalisation's order statistics incrementally, so:
+  `achieved` / `peak` / `frac` (= `frac_hbm_algorithmic`) = 1540 B x envs per launch / the kernel's average launch duration
+      (HIP events on the launch stream over the timed region) against 8000 GB/s -- 8(d)'s figure WITHOUT the history term;
+  `frac_hbm_algorithmic_with_history_term` = the same with B(10 000) = 41 540 B: bytes the kernel does not move, may exceed 1;
+  `traffic` = PMC bytes per launch (FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections), `hbm_frac` = traffic / kernel
+      time / 8 TB/s (physical), `traffic_over_alg_bytes` = traffic / (1540 x envs): re-reads and layout overhead;
+  `valu_busy_frac` = SQ_ACTIVE_INST_VALU x 4 / the SIMD-cycles of the launch: what the kernel is actually bound by (wave-uniform
+      fp64 physics issued once per pair / quad of envs), `issue_frac` likewise for every instruction class.
+The PMC counters are collected in this very run (rank 0, N = 1) by short `rocprofv3 --pmc ... --kernel-trace` passes over
+`bench.py --pmc-inner`; if rocprofv3 is not usable the numbers fall back to profiles/pmc_latest.json, which carries the hash of
+the kernel sources it was measured at (`pmc_source`, `pmc_current`).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).  For N > 1 it runs one rank
 per GPU over RCCL: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
@@ -64,6 +68,7 @@ N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
 MAX_CLOCK_GHZ = 2.4
 HIST_CAP = 10000
 ALG_BYTES_FIXED = 1540      # B(H) = 4*H + 1540 bytes per env-step
+WIDE_MIN_ENVS = 1 << 30     # (no lane-per-env step kernel in this build: see sdc_capi.hip wide_case)
 STEP_KERNEL = "sdc_dynamics_fast_kernel"   # the step kernel specialised for the common case, which is what this workload is
 STEP_KERNEL_PREFIX = "sdc_dynamics"            # (the general kernel sdc_dynamics_kernel serves every other case)
 MIN_REGION_S = 0.2
@@ -337,6 +342,13 @@ def pmc_summary(c):
     return out
 
 
+def scan_kernel_name(n_envs):
+    """Which step kernel the host picks for a single-config lock-step batch of this size (sdc_capi.hip)."""
+    if n_envs >= WIDE_MIN_ENVS and n_envs % 64 == 0:
+        return "sdc_dynamics_wide_kernel"
+    return "sdc_dynamics_quad_kernel" if n_envs >= 5636 and n_envs % 4 == 0 else STEP_KERNEL
+
+
 def scan_roofline(n_envs, episode_steps, us_per_step, args):
     """The counter passes of `pmc_collect` at another batch size (the four-envs-per-wavefront kernel above 5632 envs):
     the same physical figures as the headline's `roofline`, against the wall-clock time per step of that batch."""
@@ -351,14 +363,17 @@ def scan_roofline(n_envs, episode_steps, us_per_step, args):
     simd_cycles = N_SIMD * t * MAX_CLOCK_GHZ * 1e9
     traffic = pm.get("hbm_bytes_per_launch")
     valu = pm.get("valu_active_simd_cycles_per_launch")
-    out = {"bound": "valu", "kernel": "sdc_dynamics_quad_kernel" if n_envs >= 5636 and n_envs % 4 == 0 else STEP_KERNEL,
-           "frac": round(valu / simd_cycles, 4) if valu else None,
+    alg = ALG_BYTES_FIXED * n_envs
+    out = {"bound": "hbm", "kernel": scan_kernel_name(n_envs),
+           "achieved": round(alg / t / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": round(alg / t / 1e9 / HBM_PEAK_GBPS, 5), "frac_hbm_algorithmic": round(alg / t / 1e9 / HBM_PEAK_GBPS, 5),
+           "valu_busy_frac": round(valu / simd_cycles, 4) if valu else None,
            "issue_frac": (round(pm["issue_active_simd_cycles_per_launch"] / simd_cycles, 4)
                           if pm.get("issue_active_simd_cycles_per_launch") else None),
            "wave_issue_frac": pm.get("wave_issue_frac"), "traffic": traffic,
            "hbm_frac": round(traffic / t / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
-           "alg_bytes_per_launch_without_history_term": ALG_BYTES_FIXED * n_envs,
-           "traffic_over_alg_bytes_without_history_term": round(traffic / (ALG_BYTES_FIXED * n_envs), 3) if traffic else None,
+           "alg_bytes_per_launch": alg,
+           "traffic_over_alg_bytes": round(traffic / alg, 3) if traffic else None,
            "instructions_per_wavefront": pm.get("per_wave"), "wavefronts_per_launch": pm.get("waves_per_launch"),
            "us_per_step": us_per_step, "raw": pm.get("raw")}
     if err:
@@ -539,8 +554,23 @@ def main():
             dist.destroy_process_group()
         sys.exit(0 if seen == world else 5)
     ndev = torch.cuda.device_count()
-    if world > 1:
+    # the collectives' code path (rendezvous, ranks_seen, the MAX reductions, the barriers, the return-statistics all-reduce) runs
+    # for every job of more than one rank -- and for ONE rank when SDC_DIST_BACKEND is set explicitly: `SDC_DIST_BACKEND=nccl
+    # python bench.py --gpus 1` takes this very path through RCCL with a world of one (tests/test_gpu_distributed.py), so that
+    # the first multi-GPU run meets nothing but the transport for the first time
+    dist_on = world > 1 or "SDC_DIST_BACKEND" in os.environ
+    if dist_on and world == 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (this image's host driver supports dmabuf device-memory IPC only -- what RCCL's intra-node transports open their peers'
+        # buffers with; the variable is set in the image's environment already and kept here for a shell that dropped it.  The
+        # mechanism is measured on one GPU by tests/test_gpu_distributed.py::test_device_memory_ipc_needs_the_dmabuf_mode)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl" and ndev < world:
             if rank == 0:
@@ -559,7 +589,7 @@ def main():
 
     def all_reduce(t, op=None):
         """RCCL on device tensors; with gloo the (tiny) tensor takes the host round trip."""
-        if world == 1:
+        if not dist_on:
             return t
         op = op or dist.ReduceOp.SUM
         if backend == "nccl":
@@ -571,7 +601,7 @@ def main():
         return t
 
     ranks_seen = 1
-    if world > 1:
+    if dist_on:
         ranks_seen = int(all_reduce(torch.ones(1, dtype=torch.float64, device=cdev)).item())
         if ranks_seen != world:
             if rank == 0:
@@ -636,14 +666,14 @@ def main():
     torch.cuda.synchronize()
     est = (time.perf_counter() - t0) / 64
     R = args.repeats if args.repeats > 0 else max(1, int(np.ceil(MIN_REGION_S / max(1e-9, est * K))))
-    if world > 1:   # every rank times the same number of blocks
+    if dist_on:   # every rank times the same number of blocks
         R = int(all_reduce(torch.tensor([float(R)], dtype=torch.float64, device=cdev), dist.ReduceOp.MAX).item())
     R = min(R, 4096)
 
     eng.profile(args.profile_every)   # in-kernel wall-clock stamps of every k-th timed step (sdc_profile_enable)
     eng.profile_read(reset=True)
     coll0 = n_collectives
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     # HIP events on the launch stream (the engine launches on torch's current stream) at the block boundaries
@@ -662,7 +692,7 @@ def main():
         if (b + 1) % bpe == 0 or b == R - 1:
             evs.append(torch.cuda.Event(enable_timing=True))
             evs[-1].record()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -677,7 +707,7 @@ def main():
             one_step(i)
         prof = eng.profile_read(reset=True)
     eng.profile(0)
-    if world > 1:
+    if dist_on:
         dt = float(all_reduce(torch.tensor([dt], dtype=torch.float64, device=cdev), dist.ReduceOp.MAX).item())
     faults = int((eng.info[:, 37] != 0).sum().item())
     fallbacks = [int((eng.info[:, 39] == v).sum().item()) for v in (1, 3, 2)]
@@ -712,7 +742,7 @@ def main():
             "ms_per_step": round(dt / timed_steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 dynamics / f32 history ring + outputs", "data": "synthetic",
             "repeats": R, "timed_steps": timed_steps, "ranks_seen": ranks_seen,
-            "dist_backend": (backend if world > 1 else None),
+            "dist_backend": (dist.get_backend() if dist_on else None),
             "block_ms_median": round(float(np.median(block_ms)), 5), "block_ms_min": round(float(block_ms.min()), 5),
             "block_ms_max": round(float(block_ms.max()), 5),
             "config": {"workload": ("4096 envs x mixed 16/20/25-rack dc configs" if args.mixed_racks else
@@ -753,36 +783,45 @@ def main():
         simd_cycles = N_SIMD * k_evt * MAX_CLOCK_GHZ * 1e9            # SIMD-cycles the launch occupies at max clock
         valu_busy = (valu_cyc / simd_cycles) if valu_cyc else None
         eff = b * N / k_evt / 1e9
+        alg_fixed = ALG_BYTES_FIXED * N
         roof = {
-            "bound": "valu", "kernel": STEP_KERNEL,
-            # achieved / peak in SIMD-cycles with a VALU instruction executing per launch (PMC SQ_ACTIVE_INST_VALU x 4)
+            "bound": "hbm", "kernel": STEP_KERNEL,
+            # algorithmic bytes per launch (WITHOUT the history term: the kernel keeps the order statistics
+            # incrementally) / the kernel's average launch duration, against the 8 TB/s HBM peak
+            "achieved": round(alg_fixed / k_evt / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(alg_fixed / k_evt / 1e9 / HBM_PEAK_GBPS, 5),
+            "frac_hbm_algorithmic": round(alg_fixed / k_evt / 1e9 / HBM_PEAK_GBPS, 5),
+            "frac_hbm_algorithmic_with_history_term": round(eff / HBM_PEAK_GBPS, 4),
+            "traffic": traffic,
+            "hbm_frac": round(traffic / k_evt / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+            "hbm_achieved_GBps": round(traffic / k_evt / 1e9, 1) if traffic else None,
+            "traffic_over_alg_bytes": round(traffic / alg_fixed, 3) if traffic else None,
+            # what the kernel is bound by: SIMD-cycles with a VALU instruction executing per launch (PMC SQ_ACTIVE_INST_VALU x 4)
             # against the SIMD-cycles of the launch: 1024 SIMDs x kernel_avg_us x 2.4 GHz
-            "achieved": round(valu_cyc / 1e6, 3) if valu_cyc else None, "peak": round(simd_cycles / 1e6, 3),
-            "unit": "M SIMD-cycles per launch (VALU active / available)",
-            "frac": round(valu_busy, 4) if valu_busy else None,
+            "valu_busy_frac": round(valu_busy, 4) if valu_busy else None,
+            "valu_active_M_simd_cycles_per_launch": round(valu_cyc / 1e6, 3) if valu_cyc else None,
+            "available_M_simd_cycles_per_launch": round(simd_cycles / 1e6, 3),
             # every instruction class (VALU, scalar, LDS, memory, branch) against the same SIMD-cycles: what the two wavefronts
             # of a SIMD keep its issue port busy with over the whole launch, launch gap and dispatch ramp included
             "issue_frac": (round(pmc["issue_active_simd_cycles_per_launch"] / simd_cycles, 4)
                            if pmc and pmc.get("issue_active_simd_cycles_per_launch") else None),
             "wave_issue_frac": pmc.get("wave_issue_frac") if pmc else None,
-            "traffic": traffic,
-            "hbm_frac": round(traffic / k_evt / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
-            "hbm_achieved_GBps": round(traffic / k_evt / 1e9, 1) if traffic else None, "hbm_peak_GBps": HBM_PEAK_GBPS,
             "kernel_avg_us": round(k_evt * 1e6, 2),
             "kernel_first_entry_to_last_exit_us": round(k_dyn * 1e6, 2),
             "timed_launches": timed_steps,
             "instructions_per_wavefront": pmc.get("per_wave") if pmc else None,
             "wavefronts_per_launch": pmc.get("waves_per_launch") if pmc else None,
-            "alg_bytes_per_env_step": b, "alg_bytes_per_launch": b * N,
-            "effective_hbm_GBps": round(eff, 1), "effective_hbm_frac": round(eff / HBM_PEAK_GBPS, 4),
-            "effective_hbm_frac_without_history_term": round(ALG_BYTES_FIXED * N / k_evt / 1e9 / HBM_PEAK_GBPS, 5),
+            "alg_bytes_per_env_step": ALG_BYTES_FIXED, "alg_bytes_per_launch": alg_fixed,
+            "alg_bytes_per_env_step_with_history_term": b,
             "pmc_source": pmc_src, "pmc_current": bool(pmc and pmc.get("csrc_sha") == here), "csrc_sha": here,
             # where the counter passes ran against where the timed region ran (boxes of the pool differ by 1-3 %: a kernel
             # figure from one box next to a wall clock from another can differ by that much in either direction)
             "timed_on_host": HOSTNAME, "pmc_on_host": (pmc.get("host") if pmc else None),
-            "note": "frac = VALU-busy fraction (physical, <= 1); hbm_frac = PMC bytes / kernel time / 8 TB/s (physical); "
-                    "effective_hbm_* price the REFERENCE algorithm's bytes (whole history window read every step), "
-                    "which this kernel does not move -- not a physical bandwidth (DESIGN.md section 4)",
+            "note": "frac = SURVEY 8(d)'s algorithmic-HBM fraction WITHOUT the history term (1540 B per env-step / kernel time / 8 TB/s); "
+                    "hbm_frac = PMC bytes / kernel time / 8 TB/s (physical); traffic_over_alg_bytes = their ratio; "
+                    "valu_busy_frac = what bounds this kernel (physical, <= 1); frac_hbm_algorithmic_with_history_term prices the "
+                    "REFERENCE algorithm's bytes (whole history window read every step), which this kernel does not move -- not a "
+                    "physical bandwidth (DESIGN.md section 4)",
         }
         if pmc_err:
             roof["pmc_error"] = pmc_err[:400]
@@ -888,7 +927,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
