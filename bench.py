@@ -890,8 +890,9 @@ def main():
             except Exception as e:
                 sec["harl_yaml_shape"] = {"error": repr(e)}
             try:
-                # BASELINE configs[3]: 4096 envs x 16 / 20 / 25-rack configs by env_id % 3 -- the GENERAL kernel (several
-                # configs are not the common case); parity at this size: tests/test_gpu_production_sizes.py
+                # BASELINE configs[3]: 4096 envs x 16 / 20 / 25-rack configs by env_id % 3 -- since round 4 the common-case kernel too
+                # (two envs per wavefront; every env carries its own copy of its config's scalars, SdcDev::prm_env; the four-env
+                # mapping needs ONE config); parity at this size: tests/test_gpu_production_sizes.py
                 sec["mixed_racks"] = secondary_rate(N, args.episode_steps, "ny", dev, 2016,
                                                     dc_files=("dc_config.json", "dc_config_r16.json", "dc_config_r25.json"))
                 sec["mixed_racks"]["workload"] = "BASELINE configs[3]: 4096 envs x mixed 16/20/25-rack dc configs"

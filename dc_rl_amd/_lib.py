@@ -151,13 +151,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    build_infos(force)
+    try:
+        build_infos(force)      # (host-side helper of the vector env's `infos`; an engine-only user does not need it)
+    except Exception as e:
+        print(f"dc_rl_amd: {INFOS_LIB} not built ({e!r}); SdcEngine works without it, SustainDCVecEnv needs it")
     return LIB_PATH
 
 
 # ---- the host-side helper behind SustainDCVecEnv's `infos` (csrc/sdc_infos.c: CPython C API, gcc, no GPU code) ----------
 INFOS_SRC = os.path.join(CSRC, "sdc_infos.c")
-INFOS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_sdc_infos.so")
+# (named with the interpreter's ABI tag -- _sdc_infos.cpython-310-x86_64-linux-gnu.so -- so that another Python version builds
+# its own instead of importing this one)
+import sysconfig as _sysconfig
+INFOS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_sdc_infos" + (_sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 
 def build_infos(force: bool = False) -> str:
@@ -169,6 +175,9 @@ def build_infos(force: bool = False) -> str:
     tmp = INFOS_LIB + f".{os.getpid()}.tmp"      # (several ranks / test workers may build at once: rename is atomic)
     subprocess.check_call([cc, "-O2", "-Wall", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], INFOS_SRC, "-o", tmp])
     os.replace(tmp, INFOS_LIB)
+    untagged = os.path.join(os.path.dirname(INFOS_LIB), "_sdc_infos.so")
+    if untagged != INFOS_LIB and os.path.exists(untagged):      # (a build of an earlier revision: the import system would still find it)
+        os.remove(untagged)
     return INFOS_LIB
 
 
@@ -183,8 +192,9 @@ def load_infos():
             build_infos()
         except Exception as e:
             if not os.path.exists(INFOS_LIB):
-                raise RuntimeError(f"dc_rl_amd/_sdc_infos.so is missing and could not be built ({e!r}); run "
-                                   "`python -c 'import __graft_entry__ as g; g.build()'`") from e
+                raise RuntimeError(f"{INFOS_LIB} is missing and could not be built ({e!r}: it needs gcc and the Python headers, "
+                                   "one second); run `python -c 'import __graft_entry__ as g; g.build()'` on a machine that has "
+                                   "them.  dc_rl_amd.SdcEngine (the C-ABI wrapper) works without it.") from e
         import importlib
         _infos_mod = importlib.import_module("dc_rl_amd._sdc_infos")
     return _infos_mod

@@ -1001,6 +1001,17 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
   if (!f) return fail_msg(std::string("sdc_set_state: unknown field ") + field);
   const size_t need = f->elem * (size_t)h->cfg.n_envs;
   if (bytes != need) return fail_msg(std::string("sdc_set_state: size mismatch for ") + field);
+  // what the kernels index with is validated BEFORE anything reaches the device: a config id out of range would index
+  // S.dc[] / the per-env config scalars out of bounds on the next step (with one config the kernels never read the id)
+  const bool is_cfg = std::strcmp(field, "cfg_id") == 0, is_record = std::strcmp(field, "record") == 0;
+  if (is_cfg || is_record) {
+    const int* c = static_cast<const int*>(host_buf);
+    for (int e = 0; e < h->cfg.n_envs; e++) {
+      const int id = is_cfg ? c[e] : (int)static_cast<const unsigned*>(host_buf)[(size_t)e * SDC_REC_DWORDS + R_CFG];
+      if (id < 0 || id >= h->cfg.n_dc_configs)
+        return fail_msg(is_cfg ? "sdc_set_state: cfg_id out of range" : "sdc_set_state: record with a cfg_id out of range");
+    }
+  }
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   if (!f->ptr) {
@@ -1019,18 +1030,14 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
     HIP_TRY(hipMemcpy(*f->ptr, host_buf, need, hipMemcpyHostToDevice));
   }
   if (h->cfg.n_dc_configs > 1) {             // the envs' own copies of their configs' scalars follow the assignment
-    if (std::strcmp(field, "cfg_id") == 0) {
+    if (is_cfg) {
       const int* c = static_cast<const int*>(host_buf);
-      for (int e = 0; e < h->cfg.n_envs; e++)
-        if (c[e] < 0 || c[e] >= h->cfg.n_dc_configs) return fail_msg("sdc_set_state: cfg_id out of range");
       h->cfg_host.assign(c, c + h->cfg.n_envs);
       if (rebuild_prm_env(h)) return -1;
-    } else if (std::strcmp(field, "record") == 0) {
+    } else if (is_record) {
       const unsigned* r = static_cast<const unsigned*>(host_buf);
       h->cfg_host.resize((size_t)h->cfg.n_envs);
       for (int e = 0; e < h->cfg.n_envs; e++) h->cfg_host[e] = (int)r[(size_t)e * SDC_REC_DWORDS + R_CFG];
-      for (int e = 0; e < h->cfg.n_envs; e++)
-        if (h->cfg_host[e] < 0 || h->cfg_host[e] >= h->cfg.n_dc_configs) return fail_msg("sdc_set_state: record with a cfg_id out of range");
       if (rebuild_prm_env(h)) return -1;
     }
   }

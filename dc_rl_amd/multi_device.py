@@ -173,9 +173,18 @@ class SustainDCMultiDeviceVecEnv(ShareVecEnv):
         return np.broadcast_to(share[:, None, :], (self.num_envs, self.n_agents, share.shape[1]))
 
     def step_async(self, actions):
-        """actions: [N, n_agents(, 1)] NumPy / host tensor, or a sequence of per-device tensors (one per shard, env order)."""
-        if isinstance(actions, (list, tuple)) and len(actions) == len(self.shards) and hasattr(actions[0], "shape") and \
-                actions[0].shape[0] == self.ranges[0][1] - self.ranges[0][0] and len(self.shards) > 1:
+        """actions: ONE [N, n_agents(, 1)] batch (NumPy array, host tensor, nested list: the ShareVecEnv contract), or -- the
+        device-resident form -- a TUPLE of torch tensors, one per shard in env order, each of its shard's [n, n_agents(, 1)] and on
+        its shard's device.  Only that exact form is taken as per-device parts (a plain list of per-env rows never is, whatever its
+        length); `return_torch=True` correspondingly RETURNS per-device tuples (see step_wait), not [N, ...] arrays."""
+        t = self._torch
+        per_device = (isinstance(actions, tuple) and len(actions) == len(self.shards) and
+                      all(isinstance(p, t.Tensor) for p in actions))
+        if per_device:
+            for p, (lo, hi), sh in zip(actions, self.ranges, self.shards):
+                if p.shape[0] != hi - lo or p.device != sh.engine.device:
+                    raise ValueError(f"per-device actions: shard [{lo}, {hi}) on {sh.engine.device} was handed a tensor of "
+                                     f"{tuple(p.shape)} on {p.device}")
             parts = list(actions)
         else:
             a = actions.reshape(self.num_envs, self.n_agents) if hasattr(actions, "reshape") else \

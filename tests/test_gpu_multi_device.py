@@ -73,11 +73,14 @@ def test_device_resident_outputs_per_device():
     g = torch.Generator(device="cpu").manual_seed(1)
     for t in range(100):
         a = torch.randint(0, 3, (N, 3), generator=g, dtype=torch.int32).cuda()
-        parts = [a[lo:hi] for lo, hi in multi.ranges]          # a policy per device hands its own device's actions over
+        parts = tuple(a[lo:hi] for lo, hi in multi.ranges)     # a policy per device hands its own device's actions over (a TUPLE of tensors)
         om, sm, rm, dm, im, _ = multi.step(parts)
         ow, sw, rw, dw, iw, _ = whole.step(a)
         assert torch.equal(torch.cat(om), ow) and torch.equal(torch.cat(sm), sw) and torch.equal(torch.cat(rm), rw)
         assert torch.equal(torch.cat(dm), dw)
+        if t == 3:     # a plain LIST of per-env rows is one [N, k] batch, whatever its length (here N == 32 rows, never "2 parts")
+            with pytest.raises(ValueError):
+                multi.step_async((a[:3], a[3:]))           # per-device parts of the wrong sizes are refused, not reshaped
         assert im[1][3][0]["bat_SOC"] == iw[multi.ranges[1][0] + 3][0]["bat_SOC"]
     multi.close()
     whole.close()
