@@ -568,9 +568,10 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # (this image's host driver supports dmabuf device-memory IPC only -- what RCCL's intra-node transports open their peers'
-        # buffers with; the variable is set in the image's environment already and kept here for a shell that dropped it.  The
-        # mechanism is measured on one GPU by tests/test_gpu_distributed.py::test_device_memory_ipc_needs_the_dmabuf_mode)
+        # (a documented requirement of this platform, not a tuning choice: its host driver supports dmabuf device-memory IPC only --
+        # what RCCL's intra-node transports open their peers' buffers with -- and without the variable `hipIpcGetMemHandle` fails
+        # with "invalid argument".  The image exports it already; this line is for a launcher that dropped it.  It cannot be
+        # measured on a one-GPU lease: a world of one rank opens no peer buffer, with or without it)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl" and ndev < world:
             if rank == 0:

@@ -24,6 +24,8 @@ extern "C" __global__ void sdc_dynamics_fast_kernel(SdcDev S, int rel_hint, cons
                                                     unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_dynamics_quad_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                                     unsigned char* done, float* info, float* final_obs, float* rew);
+extern "C" __global__ void sdc_dynamics_wide_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
+                                                    unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_rollout_quad_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs,
                                                    float* share_obs, unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_rollout_fast_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs,
@@ -241,11 +243,23 @@ bool quad_case(const sdc_handle* h, const bool multi_step) {
          (h->cfg.n_envs >= (multi_step ? SDC_QUAD_MIN_ENVS_LOOP : SDC_QUAD_MIN_ENVS_STEP) || (h->d.debug_flags & 1024));
 }
 int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
+// ONE LANE PER ENV (sdc_wide.hip): single steps of the largest lock-step batches -- a multiple of 64 envs, one config of <= 31
+// racks, 16-byte aligned output rows (whole-line stores through the wavefront's staging block); debug_flags bit 11 forces it
+// for any such batch, bit 12 keeps it off
+#ifndef SDC_WIDE_MIN_ENVS
+#define SDC_WIDE_MIN_ENVS 16384
+#endif
+bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, const float* info) {
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  return (h->cfg.n_envs & 63) == 0 && h->d.n_cfg == 1 && h->racks_cfg0 <= 31 && (h->d.debug_flags & (512 | 1024 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
+         (h->cfg.n_envs >= SDC_WIDE_MIN_ENVS || (h->d.debug_flags & 2048)) && al16(obs) && al16(share_obs) && al16(info);
+}
+int wide_sweep_blocks(const sdc_handle* h) { return std::min(h->d.rq_max, 256); }
 bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_obs, const float* info, bool timed) {
   const SdcDev& d = h->d;
   return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs &&
          (d.n_cfg == 1 ? (h->racks_cfg0 > 0 && h->racks_cfg0 <= 32) : (h->prm_env_ok && h->racks_max <= 32)) && actions && share_obs &&
-         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | 512 | 1024 | FAST_DEBUG_FLAGS)) == 0 &&
+         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | 512 | 1024 | 2048 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
          d.policy[0] == SDC_POLICY_EXTERNAL && d.policy[1] == SDC_POLICY_EXTERNAL && d.policy[2] == SDC_POLICY_EXTERNAL &&
          d.reward_method[0] == SDC_REWARD_DEFAULT && d.reward_method[1] == SDC_REWARD_DEFAULT &&
          d.reward_method[2] == SDC_REWARD_DEFAULT;
@@ -703,7 +717,11 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   }
   d.step_no = h->step_no;
   h->step_no = next_step_no(h->step_no, 1);
-  if (fast_case(h, actions, share_obs, info, timed) && quad_case(h, false))
+  if (fast_case(h, actions, share_obs, info, timed) && wide_case(h, obs, share_obs, info)) {
+    d.sweep_blocks = wide_sweep_blocks(h);
+    hipLaunchKernelGGL(sdc_dynamics_wide_kernel, dim3(d.sweep_blocks + N / SDC_WAVE), dim3(SDC_WAVE), 0, st, d, h->rel_hint, actions,
+                       obs, share_obs, done, info, final_obs, rew);
+  } else if (fast_case(h, actions, share_obs, info, timed) && quad_case(h, false))
     hipLaunchKernelGGL(sdc_dynamics_quad_kernel, dim3(d.sweep_blocks + quad_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
                        h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
   else if (fast_case(h, actions, share_obs, info, timed))

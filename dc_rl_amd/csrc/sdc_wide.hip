@@ -1,0 +1,543 @@
+// sdc_wide.hip -- the step kernel for the LARGEST batches: ONE LANE PER ENVIRONMENT (a wavefront = 64 consecutive envs).
+//
+// The pair / quad kernels (sdc_pairstep.hpp) carry an env on 32 / 16 lanes: the rack model runs lane = rack, and every per-env
+// scalar instruction -- most of the step -- is issued once per 2 / 4 envs.  That is the right trade while the batch is small
+// enough that a launch is a latency chain per wavefront (4096 envs).  At 32 768 envs the quad kernel issues 363 VALU instructions
+// per env-step and the SIMDs are the bound.  Here an env is ONE lane: the scalar physics is issued once per 64 envs, the rack
+// model is a per-lane loop over the config's racks (its parameters wave-uniform: scalar operands), and nothing in the dynamics
+// crosses lanes.  ~55 VALU instructions per env-step; what bounds the kernel is then what SURVEY.md section 8(d) says bounds
+// the path: the bytes of state, traces and outputs it moves.
+//
+// The arithmetic is pair_dynamics' / pair_reward_fast's, expression for expression in the same order (the rack sums in the
+// half-wave reduction's tree order), so the outputs and the state are the same bits whichever kernel steps a batch.
+//
+// Reward normalisation (utils/reward_creator.py:16-45): the O(1) path per lane -- the rank windows' first / last keys and ranks
+// from the header, the few keys around the wanted ranks gathered from the windows in memory (sdc_trackers.hpp: a window lists 64
+// of the 10 000 keys, a step's keys land inside one on ~5 % of the env-steps).  What needs a window's 64 keys side by side -- a key
+// landing inside it, a re-centred window arriving, a re-centring request to file -- is done by the WHOLE wavefront for that one
+// env (lane = key, the sdc_trackers.hpp primitives), env after env; anything unusual falls back to env_reward() (sdc_pairstep.hpp).
+//
+// The host picks this kernel for a lock-step, single-config, default-reward batch of a multiple of 64 envs above
+// SDC_WIDE_MIN_ENVS (sdc_capi.hip wide_case).  Reference: sustaindc_env.py:533-737 (per-block citations: sdc_pairstep.hpp).
+#include "sdc_pairstep.hpp"
+#include "sdc_sweep.hpp"
+
+namespace {
+
+constexpr int WE = SDC_WAVE;     // envs per wavefront: lane = env
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v nt_load4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p)); }
+__device__ __forceinline__ void nt_store4(float* p, const f4v v) { __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p)); }
+
+struct WideShared {
+  float stage[WE * SDC_OBS_OUT];   // output transposition: the wavefront's 64 obs rows (78 floats each), then its share_obs rows
+  float back[WE][8];               // what a whole-wavefront reward step hands back to its env's lane {z, path, ret[3]}
+  sdc_rw::TailLds tl;              // scratch of the ring paths (env_reward: window refill, rebuild)
+};
+
+// pairwise (binary-tree) sum over rack slots 0..31 in slot order, streamed: push(v) for slot 0, 1, ... ; total() when done.  The tree
+// is half_sum_f64's (strides 1, 2, 4, 8 inside the rows, then the two rows), so the sums round as in the other mappings;
+// slots without a rack hold zeros there, which change nothing here.
+struct TreeSum32 {
+  double a1, a2, a4, a8, a16;
+  int k;
+  __device__ __forceinline__ void init() { k = 0; a1 = a2 = a4 = a8 = a16 = 0.0; }
+  // (k is wave-uniform: the branches below are scalar.  Level a_m holds the sum of a complete group of m slots that still waits
+  // for its right-hand neighbour)
+  __device__ __forceinline__ void push(double v) {
+    if (k & 1) {
+      v = a1 + v;
+      if (k & 2) {
+        v = a2 + v;
+        if (k & 4) {
+          v = a4 + v;
+          if (k & 8) a16 = a8 + v;      // (slots 0..15 complete; the host keeps this kernel to <= 31 racks: bit 4 never carries)
+          else a8 = v;
+        } else {
+          a4 = v;
+        }
+      } else {
+        a2 = v;
+      }
+    } else {
+      a1 = v;
+    }
+    k++;
+  }
+  // the tree's upper levels: a count that is not a power of two leaves partial sums on several levels (lower level = later slots)
+  __device__ __forceinline__ double total() const {
+    double t = 0.0;
+    bool have = false;
+    if (k & 1) { t = a1; have = true; }
+    if (k & 2) { t = have ? a2 + t : a2; have = true; }
+    if (k & 4) { t = have ? a4 + t : a4; have = true; }
+    if (k & 8) { t = have ? a8 + t : a8; have = true; }
+    if (k & 16) { t = have ? a16 + t : a16; }
+    return t;
+  }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// One launch = one env-step of all N environments.  Grid: S.sweep_blocks one-wavefront sweep workgroups (first: they serve the
+// previous step's re-centring requests while the envs step), then N / 64 env workgroups of one wavefront.
+extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) void sdc_dynamics_wide_kernel(
+    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
+    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+  __shared__ WideShared sh;
+  using namespace sdc_rw;
+  const int lane = threadIdx.x;
+  const int bx = (int)blockIdx.x;
+  if (bx < S.sweep_blocks) {
+    // one wavefront per request (requests bx, bx + sweep_blocks, ...): a sweep is 40 KB through one wavefront, ~5 us -- shorter
+    // than the step it runs beside
+    const int set = S.step_no % 3;
+    const int cnt = min(S.rq_count[set], S.rq_max);
+    if (bx == 0 && lane == 0) S.rq_count[(S.step_no + 2) % 3] = 0;     // the set the NEXT step's requests go to
+    if (bx < cnt) __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
+#pragma unroll 1
+    for (int j = bx; j < cnt; j += S.sweep_blocks) serve_recentring_request(S, set, j, lane, sh.tl);
+    return;
+  }
+  const int nb = (int)gridDim.x - S.sweep_blocks;
+  const int env0 = first_pair_of_block(bx - S.sweep_blocks, nb, 1) * WE;     // (every XCD a contiguous range of envs)
+  if (env0 >= S.n_envs) return;
+  const int env = env0 + lane;
+  KLit kt{};
+
+  // ---- loads: actions, state record, feature row, queue-history probes ----------------------------------------------------
+  const int32_t* ap = actions + (size_t)env * 3;
+  int a_ls = ap[0], a_dc = ap[1], a_bat = ap[2];
+  const uint4* rp4 = reinterpret_cast<const uint4*>(S.rec + (size_t)env * SDC_REC_DWORDS);
+  const uint4 r0 = rp4[0], r1 = rp4[1], r2 = rp4[2], r3 = rp4[3], r4 = rp4[4], r6 = rp4[6];
+  const uint2 r9 = reinterpret_cast<const uint2*>(S.rec + (size_t)env * SDC_REC_DWORDS)[R_HIST_REF / 2];
+  static_assert(R_CURSOR == 0 && R_TREL == 1 && R_DAY == 2 && R_HOURQ == 3 && R_QPOPPED == 4 && R_QCUM == 5 && R_QCUMT == 6 &&
+                R_QHEAD == 7 && R_QCUM_HM1 == 8 && R_QCUMT_HM1 == 9 && R_LAST_DELTA == 10 && R_CONSEC == 11 && R_SCALE == 12 &&
+                R_HIST_LEN == 13 && R_HIST_POS == 14 && R_FAULT == 16 && R_STPT == 24 && R_BAT == 26 && R_HIST_REF == 36 &&
+                R_LAST_ROOM == 40, "record layout the per-lane loads assume");
+  const float* fr = S.feat + feat_row_offset(S, env, rel_hint + 1);
+  float row[SDC_FEAT_ROW];
+#pragma unroll
+  for (int q = 0; q < SDC_FEAT_ROW / 4; q++) {
+    const f4v v = nt_load4(fr + 4 * q);
+    row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
+  }
+  const uint2* qt = S.qtab + (size_t)env * S.qstride;
+  int cumq[5];     // cum[now - 97], cum[now - 24], cum[now - 48], cum[now - 72], cum[now - 96] (0 before the episode's start)
+#pragma unroll
+  for (int s = 0; s < 5; s++) {
+    const int back = s == 0 ? 97 : 24 * s;
+    const int t = rel_hint - back;
+    cumq[s] = t >= 0 ? (int)qt[t].x : 0;
+  }
+
+  const int i = (int)r0.x, rel = (int)r0.y, day = (int)r0.z, hourq = (int)r0.w;
+  const int popped0 = (int)r1.x, cum_prev = (int)r1.y;
+  const unsigned cumT_prev = r1.z;
+  int head = (int)r1.w;
+  int cum_hm1 = (int)r2.x;
+  unsigned cumT_hm1 = r2.y;
+  int last_delta = (int)r2.z, consecutive = (int)r2.w, scale = (int)r3.x;
+  int hl = (int)r3.y, hpos = (int)r3.z;
+  const unsigned fault0 = r4.x;
+  const double stpt0 = __hiloint2double((int)r6.y, (int)r6.x);
+  double bat_load = __hiloint2double((int)r6.w, (int)r6.z);
+  const double href0 = __hiloint2double((int)r9.y, (int)r9.x);
+
+  unsigned fault = 0;
+  if (i + 9 > S.table_len - 1) fault |= SDC_FAULT_TABLE_RANGE;
+  if ((unsigned)a_ls > 2u || (unsigned)a_dc > 2u || (unsigned)a_bat > 2u) {
+    fault |= SDC_FAULT_ACTION;
+    if ((unsigned)a_ls > 2u) a_ls = 1;
+    if ((unsigned)a_dc > 2u) a_dc = 1;
+    if ((unsigned)a_bat > 2u) a_bat = 2;
+  }
+  // the evicted ring key (read BEFORE this step's key goes into that slot) and the queue table ahead of the oldest task
+  const int slot0 = hl < S.hist_cap ? hl : hpos;
+  unsigned x_old = 0xFFFFFFFFu;
+  if (hl >= S.hist_cap) x_old = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
+  constexpr int QA = 16;        // table entries ahead of the oldest task's step requested up front (two per dwordx4)
+  uint4 qa[QA / 2];
+#pragma unroll
+  for (int q = 0; q < QA / 2; q++) qa[q] = make_uint4(0u, 0u, 0u, 0u);
+  const bool may_pop = a_ls == 2 || cumq[0] - popped0 > 0;       // (drain, or overdue tasks to run)
+  if (may_pop) {
+#pragma unroll
+    for (int q = 0; q < QA / 2; q++) {
+      const int t = head + 2 * q;
+      if (t + 1 < rel) qa[q] = *reinterpret_cast<const uint4*>(qt + t);
+      else if (t < rel) { const uint2 e = qt[t]; qa[q] = make_uint4(e.x, e.y, 0u, 0u); }
+    }
+  }
+
+  static_assert(SDC_FEAT_W == 10 && SDC_FEAT_T1 == 12 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 &&
+                SDC_FEAT_NCNEXT == 30, "feature-row slots of the step's inputs");
+  auto row_f64 = [&](const int j) { return __hiloint2double(__float_as_int(row[j + 1]), __float_as_int(row[j])); };
+  const double wl = row_f64(SDC_FEAT_W), ci_i = row_f64(SDC_FEAT_C), amb = row_f64(SDC_FEAT_T), wet_bulb = row_f64(SDC_FEAT_WB);
+  const double norm_ci = row_f64(SDC_FEAT_NCNEXT);
+  const double amb_next = (double)row[SDC_FEAT_T1];
+  const double hour = (double)hourq * 0.25;
+
+  // ---- load shifting: envs/carbon_ls.py:172-324 (pair_dynamics, same expressions) ---------------------------------------------
+  if (wl < 0 || wl > 1) fault |= SDC_FAULT_WORKLOAD;
+  const double flex = KC(0.2), nonflex = KC(0.8);
+  const int ns = (int)ceil(wl * nonflex * 100);
+  const int shf = (int)floor(wl * flex * 100);
+  const int now = rel;
+  int popped = popped0;
+  const int overdue = max(0, cumq[0] - popped);
+  int avail = 90 - (ns + shf);
+  int od_proc = 0;
+  if (avail > 0 && overdue > 0) od_proc = min(overdue, avail);
+  popped += od_proc;
+  avail = 90 - (ns + shf + od_proc);
+  const int qlen = cum_prev - popped;
+  const bool defer = a_ls == 0, drain = a_ls == 2 && avail >= 1;
+  const int add = defer ? min(shf, S.queue_max - qlen) : 0;
+  const int dropped = defer ? shf - add : 0;
+  const int processed = drain ? min(min(shf, avail), qlen) : 0;
+  popped += processed;
+  const int util_tasks = od_proc + (defer ? shf - add : shf + processed);
+  double util = KDIV((double)util_tasks, 100);
+  util += KDIV((double)ns, 100);
+  const int cum_now = cum_prev + add;
+  const unsigned cumT_now = cumT_prev + (unsigned)add * (unsigned)now;
+  const int total = cum_now - popped;
+  const int a24 = max(0, cumq[1] - popped), a48 = max(0, cumq[2] - popped);
+  const int a72 = max(0, cumq[3] - popped), a96 = max(0, cumq[4] - popped);
+  double hist[5];
+  const double den = (double)max(total, 1), rden = 1.0 / den;
+  hist[0] = sdc_div_const((double)(total - a24), den, rden);
+  hist[1] = sdc_div_const((double)(a24 - a48), den, rden);
+  hist[2] = sdc_div_const((double)(a48 - a72), den, rden);
+  hist[3] = sdc_div_const((double)(a72 - a96), den, rden);
+  hist[4] = a96 > 0 ? 1.0 : 0.0;
+  // oldest task: smallest step hd in [head, now] with cum[hd] > popped; it only moves when tasks were popped
+  double oldest = 0.0, avg = 0.0;
+  {
+    const bool was_empty = (cum_prev - popped0) == 0;
+    bool need = total > 0 && !was_empty && popped != popped0;
+    if (need) {
+      // among the QA entries requested up front (entry j = step head + j)?
+      int f = -1;
+      unsigned cm1 = 0u, ctm1 = 0u;     // cum / cumT of the entry before the first hit
+#pragma unroll
+      for (int j = QA - 1; j >= 0; j--) {
+        const int t = head + j;
+        const unsigned cx = (j & 1) ? qa[j / 2].z : qa[j / 2].x;
+        const int c = (t == now) ? cum_now : (int)cx;
+        if (t <= now && c > popped) f = j;
+      }
+#pragma unroll
+      for (int j = 0; j < QA - 1; j++) {
+        if (f == j + 1) {
+          cm1 = (j & 1) ? qa[j / 2].z : qa[j / 2].x;
+          ctm1 = (j & 1) ? qa[j / 2].w : qa[j / 2].y;
+        }
+      }
+      if (f >= 0) {
+        need = false;
+        if (f > 0) {
+          head += f;
+          cum_hm1 = (int)cm1;
+          cumT_hm1 = ctm1;
+        }
+      }
+    }
+    if (need) {
+      // further ahead than that (rare): walk the table
+      int t = head + QA;
+      while (t < now && (int)qt[t].x <= popped) t++;      // (cum[now] > popped: the walk ends at `now` at the latest)
+      head = t;
+      if (head == now) {
+        cum_hm1 = cum_prev;
+        cumT_hm1 = cumT_prev;
+      } else {
+        const uint2 e = qt[head - 1];
+        cum_hm1 = (int)e.x;
+        cumT_hm1 = e.y;
+      }
+    }
+    if (total > 0) {
+      if (was_empty) {
+        head = now;
+        cum_hm1 = cum_prev;
+        cumT_hm1 = cumT_prev;
+      }
+      const long long sum_t = (long long)cumT_now - (long long)cumT_hm1 - (long long)(popped - cum_hm1) * head;
+      const long long sum_age_steps = (long long)total * now - sum_t;
+      oldest = (double)(now - head) * 0.25;
+      avg = sdc_div_const((double)sum_age_steps * 0.25, den, rden);
+    } else {
+      head = now;
+      cum_hm1 = cum_now;
+      cumT_hm1 = cumT_now;
+    }
+  }
+  const double normq = sdc_div_const((double)total, S.queue_max_d, S.rc_queue_max);
+  const double oldest_norm = KDIV(oldest, 24), avg_norm = KDIV(avg, 24);
+
+  // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 --------------------------------------------------------------------
+  const SdcDcDev& D = S.dc[0];
+  const sdc_dc_params& P = D.p;
+  if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
+  const int delta = a_dc - 1;
+  if (last_delta != -2 && delta == last_delta && a_dc != 0) {
+    consecutive += 1;
+  } else {
+    consecutive = 1;
+    scale = 1;
+  }
+  if (consecutive > 3) scale += 1;
+  double stpt = stpt0 + (double)(delta * scale);
+  stpt = fmax(fmin(stpt, P.max_temp), P.min_temp);
+
+  // ---- rack model: envs/datacenter.py:250-317, :157-181 -- a loop over the config's racks, this lane's env --------------------
+  const int R = P.n_racks;
+  const double load_pct = util * 100;
+  bool bad_delta = false;
+  TreeSum32 s_out, s_pw;
+  s_out.init();
+  s_pw.init();
+  {
+    const double m_cpu = P.m_cpu, c_cpu = P.c_cpu, rs_cpu = P.rs_cpu;
+    const double m_fan = P.m_fan, c_fan = P.c_fan, rs_fan = P.rs_fan;
+    const double cpu_shift = rs_cpu * KDIV(load_pct, 100), fan_shift = rs_fan * KDIV(load_pct, 20);
+#pragma unroll 2
+    for (int rk = 0; rk < R; rk++) {
+      const double r_supply = P.rack_supply[rk], r_idle = P.rack_idle[rk], r_full = P.rack_full[rk], r_n = P.rack_n[rk];
+      const double sa = fmax(KC(3.8), fmin(r_supply, KC(5.3)));
+      const double inlet = sa + stpt;
+      const double ratio = ((m_cpu + KC(0.05)) * inlet + c_cpu) + cpu_shift;
+      const double cpu1 = fmax(r_idle, r_full * ratio);
+      const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
+      const double fan1 = P.itfan_ref_p * (v * D.rc_itfan_ref_v_ratio);
+      const double vf1 = P.it_fan_full_load_v * v;
+      const double pc = r_n * cpu1, pf = r_n * fan1;
+      const double vtot = r_n * vf1;
+      const double pw = pc + pf;
+      const bool plain = pw > KC(1e-300) && pw < KC(1e300) && vtot > KC(1e-300) && vtot < KC(1e300);
+      const double rise = exp2_short(KC(1.096) * log2_pos_normal(plain ? pw : 1.0, kt) - KC(0.824) * log2_pos_normal(plain ? vtot : 1.0, kt), kt);
+      const double out = inlet + D.k_outlet * rise + KC(-14.01);
+      if (out - inlet < 2 || !plain) bad_delta = true;
+      s_pw.push(pw);
+      s_out.push(out);
+    }
+  }
+  if (bad_delta) fault |= SDC_FAULT_OUTLET_DELTA;
+  const double sum_outlet = s_out.total();
+  const double p_it = s_pw.total();
+  const double avg_ret = (D.ret_sum + sum_outlet) * D.rc_n_racks;
+  const double mean_outlet = sum_outlet * D.rc_n_racks;
+
+  // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 -----------------------------------------------------------------------
+  const double c_air = P.c_air, rho_air = P.rho_air, ct_fan_ref_p = P.ct_fan_ref_p;
+  const double m_sys = rho_air * P.crac_supply_pu * p_it;
+  const double q_cool = m_sys * c_air * fmax(0.0, avg_ret - stpt);
+  const double comp = chiller_power(ct_fan_ref_p, q_cool, amb, kt);
+  double ct;
+  {
+    const double dlt = fmax(50 - (amb - stpt), 1);
+    const double m_air = sdc_div_fast(q_cool, c_air * dlt);
+    const double v_air = m_air * D.rc_rho_air;
+    const double x = fmin(v_air * D.rc_ctafr, 1);
+    ct = amb < 5 ? 0.0 : ct_fan_ref_p * (x * x * x);
+  }
+  double water;
+  {
+    const double range_temp = avg_ret - stpt;
+    const double y_int = KC(0.3528) * range_temp + KC(0.101);
+    double w = KC(0.044) * wet_bulb + y_int;
+    if (w < 0) w = 0;
+    w += w * KC(0.01);
+    water = k_round((w * 1000) / 4, 1e4);
+  }
+  const double total_kw = KDIV(p_it + ct + comp, 1e3);
+
+  // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ---------------------------------------------------
+  const double cap = P.bat_capacity_mwh;
+  const double dcload = KDIV(total_kw, 1e3);
+  const double e_nobat = dcload * 1e3 * 0.25;
+  double energy = e_nobat, co2;
+  if (a_bat != 2) {
+    const bool chg = a_bat == 0;
+    const double soc = sdc_div_const(bat_load - 0, cap - 0, D.rc_bat_capacity);
+    const double sg = 1 / (1 + exp_plain(-(10 * (soc - (chg ? 0.5 : 0.25))), kt));
+    const double rate = chg ? k_round(0.5 * (1 - sg), 1e4) : fmax(0.5, 4 * sg);
+    const double tu = KDIV(rate * 15, 60);
+    const double quo = (chg ? cap - bat_load : bat_load) / (chg ? tu + KC(0.04) : KC(0.01) + tu);
+    if (chg) {
+      const double max_charge = fmin((cap / 1) * KC(0.1), quo);
+      const double charging_load = fmin(max_charge, cap) * 1 * tu;
+      bat_load = k_round(bat_load + charging_load, 1e8);
+      energy = e_nobat + charging_load * 1e3;
+    } else {
+      const double max_d = fmin(fmin((cap / 1) * 1, quo), dcload * 0.25);
+      bat_load = k_round(bat_load - (fmin(max_d, cap) * 1 * tu), 1e8);
+      const double discharge = max_d < cap ? max_d * tu : cap * tu;
+      if (!(e_nobat >= discharge * 1e3)) fault |= SDC_FAULT_BAT_DISCHARGE;
+      energy = e_nobat - discharge * 1e3;
+    }
+  }
+  co2 = (a_bat == 1 ? fmax(energy, 0.0) : energy) * ci_i;
+  const double soc_after = sdc_div_const(bat_load, cap, D.rc_bat_capacity);
+
+  // ---- time: utils/managers.py:127-147 -------------------------------------------------------------------------------------------
+  int hourq_n = hourq + 1, day_n = day;
+  if (hourq_n >= 96) {
+    hourq_n = 0;
+    day_n += 1;
+  }
+  const int ip = i + 1;
+
+  // ---- history append (utils/reward_creator.py:7-14) -------------------------------------------------------------------------------
+  const double href = hl == 0 ? energy : href0;
+  const double e_off = energy - href;
+  int slot;
+  if (hl < S.hist_cap) {
+    slot = hl;
+    hl += 1;
+  } else {
+    slot = hpos;
+    hpos = hpos + 1 == S.hist_cap ? 0 : hpos + 1;
+  }
+  const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
+  S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
+  S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
+  const unsigned f_all = fault0 | fault;
+
+  // ---- new state record ----------------------------------------------------------------------------------------------------------------
+  {
+    uint4* wp4 = reinterpret_cast<uint4*>(S.rec + (size_t)env * SDC_REC_DWORDS);
+    wp4[0] = make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n);
+    wp4[1] = make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head);
+    wp4[2] = make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive);
+    wp4[3] = make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, r3.w);
+    S.rec[(size_t)env * SDC_REC_DWORDS + R_FAULT] = f_all;
+    wp4[6] = make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
+                        (unsigned)__double2hiint(bat_load));
+    uint2* wp2 = reinterpret_cast<uint2*>(S.rec + (size_t)env * SDC_REC_DWORDS);
+    wp2[R_HIST_REF / 2] = make_uint2((unsigned)__double2loint(href), (unsigned)__double2hiint(href));
+    wp2[R_LAST_ROOM / 2] = make_uint2((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet));
+  }
+
+  // ---- rewards + reward-state upkeep ------------------------------------------------------------------------------------------------
+  // (stage 1: every env through the whole-wavefront form, env by env)
+  float z_f = 0.0f, path_f = 0.0f, ret_f[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+  for (int e = 0; e < WE; e++) {
+    const int env_e = env0 + e;
+    auto pi = [&](const int v) { return __builtin_amdgcn_readlane(v, e); };
+    auto pf = [&](const double v) { return readlane_f64(v, e); };
+    const unsigned hd_e = S.hdr[(size_t)env_e * SDC_HDR_DWORDS + lane];
+    const uint4 qw_e = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env_e * SDC_WIN + lane];
+    env_reward(S, env_e, lane, hd_e, qw_e, pi(hl), pi(slot), (unsigned)pi((int)x_new), (unsigned)pi((int)x_old), pf(e_off), pf(energy),
+               pf(norm_ci), pf(oldest_norm), pi(overdue), pi(hourq_n), pf(p_it), pf(total_kw), pf(water), rew, &sh.back[0][0] + e * 8 - SDC_INFO_ENERGY_Z, sh.tl);
+  }
+  wave_sync();
+  z_f = sh.back[lane][0]; path_f = sh.back[lane][1]; ret_f[0] = sh.back[lane][2]; ret_f[1] = sh.back[lane][3]; ret_f[2] = sh.back[lane][4];
+
+  // ---- outputs ----------------------------------------------------------------------------------------------------------------------
+  // the observation pool (sdc_device.hpp SDC_P_*): the trace-only entries are the feature row's, nine depend on the step
+  float pool[SDC_POOL_DIM];
+#pragma unroll
+  for (int j = 0; j < SDC_POOL_DIM; j++) pool[j] = row[j];
+  pool[SDC_P_OLDEST] = (float)oldest_norm;
+  pool[SDC_P_AVG] = (float)avg_norm;
+  pool[SDC_P_NORMQ] = (float)normq;
+#pragma unroll
+  for (int b = 0; b < 5; b++) pool[SDC_P_HIST + b] = (float)hist[b];
+  pool[SDC_P_SOC] = (float)soc_after;
+  const bool terminal = rel + 1 >= S.episode_steps;
+  {
+    // obs [3][26] of this lane's env into its row of the staging block, then the block out in whole lines
+    float* srow = sh.stage + lane * SDC_OBS_OUT;
+#pragma unroll
+    for (int j = 0; j < SDC_OBS_OUT; j += 2) {
+      float2 v;
+      v.x = obs_pool_index(j) < 0 ? 0.0f : pool[obs_pool_index(j) < 0 ? 0 : obs_pool_index(j)];
+      v.y = obs_pool_index(j + 1) < 0 ? 0.0f : pool[obs_pool_index(j + 1) < 0 ? 0 : obs_pool_index(j + 1)];
+      *reinterpret_cast<float2*>(srow + j) = v;
+    }
+    wave_sync();
+    const f4v* s4 = reinterpret_cast<const f4v*>(sh.stage);
+    float* o4 = obs + (size_t)env0 * SDC_OBS_OUT;
+    f4v* f4 = reinterpret_cast<f4v*>(final_obs + (size_t)env0 * SDC_OBS_OUT);
+    constexpr int NV = WE * SDC_OBS_OUT / 4;
+#pragma unroll
+    for (int k = 0; k < (NV + WE - 1) / WE; k++) {
+      const int q = k * WE + lane;
+      if (q < NV) {
+        const f4v v = s4[q];
+        nt_store4(o4 + 4 * q, v);
+        if (final_obs && terminal) f4[q] = v;
+      }
+    }
+    wave_sync();
+    float* hrow = sh.stage + lane * SDC_SHARE_OBS_DIM;
+#pragma unroll
+    for (int j = 0; j < SDC_SHARE_OBS_DIM; j++) hrow[j] = j == SDC_P_SOC ? 0.0f : pool[j];
+    wave_sync();
+    float* h4 = share_obs + (size_t)env0 * SDC_SHARE_OBS_DIM;
+    constexpr int NH = WE * SDC_SHARE_OBS_DIM / 4;
+#pragma unroll
+    for (int k = 0; k < (NH + WE - 1) / WE; k++) {
+      const int q = k * WE + lane;
+      if (q < NH) nt_store4(h4 + 4 * q, s4[q]);
+    }
+  }
+  {
+    float inf[SDC_INFO_DIM];
+    inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)wl;
+    inf[SDC_INFO_LS_SHIFTED_WORKLOAD] = (float)util;
+    inf[SDC_INFO_LS_TASKS_IN_QUEUE] = (float)total;
+    inf[SDC_INFO_LS_NORM_TASKS_IN_QUEUE] = (float)normq;
+    inf[SDC_INFO_LS_TASKS_DROPPED] = (float)dropped;
+    inf[SDC_INFO_LS_TASKS_PROCESSED] = (float)processed;
+    inf[SDC_INFO_LS_OLDEST_TASK_AGE] = (float)oldest_norm;
+    inf[SDC_INFO_LS_AVERAGE_TASK_AGE] = (float)avg_norm;
+    inf[SDC_INFO_LS_OVERDUE_PENALTY] = (float)overdue;
+    inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(util * 100);
+    inf[SDC_INFO_LS_CURRENT_HOUR] = (float)hour;
+#pragma unroll
+    for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
+    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)(p_it * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)(ct * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)(comp * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)((ct + comp) * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
+    inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
+    inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
+    inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)util;
+    inf[SDC_INFO_DC_INT_TEMPERATURE] = (float)mean_outlet;
+    inf[SDC_INFO_DC_EXTERIOR_AMBIENT_TEMP] = (float)amb;
+    inf[SDC_INFO_DC_WATER_USAGE] = (float)water;
+    inf[SDC_INFO_BAT_ACTION] = (float)a_bat;
+    inf[SDC_INFO_BAT_SOC] = (float)soc_after;
+    inf[SDC_INFO_BAT_CO2_FOOTPRINT] = (float)co2;
+    inf[SDC_INFO_BAT_AVG_CI] = (float)ci_i;
+    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH] = (float)e_nobat;
+    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH] = (float)energy;
+    inf[SDC_INFO_NORM_CI] = (float)norm_ci;
+    inf[SDC_INFO_OUTSIDE_TEMP] = (float)amb_next;
+    inf[SDC_INFO_DAY] = (float)day_n;
+    inf[SDC_INFO_HOUR] = (float)((double)hourq_n * 0.25);
+    inf[SDC_INFO_FAULT] = (float)f_all;
+    inf[SDC_INFO_ENERGY_Z] = z_f;
+    inf[SDC_INFO_RESERVED] = path_f;
+    inf[SDC_INFO_EP_RETURN_LS] = ret_f[0];
+    inf[SDC_INFO_EP_RETURN_DC] = ret_f[1];
+    inf[SDC_INFO_EP_RETURN_BAT] = ret_f[2];
+    inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
+    float* i4 = info + (size_t)env * SDC_INFO_DIM;
+#pragma unroll
+    for (int q = 0; q < SDC_INFO_DIM / 4; q++) {
+      f4v v;
+      v.x = inf[4 * q]; v.y = inf[4 * q + 1]; v.z = inf[4 * q + 2]; v.w = inf[4 * q + 3];
+      nt_store4(i4 + 4 * q, v);
+    }
+  }
+  done[env] = (unsigned char)(terminal ? 1 : 0);
+}

@@ -29,9 +29,10 @@ def init_process_group(backend: str = None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # device-memory IPC between the ranks' processes (RCCL's intra-node transports) works on this platform's host driver in
-        # dmabuf mode only (without it: `hipIpcGetMemHandle: invalid argument`); the image exports the variable already, this is
-        # for a launcher that dropped it.  Measured: tests/test_gpu_distributed.py::test_device_memory_ipc_needs_the_dmabuf_mode
+        # a documented requirement of this platform, not a tuning choice: its host driver supports dmabuf device-memory IPC only
+        # (RCCL's intra-node transports open their peers' buffers with it; without the variable: `hipIpcGetMemHandle: invalid
+        # argument`).  The image exports it already; this is for a launcher that dropped it.  Not measurable on a one-GPU lease
+        # (a world of one rank opens no peer buffer)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

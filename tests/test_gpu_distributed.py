@@ -264,41 +264,3 @@ def test_bench_eight_shards_in_one_process_on_one_gpu():
     assert d["n_gpus"] == 8 and d["single_process"] is True and d["value"] > 0 and d["config"]["faults"] == 0
     assert d["config"]["distinct_devices"] == 1 and d["timed_steps"] == 120
     assert d["return_stats"]["episodes"] % 4096 == 0 and d["return_stats"]["episodes"] > 0
-
-
-_IPC_SCRIPT = r"""
-import os, sys, json
-import torch, torch.multiprocessing as mp
-def child(q, r):
-    t = q.get()
-    r.put(float(t.sum().item()))
-if __name__ == "__main__":
-    mp.set_start_method("spawn")
-    q, r = mp.Queue(), mp.Queue()
-    p = mp.Process(target=child, args=(q, r))
-    p.start()
-    t = torch.arange(1024, dtype=torch.float32, device="cuda")
-    q.put(t)                      # a CUDA tensor handed to another process = hipIpcGetMemHandle / hipIpcOpenMemHandle
-    print(json.dumps({"sum": r.get(timeout=120)}))
-    p.join()
-"""
-
-
-def test_device_memory_ipc_needs_the_dmabuf_mode(tmp_path):
-    """Why every multi-process GPU environment this repo builds carries HSA_ENABLE_IPC_MODE_LEGACY=0 (dc_rl_amd/distributed.py,
-    bench.py): device-memory IPC between processes -- what RCCL's intra-node transports open their peers' buffers with -- works on
-    this host driver in dmabuf mode only.  Measured here on one GPU with the mechanism itself (a CUDA tensor handed to a second
-    process): it must work with the variable at 0; what happens with the legacy mode is RECORDED (gpurun_out/ipc_mode.json), not
-    asserted -- it is the platform's behaviour, not this repo's."""
-    script = tmp_path / "ipc.py"
-    script.write_text(_IPC_SCRIPT)
-    res = {}
-    for mode in ("0", "1"):
-        p = subprocess.run([sys.executable, str(script)], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=mode), cwd=str(tmp_path),
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-        ok = p.returncode == 0 and any(ln.startswith("{") for ln in p.stdout.decode().splitlines())
-        res[mode] = {"ok": ok, "rc": p.returncode, "stderr_tail": p.stderr.decode(errors="replace")[-400:]}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "ipc_mode.json"), "w"), indent=1)
-    print("device-memory IPC by HSA_ENABLE_IPC_MODE_LEGACY:", {k: v["ok"] for k, v in res.items()})
-    assert res["0"]["ok"], res["0"]

@@ -11,7 +11,9 @@ A compiler bump or an innocent edit regresses these silently -- the kernels stay
   * the episode boundary's two kernels keep their residency: `sdc_reset_kernel` <= 128 VGPRs (four wavefronts per SIMD = all
     4096 resets of the timed configuration in flight at once: the kernel is VALU-issue bound and ends with its last wavefront)
     and `sdc_features_kernel` <= 168 (three per SIMD; its LDS windows are shared by the four wavefronts of an env), no scratch.
-sdc_step.hip is compiled once, with the production flags of dc_rl_amd/_lib.py."""
+  * the lane-per-env kernel (sdc_wide.hip) keeps two wavefronts per SIMD (<= 256 VGPRs) without scratch.
+The step kernels' translation units (sdc_step.hip, sdc_rollout.hip, sdc_wide.hip) are compiled once, with the production flags of
+dc_rl_amd/_lib.py."""
 import os
 import re
 import subprocess
@@ -34,14 +36,17 @@ def compiled():
         pytest.skip("no hipcc")
     flags = [f for f in L.HIPCC_FLAGS if f != "-shared"]
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "sdc_step.s")
-        r = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "sdc_step.hip", "-o", out],
-                           cwd=L.CSRC, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        asm = open(out).read()
+        asm, err = "", ""
+        for src in ("sdc_step.hip", "sdc_rollout.hip", "sdc_wide.hip"):      # (the step kernels' three translation units)
+            out = os.path.join(td, src[:-4] + ".s")
+            r = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", src, "-o", out],
+                               cwd=L.CSRC, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            asm += open(out).read()
+            err += r.stderr
     usage = {}
     name = None
-    for line in r.stderr.splitlines():
+    for line in err.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)
@@ -86,7 +91,9 @@ def test_no_scratch_and_register_budget(compiled):
         assert u["ScratchSize"] == 0 and u["VGPRs Spill"] == 0, (k, u)
     for k in STEP_KERNELS + ["sdc_rollout_quad_kernel"]:
         assert usage[k]["VGPRs"] <= VGPR_CAP_3_WAVES and usage[k]["Occupancy"] >= 3, (k, usage[k])
-    print({k: (usage[k]["VGPRs"], usage[k]["Occupancy"]) for k in STEP_KERNELS + LOOP_KERNELS})
+    w = usage["sdc_dynamics_wide_kernel"]
+    assert w["ScratchSize"] == 0 and w["VGPRs Spill"] == 0 and w["VGPRs"] <= 256 and w["Occupancy"] >= 2, w
+    print({k: (usage[k]["VGPRs"], usage[k]["Occupancy"]) for k in STEP_KERNELS + LOOP_KERNELS + ["sdc_dynamics_wide_kernel"]})
 
 
 def _kernel_body(asm, name):
