@@ -247,7 +247,7 @@ int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 // racks, 16-byte aligned output rows (whole-line stores through the wavefront's staging block); debug_flags bit 11 forces it
 // for any such batch, bit 12 keeps it off
 #ifndef SDC_WIDE_MIN_ENVS
-#define SDC_WIDE_MIN_ENVS 16384
+#define SDC_WIDE_MIN_ENVS (1 << 30)     // (not the default for any batch yet: measured slower than four envs per wavefront)
 #endif
 bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, const float* info) {
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };

@@ -26,6 +26,12 @@ namespace {
 
 constexpr int WE = SDC_WAVE;     // envs per wavefront: lane = env
 
+// (a value the optimiser may not look through: a chain of selects between elements of a small local array is otherwise merged into
+// ONE load with a computed index -- and the array then lives in scratch memory)
+__device__ __forceinline__ unsigned opq(unsigned x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4v nt_load4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p)); }
 __device__ __forceinline__ void nt_store4(float* p, const f4v v) { __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p)); }
@@ -170,6 +176,54 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
       if (t + 1 < rel) qa[q] = *reinterpret_cast<const uint4*>(qt + t);
       else if (t < rel) { const uint2 e = qt[t]; qa[q] = make_uint4(e.x, e.y, 0u, 0u); }
     }
+  }
+
+  // ---- reward-side state: the env's header (its 64 dwords in this lane's registers), then the few window keys a step usually needs
+  unsigned hd[SDC_HDR_DWORDS];
+  {
+    const uint4* hp4 = reinterpret_cast<const uint4*>(S.hdr + (size_t)env * SDC_HDR_DWORDS);
+#pragma unroll
+    for (int q = 0; q < SDC_HDR_DWORDS / 4; q++) {
+      const uint4 v = hp4[q];
+      hd[4 * q] = v.x; hd[4 * q + 1] = v.y; hd[4 * q + 2] = v.z; hd[4 * q + 3] = v.w;
+    }
+  }
+  auto hd_f64 = [&](const int j) { return __hiloint2double((int)hd[j + 1], (int)hd[j]); };
+  // window w of this lane's env: rank of its first key, valid keys, cached first / last key (window order: Q1, Q3, BU, BL)
+  constexpr int HW[4] = {H_Q1, H_Q3, H_BU, H_BL};
+  int wr0[4], whi[4];
+  unsigned wf[4], wlast[4], pend[4];
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    wr0[w] = (int)hd[HW[w] + T_R0];
+    whi[w] = (int)hd[HW[w] + T_HI];
+    wf[w] = hd[H_WFIRST + w];
+    wlast[w] = hd[H_WLAST + w];
+    pend[w] = hd[H_PEND + w];
+  }
+  // history length after this step's append, the quartile ranks it asks for
+  const int n_pre = hl;
+  const int n_step = hl < S.hist_cap ? hl + 1 : hl;
+  int k1, k3;
+  quartile_ranks(n_step, k1, k3);
+  // FOUR keys of every window, gathered now: around the wanted rank (quartile windows: the rank moves by at most one position
+  // when both of the step's keys land outside the window) and around last step's clip bound (bound windows: the two keys
+  // either side of it).  ck[w][j] = key at window position cb[w] + j.
+  unsigned ck[4][4];
+  int cb[4];
+  cb[0] = k1 - wr0[0] - 1;
+  cb[1] = k3 - wr0[1] - 1;
+  cb[2] = n_pre - (int)hd[H_QC] - wr0[2] - 2;
+  cb[3] = n_pre - (int)hd[H_QC + 1] - wr0[3] - 2;
+  {
+    const unsigned* qw = S.qwin + (size_t)env * SDC_WIN * 4;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int p = min(max(cb[w] + j, 0), SDC_WIN - 1);
+        ck[w][j] = qw[p * 4 + w];
+      }
   }
 
   static_assert(SDC_FEAT_W == 10 && SDC_FEAT_T1 == 12 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 &&
@@ -423,21 +477,356 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     wp2[R_LAST_ROOM / 2] = make_uint2((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet));
   }
 
-  // ---- rewards + reward-state upkeep ------------------------------------------------------------------------------------------------
-  // (stage 1: every env through the whole-wavefront form, env by env)
-  float z_f = 0.0f, path_f = 0.0f, ret_f[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-  for (int e = 0; e < WE; e++) {
-    const int env_e = env0 + e;
-    auto pi = [&](const int v) { return __builtin_amdgcn_readlane(v, e); };
-    auto pf = [&](const double v) { return readlane_f64(v, e); };
-    const unsigned hd_e = S.hdr[(size_t)env_e * SDC_HDR_DWORDS + lane];
-    const uint4 qw_e = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env_e * SDC_WIN + lane];
-    env_reward(S, env_e, lane, hd_e, qw_e, pi(hl), pi(slot), (unsigned)pi((int)x_new), (unsigned)pi((int)x_old), pf(e_off), pf(energy),
-               pf(norm_ci), pf(oldest_norm), pi(overdue), pi(hourq_n), pf(p_it), pf(total_kw), pf(water), rew, &sh.back[0][0] + e * 8 - SDC_INFO_ENERGY_Z, sh.tl);
+  // ---- rewards + reward-state upkeep (utils/reward_creator.py:16-130): pair_reward_fast, lane = env ---------------------------------
+  const int n = hl;
+  const bool has_old = x_old != KEY_NONE;
+  const int n_prev = has_old ? n : n - 1;
+  const int m_hist = has_old ? n_prev - 1 : n_prev;
+  double A1 = hd_f64(H_A1), A2 = hd_f64(H_A2);
+  bool ok = (n >= SMALL_N) & (whi[0] > 0) & (whi[1] > 0) & (whi[2] > 0) & (whi[3] > 0) & ((int)hd[H_VALID] == 1);
+  bool touched = false;     // a window of this env has been rewritten in memory by this step (a fallback must then rebuild)
+  bool arrived = false;
+  const unsigned kbl[2] = {hd[H_KB], hd[H_KB + 1]};
+  unsigned* qwin_env0 = S.qwin + (size_t)env0 * SDC_WIN * 4;
+
+  // what a whole-wavefront step on window w of env e (lane = key) hands to e's lane: the window's header values and the four keys
+  // around the position the lane will look at
+  auto deliver = [&](const int e, const int w, const QTrack& q, const int base) __attribute__((always_inline)) {
+    const unsigned first = lane_key(q.w, 0), last = lane_key(q.w, max(q.hi - 1, 0));
+    unsigned c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[j] = lane_key(q.w, min(max(base + j, 0), SDC_WIN - 1));
+    if (lane == e) {
+#pragma unroll
+      for (int x = 0; x < 4; x++)
+        if (x == w) {
+          wr0[x] = q.r0; whi[x] = q.hi; wf[x] = first; wlast[x] = last; cb[x] = base;
+#pragma unroll
+          for (int j = 0; j < 4; j++) ck[x][j] = c[j];
+        }
+    }
+  };
+  // where lane e will look in window w: the wanted rank's position - 1 (quartiles), the old bound's position - 2 (bounds)
+  auto look_base = [&](const int w, const QTrack& q, const int k_w, const unsigned kbl_w) __attribute__((always_inline)) {
+    if (w < 2) return k_w - q.r0 - 1;
+    return (int)__popcll(__ballot(q.w < kbl_w)) - 2;      // (valid keys below the bound; KEY_NONE never counts)
+  };
+
+  // ---- deferred re-centrings (SdcRefillReq / SdcRefillRes): a window requested two steps ago arrives now ---------------------------
+  {
+    bool due[4];
+    unsigned age[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      age[w] = ((unsigned)S.step_no - (pend[w] >> 13)) & 0x7FFFFu;
+      due[w] = pend[w] != 0u && age[w] >= 2u;     // (1: being swept right now; anything else but 2: stale)
+    }
+    unsigned long long dm = __ballot(due[0] | due[1] | due[2] | due[3]);
+    if (__builtin_expect(dm != 0ull, 0)) {
+      const unsigned lx_new = hd[H_LAST_XNEW], lx_old = hd[H_LAST_XOLD];
+      const int l_nprev = (int)hd[H_LAST_NPREV];
+      while (dm) {
+        const int e = __ffsll((long long)dm) - 1;
+        dm &= dm - 1;
+        const unsigned e_new = lane_key(lx_new, e), e_old = lane_key(lx_old, e);
+        const int e_nprev = (int)lane_key((unsigned)l_nprev, e);
+        const bool e_ok = lane_key(ok ? 1u : 0u, e) != 0u;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          if (!lane_key(due[w] ? 1u : 0u, e)) continue;
+          const unsigned pd = lane_key(pend[w], e);
+          const int idx = (int)(pd & 0x7FFu) - 1, set = (int)((pd >> 11) & 3u);
+          const SdcRefillRes* rs = S.rs + (set > 2 ? 0 : set) * S.rq_max + (idx < 0 ? 0 : idx);
+          const int4 rh = *reinterpret_cast<const int4*>(rs);
+          QTrack r = {rs->keys[lane], rh.x, rh.y};
+          const unsigned flip = w == 3 ? KEY_NONE : 0u;
+          const bool good = lane_key(age[w], e) == 2u && rh.z == S.step_no - 1 && rh.w == (env0 + e) * 4 + w && r.hi > 0 && e_ok;
+          // the result describes the ring as the request's step left it: replay the previous step's insertion / eviction
+          if (good) qt_update(r, e_new ^ flip, e_old ^ flip, e_old != KEY_NONE, e_nprev, lane);
+          if (good && r.hi > 0) {
+            qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w] = r.w;
+            const int kw = w == 0 ? (int)lane_key((unsigned)k1, e) : (int)lane_key((unsigned)k3, e);
+            deliver(e, w, r, look_base(w, r, kw, lane_key(kbl[w == 3 ? 1 : 0], e)));
+            if (lane == e) { touched = true; arrived = true; }
+          }
+          if (lane == e) pend[w] = 0u;
+        }
+      }
+    }
   }
-  wave_sync();
-  z_f = sh.back[lane][0]; path_f = sh.back[lane][1]; ret_f[0] = sh.back[lane][2]; ret_f[1] = sh.back[lane][3]; ret_f[2] = sh.back[lane][4];
+
+  // ---- O(1) updates: running sums, the four windows ------------------------------------------------------------------------------------
+  const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
+  A1 += vn - vo;
+  A2 += vn * vn - vo * vo;
+  {
+    bool upd[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const unsigned flip = w == 3 ? KEY_NONE : 0u;
+      const unsigned y = x_old ^ flip, x = x_new ^ flip;
+      const bool e_below = has_old && y < wf[w];
+      const bool e_ok = !has_old || y > wlast[w] || e_below;          // (evicted key above the window / below it)
+      const int r0e = wr0[w] - (e_below ? 1 : 0);
+      const bool ends = r0e + whi[w] == m_hist;
+      const bool i_below = x < wf[w] && r0e != 0;
+      const bool i_ok = i_below || (x >= wlast[w] && !ends);          // (appended key below the window / above it)
+      const bool out = e_ok && i_ok;
+      upd[w] = ok && !out;
+      if (out) {
+        // the window's keys stay where they are, its ranks move: so do the positions this lane looks at
+        const int r0n = r0e + (i_below ? 1 : 0);
+        if (w < 2) cb[w] += 0;
+        wr0[w] = r0n;
+      }
+    }
+    unsigned long long um = __ballot(upd[0] | upd[1] | upd[2] | upd[3]);
+    while (__builtin_expect(um != 0ull, 0)) {
+      // a key lands INSIDE a window of env e (or the window starts / ends the history where it would land): the whole wavefront
+      // updates that window, lane = key
+      const int e = __ffsll((long long)um) - 1;
+      um &= um - 1;
+      const unsigned e_new = lane_key(x_new, e), e_old = lane_key(x_old, e);
+      const bool e_has_old = e_old != KEY_NONE;
+      const int e_nprev = (int)lane_key((unsigned)n_prev, e);
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        if (!lane_key(upd[w] ? 1u : 0u, e)) continue;
+        const unsigned flip = w == 3 ? KEY_NONE : 0u;
+        QTrack q = {qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w], (int)lane_key((unsigned)wr0[w], e), (int)lane_key((unsigned)whi[w], e)};
+        const bool wd = qt_update(q, e_new ^ flip, e_old ^ flip, e_has_old, e_nprev, lane);
+        if (wd) qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w] = q.w;
+        const int kw = w == 0 ? (int)lane_key((unsigned)k1, e) : (int)lane_key((unsigned)k3, e);
+        deliver(e, w, q, look_base(w, q, kw, lane_key(kbl[w == 3 ? 1 : 0], e)));
+        if (wd && lane == e) touched = true;
+      }
+    }
+  }
+  ok = ok && whi[0] > 0 && whi[1] > 0 && whi[2] > 0 && whi[3] > 0;
+  // key at position p of window w, if it is one of the four this lane holds
+  auto key_at_w = [&](const int w, const int p, bool& have) __attribute__((always_inline)) {
+    const int j = p - cb[w];
+    have = have && j >= 0 && j < 4;
+    const unsigned c0 = opq(ck[w][0]), c1 = opq(ck[w][1]), c2 = opq(ck[w][2]), c3 = opq(ck[w][3]);
+    return j <= 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
+  };
+  unsigned a1, b1, a3, b3;
+  {
+    // keys at ranks k and k + 1 (the second only if it exists): hw_resolve
+    bool have = true;
+    const int t1 = k1 - wr0[0], tb1 = (k1 + 1 > n - 1) ? t1 : t1 + 1;
+    const int t3 = k3 - wr0[1], tb3 = (k3 + 1 > n - 1) ? t3 : t3 + 1;
+    a1 = key_at_w(0, t1, have); b1 = key_at_w(0, tb1, have);
+    a3 = key_at_w(1, t3, have); b3 = key_at_w(1, tb3, have);
+    const bool r1 = whi[0] > 0 && t1 >= 0 && tb1 < whi[0], r3 = whi[1] > 0 && t3 >= 0 && tb3 < whi[1];
+    ok = ok && r1 && r3 && have;
+  }
+  const Bounds b = clip_bounds(n, a1, b1, a3, b3);
+  const unsigned kb0 = b.kub;               // upper tail: keys >= kub
+  const unsigned kb1 = ~(b.klb - 1u);       // lower tail, flipped: ~x >= ~(klb-1)  <=>  x < klb
+  int qc0 = (int)hd[H_QC], qc1 = (int)hd[H_QC + 1];
+  double qs1_0 = hd_f64(H_QS1), qs1_1 = hd_f64(H_QS1 + 2);
+  double qs2_0 = hd_f64(H_QS2_HI), qs2_1 = hd_f64(H_QS2_LO);
+  {
+    const double vo2 = key_f64(x_old);
+    if (has_old && x_old >= kbl[0]) { qc0 -= 1; qs1_0 -= vo2; qs2_0 -= vo2 * vo2; }
+    if (has_old && ~x_old >= kbl[1]) { qc1 -= 1; qs1_1 -= vo2; qs2_1 -= vo2 * vo2; }
+    if (x_new >= kbl[0]) { qc0 += 1; qs1_0 += vn; qs2_0 += vn * vn; }
+    if (~x_new >= kbl[1]) { qc1 += 1; qs1_1 += vn; qs2_1 += vn * vn; }
+  }
+  {
+    const unsigned lo0 = min(kb0, kbl[0]), hi0 = max(kb0, kbl[0]), lo1 = min(kb1, kbl[1]), hi1 = max(kb1, kbl[1]);
+    const bool sp0 = whi[2] > 0 && (wr0[2] == 0 || wf[2] < lo0) && (wr0[2] + whi[2] >= n || hi0 <= wlast[2]);
+    const bool sp1 = whi[3] > 0 && (wr0[3] == 0 || wf[3] < lo1) && (wr0[3] + whi[3] >= n || hi1 <= wlast[3]);
+    ok = ok && (kb0 == kbl[0] || sp0) && (kb1 == kbl[1] || sp1);
+    // the keys a bound has crossed since last step (the window lists them: sp0 / sp1): this lane holds the two keys either side
+    // of the OLD bound (positions pos - 2 .. pos + 1, pos = the first key at or beyond it).  None or ONE crossed key is settled
+    // here; more -- or a picture of the neighbourhood that does not check out -- by the whole wavefront on the window's 64 keys.
+    auto crossing = [&](const int w, const unsigned kb, const unsigned kbo, const unsigned flip, int& qc, double& qs1, double& qs2) __attribute__((always_inline)) {
+      if (kb == kbo) return false;
+      const int pos = cb[w] + 2;
+      const bool xA2 = pos - 2 >= 0 && pos - 2 < whi[w], xA = pos - 1 >= 0 && pos - 1 < whi[w];
+      const bool xB = pos >= 0 && pos < whi[w], xB2 = pos + 1 >= 0 && pos + 1 < whi[w];
+      const unsigned kA2 = opq(ck[w][0]), kA = opq(ck[w][1]), kB = opq(ck[w][2]), kB2 = opq(ck[w][3]);
+      // the lane's picture must be the window's: `pos` keys lie below the old bound
+      if (pos < 0 || pos > whi[w] || (xA && !(kA < kbo)) || (xB && !(kB >= kbo))) return true;
+      if (kb > kbo) {
+        // bound moved out: the keys in [kbo, kb) leave the tail
+        if (!xB || kB >= kb) return false;
+        if (xB2 && kB2 < kb) return true;
+        const double v = key_f64(kB ^ flip);
+        qc += -1; qs1 += -1.0 * v; qs2 += -1.0 * (v * v);
+      } else {
+        // bound moved in: the keys in [kb, kbo) enter the tail
+        if (!xA || kA < kb) return false;
+        if (xA2 && kA2 >= kb) return true;
+        const double v = key_f64(kA ^ flip);
+        qc += 1; qs1 += 1.0 * v; qs2 += 1.0 * (v * v);
+      }
+      return false;
+    };
+    const bool cx0 = ok && crossing(2, kb0, kbl[0], 0u, qc0, qs1_0, qs2_0);
+    const bool cx1 = ok && crossing(3, kb1, kbl[1], KEY_NONE, qc1, qs1_1, qs2_1);
+    unsigned long long cm = __ballot(cx0 | cx1);
+    if (__builtin_expect(cm != 0ull, 0)) {
+      if (__ballot(touched) != 0ull) {     // (the windows' keys come from memory: this wavefront's own stores to them must have landed)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      while (cm) {
+        const int e = __ffsll((long long)cm) - 1;
+        cm &= cm - 1;
+#pragma unroll
+        for (int w = 2; w < 4; w++) {
+          if (!lane_key(((w == 2 ? cx0 : cx1)) ? 1u : 0u, e)) continue;
+          const unsigned flip = w == 3 ? KEY_NONE : 0u;
+          const unsigned e_lo = lane_key(w == 2 ? lo0 : lo1, e), e_hi = lane_key(w == 2 ? hi0 : hi1, e);
+          const unsigned key = qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w];
+          const bool in = key >= e_lo && key < e_hi;        // (KEY_NONE lanes: hi <= KEY_NONE)
+          const int c = (int)__popcll(__ballot(in));
+          const double v = in ? key_f64(key ^ flip) : 0.0;
+          const double s1 = wave_sum_f64(v), s2 = wave_sum_f64(v * v);
+          if (lane == e) {
+            const bool outw = (w == 2 ? kb0 > kbl[0] : kb1 > kbl[1]);       // bound moved out: the keys in between leave the tail
+            const double sg = outw ? -1.0 : 1.0;
+            if (w == 2) { qc0 += (outw ? -1 : 1) * c; qs1_0 += sg * s1; qs2_0 += sg * s2; }
+            else { qc1 += (outw ? -1 : 1) * c; qs1_1 += sg * s1; qs2_1 += sg * s2; }
+          }
+        }
+      }
+    }
+  }
+  // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
+  const double tt1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
+  const double tt2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
+  double mean, sd, inv_sd;
+  clipped_moments(n, b, A1, A2, tt1, tt2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap, S.hist_cap_d);
+  // ---- a window that the next step could exhaust: file a re-centring request (served by the NEXT launch's sweep wavefronts) -----------
+  {
+    int k1n, k3n;
+    quartile_ranks(n < S.hist_cap ? n + 1 : n, k1n, k3n);
+    const int ktw[4] = {k1n, k3n, n - qc0, n - qc1};
+    bool want[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const int m_lo = w < 2 ? 3 : 10, m_hi = w < 2 ? 6 : 10;
+      const int t = ktw[w] - wr0[w];
+      want[w] = ok & (pend[w] == 0u) & (((t > whi[w] - m_hi) & (wr0[w] + whi[w] < n)) | ((t < m_lo) & (wr0[w] > 0)));
+    }
+    unsigned long long rm = __ballot(want[0] | want[1] | want[2] | want[3]);
+    if (__builtin_expect(rm != 0ull, 0)) {
+      // (the windows' keys come from memory: this wavefront's own stores to them above must have landed)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int set = (S.step_no + 1) % 3;
+      while (rm) {
+        const int e = __ffsll((long long)rm) - 1;
+        rm &= rm - 1;
+        const int e_n = (int)lane_key((unsigned)n, e), e_slot = (int)lane_key((unsigned)slot, e);
+        const int slot_next = e_n < S.hist_cap ? e_n : (e_slot + 1 == S.hist_cap ? 0 : e_slot + 1);
+        const unsigned patch_x = S.hist[(size_t)(env0 + e) * SDC_HIST_STRIDE + slot_next];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          if (!lane_key((want[w] && ok) ? 1u : 0u, e)) continue;
+          int idx = -1;
+          if (lane == 0) idx = atomicAdd(&S.rq_count[set], 1);
+          idx = (int)sfl((unsigned)idx);
+          if (idx < 0 || idx >= S.rq_max) {
+            if (lane == e) ok = false;          // no room: re-centre inline on the fallback path
+            continue;
+          }
+          SdcRefillReq* rq = S.rq + set * S.rq_max + idx;
+          rq->keys[lane] = qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w];
+          const int q_r0 = (int)lane_key((unsigned)wr0[w], e), q_hi = (int)lane_key((unsigned)whi[w], e);
+          const int kt_w = (int)lane_key((unsigned)ktw[w], e);
+          if (lane == 0) {
+            const int t = kt_w - q_r0;
+            rq->env = env0 + e; rq->win = w;
+            rq->dir = (t > q_hi - (w < 2 ? 6 : 10) && q_r0 + q_hi < e_n) ? REFILL_UP : REFILL_DOWN;
+            rq->kt = kt_w; rq->n = e_n; rq->r0 = q_r0; rq->hi = q_hi;
+            rq->patch_slot = slot_next; rq->patch_x = patch_x; rq->step = S.step_no;
+          }
+          if (lane == e) pend[w] = (((unsigned)S.step_no & 0x7FFFFu) << 13) | ((unsigned)set << 11) | (unsigned)(idx + 1);
+        }
+      }
+    }
+  }
+  const double z = (e_off - mean) * inv_sd;     // (n >= SMALL_N >= 2 here)
+  double r_a[3], ret_a[3];
+  {
+    const double foot = -1.0 * (norm_ci * z / 0.50);
+    const double overdue_pen = -0.3 * sqrt_count((double)overdue) + 0.3;
+    const double age_pen = -0.1 * oldest_norm;
+    double rls = foot + overdue_pen + age_pen;
+    rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
+    r_a[0] = rls; r_a[1] = foot; r_a[2] = foot;
+#pragma unroll
+    for (int a = 0; a < 3; a++) ret_a[a] = hd_f64(H_RET + 2 * a) + r_a[a];
+  }
+  float z_f = (float)z, path_f = arrived ? 2.0f : 0.0f, ret_f[3] = {(float)ret_a[0], (float)ret_a[1], (float)ret_a[2]};
+  if (ok) {
+    auto put64 = [&](const int j, const double v) { hd[j] = (unsigned)__double2loint(v); hd[j + 1] = (unsigned)__double2hiint(v); };
+    hd[H_KB] = kb0;
+    hd[H_KB + 1] = kb1;
+    hd[H_VALID] = 1u;
+    put64(H_A1, A1);
+    put64(H_A2, A2);
+    hd[H_QC] = (unsigned)qc0;
+    hd[H_QC + 1] = (unsigned)qc1;
+    put64(H_QS1, qs1_0);
+    put64(H_QS1 + 2, qs1_1);
+    put64(H_QS2_HI, qs2_0);
+    put64(H_QS2_LO, qs2_1);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      hd[HW[w] + T_R0] = (unsigned)wr0[w];
+      hd[HW[w] + T_HI] = (unsigned)whi[w];
+      hd[H_PEND + w] = pend[w];
+      hd[H_WFIRST + w] = wf[w];
+      hd[H_WLAST + w] = wlast[w];
+    }
+    hd[H_N] = (unsigned)n;
+    hd[H_LAST_XNEW] = x_new;
+    hd[H_LAST_XOLD] = x_old;
+    hd[H_LAST_NPREV] = (unsigned)n_prev;
+    put64(H_EOFF, e_off);
+    put64(H_RET, ret_a[0]);
+    put64(H_RET + 2, ret_a[1]);
+    put64(H_RET + 4, ret_a[2]);
+    uint4* hp4 = reinterpret_cast<uint4*>(S.hdr + (size_t)env * SDC_HDR_DWORDS);
+#pragma unroll
+    for (int q = 0; q < SDC_HDR_DWORDS / 4; q++) hp4[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
+    rew[(size_t)env * 3 + 0] = (float)r_a[0];
+    rew[(size_t)env * 3 + 1] = (float)r_a[1];
+    rew[(size_t)env * 3 + 2] = (float)r_a[2];
+  }
+  // ---- an env whose step needs anything else (no reward state yet, a window that does not cover, several keys across a bound, no
+  // room for a request): env_reward() redoes it whole-wavefront from its state in memory -- which this step has not touched, or
+  // else is told to rebuild ------------------------------------------------------------------------------------------------------
+  {
+    unsigned long long fm = __ballot(!ok);
+    if (__builtin_expect(fm != 0ull, 0)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      while (fm) {
+        const int e = __ffsll((long long)fm) - 1;
+        fm &= fm - 1;
+        const int env_e = env0 + e;
+        auto pi = [&](const int v) { return __builtin_amdgcn_readlane(v, e); };
+        auto pf = [&](const double v) { return readlane_f64(v, e); };
+        unsigned hd_e = S.hdr[(size_t)env_e * SDC_HDR_DWORDS + lane];
+        if (pi(touched ? 1 : 0)) put_u32(hd_e, H_VALID, 0u);
+        const uint4 qw_e = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env_e * SDC_WIN + lane];
+        env_reward(S, env_e, lane, hd_e, qw_e, pi(hl), pi(slot), (unsigned)pi((int)x_new), (unsigned)pi((int)x_old), pf(e_off), pf(energy),
+                   pf(norm_ci), pf(oldest_norm), pi(overdue), pi(hourq_n), pf(p_it), pf(total_kw), pf(water), rew,
+                   &sh.back[0][0] + e * 8 - SDC_INFO_ENERGY_Z, sh.tl);
+      }
+      wave_sync();
+      if (!ok) {
+        z_f = sh.back[lane][0]; path_f = sh.back[lane][1]; ret_f[0] = sh.back[lane][2]; ret_f[1] = sh.back[lane][3]; ret_f[2] = sh.back[lane][4];
+      }
+    }
+  }
 
   // ---- outputs ----------------------------------------------------------------------------------------------------------------------
   // the observation pool (sdc_device.hpp SDC_P_*): the trace-only entries are the feature row's, nine depend on the step
