@@ -36,11 +36,54 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4v nt_load4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p)); }
 __device__ __forceinline__ void nt_store4(float* p, const f4v v) { __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p)); }
 
+// LDS of an env wavefront: two 16 KB blocks that hold the wavefront's 64 state records / headers (and its 64 feature rows on the
+// way in, the output rows on the way out) + the whole-wavefront reward paths' scratch.  32 KB + 4 KB: four wavefronts per CU.
 struct WideShared {
-  float stage[WE * SDC_OBS_OUT];   // output transposition: the wavefront's 64 obs rows (78 floats each), then its share_obs rows
+  unsigned blk[2][WE * 64];        // [0]: the 64 records; [1]: the 64 feature rows, then the 64 headers; at the end: output staging
   float back[WE][8];               // what a whole-wavefront reward step hands back to its env's lane {z, path, ret[3]}
-  sdc_rw::TailLds tl;              // scratch of the ring paths (env_reward: window refill, rebuild)
+  sdc_rw::TailLds tl;              // scratch of the ring paths (env_reward: window refill, rebuild; the sweep wavefronts)
 };
+static_assert(sizeof(unsigned) * 2 * WE * 64 >= sizeof(float) * WE * SDC_OBS_OUT, "the obs rows are staged across both blocks");
+
+// ---- BLOCK I/O: an env's 256-byte record / header as 64 x 4-byte accesses per lane would be 64 L2 requests per instruction (every
+// lane another line: measured 2.6 M requests per launch at 32 768 envs, the kernel's bound).  The wavefront's 64 records ARE one
+// contiguous 16 KB block: it comes in with 16 whole-line LDS-DMA loads (global_load_lds_dwordx4: no staging registers), each lane
+// reads its env's 16-byte chunks from LDS, patches them, and the block goes back out with 16 whole-line stores.
+// LDS image: chunk c of record e sits in 16-byte slot e * CPR + ((c + e) mod CPR) -- the DMA writes LDS linearly (base + lane x 16),
+// so the rotation is applied to the SOURCE address; with it the lanes' reads of "their chunk c" spread over all banks.
+typedef __attribute__((address_space(1))) const void* sdc_gptr;
+typedef __attribute__((address_space(3))) void* sdc_lptr;
+template <int CPR>     // 16-byte chunks per record: 16 (256-byte records / headers), 8 (128-byte feature rows)
+__device__ __forceinline__ void block_load(const void* gbase, unsigned* lds, const int lane) {
+  static_assert(CPR == 16 || CPR == 8, "");
+#pragma unroll
+  for (int k = 0; k < CPR; k++) {
+    const int sl = k * WE + lane;
+    const int e = sl / CPR, c = ((sl % CPR) - e) & (CPR - 1);
+    const char* g = reinterpret_cast<const char*>(gbase) + (size_t)(e * CPR + c) * 16;
+    __builtin_amdgcn_global_load_lds((sdc_gptr)g, (sdc_lptr)(lds + k * WE * 4), 16, 0, 0);
+  }
+}
+template <int CPR>
+__device__ __forceinline__ uint4 block_get(const unsigned* lds, const int e, const int c) {
+  return reinterpret_cast<const uint4*>(lds)[e * CPR + ((c + e) & (CPR - 1))];
+}
+template <int CPR>
+__device__ __forceinline__ void block_put(unsigned* lds, const int e, const int c, const uint4 v) {
+  reinterpret_cast<uint4*>(lds)[e * CPR + ((c + e) & (CPR - 1))] = v;
+}
+// the block back to memory in whole lines; records whose bit is set in `skip` are left alone (their env's state was written by
+// the whole-wavefront fallback)
+__device__ __forceinline__ void block_store16(void* gbase, const unsigned* lds, const int lane, const unsigned long long skip) {
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int sl = k * WE + lane;
+    const int e = sl >> 4, c = ((sl & 15) - e) & 15;
+    const uint4 v = reinterpret_cast<const uint4*>(lds)[sl];
+    if (!((skip >> e) & 1ull)) reinterpret_cast<uint4*>(gbase)[e * 16 + c] = v;
+  }
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // pairwise (binary-tree) sum over rack slots 0..31 in slot order, streamed: push(v) for slot 0, 1, ... ; total() when done.  The tree
 // is half_sum_f64's (strides 1, 2, 4, 8 inside the rows, then the two rows), so the sums round as in the other mappings;
@@ -116,20 +159,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   // ---- loads: actions, state record, feature row, queue-history probes ----------------------------------------------------
   const int32_t* ap = actions + (size_t)env * 3;
   int a_ls = ap[0], a_dc = ap[1], a_bat = ap[2];
-  const uint4* rp4 = reinterpret_cast<const uint4*>(S.rec + (size_t)env * SDC_REC_DWORDS);
-  const uint4 r0 = rp4[0], r1 = rp4[1], r2 = rp4[2], r3 = rp4[3], r4 = rp4[4], r6 = rp4[6];
-  const uint2 r9 = reinterpret_cast<const uint2*>(S.rec + (size_t)env * SDC_REC_DWORDS)[R_HIST_REF / 2];
+  // the wavefront's 64 records and 64 feature rows: two contiguous blocks, in through the LDS (block I/O above)
+  block_load<16>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.blk[0], lane);
+  block_load<8>(S.feat + feat_row_offset(S, env0, rel_hint + 1), sh.blk[1], lane);
   static_assert(R_CURSOR == 0 && R_TREL == 1 && R_DAY == 2 && R_HOURQ == 3 && R_QPOPPED == 4 && R_QCUM == 5 && R_QCUMT == 6 &&
                 R_QHEAD == 7 && R_QCUM_HM1 == 8 && R_QCUMT_HM1 == 9 && R_LAST_DELTA == 10 && R_CONSEC == 11 && R_SCALE == 12 &&
                 R_HIST_LEN == 13 && R_HIST_POS == 14 && R_FAULT == 16 && R_STPT == 24 && R_BAT == 26 && R_HIST_REF == 36 &&
-                R_LAST_ROOM == 40, "record layout the per-lane loads assume");
-  const float* fr = S.feat + feat_row_offset(S, env, rel_hint + 1);
-  float row[SDC_FEAT_ROW];
-#pragma unroll
-  for (int q = 0; q < SDC_FEAT_ROW / 4; q++) {
-    const f4v v = nt_load4(fr + 4 * q);
-    row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
-  }
+                R_LAST_ROOM == 40, "record layout the chunk reads assume");
   const uint2* qt = S.qtab + (size_t)env * S.qstride;
   int cumq[5];     // cum[now - 97], cum[now - 24], cum[now - 48], cum[now - 72], cum[now - 96] (0 before the episode's start)
 #pragma unroll
@@ -139,6 +175,21 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     cumq[s] = t >= 0 ? (int)qt[t].x : 0;
   }
 
+  dma_wait();
+  wave_sync();
+  const uint4 r0 = block_get<16>(sh.blk[0], lane, 0), r1 = block_get<16>(sh.blk[0], lane, 1), r2 = block_get<16>(sh.blk[0], lane, 2);
+  const uint4 r3 = block_get<16>(sh.blk[0], lane, 3), r4 = block_get<16>(sh.blk[0], lane, 4), r6 = block_get<16>(sh.blk[0], lane, 6);
+  const uint4 r9q = block_get<16>(sh.blk[0], lane, 9);
+  const uint2 r9 = make_uint2(r9q.x, r9q.y);
+  float row[SDC_FEAT_ROW];
+#pragma unroll
+  for (int q = 0; q < SDC_FEAT_ROW / 4; q++) {
+    const uint4 v = block_get<8>(sh.blk[1], lane, q);
+    row[4 * q] = __uint_as_float(v.x); row[4 * q + 1] = __uint_as_float(v.y); row[4 * q + 2] = __uint_as_float(v.z); row[4 * q + 3] = __uint_as_float(v.w);
+  }
+  wave_sync();
+  // ... and its 64 headers, into the block the feature rows have just left (wanted after the dynamics)
+  block_load<16>(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.blk[1], lane);
   const int i = (int)r0.x, rel = (int)r0.y, day = (int)r0.z, hourq = (int)r0.w;
   const int popped0 = (int)r1.x, cum_prev = (int)r1.y;
   const unsigned cumT_prev = r1.z;
@@ -180,13 +231,12 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
 
   // ---- reward-side state: the env's header (its 64 dwords in this lane's registers), then the few window keys a step usually needs
   unsigned hd[SDC_HDR_DWORDS];
-  {
-    const uint4* hp4 = reinterpret_cast<const uint4*>(S.hdr + (size_t)env * SDC_HDR_DWORDS);
+  dma_wait();
+  wave_sync();
 #pragma unroll
-    for (int q = 0; q < SDC_HDR_DWORDS / 4; q++) {
-      const uint4 v = hp4[q];
-      hd[4 * q] = v.x; hd[4 * q + 1] = v.y; hd[4 * q + 2] = v.z; hd[4 * q + 3] = v.w;
-    }
+  for (int q = 0; q < SDC_HDR_DWORDS / 4; q++) {
+    const uint4 v = block_get<16>(sh.blk[1], lane, q);
+    hd[4 * q] = v.x; hd[4 * q + 1] = v.y; hd[4 * q + 2] = v.z; hd[4 * q + 3] = v.w;
   }
   auto hd_f64 = [&](const int j) { return __hiloint2double((int)hd[j + 1], (int)hd[j]); };
   // window w of this lane's env: rank of its first key, valid keys, cached first / last key (window order: Q1, Q3, BU, BL)
@@ -462,20 +512,21 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
   const unsigned f_all = fault0 | fault;
 
-  // ---- new state record ----------------------------------------------------------------------------------------------------------------
+  // ---- new state record: the changed chunks into the block, the block out --------------------------------------------------------------
+  block_put<16>(sh.blk[0], lane, 0, make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n));
+  block_put<16>(sh.blk[0], lane, 1, make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head));
+  block_put<16>(sh.blk[0], lane, 2, make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive));
+  block_put<16>(sh.blk[0], lane, 3, make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, r3.w));
+  block_put<16>(sh.blk[0], lane, 4, make_uint4(f_all, r4.y, r4.z, r4.w));
+  block_put<16>(sh.blk[0], lane, 6, make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
+                                               (unsigned)__double2hiint(bat_load)));
+  block_put<16>(sh.blk[0], lane, 9, make_uint4((unsigned)__double2loint(href), (unsigned)__double2hiint(href), r9q.z, r9q.w));
   {
-    uint4* wp4 = reinterpret_cast<uint4*>(S.rec + (size_t)env * SDC_REC_DWORDS);
-    wp4[0] = make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n);
-    wp4[1] = make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head);
-    wp4[2] = make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive);
-    wp4[3] = make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, r3.w);
-    S.rec[(size_t)env * SDC_REC_DWORDS + R_FAULT] = f_all;
-    wp4[6] = make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
-                        (unsigned)__double2hiint(bat_load));
-    uint2* wp2 = reinterpret_cast<uint2*>(S.rec + (size_t)env * SDC_REC_DWORDS);
-    wp2[R_HIST_REF / 2] = make_uint2((unsigned)__double2loint(href), (unsigned)__double2hiint(href));
-    wp2[R_LAST_ROOM / 2] = make_uint2((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet));
+    const uint4 r10 = block_get<16>(sh.blk[0], lane, 10);
+    block_put<16>(sh.blk[0], lane, 10, make_uint4((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet), r10.z, r10.w));
   }
+  wave_sync();
+  block_store16(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.blk[0], lane, 0ull);
 
   // ---- rewards + reward-state upkeep (utils/reward_creator.py:16-130): pair_reward_fast, lane = env ---------------------------------
   const int n = hl;
@@ -793,9 +844,9 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     put64(H_RET, ret_a[0]);
     put64(H_RET + 2, ret_a[1]);
     put64(H_RET + 4, ret_a[2]);
-    uint4* hp4 = reinterpret_cast<uint4*>(S.hdr + (size_t)env * SDC_HDR_DWORDS);
 #pragma unroll
-    for (int q = 0; q < SDC_HDR_DWORDS / 4; q++) hp4[q] = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
+    for (int q = 0; q < SDC_HDR_DWORDS / 4; q++)
+      block_put<16>(sh.blk[1], lane, q, make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]));
     rew[(size_t)env * 3 + 0] = (float)r_a[0];
     rew[(size_t)env * 3 + 1] = (float)r_a[1];
     rew[(size_t)env * 3 + 2] = (float)r_a[2];
@@ -805,6 +856,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   // else is told to rebuild ------------------------------------------------------------------------------------------------------
   {
     unsigned long long fm = __ballot(!ok);
+    wave_sync();
+    block_store16(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.blk[1], lane, fm);     // (the fallback's envs: their headers come from env_reward)
     if (__builtin_expect(fm != 0ull, 0)) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -842,7 +895,9 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   const bool terminal = rel + 1 >= S.episode_steps;
   {
     // obs [3][26] of this lane's env into its row of the staging block, then the block out in whole lines
-    float* srow = sh.stage + lane * SDC_OBS_OUT;
+    float* const stage = reinterpret_cast<float*>(&sh.blk[0][0]);
+    wave_sync();
+    float* srow = stage + lane * SDC_OBS_OUT;
 #pragma unroll
     for (int j = 0; j < SDC_OBS_OUT; j += 2) {
       float2 v;
@@ -851,7 +906,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
       *reinterpret_cast<float2*>(srow + j) = v;
     }
     wave_sync();
-    const f4v* s4 = reinterpret_cast<const f4v*>(sh.stage);
+    const f4v* s4 = reinterpret_cast<const f4v*>(stage);
     float* o4 = obs + (size_t)env0 * SDC_OBS_OUT;
     f4v* f4 = reinterpret_cast<f4v*>(final_obs + (size_t)env0 * SDC_OBS_OUT);
     constexpr int NV = WE * SDC_OBS_OUT / 4;
@@ -865,7 +920,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
       }
     }
     wave_sync();
-    float* hrow = sh.stage + lane * SDC_SHARE_OBS_DIM;
+    float* hrow = stage + lane * SDC_SHARE_OBS_DIM;
 #pragma unroll
     for (int j = 0; j < SDC_SHARE_OBS_DIM; j++) hrow[j] = j == SDC_P_SOC ? 0.0f : pool[j];
     wave_sync();
@@ -920,13 +975,21 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     inf[SDC_INFO_EP_RETURN_DC] = ret_f[1];
     inf[SDC_INFO_EP_RETURN_BAT] = ret_f[2];
     inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
-    float* i4 = info + (size_t)env * SDC_INFO_DIM;
+    // ... through the staging block too: the wavefront's 64 info rows are 11 KB of whole lines
+    float* const stage = reinterpret_cast<float*>(&sh.blk[0][0]);
+    wave_sync();
+    f4v* irow = reinterpret_cast<f4v*>(stage + lane * SDC_INFO_DIM);
 #pragma unroll
     for (int q = 0; q < SDC_INFO_DIM / 4; q++) {
       f4v v;
       v.x = inf[4 * q]; v.y = inf[4 * q + 1]; v.z = inf[4 * q + 2]; v.w = inf[4 * q + 3];
-      nt_store4(i4 + 4 * q, v);
+      irow[q] = v;
     }
+    wave_sync();
+    const f4v* s4 = reinterpret_cast<const f4v*>(stage);
+    float* i4 = info + (size_t)env0 * SDC_INFO_DIM;
+#pragma unroll
+    for (int k = 0; k < SDC_INFO_DIM / 4; k++) nt_store4(i4 + 4 * (k * WE + lane), s4[k * WE + lane]);
   }
   done[env] = (unsigned char)(terminal ? 1 : 0);
 }
