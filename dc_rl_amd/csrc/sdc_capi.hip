@@ -110,6 +110,7 @@ struct sdc_handle {
   float* obs_latch = nullptr;
   bool latch_valid = false;
   int racks_cfg0 = 0;                     // racks of data-centre config 0 (the specialised kernels take <= 32: one pass)
+  int rack_cls_cfg0 = 0;                  // ... and its rack classes (SdcRackClasses; 0: more than the lane-per-env kernel's tables hold)
   // several data-centre configs: host copies of the configs and of the assignment, from which every env's own copy of its
   // config's scalars is built (SdcDev::prm_env) -- the common-case kernels then serve the batch as they serve one config
   std::vector<SdcDcDev> dc_host;
@@ -251,7 +252,7 @@ int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 #endif
 bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, const float* info) {
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-  return (h->cfg.n_envs & 63) == 0 && h->d.n_cfg == 1 && h->racks_cfg0 <= 31 && (h->d.debug_flags & (512 | 1024 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
+  return (h->cfg.n_envs & 63) == 0 && h->d.n_cfg == 1 && h->racks_cfg0 <= 31 && h->rack_cls_cfg0 > 0 && (h->d.debug_flags & (512 | 1024 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
          (h->cfg.n_envs >= SDC_WIDE_MIN_ENVS || (h->d.debug_flags & 2048)) && al16(obs) && al16(share_obs) && al16(info);
 }
 int wide_sweep_blocks(const sdc_handle* h) { return std::min(h->d.rq_max, 256); }
@@ -553,9 +554,60 @@ int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
   e.n_racks_f = (double)p->n_racks;
   e.ret_sum = 0.0;
   for (int r = 0; r < p->n_racks; r++) e.ret_sum += p->rack_return[r];
+  // rack classes: distinct (cpus, full, idle, supply) tuples in order of first appearance, grouped by (cpus, supply)
+  {
+    SdcRackClasses& rc = e.rc;
+    std::memset(&rc, 0, sizeof(rc));
+    struct Cls { double n, full, idle, supply; int grp; };
+    std::vector<Cls> cls;
+    std::vector<std::pair<double, double>> grp;
+    std::vector<int> of_rack((size_t)p->n_racks, 0);
+    bool fits = p->n_racks <= 31;
+    for (int r = 0; r < p->n_racks && fits; r++) {
+      const Cls c = {p->rack_n[r], p->rack_full[r], p->rack_idle[r], p->rack_supply[r], 0};
+      int k = -1;
+      for (size_t j = 0; j < cls.size(); j++)
+        if (cls[j].n == c.n && cls[j].full == c.full && cls[j].idle == c.idle && cls[j].supply == c.supply) k = (int)j;
+      if (k < 0) {
+        int g = -1;
+        for (size_t j = 0; j < grp.size(); j++)
+          if (grp[j].first == c.n && grp[j].second == c.supply) g = (int)j;
+        if (g < 0) { g = (int)grp.size(); grp.push_back({c.n, c.supply}); }
+        k = (int)cls.size();
+        cls.push_back(c);
+        cls.back().grp = g;
+      }
+      of_rack[(size_t)r] = k;
+      if (cls.size() > SDC_MAX_RACK_CLS) fits = false;
+    }
+    if (fits) {
+      // renumber the classes group by group
+      std::vector<int> renum(cls.size(), 0);
+      int next = 0;
+      rc.n_grp = (int)grp.size();
+      for (int g = 0; g < rc.n_grp; g++) {
+        rc.grp_begin[g] = next;
+        rc.grp_n[g] = grp[(size_t)g].first;
+        rc.grp_supply[g] = grp[(size_t)g].second;
+        for (size_t j = 0; j < cls.size(); j++)
+          if (cls[j].grp == g) {
+            renum[j] = next;
+            rc.cls_full[next] = cls[j].full;
+            rc.cls_idle[next] = cls[j].idle;
+            next++;
+          }
+      }
+      rc.grp_begin[rc.n_grp] = next;
+      rc.n_cls = next;
+      for (int r = 0; r < p->n_racks; r++) rc.cls_of_rack[r] = renum[(size_t)of_rack[(size_t)r]];
+    }
+  }
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(const_cast<SdcDcDev*>(h->d.dc) + cfg_id, &e, sizeof(e), hipMemcpyHostToDevice));
-  if (cfg_id == 0) h->racks_cfg0 = p->n_racks;
+  if (cfg_id == 0) {
+    h->racks_cfg0 = p->n_racks;
+    h->rack_cls_cfg0 = e.rc.n_cls;
+  }
   h->dc_host.resize((size_t)h->cfg.n_dc_configs);
   h->dc_set.resize((size_t)h->cfg.n_dc_configs, 0);
   h->dc_host[cfg_id] = e;

@@ -120,6 +120,19 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#define SDC_MAX_RACK_CLS 8     // rack classes (and groups) the lane-per-env kernel keeps tables for
+// (128 dwords: a wavefront holds the table in two registers, dword j in lane j % 64, and reads entries with v_readlane; the
+// doubles fill the first 64 dwords, the integers the second)
+struct SdcRackClasses {
+  double grp_n[SDC_MAX_RACK_CLS], grp_supply[SDC_MAX_RACK_CLS];     // group g: racks of grp_n cpus with supply approach grp_supply
+  double cls_full[SDC_MAX_RACK_CLS], cls_idle[SDC_MAX_RACK_CLS];    // class c (of group g: grp_begin[g] <= c < grp_begin[g + 1])
+  int n_grp, n_cls;
+  int grp_begin[SDC_MAX_RACK_CLS + 1];
+  int cls_of_rack[32];                                               // rack slot -> class
+  int pad[21];
+};
+static_assert(sizeof(SdcRackClasses) == 512 && SDC_MAX_RACK_CLS == 8, "two registers of a wavefront hold the table");
+
 // A data-centre parameter set as the kernels see it: the caller's struct plus correctly rounded reciprocals of the
 // parameters the step divides by (computed on the host by sdc_set_dc_params), so that those divisions take the
 // 3-instruction form of sdc_div_const.
@@ -129,6 +142,11 @@ struct SdcDcDev {
   double k_outlet;   // 1.918 / (c_air rho_air 0.526): the constant factor of the rack outlet-temperature rise
   double n_racks_f;  // p.n_racks as a double (the step kernel hands the scalars from p.m_cpu to here round as doubles)
   double ret_sum;    // sum of rack_return over the config's racks (the CRAC return temperature is (this + sum of outlets) / racks)
+  // RACK CLASSES (the lane-per-env kernel, sdc_wide.hip: its rack model is a per-lane LOOP, and a rack's power / outlet temperature
+  // depend on its four parameters only): the config's DISTINCT (cpus, full load, idle, supply approach) tuples, grouped by their
+  // (cpus, supply approach) pair -- what the fan / airflow / inlet part depends on.  The shipped 20-rack config has 7 classes in 2
+  // groups.  n_cls == 0: too many classes for the kernel's tables (sdc_set_dc_params).
+  SdcRackClasses rc;
 };
 
 // DEFERRED WINDOW RE-CENTRING.  A rank window that the next step could exhaust has to be re-centred with one sweep over

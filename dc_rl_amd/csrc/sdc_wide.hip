@@ -36,14 +36,22 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4v nt_load4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p)); }
 __device__ __forceinline__ void nt_store4(float* p, const f4v v) { __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p)); }
 
-// LDS of an env wavefront: two 16 KB blocks that hold the wavefront's 64 state records / headers (and its 64 feature rows on the
-// way in, the output rows on the way out) + the whole-wavefront reward paths' scratch.  32 KB + 4 KB: four wavefronts per CU.
+// LDS of an env wavefront, 40 KB (four wavefronts per CU):
+//   rec  16 KB  the wavefront's 64 state records, from the first loads until the patched block has gone back to memory
+//   hdr  16 KB  its 64 headers, likewise
+//   row   8 KB  its 64 feature rows on the way in; then, during the rack model, the rack classes' results {power, outlet} per lane
+// and once both blocks are out: the whole-wavefront fallback's scratch (tl / back) and the output staging (obs rows: 20 KB) on top.
 struct WideShared {
-  unsigned blk[2][WE * 64];        // [0]: the 64 records; [1]: the 64 feature rows, then the 64 headers; at the end: output staging
-  float back[WE][8];               // what a whole-wavefront reward step hands back to its env's lane {z, path, ret[3]}
-  sdc_rw::TailLds tl;              // scratch of the ring paths (env_reward: window refill, rebuild; the sweep wavefronts)
+  unsigned rec[WE * 64];
+  unsigned hdr[WE * 64];
+  unsigned row[WE * 32];
 };
 static_assert(sizeof(unsigned) * 2 * WE * 64 >= sizeof(float) * WE * SDC_OBS_OUT, "the obs rows are staged across both blocks");
+struct WideLate {                  // (aliases WideShared::rec once the record block has been stored; the sweep wavefronts: from the start)
+  sdc_rw::TailLds tl;              // scratch of the ring paths (env_reward: window refill, rebuild; the sweep wavefronts)
+  float back[WE][8];               // what a whole-wavefront reward step hands back to its env's lane {z, path, ret[3]}
+};
+static_assert(sizeof(WideLate) <= sizeof(unsigned) * WE * 64, "");
 
 // ---- BLOCK I/O: an env's 256-byte record / header as 64 x 4-byte accesses per lane would be 64 L2 requests per instruction (every
 // lane another line: measured 2.6 M requests per launch at 32 768 envs, the kernel's bound).  The wavefront's 64 records ARE one
@@ -84,6 +92,13 @@ __device__ __forceinline__ void block_store16(void* gbase, const unsigned* lds, 
   }
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// (measurement build -DSDC_WIDE_STAMPS: lane 0 of every env wavefront stamps the wall clock (100 MHz) at the marks WSTAMP(i) and
+// leaves the differences in columns 0..9 of its env's info row -- tools/dev/wide_phases.py)
+#ifdef SDC_WIDE_STAMPS
+#define WSTAMP(i) do { __builtin_amdgcn_s_waitcnt(0); wstamp[i] = wall_clock64(); } while (0)
+#else
+#define WSTAMP(i)
+#endif
 
 // pairwise (binary-tree) sum over rack slots 0..31 in slot order, streamed: push(v) for slot 0, 1, ... ; total() when done.  The tree
 // is half_sum_f64's (strides 1, 2, 4, 8 inside the rows, then the two rows), so the sums round as in the other mappings;
@@ -114,6 +129,18 @@ struct TreeSum32 {
     }
     k++;
   }
+  // four slots at once (k a multiple of 4): their two bottom levels are plain adds, (v0 + v1) + (v2 + v3)
+  __device__ __forceinline__ void push4(const double v0, const double v1, const double v2, const double v3) {
+    double v = (v0 + v1) + (v2 + v3);
+    if (k & 4) {
+      v = a4 + v;
+      if (k & 8) a16 = a8 + v;
+      else a8 = v;
+    } else {
+      a4 = v;
+    }
+    k += 4;
+  }
   // the tree's upper levels: a count that is not a power of two leaves partial sums on several levels (lower level = later slots)
   __device__ __forceinline__ double total() const {
     double t = 0.0;
@@ -136,6 +163,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
     unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
   __shared__ WideShared sh;
+  WideLate& late = *reinterpret_cast<WideLate*>(sh.rec);
   using namespace sdc_rw;
   const int lane = threadIdx.x;
   const int bx = (int)blockIdx.x;
@@ -147,7 +175,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     if (bx == 0 && lane == 0) S.rq_count[(S.step_no + 2) % 3] = 0;     // the set the NEXT step's requests go to
     if (bx < cnt) __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
 #pragma unroll 1
-    for (int j = bx; j < cnt; j += S.sweep_blocks) serve_recentring_request(S, set, j, lane, sh.tl);
+    for (int j = bx; j < cnt; j += S.sweep_blocks) serve_recentring_request(S, set, j, lane, late.tl);
     return;
   }
   const int nb = (int)gridDim.x - S.sweep_blocks;
@@ -155,13 +183,24 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   if (env0 >= S.n_envs) return;
   const int env = env0 + lane;
   KLit kt{};
+#ifdef SDC_WIDE_STAMPS
+  unsigned long long wstamp[16];
+#endif
 
   // ---- loads: actions, state record, feature row, queue-history probes ----------------------------------------------------
+  WSTAMP(0);
   const int32_t* ap = actions + (size_t)env * 3;
   int a_ls = ap[0], a_dc = ap[1], a_bat = ap[2];
+  // the config's scalars (P_*: double j in lane j) and its rack-class table (dword j in lane j % 64 of two registers), requested with
+  // the first loads and read with v_readlane where they are used: wave-uniform operands, no load in the middle of the step
+  const SdcDcDev& D = S.dc[0];
+  const double prm_l = lane < P_COUNT ? reinterpret_cast<const double*>(&D.p.m_cpu)[lane] : 0.0;
+  const unsigned tab0 = reinterpret_cast<const unsigned*>(&D.rc)[lane], tab1 = reinterpret_cast<const unsigned*>(&D.rc)[lane + 64];
+  auto PRM = [&](const int j) { return readlane_f64(prm_l, j); };
   // the wavefront's 64 records and 64 feature rows: two contiguous blocks, in through the LDS (block I/O above)
-  block_load<16>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.blk[0], lane);
-  block_load<8>(S.feat + feat_row_offset(S, env0, rel_hint + 1), sh.blk[1], lane);
+  block_load<16>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane);
+  block_load<8>(S.feat + feat_row_offset(S, env0, rel_hint + 1), sh.row, lane);
+  block_load<16>(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.hdr, lane);
   static_assert(R_CURSOR == 0 && R_TREL == 1 && R_DAY == 2 && R_HOURQ == 3 && R_QPOPPED == 4 && R_QCUM == 5 && R_QCUMT == 6 &&
                 R_QHEAD == 7 && R_QCUM_HM1 == 8 && R_QCUMT_HM1 == 9 && R_LAST_DELTA == 10 && R_CONSEC == 11 && R_SCALE == 12 &&
                 R_HIST_LEN == 13 && R_HIST_POS == 14 && R_FAULT == 16 && R_STPT == 24 && R_BAT == 26 && R_HIST_REF == 36 &&
@@ -175,21 +214,20 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     cumq[s] = t >= 0 ? (int)qt[t].x : 0;
   }
 
+  WSTAMP(1);
   dma_wait();
   wave_sync();
-  const uint4 r0 = block_get<16>(sh.blk[0], lane, 0), r1 = block_get<16>(sh.blk[0], lane, 1), r2 = block_get<16>(sh.blk[0], lane, 2);
-  const uint4 r3 = block_get<16>(sh.blk[0], lane, 3), r4 = block_get<16>(sh.blk[0], lane, 4), r6 = block_get<16>(sh.blk[0], lane, 6);
-  const uint4 r9q = block_get<16>(sh.blk[0], lane, 9);
+  const uint4 r0 = block_get<16>(sh.rec, lane, 0), r1 = block_get<16>(sh.rec, lane, 1), r2 = block_get<16>(sh.rec, lane, 2);
+  const uint4 r3 = block_get<16>(sh.rec, lane, 3), r4 = block_get<16>(sh.rec, lane, 4), r6 = block_get<16>(sh.rec, lane, 6);
+  const uint4 r9q = block_get<16>(sh.rec, lane, 9);
   const uint2 r9 = make_uint2(r9q.x, r9q.y);
   float row[SDC_FEAT_ROW];
 #pragma unroll
   for (int q = 0; q < SDC_FEAT_ROW / 4; q++) {
-    const uint4 v = block_get<8>(sh.blk[1], lane, q);
+    const uint4 v = block_get<8>(sh.row, lane, q);
     row[4 * q] = __uint_as_float(v.x); row[4 * q + 1] = __uint_as_float(v.y); row[4 * q + 2] = __uint_as_float(v.z); row[4 * q + 3] = __uint_as_float(v.w);
   }
   wave_sync();
-  // ... and its 64 headers, into the block the feature rows have just left (wanted after the dynamics)
-  block_load<16>(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.blk[1], lane);
   const int i = (int)r0.x, rel = (int)r0.y, day = (int)r0.z, hourq = (int)r0.w;
   const int popped0 = (int)r1.x, cum_prev = (int)r1.y;
   const unsigned cumT_prev = r1.z;
@@ -229,13 +267,12 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     }
   }
 
+  WSTAMP(2);
   // ---- reward-side state: the env's header (its 64 dwords in this lane's registers), then the few window keys a step usually needs
   unsigned hd[SDC_HDR_DWORDS];
-  dma_wait();
-  wave_sync();
 #pragma unroll
   for (int q = 0; q < SDC_HDR_DWORDS / 4; q++) {
-    const uint4 v = block_get<16>(sh.blk[1], lane, q);
+    const uint4 v = block_get<16>(sh.hdr, lane, q);
     hd[4 * q] = v.x; hd[4 * q + 1] = v.y; hd[4 * q + 2] = v.z; hd[4 * q + 3] = v.w;
   }
   auto hd_f64 = [&](const int j) { return __hiloint2double((int)hd[j + 1], (int)hd[j]); };
@@ -276,6 +313,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
       }
   }
 
+  WSTAMP(3);
   static_assert(SDC_FEAT_W == 10 && SDC_FEAT_T1 == 12 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 &&
                 SDC_FEAT_NCNEXT == 30, "feature-row slots of the step's inputs");
   auto row_f64 = [&](const int j) { return __hiloint2double(__float_as_int(row[j + 1]), __float_as_int(row[j])); };
@@ -383,9 +421,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   const double normq = sdc_div_const((double)total, S.queue_max_d, S.rc_queue_max);
   const double oldest_norm = KDIV(oldest, 24), avg_norm = KDIV(avg, 24);
 
+  WSTAMP(4);
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 --------------------------------------------------------------------
-  const SdcDcDev& D = S.dc[0];
-  const sdc_dc_params& P = D.p;
   if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
   const int delta = a_dc - 1;
   if (last_delta != -2 && delta == last_delta && a_dc != 0) {
@@ -396,57 +433,97 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   }
   if (consecutive > 3) scale += 1;
   double stpt = stpt0 + (double)(delta * scale);
-  stpt = fmax(fmin(stpt, P.max_temp), P.min_temp);
+  stpt = fmax(fmin(stpt, PRM(P_MAX_TEMP)), PRM(P_MIN_TEMP));
 
-  // ---- rack model: envs/datacenter.py:250-317, :157-181 -- a loop over the config's racks, this lane's env --------------------
-  const int R = P.n_racks;
+  // ---- rack model: envs/datacenter.py:250-317, :157-181 -------------------------------------------------------------------------
+  // A rack's power and outlet temperature depend on its four parameters (and the env's set-point and load) only, and configs
+  // repeat them: the model is evaluated once per rack CLASS (SdcRackClasses: 7 classes in 2 groups for the shipped 20 racks) --
+  // what depends on (cpus, supply approach) once per group -- the results parked per lane in LDS, and the racks' sums then take
+  // every slot's class value in slot order (the half-wave reduction's tree).  Same expressions on the same inputs as a pass over
+  // all racks: the same bits.
+  const int R = (int)PRM(P_N_RACKS);
   const double load_pct = util * 100;
   bool bad_delta = false;
   TreeSum32 s_out, s_pw;
   s_out.init();
   s_pw.init();
   {
-    const double m_cpu = P.m_cpu, c_cpu = P.c_cpu, rs_cpu = P.rs_cpu;
-    const double m_fan = P.m_fan, c_fan = P.c_fan, rs_fan = P.rs_fan;
+    // the class table: dword j in lane j % 64 of two registers, entries read with v_readlane (wave-uniform operands)
+    auto tab_f64 = [&](const int j) { return __hiloint2double((int)lane_key(tab0, 2 * j + 1), (int)lane_key(tab0, 2 * j)); };   // double j of the first 32
+    auto tab_i32 = [&](const int j) { return (int)lane_key(tab1, j); };                                                        // int j of the second half
+    static_assert(offsetof(SdcRackClasses, grp_n) == 0 && offsetof(SdcRackClasses, grp_supply) == 64 && offsetof(SdcRackClasses, cls_full) == 128 &&
+                  offsetof(SdcRackClasses, cls_idle) == 192 && offsetof(SdcRackClasses, n_grp) == 256 && offsetof(SdcRackClasses, grp_begin) == 264 &&
+                  offsetof(SdcRackClasses, cls_of_rack) == 300, "table entries by index");
+    const int n_grp = tab_i32(0);
+    double* cls_pw = reinterpret_cast<double*>(sh.row);                 // [class][lane]
+    double* cls_out = cls_pw + SDC_MAX_RACK_CLS * WE;
+    const double m_cpu = PRM(P_M_CPU), c_cpu = PRM(P_C_CPU), rs_cpu = PRM(P_RS_CPU);
+    const double m_fan = PRM(P_M_FAN), c_fan = PRM(P_C_FAN), rs_fan = PRM(P_RS_FAN);
     const double cpu_shift = rs_cpu * KDIV(load_pct, 100), fan_shift = rs_fan * KDIV(load_pct, 20);
-#pragma unroll 2
-    for (int rk = 0; rk < R; rk++) {
-      const double r_supply = P.rack_supply[rk], r_idle = P.rack_idle[rk], r_full = P.rack_full[rk], r_n = P.rack_n[rk];
+#pragma unroll 1
+    for (int g = 0; g < n_grp; g++) {
+      const double r_n = tab_f64(g), r_supply = tab_f64(8 + g);
       const double sa = fmax(KC(3.8), fmin(r_supply, KC(5.3)));
       const double inlet = sa + stpt;
       const double ratio = ((m_cpu + KC(0.05)) * inlet + c_cpu) + cpu_shift;
-      const double cpu1 = fmax(r_idle, r_full * ratio);
       const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
-      const double fan1 = P.itfan_ref_p * (v * D.rc_itfan_ref_v_ratio);
-      const double vf1 = P.it_fan_full_load_v * v;
-      const double pc = r_n * cpu1, pf = r_n * fan1;
+      const double fan1 = PRM(P_ITFAN_REF_P) * (v * PRM(P_RC_ITFAN_REF_V_RATIO));
+      const double vf1 = PRM(P_IT_FAN_FULL_LOAD_V) * v;
+      const double pf = r_n * fan1;
       const double vtot = r_n * vf1;
-      const double pw = pc + pf;
-      const bool plain = pw > KC(1e-300) && pw < KC(1e300) && vtot > KC(1e-300) && vtot < KC(1e300);
-      const double rise = exp2_short(KC(1.096) * log2_pos_normal(plain ? pw : 1.0, kt) - KC(0.824) * log2_pos_normal(plain ? vtot : 1.0, kt), kt);
-      const double out = inlet + D.k_outlet * rise + KC(-14.01);
-      if (out - inlet < 2 || !plain) bad_delta = true;
-      s_pw.push(pw);
-      s_out.push(out);
+      const bool plain_v = vtot > KC(1e-300) && vtot < KC(1e300);
+      const double l2v = log2_pos_normal(plain_v ? vtot : 1.0, kt);
+      const int c0 = tab_i32(2 + g), c1 = tab_i32(3 + g);
+#pragma unroll 2
+      for (int c = c0; c < c1; c++) {
+        const double r_full = tab_f64(16 + c), r_idle = tab_f64(24 + c);
+        const double cpu1 = fmax(r_idle, r_full * ratio);
+        const double pc = r_n * cpu1;
+        const double pw = pc + pf;
+        const bool plain = pw > KC(1e-300) && pw < KC(1e300) && plain_v;
+        // (log2 of 1.0 is exactly 0.0: what the all-racks pass evaluates for the airflow when the power is not a plain number)
+        const double rise = exp2_short(KC(1.096) * log2_pos_normal(plain ? pw : 1.0, kt) - KC(0.824) * (plain ? l2v : 0.0), kt);
+        const double out = inlet + PRM(P_K_OUTLET) * rise + KC(-14.01);
+        if (out - inlet < 2 || !plain) bad_delta = true;
+        cls_pw[c * WE + lane] = pw;
+        cls_out[c * WE + lane] = out;
+      }
+    }
+    WSTAMP(5);
+    wave_sync();
+    // (four slots per trip: the values come from LDS together, the tree's two bottom levels need no bookkeeping; a slot beyond the
+    // last rack adds the 0.0 the other mappings' idle lanes add)
+#pragma unroll 2
+    for (int rk = 0; rk < R; rk += 4) {
+      double vp[4], vo[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int c = tab_i32(11 + rk + j);
+        const bool in = rk + j < R;
+        vp[j] = in ? cls_pw[c * WE + lane] : 0.0;
+        vo[j] = in ? cls_out[c * WE + lane] : 0.0;
+      }
+      s_pw.push4(vp[0], vp[1], vp[2], vp[3]);
+      s_out.push4(vo[0], vo[1], vo[2], vo[3]);
     }
   }
   if (bad_delta) fault |= SDC_FAULT_OUTLET_DELTA;
   const double sum_outlet = s_out.total();
   const double p_it = s_pw.total();
-  const double avg_ret = (D.ret_sum + sum_outlet) * D.rc_n_racks;
-  const double mean_outlet = sum_outlet * D.rc_n_racks;
+  const double avg_ret = (PRM(P_RET_SUM) + sum_outlet) * PRM(P_RC_N_RACKS);
+  const double mean_outlet = sum_outlet * PRM(P_RC_N_RACKS);
 
   // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 -----------------------------------------------------------------------
-  const double c_air = P.c_air, rho_air = P.rho_air, ct_fan_ref_p = P.ct_fan_ref_p;
-  const double m_sys = rho_air * P.crac_supply_pu * p_it;
+  const double c_air = PRM(P_C_AIR), rho_air = PRM(P_RHO_AIR), ct_fan_ref_p = PRM(P_CT_FAN_REF_P);
+  const double m_sys = rho_air * PRM(P_CRAC_SUPPLY_PU) * p_it;
   const double q_cool = m_sys * c_air * fmax(0.0, avg_ret - stpt);
   const double comp = chiller_power(ct_fan_ref_p, q_cool, amb, kt);
   double ct;
   {
     const double dlt = fmax(50 - (amb - stpt), 1);
     const double m_air = sdc_div_fast(q_cool, c_air * dlt);
-    const double v_air = m_air * D.rc_rho_air;
-    const double x = fmin(v_air * D.rc_ctafr, 1);
+    const double v_air = m_air * PRM(P_RC_RHO_AIR);
+    const double x = fmin(v_air * PRM(P_RC_CTAFR), 1);
     ct = amb < 5 ? 0.0 : ct_fan_ref_p * (x * x * x);
   }
   double water;
@@ -461,13 +538,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   const double total_kw = KDIV(p_it + ct + comp, 1e3);
 
   // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ---------------------------------------------------
-  const double cap = P.bat_capacity_mwh;
+  const double cap = PRM(P_BAT_CAP);
   const double dcload = KDIV(total_kw, 1e3);
   const double e_nobat = dcload * 1e3 * 0.25;
   double energy = e_nobat, co2;
   if (a_bat != 2) {
     const bool chg = a_bat == 0;
-    const double soc = sdc_div_const(bat_load - 0, cap - 0, D.rc_bat_capacity);
+    const double soc = sdc_div_const(bat_load - 0, cap - 0, PRM(P_RC_BAT_CAP));
     const double sg = 1 / (1 + exp_plain(-(10 * (soc - (chg ? 0.5 : 0.25))), kt));
     const double rate = chg ? k_round(0.5 * (1 - sg), 1e4) : fmax(0.5, 4 * sg);
     const double tu = KDIV(rate * 15, 60);
@@ -486,7 +563,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     }
   }
   co2 = (a_bat == 1 ? fmax(energy, 0.0) : energy) * ci_i;
-  const double soc_after = sdc_div_const(bat_load, cap, D.rc_bat_capacity);
+  const double soc_after = sdc_div_const(bat_load, cap, PRM(P_RC_BAT_CAP));
 
   // ---- time: utils/managers.py:127-147 -------------------------------------------------------------------------------------------
   int hourq_n = hourq + 1, day_n = day;
@@ -508,25 +585,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     hpos = hpos + 1 == S.hist_cap ? 0 : hpos + 1;
   }
   const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
-  S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
-  S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
   const unsigned f_all = fault0 | fault;
-
-  // ---- new state record: the changed chunks into the block, the block out --------------------------------------------------------------
-  block_put<16>(sh.blk[0], lane, 0, make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n));
-  block_put<16>(sh.blk[0], lane, 1, make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head));
-  block_put<16>(sh.blk[0], lane, 2, make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive));
-  block_put<16>(sh.blk[0], lane, 3, make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, r3.w));
-  block_put<16>(sh.blk[0], lane, 4, make_uint4(f_all, r4.y, r4.z, r4.w));
-  block_put<16>(sh.blk[0], lane, 6, make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
-                                               (unsigned)__double2hiint(bat_load)));
-  block_put<16>(sh.blk[0], lane, 9, make_uint4((unsigned)__double2loint(href), (unsigned)__double2hiint(href), r9q.z, r9q.w));
-  {
-    const uint4 r10 = block_get<16>(sh.blk[0], lane, 10);
-    block_put<16>(sh.blk[0], lane, 10, make_uint4((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet), r10.z, r10.w));
-  }
-  wave_sync();
-  block_store16(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.blk[0], lane, 0ull);
 
   // ---- rewards + reward-state upkeep (utils/reward_creator.py:16-130): pair_reward_fast, lane = env ---------------------------------
   const int n = hl;
@@ -563,6 +622,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     return (int)__popcll(__ballot(q.w < kbl_w)) - 2;      // (valid keys below the bound; KEY_NONE never counts)
   };
 
+  WSTAMP(7);
   // ---- deferred re-centrings (SdcRefillReq / SdcRefillRes): a window requested two steps ago arrives now ---------------------------
   {
     bool due[4];
@@ -606,6 +666,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     }
   }
 
+  WSTAMP(8);
   // ---- O(1) updates: running sums, the four windows ------------------------------------------------------------------------------------
   const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
   A1 += vn - vo;
@@ -631,28 +692,65 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
         wr0[w] = r0n;
       }
     }
-    unsigned long long um = __ballot(upd[0] | upd[1] | upd[2] | upd[3]);
-    while (__builtin_expect(um != 0ull, 0)) {
-      // a key lands INSIDE a window of env e (or the window starts / ends the history where it would land): the whole wavefront
-      // updates that window, lane = key
-      const int e = __ffsll((long long)um) - 1;
-      um &= um - 1;
-      const unsigned e_new = lane_key(x_new, e), e_old = lane_key(x_old, e);
-      const bool e_has_old = e_old != KEY_NONE;
-      const int e_nprev = (int)lane_key((unsigned)n_prev, e);
+    // a key lands INSIDE a window of some env (or the window starts / ends the history where it would land): the whole wavefront
+    // updates that window, lane = key.  ~3 such (env, window) tasks per wavefront and step: their windows are requested four at
+    // a time (each is a memory round trip that nothing else of this wavefront could hide).
+    unsigned long long um[4];
 #pragma unroll
-      for (int w = 0; w < 4; w++) {
-        if (!lane_key(upd[w] ? 1u : 0u, e)) continue;
+    for (int w = 0; w < 4; w++) um[w] = __ballot(upd[w]);
+    while (__builtin_expect((um[0] | um[1] | um[2] | um[3]) != 0ull, 0)) {
+      int te[4], tw[4];
+      bool have[4];
+      unsigned tkey[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        have[j] = false;
+        te[j] = 0; tw[j] = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+          if (!have[j] && um[w] != 0ull) {
+            te[j] = __ffsll((long long)um[w]) - 1;
+            um[w] &= um[w] - 1;
+            tw[j] = w;
+            have[j] = true;
+          }
+        tkey[j] = KEY_NONE;
+        if (have[j]) tkey[j] = qwin_env0[((size_t)te[j] * SDC_WIN + lane) * 4 + tw[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (!have[j]) continue;
+        const int e = te[j], w = tw[j];
+        const unsigned e_new = lane_key(x_new, e), e_old = lane_key(x_old, e);
+        const bool e_has_old = e_old != KEY_NONE;
+        const int e_nprev = (int)lane_key((unsigned)n_prev, e);
         const unsigned flip = w == 3 ? KEY_NONE : 0u;
-        QTrack q = {qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w], (int)lane_key((unsigned)wr0[w], e), (int)lane_key((unsigned)whi[w], e)};
+        const int q_r0 = (int)lane_key((unsigned)(w == 0 ? wr0[0] : (w == 1 ? wr0[1] : (w == 2 ? wr0[2] : wr0[3]))), e);
+        const int q_hi = (int)lane_key((unsigned)(w == 0 ? whi[0] : (w == 1 ? whi[1] : (w == 2 ? whi[2] : whi[3]))), e);
+        QTrack q = {tkey[j], q_r0, q_hi};
         const bool wd = qt_update(q, e_new ^ flip, e_old ^ flip, e_has_old, e_nprev, lane);
         if (wd) qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w] = q.w;
         const int kw = w == 0 ? (int)lane_key((unsigned)k1, e) : (int)lane_key((unsigned)k3, e);
-        deliver(e, w, q, look_base(w, q, kw, lane_key(kbl[w == 3 ? 1 : 0], e)));
-        if (wd && lane == e) touched = true;
+        const int base = look_base(w, q, kw, lane_key(kbl[w == 3 ? 1 : 0], e));
+        // (deliver(): w is a run-time value here)
+        const unsigned first = lane_key(q.w, 0), last = lane_key(q.w, max(q.hi - 1, 0));
+        unsigned c[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) c[x] = lane_key(q.w, min(max(base + x, 0), SDC_WIN - 1));
+        if (lane == e) {
+#pragma unroll
+          for (int x = 0; x < 4; x++)
+            if (x == w) {
+              wr0[x] = q.r0; whi[x] = q.hi; wf[x] = first; wlast[x] = last; cb[x] = base;
+#pragma unroll
+              for (int y = 0; y < 4; y++) ck[x][y] = c[y];
+            }
+          if (wd) touched = true;
+        }
       }
     }
   }
+  WSTAMP(9);
   ok = ok && whi[0] > 0 && whi[1] > 0 && whi[2] > 0 && whi[3] > 0;
   // key at position p of window w, if it is one of the four this lane holds
   auto key_at_w = [&](const int w, const int p, bool& have) __attribute__((always_inline)) {
@@ -747,11 +845,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
       }
     }
   }
+  WSTAMP(10);
   // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
   const double tt1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
   const double tt2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
   double mean, sd, inv_sd;
   clipped_moments(n, b, A1, A2, tt1, tt2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap, S.hist_cap_d);
+  WSTAMP(11);
   // ---- a window that the next step could exhaust: file a re-centring request (served by the NEXT launch's sweep wavefronts) -----------
   {
     int k1n, k3n;
@@ -846,18 +946,41 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     put64(H_RET + 4, ret_a[2]);
 #pragma unroll
     for (int q = 0; q < SDC_HDR_DWORDS / 4; q++)
-      block_put<16>(sh.blk[1], lane, q, make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]));
+      block_put<16>(sh.hdr, lane, q, make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]));
     rew[(size_t)env * 3 + 0] = (float)r_a[0];
     rew[(size_t)env * 3 + 1] = (float)r_a[1];
     rew[(size_t)env * 3 + 2] = (float)r_a[2];
   }
+  WSTAMP(12);
+  // ---- new state: this step's key into the ring, its prefix counts into the queue table, the record's changed chunks into the block and
+  // the block out.  (All of the step's stores sit HERE, behind the reward part: this hardware counts loads and stores in one
+  // counter and retires them in order, so a wait for a late load -- a window's keys for the whole-wavefront steps above -- is also
+  // a wait for every store issued before it.)
+  S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
+  S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
+  block_put<16>(sh.rec, lane, 0, make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n));
+  block_put<16>(sh.rec, lane, 1, make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head));
+  block_put<16>(sh.rec, lane, 2, make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive));
+  block_put<16>(sh.rec, lane, 3, make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, r3.w));
+  block_put<16>(sh.rec, lane, 4, make_uint4(f_all, r4.y, r4.z, r4.w));
+  block_put<16>(sh.rec, lane, 6, make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
+                                               (unsigned)__double2hiint(bat_load)));
+  block_put<16>(sh.rec, lane, 9, make_uint4((unsigned)__double2loint(href), (unsigned)__double2hiint(href), r9q.z, r9q.w));
+  {
+    const uint4 r10 = block_get<16>(sh.rec, lane, 10);
+    block_put<16>(sh.rec, lane, 10, make_uint4((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet), r10.z, r10.w));
+  }
+  wave_sync();
+  block_store16(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane, 0ull);
+
+  WSTAMP(13);
   // ---- an env whose step needs anything else (no reward state yet, a window that does not cover, several keys across a bound, no
   // room for a request): env_reward() redoes it whole-wavefront from its state in memory -- which this step has not touched, or
   // else is told to rebuild ------------------------------------------------------------------------------------------------------
   {
     unsigned long long fm = __ballot(!ok);
     wave_sync();
-    block_store16(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.blk[1], lane, fm);     // (the fallback's envs: their headers come from env_reward)
+    block_store16(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.hdr, lane, fm);     // (the fallback's envs: their headers come from env_reward)
     if (__builtin_expect(fm != 0ull, 0)) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -872,15 +995,16 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
         const uint4 qw_e = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env_e * SDC_WIN + lane];
         env_reward(S, env_e, lane, hd_e, qw_e, pi(hl), pi(slot), (unsigned)pi((int)x_new), (unsigned)pi((int)x_old), pf(e_off), pf(energy),
                    pf(norm_ci), pf(oldest_norm), pi(overdue), pi(hourq_n), pf(p_it), pf(total_kw), pf(water), rew,
-                   &sh.back[0][0] + e * 8 - SDC_INFO_ENERGY_Z, sh.tl);
+                   &late.back[0][0] + e * 8 - SDC_INFO_ENERGY_Z, late.tl);
       }
       wave_sync();
       if (!ok) {
-        z_f = sh.back[lane][0]; path_f = sh.back[lane][1]; ret_f[0] = sh.back[lane][2]; ret_f[1] = sh.back[lane][3]; ret_f[2] = sh.back[lane][4];
+        z_f = late.back[lane][0]; path_f = late.back[lane][1]; ret_f[0] = late.back[lane][2]; ret_f[1] = late.back[lane][3]; ret_f[2] = late.back[lane][4];
       }
     }
   }
 
+  WSTAMP(14);
   // ---- outputs ----------------------------------------------------------------------------------------------------------------------
   // the observation pool (sdc_device.hpp SDC_P_*): the trace-only entries are the feature row's, nine depend on the step
   float pool[SDC_POOL_DIM];
@@ -895,7 +1019,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   const bool terminal = rel + 1 >= S.episode_steps;
   {
     // obs [3][26] of this lane's env into its row of the staging block, then the block out in whole lines
-    float* const stage = reinterpret_cast<float*>(&sh.blk[0][0]);
+    float* const stage = reinterpret_cast<float*>(&sh.rec[0]);
     wave_sync();
     float* srow = stage + lane * SDC_OBS_OUT;
 #pragma unroll
@@ -976,7 +1100,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     inf[SDC_INFO_EP_RETURN_BAT] = ret_f[2];
     inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
     // ... through the staging block too: the wavefront's 64 info rows are 11 KB of whole lines
-    float* const stage = reinterpret_cast<float*>(&sh.blk[0][0]);
+    float* const stage = reinterpret_cast<float*>(&sh.rec[0]);
     wave_sync();
     f4v* irow = reinterpret_cast<f4v*>(stage + lane * SDC_INFO_DIM);
 #pragma unroll
@@ -992,4 +1116,10 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     for (int k = 0; k < SDC_INFO_DIM / 4; k++) nt_store4(i4 + 4 * (k * WE + lane), s4[k * WE + lane]);
   }
   done[env] = (unsigned char)(terminal ? 1 : 0);
+#ifdef SDC_WIDE_STAMPS
+  WSTAMP(15);
+  if (lane == 0)
+    for (int q = 0; q < 15; q++) info[(size_t)env0 * SDC_INFO_DIM + q] = (float)(wstamp[q + 1] - wstamp[q]);
+  if (lane == 1) info[(size_t)env0 * SDC_INFO_DIM + 15] = (float)(wstamp[0] & 0xFFFFFull);
+#endif
 }
