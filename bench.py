@@ -68,7 +68,7 @@ N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
 MAX_CLOCK_GHZ = 2.4
 HIST_CAP = 10000
 ALG_BYTES_FIXED = 1540      # B(H) = 4*H + 1540 bytes per env-step
-WIDE_MIN_ENVS = 1 << 30     # (no lane-per-env step kernel in this build: see sdc_capi.hip wide_case)
+WIDE_MIN_ENVS = 24576       # sdc_capi.hip SDC_WIDE_MIN_ENVS: single steps of a batch this large run one lane per env (sdc_wide.hip)
 STEP_KERNEL = "sdc_dynamics_fast_kernel"   # the step kernel specialised for the common case, which is what this workload is
 STEP_KERNEL_PREFIX = "sdc_dynamics"            # (the general kernel sdc_dynamics_kernel serves every other case)
 MIN_REGION_S = 0.2

@@ -18,7 +18,7 @@ INFO_DIM = 44
 TABLE_LEN = 35040
 HDR_DWORDS = 64    # csrc/sdc_device.hpp SdcHdr: 256-byte per-env header
 QWIN = 64          # csrc/sdc_device.hpp SDC_WIN: keys per rank window (4 windows per env: Q1, Q3, upper / lower clip bound)
-ABI_VERSION = 310  # include/sustaindc_hip.h SDC_ABI_VERSION: the struct layouts and argument lists this binding was written for
+ABI_VERSION = 311  # include/sustaindc_hip.h SDC_ABI_VERSION: the struct layouts and argument lists this binding was written for
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libsustaindc_hip.so")
@@ -130,7 +130,7 @@ class SdcActorParams(C.Structure):
 EXPORTS = [
     "sdc_last_error", "sdc_version", "sdc_create", "sdc_destroy", "sdc_set_seed", "sdc_weather_window_len", "sdc_set_tables",
     "sdc_set_dc_params", "sdc_assign_envs", "sdc_reset", "sdc_step", "sdc_rollout", "sdc_steps_to_episode_end",
-    "sdc_last_done",
+    "sdc_last_done", "sdc_last_step_kernel",
     "sdc_get_state", "sdc_set_state",
     "sdc_hist_stride", "sdc_queue_stride", "sdc_profile_enable", "sdc_profile_read",
     "sdc_set_actor", "sdc_rollout_actor",
@@ -259,6 +259,8 @@ def load():
     L.sdc_rollout.argtypes = [vp, C.c_int, vp, fp, fp, fp, vp, fp, fp, vp, vp]
     L.sdc_steps_to_episode_end.argtypes = [vp]
     L.sdc_last_done.argtypes = [vp, u8p]
+    L.sdc_last_step_kernel.argtypes = [vp]
+    L.sdc_last_step_kernel.restype = C.c_char_p
     L.sdc_get_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_set_state.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.sdc_profile_enable.argtypes = [vp, C.c_int]

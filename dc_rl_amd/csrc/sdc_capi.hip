@@ -110,6 +110,7 @@ struct sdc_handle {
   float* obs_latch = nullptr;
   bool latch_valid = false;
   int racks_cfg0 = 0;                     // racks of data-centre config 0 (the specialised kernels take <= 32: one pass)
+  const char* last_step_kernel = "";      // sdc_last_step_kernel
   int rack_cls_cfg0 = 0;                  // ... and its rack classes (SdcRackClasses; 0: more than the lane-per-env kernel's tables hold)
   // several data-centre configs: host copies of the configs and of the assignment, from which every env's own copy of its
   // config's scalars is built (SdcDev::prm_env) -- the common-case kernels then serve the batch as they serve one config
@@ -248,7 +249,9 @@ int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 // racks, 16-byte aligned output rows (whole-line stores through the wavefront's staging block); debug_flags bit 11 forces it
 // for any such batch, bit 12 keeps it off
 #ifndef SDC_WIDE_MIN_ENVS
-#define SDC_WIDE_MIN_ENVS (1 << 30)     // (not the default for any batch yet: measured slower than four envs per wavefront)
+// (measured, us per step inside an episode, lane-per-env / four per wavefront: 20 480 envs 29.2 / 27.9, 24 576: 31.1 / 33.4,
+// 28 672: 32.6 / 36.6, 32 768: 34.4 / 40.2, 65 536: 55.0 / 72.6)
+#define SDC_WIDE_MIN_ENVS 24576
 #endif
 bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, const float* info) {
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
@@ -771,17 +774,22 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   h->step_no = next_step_no(h->step_no, 1);
   if (fast_case(h, actions, share_obs, info, timed) && wide_case(h, obs, share_obs, info)) {
     d.sweep_blocks = wide_sweep_blocks(h);
+    h->last_step_kernel = "sdc_dynamics_wide_kernel";
     hipLaunchKernelGGL(sdc_dynamics_wide_kernel, dim3(d.sweep_blocks + N / SDC_WAVE), dim3(SDC_WAVE), 0, st, d, h->rel_hint, actions,
                        obs, share_obs, done, info, final_obs, rew);
-  } else if (fast_case(h, actions, share_obs, info, timed) && quad_case(h, false))
+  } else if (fast_case(h, actions, share_obs, info, timed) && quad_case(h, false)) {
+    h->last_step_kernel = "sdc_dynamics_quad_kernel";
     hipLaunchKernelGGL(sdc_dynamics_quad_kernel, dim3(d.sweep_blocks + quad_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
                        h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
-  else if (fast_case(h, actions, share_obs, info, timed))
+  } else if (fast_case(h, actions, share_obs, info, timed)) {
+    h->last_step_kernel = "sdc_dynamics_fast_kernel";
     hipLaunchKernelGGL(sdc_dynamics_fast_kernel, dim3(d.sweep_blocks + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d,
                        h->rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
-  else
+  } else {
+    h->last_step_kernel = "sdc_dynamics_kernel";
     hipLaunchKernelGGL(sdc_dynamics_kernel, dim3(d.sweep_blocks + step_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, h->rel_hint,
                        actions, obs, share_obs, done, info, final_obs, rew);
+  }
   if (h->cfg.debug_flags & 1) hipLaunchKernelGGL(sdc_reward_verify_kernel, dim3(N), dim3(SDC_BLOCK), 0, st, d, info);
   HIP_TRY(hipGetLastError());
   h->n_last_done = 0;
@@ -987,6 +995,8 @@ int sdc_rollout_actor(sdc_handle* h, int n_steps, int sample, float* obs, float*
 }
 
 int sdc_steps_to_episode_end(const sdc_handle* h) { return h ? h->steps_to_terminal : -1; }
+
+const char* sdc_last_step_kernel(const sdc_handle* h) { return h ? h->last_step_kernel : ""; }
 
 int sdc_last_done(const sdc_handle* h, uint8_t* done_host) {
   if (!h) return -1;

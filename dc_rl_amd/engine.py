@@ -258,6 +258,11 @@ class SdcEngine:
         return (fl[:a].view(N, L.N_AGENTS, L.OBS_PAD), fl[a:b].view(N, L.SHARE_OBS_DIM), fl[b:c].view(N, L.N_AGENTS),
                 flat[n_f * 4:], fl[c:].view(N, L.INFO_DIM))
 
+    def last_step_kernel(self) -> str:
+        """Name of the step kernel the last `step()` launched (the host picks by batch size and configuration; all give the same
+        results)."""
+        return self.lib.sdc_last_step_kernel(self._h).decode()
+
     def last_done(self):
         """bool [N]: which envs finished in the last step() / rollout() -- from the host's mirror of the step counters, no
         device synchronisation.  None when no env finished."""

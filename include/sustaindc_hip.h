@@ -210,7 +210,7 @@ const char* sdc_last_error(void);
  *                            roll_days; sdc_rollout: actions_out; debug_flags bit 6
  *   310  sdc_set_actor, sdc_rollout_actor (closed loop with the actor networks inside the kernel); debug_flags bit 7
  *        (debug_flags bits 9 / 10 came later without a bump: no layout or argument list changed) */
-#define SDC_ABI_VERSION 310
+#define SDC_ABI_VERSION 311
 int sdc_version(void);
 
 int sdc_create(const sdc_config* cfg, sdc_handle** out);
@@ -297,6 +297,11 @@ int sdc_steps_to_episode_end(const sdc_handle* h);
  * about episode boundaries (harl/envs/env_wrappers.py:176-190: "original_obs" bookkeeping) without a device->host
  * read.  Returns the number of finished envs; done_host [N] (host, may be NULL) is filled only when it is > 0. */
 int sdc_last_done(const sdc_handle* h, uint8_t* done_host);
+/* name of the step kernel the last sdc_step launched ("" before the first): the host picks by batch size and configuration
+ * between the general kernel, the common-case kernels with two / four envs per wavefront and the lane-per-env kernel of the
+ * largest batches (sdc_capi.hip fast_case / quad_case / wide_case) -- all give the same results; tests and benchmarks name
+ * what they measured with this. */
+const char* sdc_last_step_kernel(const sdc_handle* h);
 
 /* parity injection + env checkpoint: copy one named state field to / from HOST memory, dense per env.
  * int32[N]:  cursor t_rel day hourq q_popped q_cum q_cumT q_head q_cum_hm1 q_cumT_hm1 last_delta consecutive

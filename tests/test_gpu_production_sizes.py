@@ -24,9 +24,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("N", [12288, 16384, 32768])
 def test_quad_step_kernel_production_vs_oracle(N):
-    """Four envs per wavefront by default (debug_flags = 0) at 12 288 / 16 384 / 32 768 envs (the largest batch a rate is quoted
-    for: eight wavefronts per SIMD, three resident): 330 single steps over two auto-resets,
-    all four rows of the first / last wavefronts and both sides of every occupancy round sampled, every reward-state path."""
+    """The default kernel of a large batch (debug_flags = 0) at 12 288 / 16 384 envs -- four envs per wavefront -- and at 32 768, the
+    largest batch a rate is quoted for -- ONE LANE PER ENV (sdc_wide.hip) since round 5: 330 single steps over two auto-resets, the
+    first / last wavefronts and both sides of every occupancy round sampled, every reward-state path."""
     rig = ProductionRig(N, debug_flags=0, episode_steps=120, seed=1000 + N, envs_per_wave=4)
     assert len(rig.sample) >= 72
     obs, _ = rig.eng.reset()
@@ -35,8 +35,21 @@ def test_quad_step_kernel_production_vs_oracle(N):
     print(f"quad step kernel, {N} envs:", rig.worst, "reward-state paths:", rig.paths[:4], "auto-resets:", rig.resets,
           "sampled envs:", len(rig.sample))
     assert rig.resets >= 2
+    assert rig.eng.last_step_kernel() == ("sdc_dynamics_wide_kernel" if N >= 24576 else "sdc_dynamics_quad_kernel")
     rig.assert_ok()
     rig.assert_all_reward_state_paths_seen()
+    rig.eng.close()
+
+
+def test_quad_step_kernel_32768_envs_vs_oracle():
+    """... and the four-envs-per-wavefront kernel at 32 768 envs (debug_flags bit 12 keeps the lane-per-env kernel off): what
+    `sdc_rollout` and the closed loop still run at that size."""
+    rig = ProductionRig(32768, debug_flags=4096, episode_steps=120, seed=33768, envs_per_wave=4)
+    obs, _ = rig.eng.reset()
+    rig.begin_all(obs)
+    rig.single_steps(150)
+    assert rig.eng.last_step_kernel() == "sdc_dynamics_quad_kernel" and rig.resets >= 1
+    rig.assert_ok()
     rig.eng.close()
 
 

@@ -50,6 +50,9 @@ def test_lane_per_env_kernel_equals_the_pair_kernel(cfg):
     acts = torch.randint(0, 3, (230, N, 3), dtype=torch.int32, generator=g).cuda()
     for t in range(230):
         _same_step(a, b, acts[t], t, cfg)
+    # (25 racks: 12 distinct racks, more than the lane-per-env kernel's class tables hold -- the host keeps that config off it)
+    assert a.last_step_kernel() == ("sdc_dynamics_wide_kernel" if cfg != "dc_config_r25.json" else "sdc_dynamics_fast_kernel")
+    assert b.last_step_kernel() == "sdc_dynamics_fast_kernel"
     for name in ("record", "hist", "qtab"):
         np.testing.assert_array_equal(a.get_state(name), b.get_state(name), err_msg=name)
     assert (a.info[:, L.INFO_IDX["fault"]] == 0).all()
@@ -109,6 +112,7 @@ def test_lane_per_env_kernel_full_rings_whole_state():
                 paths[nm][int(x)] = paths[nm].get(int(x), 0) + int(k)
     # info[reserved]: 0 incremental state only, 2 a re-centred window taken over, 1 a window re-centred inline, 3 rebuilt from the ring
     print("reward-state paths (env-steps by info[reserved]):", paths)
+    assert a.last_step_kernel() == "sdc_dynamics_wide_kernel" and b.last_step_kernel() == "sdc_dynamics_fast_kernel"
     assert paths["lane per env"].get(2, 0) > 0          # re-centred windows arrived (requests were filed two steps earlier)
     # the whole-wavefront fallback with a ring read stays as rare as in the pair kernel (each is a ~5 us straggler of its launch)
     assert paths["lane per env"].get(1, 0) + paths["lane per env"].get(3, 0) <= paths["two per wavefront"].get(1, 0) + paths["two per wavefront"].get(3, 0) + 8, paths
@@ -117,3 +121,16 @@ def test_lane_per_env_kernel_full_rings_whole_state():
     assert (a.info[:, L.INFO_IDX["fault"]] == 0).all()
     a.close()
     b.close()
+
+
+def test_the_host_picks_the_kernel_by_batch_size():
+    """Single steps of a lock-step, single-config batch: two envs per wavefront up to 5 632 envs, four above, one lane per env from
+    24 576 (sdc_capi.hip fast_case / quad_case / wide_case); debug_flags bit 12 keeps the lane-per-env kernel off."""
+    import torch
+    for N, flags, want in ((4096, 0, "sdc_dynamics_fast_kernel"), (8192, 0, "sdc_dynamics_quad_kernel"),
+                           (24576, 0, "sdc_dynamics_wide_kernel"), (24576, 4096, "sdc_dynamics_quad_kernel"),
+                           (24600, 0, "sdc_dynamics_quad_kernel")):
+        (e,) = _engines(N, 96, flags=(flags,))
+        e.step(torch.ones((N, 3), dtype=torch.int32, device="cuda"))
+        assert e.last_step_kernel() == want, (N, flags, e.last_step_kernel())
+        e.close()
