@@ -258,7 +258,7 @@ bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, co
   return (h->cfg.n_envs & 63) == 0 && h->d.n_cfg == 1 && h->racks_cfg0 <= 31 && h->rack_cls_cfg0 > 0 && (h->d.debug_flags & (512 | 1024 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
          (h->cfg.n_envs >= SDC_WIDE_MIN_ENVS || (h->d.debug_flags & 2048)) && al16(obs) && al16(share_obs) && al16(info);
 }
-int wide_sweep_blocks(const sdc_handle* h) { return std::min(h->d.rq_max, 256); }
+int wide_sweep_blocks(const sdc_handle* h) { return std::min(h->d.rq_max, 256) / 2; }     // (two wavefronts each, a request per wavefront)
 bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_obs, const float* info, bool timed) {
   const SdcDev& d = h->d;
   return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs &&
@@ -775,7 +775,7 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   if (fast_case(h, actions, share_obs, info, timed) && wide_case(h, obs, share_obs, info)) {
     d.sweep_blocks = wide_sweep_blocks(h);
     h->last_step_kernel = "sdc_dynamics_wide_kernel";
-    hipLaunchKernelGGL(sdc_dynamics_wide_kernel, dim3(d.sweep_blocks + N / SDC_WAVE), dim3(SDC_WAVE), 0, st, d, h->rel_hint, actions,
+    hipLaunchKernelGGL(sdc_dynamics_wide_kernel, dim3(d.sweep_blocks + N / SDC_WAVE), dim3(2 * SDC_WAVE), 0, st, d, h->rel_hint, actions,
                        obs, share_obs, done, info, final_obs, rew);
   } else if (fast_case(h, actions, share_obs, info, timed) && quad_case(h, false)) {
     h->last_step_kernel = "sdc_dynamics_quad_kernel";

@@ -36,18 +36,26 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4v nt_load4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p)); }
 __device__ __forceinline__ void nt_store4(float* p, const f4v v) { __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p)); }
 
-// LDS of an env wavefront, 40 KB (four wavefronts per CU):
-//   rec  16 KB  the wavefront's 64 state records, from the first loads until the patched block has gone back to memory
-//   hdr  16 KB  its 64 headers, likewise
-//   row   8 KB  its 64 feature rows on the way in; then, during the rack model, the rack classes' results {power, outlet} per lane
-// and once both blocks are out: the whole-wavefront fallback's scratch (tl / back) and the output staging (obs rows: 20 KB) on top.
+// LDS of an env workgroup (64 envs, two wavefronts), 40 KB -- four workgroups per CU, two wavefronts per SIMD:
+//   rec  16 KB  the 64 state records (dynamics wavefront), from the first loads until the patched block has gone back to memory;
+//               then its output staging: the obs rows (20 KB, running into `row`), the share_obs rows, the info rows
+//   row   8 KB  the 64 feature rows on the way in; during the rack model the rack classes' results {power, outlet} per lane; from the
+//               end of the dynamics its upper half holds the HAND-OVER to the reward wavefront (WideHand)
+//   hdr  16 KB  the 64 headers (reward wavefront), likewise; then the whole-wavefront fallback's scratch (WideLate)
 struct WideShared {
   unsigned rec[WE * 64];
-  unsigned hdr[WE * 64];
   unsigned row[WE * 32];
+  unsigned hdr[WE * 64];
 };
-static_assert(sizeof(unsigned) * 2 * WE * 64 >= sizeof(float) * WE * SDC_OBS_OUT, "the obs rows are staged across both blocks");
-struct WideLate {                  // (aliases WideShared::rec once the record block has been stored; the sweep wavefronts: from the start)
+static_assert(sizeof(float) * WE * SDC_OBS_OUT <= sizeof(unsigned) * (WE * 64 + WE * 16), "the obs rows are staged across `rec` and the lower half of `row`");
+// what the dynamics hand to the reward part, per env (lane): [field][lane]
+struct WideHand {
+  double e_off[WE], energy[WE], norm_ci[WE], oldest_norm[WE];
+  unsigned x_new[WE];
+  int hl[WE], slot[WE], overdue[WE], hourq_n[WE];
+};
+static_assert(sizeof(WideHand) <= sizeof(unsigned) * WE * 16, "the hand-over sits in the upper half of `row`");
+struct WideLate {                  // (aliases a 16 KB block that has gone back to memory; the sweep wavefronts: from the start)
   sdc_rw::TailLds tl;              // scratch of the ring paths (env_reward: window refill, rebuild; the sweep wavefronts)
   float back[WE][8];               // what a whole-wavefront reward step hands back to its env's lane {z, path, ret[3]}
 };
@@ -92,13 +100,6 @@ __device__ __forceinline__ void block_store16(void* gbase, const unsigned* lds, 
   }
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// (measurement build -DSDC_WIDE_STAMPS: lane 0 of every env wavefront stamps the wall clock (100 MHz) at the marks WSTAMP(i) and
-// leaves the differences in columns 0..9 of its env's info row -- tools/dev/wide_phases.py)
-#ifdef SDC_WIDE_STAMPS
-#define WSTAMP(i) do { __builtin_amdgcn_s_waitcnt(0); wstamp[i] = wall_clock64(); } while (0)
-#else
-#define WSTAMP(i)
-#endif
 
 // pairwise (binary-tree) sum over rack slots 0..31 in slot order, streamed: push(v) for slot 0, 1, ... ; total() when done.  The tree
 // is half_sum_f64's (strides 1, 2, 4, 8 inside the rows, then the two rows), so the sums round as in the other mappings;
@@ -154,41 +155,14 @@ struct TreeSum32 {
   }
 };
 
-}  // namespace
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// One launch = one env-step of all N environments.  Grid: S.sweep_blocks one-wavefront sweep workgroups (first: they serve the
-// previous step's re-centring requests while the envs step), then N / 64 env workgroups of one wavefront.
-extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) void sdc_dynamics_wide_kernel(
-    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
-    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
-  __shared__ WideShared sh;
-  WideLate& late = *reinterpret_cast<WideLate*>(sh.rec);
+// ---- the DYNAMICS wavefront of an env workgroup: lane = env ---------------------------------------------------------------------------
+__device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, const int env0, const int lane, const int rel_hint,
+                                              const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
+                                              unsigned char* __restrict__ done, float* __restrict__ final_obs) {
   using namespace sdc_rw;
-  const int lane = threadIdx.x;
-  const int bx = (int)blockIdx.x;
-  if (bx < S.sweep_blocks) {
-    // one wavefront per request (requests bx, bx + sweep_blocks, ...): a sweep is 40 KB through one wavefront, ~5 us -- shorter
-    // than the step it runs beside
-    const int set = S.step_no % 3;
-    const int cnt = min(S.rq_count[set], S.rq_max);
-    if (bx == 0 && lane == 0) S.rq_count[(S.step_no + 2) % 3] = 0;     // the set the NEXT step's requests go to
-    if (bx < cnt) __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
-#pragma unroll 1
-    for (int j = bx; j < cnt; j += S.sweep_blocks) serve_recentring_request(S, set, j, lane, late.tl);
-    return;
-  }
-  const int nb = (int)gridDim.x - S.sweep_blocks;
-  const int env0 = first_pair_of_block(bx - S.sweep_blocks, nb, 1) * WE;     // (every XCD a contiguous range of envs)
-  if (env0 >= S.n_envs) return;
   const int env = env0 + lane;
   KLit kt{};
-#ifdef SDC_WIDE_STAMPS
-  unsigned long long wstamp[16];
-#endif
-
   // ---- loads: actions, state record, feature row, queue-history probes ----------------------------------------------------
-  WSTAMP(0);
   const int32_t* ap = actions + (size_t)env * 3;
   int a_ls = ap[0], a_dc = ap[1], a_bat = ap[2];
   // the config's scalars (P_*: double j in lane j) and its rack-class table (dword j in lane j % 64 of two registers), requested with
@@ -200,7 +174,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   // the wavefront's 64 records and 64 feature rows: two contiguous blocks, in through the LDS (block I/O above)
   block_load<16>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane);
   block_load<8>(S.feat + feat_row_offset(S, env0, rel_hint + 1), sh.row, lane);
-  block_load<16>(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.hdr, lane);
   static_assert(R_CURSOR == 0 && R_TREL == 1 && R_DAY == 2 && R_HOURQ == 3 && R_QPOPPED == 4 && R_QCUM == 5 && R_QCUMT == 6 &&
                 R_QHEAD == 7 && R_QCUM_HM1 == 8 && R_QCUMT_HM1 == 9 && R_LAST_DELTA == 10 && R_CONSEC == 11 && R_SCALE == 12 &&
                 R_HIST_LEN == 13 && R_HIST_POS == 14 && R_FAULT == 16 && R_STPT == 24 && R_BAT == 26 && R_HIST_REF == 36 &&
@@ -214,9 +187,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     cumq[s] = t >= 0 ? (int)qt[t].x : 0;
   }
 
-  WSTAMP(1);
   dma_wait();
-  wave_sync();
+  __syncthreads();      // (1) records, feature rows and headers are in LDS
   const uint4 r0 = block_get<16>(sh.rec, lane, 0), r1 = block_get<16>(sh.rec, lane, 1), r2 = block_get<16>(sh.rec, lane, 2);
   const uint4 r3 = block_get<16>(sh.rec, lane, 3), r4 = block_get<16>(sh.rec, lane, 4), r6 = block_get<16>(sh.rec, lane, 6);
   const uint4 r9q = block_get<16>(sh.rec, lane, 9);
@@ -249,10 +221,7 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     if ((unsigned)a_dc > 2u) a_dc = 1;
     if ((unsigned)a_bat > 2u) a_bat = 2;
   }
-  // the evicted ring key (read BEFORE this step's key goes into that slot) and the queue table ahead of the oldest task
-  const int slot0 = hl < S.hist_cap ? hl : hpos;
-  unsigned x_old = 0xFFFFFFFFu;
-  if (hl >= S.hist_cap) x_old = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
+  // the queue table ahead of the oldest task
   constexpr int QA = 16;        // table entries ahead of the oldest task's step requested up front (two per dwordx4)
   uint4 qa[QA / 2];
 #pragma unroll
@@ -267,53 +236,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     }
   }
 
-  WSTAMP(2);
-  // ---- reward-side state: the env's header (its 64 dwords in this lane's registers), then the few window keys a step usually needs
-  unsigned hd[SDC_HDR_DWORDS];
-#pragma unroll
-  for (int q = 0; q < SDC_HDR_DWORDS / 4; q++) {
-    const uint4 v = block_get<16>(sh.hdr, lane, q);
-    hd[4 * q] = v.x; hd[4 * q + 1] = v.y; hd[4 * q + 2] = v.z; hd[4 * q + 3] = v.w;
-  }
-  auto hd_f64 = [&](const int j) { return __hiloint2double((int)hd[j + 1], (int)hd[j]); };
-  // window w of this lane's env: rank of its first key, valid keys, cached first / last key (window order: Q1, Q3, BU, BL)
-  constexpr int HW[4] = {H_Q1, H_Q3, H_BU, H_BL};
-  int wr0[4], whi[4];
-  unsigned wf[4], wlast[4], pend[4];
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-    wr0[w] = (int)hd[HW[w] + T_R0];
-    whi[w] = (int)hd[HW[w] + T_HI];
-    wf[w] = hd[H_WFIRST + w];
-    wlast[w] = hd[H_WLAST + w];
-    pend[w] = hd[H_PEND + w];
-  }
-  // history length after this step's append, the quartile ranks it asks for
-  const int n_pre = hl;
-  const int n_step = hl < S.hist_cap ? hl + 1 : hl;
-  int k1, k3;
-  quartile_ranks(n_step, k1, k3);
-  // FOUR keys of every window, gathered now: around the wanted rank (quartile windows: the rank moves by at most one position
-  // when both of the step's keys land outside the window) and around last step's clip bound (bound windows: the two keys
-  // either side of it).  ck[w][j] = key at window position cb[w] + j.
-  unsigned ck[4][4];
-  int cb[4];
-  cb[0] = k1 - wr0[0] - 1;
-  cb[1] = k3 - wr0[1] - 1;
-  cb[2] = n_pre - (int)hd[H_QC] - wr0[2] - 2;
-  cb[3] = n_pre - (int)hd[H_QC + 1] - wr0[3] - 2;
-  {
-    const unsigned* qw = S.qwin + (size_t)env * SDC_WIN * 4;
-#pragma unroll
-    for (int w = 0; w < 4; w++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int p = min(max(cb[w] + j, 0), SDC_WIN - 1);
-        ck[w][j] = qw[p * 4 + w];
-      }
-  }
-
-  WSTAMP(3);
   static_assert(SDC_FEAT_W == 10 && SDC_FEAT_T1 == 12 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 &&
                 SDC_FEAT_NCNEXT == 30, "feature-row slots of the step's inputs");
   auto row_f64 = [&](const int j) { return __hiloint2double(__float_as_int(row[j + 1]), __float_as_int(row[j])); };
@@ -421,7 +343,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   const double normq = sdc_div_const((double)total, S.queue_max_d, S.rc_queue_max);
   const double oldest_norm = KDIV(oldest, 24), avg_norm = KDIV(avg, 24);
 
-  WSTAMP(4);
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 --------------------------------------------------------------------
   if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
   const int delta = a_dc - 1;
@@ -489,7 +410,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
         cls_out[c * WE + lane] = out;
       }
     }
-    WSTAMP(5);
     wave_sync();
     // (four slots per trip: the values come from LDS together, the tree's two bottom levels need no bookkeeping; a slot beyond the
     // last rack adds the 0.0 the other mappings' idle lanes add)
@@ -587,8 +507,216 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
   const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
   const unsigned f_all = fault0 | fault;
 
+  // ---- hand-over to the reward wavefront --------------------------------------------------------------------------------------------
+  {
+    WideHand& H = *reinterpret_cast<WideHand*>(sh.row + WE * 16);
+    H.e_off[lane] = e_off; H.energy[lane] = energy; H.norm_ci[lane] = norm_ci; H.oldest_norm[lane] = oldest_norm;
+    H.x_new[lane] = x_new; H.hl[lane] = hl; H.slot[lane] = slot; H.overdue[lane] = overdue; H.hourq_n[lane] = hourq_n;
+  }
+  __syncthreads();      // (2) the step's energy is known
+
+  // ---- new state: this step's key into the ring, its prefix counts into the queue table, the record's changed chunks into the block and
+  // the block out.  (All of the step's stores sit HERE, behind the reward part: this hardware counts loads and stores in one
+  // counter and retires them in order, so a wait for a late load -- a window's keys for the whole-wavefront steps above -- is also
+  // a wait for every store issued before it.)
+  S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
+  S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
+  block_put<16>(sh.rec, lane, 0, make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n));
+  block_put<16>(sh.rec, lane, 1, make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head));
+  block_put<16>(sh.rec, lane, 2, make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive));
+  block_put<16>(sh.rec, lane, 3, make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, r3.w));
+  block_put<16>(sh.rec, lane, 4, make_uint4(f_all, r4.y, r4.z, r4.w));
+  block_put<16>(sh.rec, lane, 6, make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
+                                               (unsigned)__double2hiint(bat_load)));
+  block_put<16>(sh.rec, lane, 9, make_uint4((unsigned)__double2loint(href), (unsigned)__double2hiint(href), r9q.z, r9q.w));
+  {
+    const uint4 r10 = block_get<16>(sh.rec, lane, 10);
+    block_put<16>(sh.rec, lane, 10, make_uint4((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet), r10.z, r10.w));
+  }
+  wave_sync();
+  block_store16(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane, 0ull);
+
+  // ---- outputs ----------------------------------------------------------------------------------------------------------------------
+  // the observation pool (sdc_device.hpp SDC_P_*): the trace-only entries are the feature row's, nine depend on the step
+  float pool[SDC_POOL_DIM];
+#pragma unroll
+  for (int j = 0; j < SDC_POOL_DIM; j++) pool[j] = row[j];
+  pool[SDC_P_OLDEST] = (float)oldest_norm;
+  pool[SDC_P_AVG] = (float)avg_norm;
+  pool[SDC_P_NORMQ] = (float)normq;
+#pragma unroll
+  for (int b = 0; b < 5; b++) pool[SDC_P_HIST + b] = (float)hist[b];
+  pool[SDC_P_SOC] = (float)soc_after;
+  const bool terminal = rel + 1 >= S.episode_steps;
+  {
+    // obs [3][26] of this lane's env into its row of the staging block, then the block out in whole lines
+    float* const stage = reinterpret_cast<float*>(&sh.rec[0]);
+    wave_sync();
+    float* srow = stage + lane * SDC_OBS_OUT;
+#pragma unroll
+    for (int j = 0; j < SDC_OBS_OUT; j += 2) {
+      float2 v;
+      v.x = obs_pool_index(j) < 0 ? 0.0f : pool[obs_pool_index(j) < 0 ? 0 : obs_pool_index(j)];
+      v.y = obs_pool_index(j + 1) < 0 ? 0.0f : pool[obs_pool_index(j + 1) < 0 ? 0 : obs_pool_index(j + 1)];
+      *reinterpret_cast<float2*>(srow + j) = v;
+    }
+    wave_sync();
+    const f4v* s4 = reinterpret_cast<const f4v*>(stage);
+    float* o4 = obs + (size_t)env0 * SDC_OBS_OUT;
+    f4v* f4 = reinterpret_cast<f4v*>(final_obs + (size_t)env0 * SDC_OBS_OUT);
+    constexpr int NV = WE * SDC_OBS_OUT / 4;
+#pragma unroll
+    for (int k = 0; k < (NV + WE - 1) / WE; k++) {
+      const int q = k * WE + lane;
+      if (q < NV) {
+        const f4v v = s4[q];
+        nt_store4(o4 + 4 * q, v);
+        if (final_obs && terminal) f4[q] = v;
+      }
+    }
+    wave_sync();
+    float* hrow = stage + lane * SDC_SHARE_OBS_DIM;
+#pragma unroll
+    for (int j = 0; j < SDC_SHARE_OBS_DIM; j++) hrow[j] = j == SDC_P_SOC ? 0.0f : pool[j];
+    wave_sync();
+    float* h4 = share_obs + (size_t)env0 * SDC_SHARE_OBS_DIM;
+    constexpr int NH = WE * SDC_SHARE_OBS_DIM / 4;
+#pragma unroll
+    for (int k = 0; k < (NH + WE - 1) / WE; k++) {
+      const int q = k * WE + lane;
+      if (q < NH) nt_store4(h4 + 4 * q, s4[q]);
+    }
+  }
+  {
+    float inf[SDC_INFO_DIM];
+    inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)wl;
+    inf[SDC_INFO_LS_SHIFTED_WORKLOAD] = (float)util;
+    inf[SDC_INFO_LS_TASKS_IN_QUEUE] = (float)total;
+    inf[SDC_INFO_LS_NORM_TASKS_IN_QUEUE] = (float)normq;
+    inf[SDC_INFO_LS_TASKS_DROPPED] = (float)dropped;
+    inf[SDC_INFO_LS_TASKS_PROCESSED] = (float)processed;
+    inf[SDC_INFO_LS_OLDEST_TASK_AGE] = (float)oldest_norm;
+    inf[SDC_INFO_LS_AVERAGE_TASK_AGE] = (float)avg_norm;
+    inf[SDC_INFO_LS_OVERDUE_PENALTY] = (float)overdue;
+    inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(util * 100);
+    inf[SDC_INFO_LS_CURRENT_HOUR] = (float)hour;
+#pragma unroll
+    for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
+    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)(p_it * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)(ct * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)(comp * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)((ct + comp) * KC(1.0 / 1e3));
+    inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
+    inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
+    inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
+    inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)util;
+    inf[SDC_INFO_DC_INT_TEMPERATURE] = (float)mean_outlet;
+    inf[SDC_INFO_DC_EXTERIOR_AMBIENT_TEMP] = (float)amb;
+    inf[SDC_INFO_DC_WATER_USAGE] = (float)water;
+    inf[SDC_INFO_BAT_ACTION] = (float)a_bat;
+    inf[SDC_INFO_BAT_SOC] = (float)soc_after;
+    inf[SDC_INFO_BAT_CO2_FOOTPRINT] = (float)co2;
+    inf[SDC_INFO_BAT_AVG_CI] = (float)ci_i;
+    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH] = (float)e_nobat;
+    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH] = (float)energy;
+    inf[SDC_INFO_NORM_CI] = (float)norm_ci;
+    inf[SDC_INFO_OUTSIDE_TEMP] = (float)amb_next;
+    inf[SDC_INFO_DAY] = (float)day_n;
+    inf[SDC_INFO_HOUR] = (float)((double)hourq_n * 0.25);
+    inf[SDC_INFO_FAULT] = (float)f_all;
+    inf[SDC_INFO_ENERGY_Z] = 0.0f;       // (the five reward-side columns: filled in by the reward wavefront, which sends the block out)
+    inf[SDC_INFO_RESERVED] = 0.0f;
+    inf[SDC_INFO_EP_RETURN_LS] = 0.0f;
+    inf[SDC_INFO_EP_RETURN_DC] = 0.0f;
+    inf[SDC_INFO_EP_RETURN_BAT] = 0.0f;
+    inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
+    // ... through the staging block too: the wavefront's 64 info rows are 11 KB of whole lines
+    float* const stage = reinterpret_cast<float*>(&sh.rec[0]);
+    wave_sync();
+    f4v* irow = reinterpret_cast<f4v*>(stage + lane * SDC_INFO_DIM);
+#pragma unroll
+    for (int q = 0; q < SDC_INFO_DIM / 4; q++) {
+      f4v v;
+      v.x = inf[4 * q]; v.y = inf[4 * q + 1]; v.z = inf[4 * q + 2]; v.w = inf[4 * q + 3];
+      irow[q] = v;
+    }
+  }
+  done[env] = (unsigned char)(terminal ? 1 : 0);
+#ifdef SDC_WIDE_STAMPS
+  if (lane == 0)
+    for (int q = 0; q < 15; q++) info[(size_t)env0 * SDC_INFO_DIM + q] = (float)(wstamp[q + 1] - wstamp[q]);
+  if (lane == 1) info[(size_t)env0 * SDC_INFO_DIM + 15] = (float)(wstamp[0] & 0xFFFFFull);
+#endif
+  __syncthreads();      // (3) the info rows are staged (minus the reward-side columns)
+}
+
+// ---- the REWARD wavefront of an env workgroup: lane = env; whole-wavefront steps (lane = key) for what needs a window's keys ----------
+__device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, const int env0, const int lane, float* __restrict__ info,
+                                             float* __restrict__ rew) {
+  using namespace sdc_rw;
+  const int env = env0 + lane;
+  WideLate& late = *reinterpret_cast<WideLate*>(sh.hdr);
+  block_load<16>(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.hdr, lane);
+  dma_wait();
+  __syncthreads();      // (1) records, feature rows and headers are in LDS
+  // history length and ring position BEFORE the step (the record block is the dynamics wavefront's; read-only here)
+  int hl, hpos;
+  {
+    const uint4 r3 = block_get<16>(sh.rec, lane, 3);
+    hl = (int)r3.y; hpos = (int)r3.z;
+  }
+  // the evicted ring key (read BEFORE this step's key goes into that slot: the dynamics wavefront stores it behind barrier 2)
+  const int slot0 = hl < S.hist_cap ? hl : hpos;
+  unsigned x_old = 0xFFFFFFFFu;
+  if (hl >= S.hist_cap) x_old = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
+
+  // ---- reward-side state: the env's header (its 64 dwords in this lane's registers), then the few window keys a step usually needs
+  unsigned hd[SDC_HDR_DWORDS];
+#pragma unroll
+  for (int q = 0; q < SDC_HDR_DWORDS / 4; q++) {
+    const uint4 v = block_get<16>(sh.hdr, lane, q);
+    hd[4 * q] = v.x; hd[4 * q + 1] = v.y; hd[4 * q + 2] = v.z; hd[4 * q + 3] = v.w;
+  }
+  auto hd_f64 = [&](const int j) { return __hiloint2double((int)hd[j + 1], (int)hd[j]); };
+  // window w of this lane's env: rank of its first key, valid keys, cached first / last key (window order: Q1, Q3, BU, BL)
+  constexpr int HW[4] = {H_Q1, H_Q3, H_BU, H_BL};
+  int wr0[4], whi[4];
+  unsigned wf[4], wlast[4], pend[4];
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    wr0[w] = (int)hd[HW[w] + T_R0];
+    whi[w] = (int)hd[HW[w] + T_HI];
+    wf[w] = hd[H_WFIRST + w];
+    wlast[w] = hd[H_WLAST + w];
+    pend[w] = hd[H_PEND + w];
+  }
+  // history length after this step's append, the quartile ranks it asks for
+  const int n_pre = hl;
+  const int n_step = hl < S.hist_cap ? hl + 1 : hl;
+  int k1, k3;
+  quartile_ranks(n_step, k1, k3);
+  // FOUR keys of every window, gathered now: around the wanted rank (quartile windows: the rank moves by at most one position
+  // when both of the step's keys land outside the window) and around last step's clip bound (bound windows: the two keys
+  // either side of it).  ck[w][j] = key at window position cb[w] + j.
+  unsigned ck[4][4];
+  int cb[4];
+  cb[0] = k1 - wr0[0] - 1;
+  cb[1] = k3 - wr0[1] - 1;
+  cb[2] = n_pre - (int)hd[H_QC] - wr0[2] - 2;
+  cb[3] = n_pre - (int)hd[H_QC + 1] - wr0[3] - 2;
+  {
+    const unsigned* qw = S.qwin + (size_t)env * SDC_WIN * 4;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int p = min(max(cb[w] + j, 0), SDC_WIN - 1);
+        ck[w][j] = qw[p * 4 + w];
+      }
+  }
+
   // ---- rewards + reward-state upkeep (utils/reward_creator.py:16-130): pair_reward_fast, lane = env ---------------------------------
-  const int n = hl;
+  const int n = n_step;         // history length after this step's append
   const bool has_old = x_old != KEY_NONE;
   const int n_prev = has_old ? n : n - 1;
   const int m_hist = has_old ? n_prev - 1 : n_prev;
@@ -622,7 +750,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     return (int)__popcll(__ballot(q.w < kbl_w)) - 2;      // (valid keys below the bound; KEY_NONE never counts)
   };
 
-  WSTAMP(7);
   // ---- deferred re-centrings (SdcRefillReq / SdcRefillRes): a window requested two steps ago arrives now ---------------------------
   {
     bool due[4];
@@ -666,7 +793,13 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     }
   }
 
-  WSTAMP(8);
+  __syncthreads();      // (2) the step's energy is known
+  const WideHand& H = *reinterpret_cast<const WideHand*>(sh.row + WE * 16);
+  const double e_off = H.e_off[lane], energy = H.energy[lane], norm_ci = H.norm_ci[lane], oldest_norm = H.oldest_norm[lane];
+  const unsigned x_new = H.x_new[lane];
+  const int slot = H.slot[lane], overdue = H.overdue[lane], hourq_n = H.hourq_n[lane];
+  hl = H.hl[lane];      // (after the append: == n)
+
   // ---- O(1) updates: running sums, the four windows ------------------------------------------------------------------------------------
   const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
   A1 += vn - vo;
@@ -753,7 +886,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
       }
     }
   }
-  WSTAMP(9);
   ok = ok && whi[0] > 0 && whi[1] > 0 && whi[2] > 0 && whi[3] > 0;
   // key at position p of window w, if it is one of the four this lane holds
   auto key_at_w = [&](const int w, const int p, bool& have) __attribute__((always_inline)) {
@@ -848,13 +980,11 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
       }
     }
   }
-  WSTAMP(10);
   // sum (v - bound), sum (v^2 - bound^2) over the keys beyond the bounds
   const double tt1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
   const double tt2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
   double mean, sd, inv_sd;
   clipped_moments(n, b, A1, A2, tt1, tt2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap, S.hist_cap_d);
-  WSTAMP(11);
   // ---- a window that the next step could exhaust: file a re-centring request (served by the NEXT launch's sweep wavefronts) -----------
   {
     int k1n, k3n;
@@ -954,29 +1084,6 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     rew[(size_t)env * 3 + 1] = (float)r_a[1];
     rew[(size_t)env * 3 + 2] = (float)r_a[2];
   }
-  WSTAMP(12);
-  // ---- new state: this step's key into the ring, its prefix counts into the queue table, the record's changed chunks into the block and
-  // the block out.  (All of the step's stores sit HERE, behind the reward part: this hardware counts loads and stores in one
-  // counter and retires them in order, so a wait for a late load -- a window's keys for the whole-wavefront steps above -- is also
-  // a wait for every store issued before it.)
-  S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
-  S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
-  block_put<16>(sh.rec, lane, 0, make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n));
-  block_put<16>(sh.rec, lane, 1, make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head));
-  block_put<16>(sh.rec, lane, 2, make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive));
-  block_put<16>(sh.rec, lane, 3, make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, r3.w));
-  block_put<16>(sh.rec, lane, 4, make_uint4(f_all, r4.y, r4.z, r4.w));
-  block_put<16>(sh.rec, lane, 6, make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
-                                               (unsigned)__double2hiint(bat_load)));
-  block_put<16>(sh.rec, lane, 9, make_uint4((unsigned)__double2loint(href), (unsigned)__double2hiint(href), r9q.z, r9q.w));
-  {
-    const uint4 r10 = block_get<16>(sh.rec, lane, 10);
-    block_put<16>(sh.rec, lane, 10, make_uint4((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet), r10.z, r10.w));
-  }
-  wave_sync();
-  block_store16(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane, 0ull);
-
-  WSTAMP(13);
   // ---- an env whose step needs anything else (no reward state yet, a window that does not cover, several keys across a bound, no
   // room for a request): env_reward() redoes it whole-wavefront from its state in memory -- which this step has not touched, or
   // else is told to rebuild ------------------------------------------------------------------------------------------------------
@@ -997,7 +1104,8 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
         if (pi(touched ? 1 : 0)) put_u32(hd_e, H_VALID, 0u);
         const uint4 qw_e = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env_e * SDC_WIN + lane];
         env_reward(S, env_e, lane, hd_e, qw_e, pi(hl), pi(slot), (unsigned)pi((int)x_new), (unsigned)pi((int)x_old), pf(e_off), pf(energy),
-                   pf(norm_ci), pf(oldest_norm), pi(overdue), pi(hourq_n), pf(p_it), pf(total_kw), pf(water), rew,
+                   pf(norm_ci), pf(oldest_norm), pi(overdue), pi(hourq_n), 0.0, 0.0, 0.0, rew,      // (ITE / total power, water: inputs of alternate reward functions, which this kernel is never launched with)
+                  
                    &late.back[0][0] + e * 8 - SDC_INFO_ENERGY_Z, late.tl);
       }
       wave_sync();
@@ -1007,122 +1115,53 @@ extern "C" __global__ __launch_bounds__(SDC_WAVE) __attribute__((amdgpu_waves_pe
     }
   }
 
-  WSTAMP(14);
-  // ---- outputs ----------------------------------------------------------------------------------------------------------------------
-  // the observation pool (sdc_device.hpp SDC_P_*): the trace-only entries are the feature row's, nine depend on the step
-  float pool[SDC_POOL_DIM];
-#pragma unroll
-  for (int j = 0; j < SDC_POOL_DIM; j++) pool[j] = row[j];
-  pool[SDC_P_OLDEST] = (float)oldest_norm;
-  pool[SDC_P_AVG] = (float)avg_norm;
-  pool[SDC_P_NORMQ] = (float)normq;
-#pragma unroll
-  for (int b = 0; b < 5; b++) pool[SDC_P_HIST + b] = (float)hist[b];
-  pool[SDC_P_SOC] = (float)soc_after;
-  const bool terminal = rel + 1 >= S.episode_steps;
+  // ---- the five reward-side info columns into the staged rows, the wavefronts' 64 info rows out as 11 KB of whole lines ------------------
+  __syncthreads();      // (3) the info rows are staged (minus these columns)
   {
-    // obs [3][26] of this lane's env into its row of the staging block, then the block out in whole lines
     float* const stage = reinterpret_cast<float*>(&sh.rec[0]);
-    wave_sync();
-    float* srow = stage + lane * SDC_OBS_OUT;
-#pragma unroll
-    for (int j = 0; j < SDC_OBS_OUT; j += 2) {
-      float2 v;
-      v.x = obs_pool_index(j) < 0 ? 0.0f : pool[obs_pool_index(j) < 0 ? 0 : obs_pool_index(j)];
-      v.y = obs_pool_index(j + 1) < 0 ? 0.0f : pool[obs_pool_index(j + 1) < 0 ? 0 : obs_pool_index(j + 1)];
-      *reinterpret_cast<float2*>(srow + j) = v;
-    }
-    wave_sync();
-    const f4v* s4 = reinterpret_cast<const f4v*>(stage);
-    float* o4 = obs + (size_t)env0 * SDC_OBS_OUT;
-    f4v* f4 = reinterpret_cast<f4v*>(final_obs + (size_t)env0 * SDC_OBS_OUT);
-    constexpr int NV = WE * SDC_OBS_OUT / 4;
-#pragma unroll
-    for (int k = 0; k < (NV + WE - 1) / WE; k++) {
-      const int q = k * WE + lane;
-      if (q < NV) {
-        const f4v v = s4[q];
-        nt_store4(o4 + 4 * q, v);
-        if (final_obs && terminal) f4[q] = v;
-      }
-    }
-    wave_sync();
-    float* hrow = stage + lane * SDC_SHARE_OBS_DIM;
-#pragma unroll
-    for (int j = 0; j < SDC_SHARE_OBS_DIM; j++) hrow[j] = j == SDC_P_SOC ? 0.0f : pool[j];
-    wave_sync();
-    float* h4 = share_obs + (size_t)env0 * SDC_SHARE_OBS_DIM;
-    constexpr int NH = WE * SDC_SHARE_OBS_DIM / 4;
-#pragma unroll
-    for (int k = 0; k < (NH + WE - 1) / WE; k++) {
-      const int q = k * WE + lane;
-      if (q < NH) nt_store4(h4 + 4 * q, s4[q]);
-    }
-  }
-  {
-    float inf[SDC_INFO_DIM];
-    inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)wl;
-    inf[SDC_INFO_LS_SHIFTED_WORKLOAD] = (float)util;
-    inf[SDC_INFO_LS_TASKS_IN_QUEUE] = (float)total;
-    inf[SDC_INFO_LS_NORM_TASKS_IN_QUEUE] = (float)normq;
-    inf[SDC_INFO_LS_TASKS_DROPPED] = (float)dropped;
-    inf[SDC_INFO_LS_TASKS_PROCESSED] = (float)processed;
-    inf[SDC_INFO_LS_OLDEST_TASK_AGE] = (float)oldest_norm;
-    inf[SDC_INFO_LS_AVERAGE_TASK_AGE] = (float)avg_norm;
-    inf[SDC_INFO_LS_OVERDUE_PENALTY] = (float)overdue;
-    inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(util * 100);
-    inf[SDC_INFO_LS_CURRENT_HOUR] = (float)hour;
-#pragma unroll
-    for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
-    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)(p_it * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)(ct * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)(comp * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)((ct + comp) * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
-    inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
-    inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
-    inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)util;
-    inf[SDC_INFO_DC_INT_TEMPERATURE] = (float)mean_outlet;
-    inf[SDC_INFO_DC_EXTERIOR_AMBIENT_TEMP] = (float)amb;
-    inf[SDC_INFO_DC_WATER_USAGE] = (float)water;
-    inf[SDC_INFO_BAT_ACTION] = (float)a_bat;
-    inf[SDC_INFO_BAT_SOC] = (float)soc_after;
-    inf[SDC_INFO_BAT_CO2_FOOTPRINT] = (float)co2;
-    inf[SDC_INFO_BAT_AVG_CI] = (float)ci_i;
-    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH] = (float)e_nobat;
-    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH] = (float)energy;
-    inf[SDC_INFO_NORM_CI] = (float)norm_ci;
-    inf[SDC_INFO_OUTSIDE_TEMP] = (float)amb_next;
-    inf[SDC_INFO_DAY] = (float)day_n;
-    inf[SDC_INFO_HOUR] = (float)((double)hourq_n * 0.25);
-    inf[SDC_INFO_FAULT] = (float)f_all;
-    inf[SDC_INFO_ENERGY_Z] = z_f;
-    inf[SDC_INFO_RESERVED] = path_f;
-    inf[SDC_INFO_EP_RETURN_LS] = ret_f[0];
-    inf[SDC_INFO_EP_RETURN_DC] = ret_f[1];
-    inf[SDC_INFO_EP_RETURN_BAT] = ret_f[2];
-    inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
-    // ... through the staging block too: the wavefront's 64 info rows are 11 KB of whole lines
-    float* const stage = reinterpret_cast<float*>(&sh.rec[0]);
-    wave_sync();
-    f4v* irow = reinterpret_cast<f4v*>(stage + lane * SDC_INFO_DIM);
-#pragma unroll
-    for (int q = 0; q < SDC_INFO_DIM / 4; q++) {
-      f4v v;
-      v.x = inf[4 * q]; v.y = inf[4 * q + 1]; v.z = inf[4 * q + 2]; v.w = inf[4 * q + 3];
-      irow[q] = v;
-    }
+    float* irow = stage + lane * SDC_INFO_DIM;
+    irow[SDC_INFO_ENERGY_Z] = z_f;
+    irow[SDC_INFO_RESERVED] = path_f;
+    irow[SDC_INFO_EP_RETURN_LS] = ret_f[0];
+    irow[SDC_INFO_EP_RETURN_DC] = ret_f[1];
+    irow[SDC_INFO_EP_RETURN_BAT] = ret_f[2];
     wave_sync();
     const f4v* s4 = reinterpret_cast<const f4v*>(stage);
     float* i4 = info + (size_t)env0 * SDC_INFO_DIM;
 #pragma unroll
     for (int k = 0; k < SDC_INFO_DIM / 4; k++) nt_store4(i4 + 4 * (k * WE + lane), s4[k * WE + lane]);
   }
-  done[env] = (unsigned char)(terminal ? 1 : 0);
-#ifdef SDC_WIDE_STAMPS
-  WSTAMP(15);
-  if (lane == 0)
-    for (int q = 0; q < 15; q++) info[(size_t)env0 * SDC_INFO_DIM + q] = (float)(wstamp[q + 1] - wstamp[q]);
-  if (lane == 1) info[(size_t)env0 * SDC_INFO_DIM + 15] = (float)(wstamp[0] & 0xFFFFFull);
-#endif
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// One launch = one env-step of all N environments.  Grid: S.sweep_blocks sweep workgroups (first: their two wavefronts each serve
+// re-centring requests of the previous step, one wavefront per request, while the envs step), then N / 64 env workgroups of TWO
+// wavefronts: wavefront 0 integrates the 64 envs' dynamics, wavefront 1 keeps their reward state -- its loads, the windows that
+// arrive, everything that does not need the step's energy run BESIDE the dynamics on another SIMD, and once the energy is handed
+// over (LDS, one barrier) the dynamics wavefront's outputs and the reward wavefront's normalisation run side by side again.
+extern "C" __global__ __launch_bounds__(2 * SDC_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) void sdc_dynamics_wide_kernel(
+    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
+    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+  __shared__ WideShared sh;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
+  const int lane = threadIdx.x % SDC_WAVE;
+  const int bx = (int)blockIdx.x;
+  if (bx < S.sweep_blocks) {
+    // one wavefront per request: a sweep is 40 KB through one wavefront, ~5 us -- shorter than the step it runs beside
+    sdc_rw::TailLds& tl = reinterpret_cast<WideLate*>(wave == 0 ? sh.rec : sh.hdr)->tl;
+    const int set = S.step_no % 3;
+    const int cnt = min(S.rq_count[set], S.rq_max);
+    if (bx == 0 && wave == 0 && lane == 0) S.rq_count[(S.step_no + 2) % 3] = 0;     // the set the NEXT step's requests go to
+    if (2 * bx + wave < cnt) __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
+#pragma unroll 1
+    for (int j = 2 * bx + wave; j < cnt; j += 2 * S.sweep_blocks) serve_recentring_request(S, set, j, lane, tl);
+    return;
+  }
+  const int nb = (int)gridDim.x - S.sweep_blocks;
+  const int env0 = first_pair_of_block(bx - S.sweep_blocks, nb, 1) * WE;     // (every XCD a contiguous range of envs)
+  if (env0 >= S.n_envs) return;
+  if (wave == 0) wide_dynamics(S, sh, env0, lane, rel_hint, actions, obs, share_obs, done, final_obs);
+  else wide_rewards(S, sh, env0, lane, info, rew);
 }
