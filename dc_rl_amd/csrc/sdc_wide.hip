@@ -50,11 +50,30 @@ struct WideShared {
 static_assert(sizeof(float) * WE * SDC_OBS_OUT <= sizeof(unsigned) * (WE * 64 + WE * 16), "the obs rows are staged across `rec` and the lower half of `row`");
 // what the dynamics hand to the reward part, per env (lane): [field][lane]
 struct WideHand {
-  double e_off[WE], energy[WE], norm_ci[WE], oldest_norm[WE];
+  double e_off[WE], energy[WE], norm_ci[WE];
   unsigned x_new[WE];
-  int hl[WE], slot[WE], overdue[WE], hourq_n[WE];
+  int hl[WE], slot[WE];
+};
+// ... and what the reward wavefront hands back (in `hdr`, which it keeps in registers between its first read and the commit)
+struct WideBack {
+  double oldest_norm[WE], avg_norm[WE];
+  int head[WE], cum_hm1[WE];
+  unsigned cumT_hm1[WE];
 };
 static_assert(sizeof(WideHand) <= sizeof(unsigned) * WE * 16, "the hand-over sits in the upper half of `row`");
+// (measurement build -DSDC_WIDE_STAMPS: lane 0 of both wavefronts stamps the wall clock (100 MHz) at the marks WST(i); the reward wavefront
+// leaves them in columns 0..15 of its first env's info row -- tools/dev/wide_timeline.py)
+#ifdef SDC_WIDE_STAMPS
+#define WST(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(sh.row + WE * 16 + 896)[i] = wall_clock64(); } while (0)
+// (the first stamps are taken while the feature rows are still streaming into `row`: kept in a register, written later)
+#define WST_HOLD(v) const unsigned long long v = wall_clock64()
+#define WST_PUT(i, v) do { if (lane == 0) reinterpret_cast<unsigned long long*>(sh.row + WE * 16 + 896)[i] = (v); } while (0)
+#else
+#define WST(i)
+#define WST_HOLD(v)
+#define WST_PUT(i, v)
+#endif
+static_assert(sizeof(WideHand) <= 896 * 4, "the stamps sit behind the hand-over");
 struct WideLate {                  // (aliases a 16 KB block that has gone back to memory; the sweep wavefronts: from the start)
   sdc_rw::TailLds tl;              // scratch of the ring paths (env_reward: window refill, rebuild; the sweep wavefronts)
   float back[WE][8];               // what a whole-wavefront reward step hands back to its env's lane {z, path, ret[3]}
@@ -155,6 +174,45 @@ struct TreeSum32 {
   }
 };
 
+// ---- load shifting, the part every consumer needs: envs/carbon_ls.py:172-324 (pair_dynamics, same expressions).  Both wavefronts of
+// an env workgroup evaluate it (integer algebra on the step's workload, the action and five queue probes): the dynamics wavefront
+// for the utilisation, the reward wavefront for the oldest-task search -- which needs a second, dependent memory round trip (the
+// queue table ahead of the oldest task) that would otherwise sit on the path to the step's energy.
+struct WideLs {
+  int ns, shf, overdue, od_proc, popped, add, dropped, processed, util_tasks, cum_now, total, a24, a48, a72, a96;
+  unsigned cumT_now;
+};
+__device__ __forceinline__ WideLs wide_ls_algebra(const SdcDev& S, const double wl, const int a_ls, const int popped0, const int cum_prev,
+                                                  const unsigned cumT_prev, const int now, const int (&cumq)[5]) {
+  KLit kt{};
+  WideLs o;
+  const double flex = KC(0.2), nonflex = KC(0.8);
+  o.ns = (int)ceil(wl * nonflex * 100);
+  o.shf = (int)floor(wl * flex * 100);
+  int popped = popped0;
+  o.overdue = max(0, cumq[0] - popped);
+  int avail = 90 - (o.ns + o.shf);
+  o.od_proc = 0;
+  if (avail > 0 && o.overdue > 0) o.od_proc = min(o.overdue, avail);
+  popped += o.od_proc;
+  avail = 90 - (o.ns + o.shf + o.od_proc);
+  const int qlen = cum_prev - popped;
+  const bool defer = a_ls == 0, drain = a_ls == 2 && avail >= 1;
+  o.add = defer ? min(o.shf, S.queue_max - qlen) : 0;
+  o.dropped = defer ? o.shf - o.add : 0;
+  o.processed = drain ? min(min(o.shf, avail), qlen) : 0;
+  popped += o.processed;
+  o.popped = popped;
+  o.util_tasks = o.od_proc + (defer ? o.shf - o.add : o.shf + o.processed);
+  o.cum_now = cum_prev + o.add;
+  o.cumT_now = cumT_prev + (unsigned)o.add * (unsigned)now;
+  o.total = o.cum_now - popped;
+  o.a24 = max(0, cumq[1] - popped); o.a48 = max(0, cumq[2] - popped);
+  o.a72 = max(0, cumq[3] - popped); o.a96 = max(0, cumq[4] - popped);
+  return o;
+}
+constexpr int WIDE_QA = 16;        // table entries ahead of the oldest task's step requested up front (two per dwordx4)
+
 // ---- the DYNAMICS wavefront of an env workgroup: lane = env ---------------------------------------------------------------------------
 __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, const int env0, const int lane, const int rel_hint,
                                               const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
@@ -162,6 +220,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   using namespace sdc_rw;
   const int env = env0 + lane;
   KLit kt{};
+  WST_HOLD(wst0);
   // ---- loads: actions, state record, feature row, queue-history probes ----------------------------------------------------
   const int32_t* ap = actions + (size_t)env * 3;
   int a_ls = ap[0], a_dc = ap[1], a_bat = ap[2];
@@ -187,6 +246,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
     cumq[s] = t >= 0 ? (int)qt[t].x : 0;
   }
 
+  WST_HOLD(wst1);
   dma_wait();
   __syncthreads();      // (1) records, feature rows and headers are in LDS
   const uint4 r0 = block_get<16>(sh.rec, lane, 0), r1 = block_get<16>(sh.rec, lane, 1), r2 = block_get<16>(sh.rec, lane, 2);
@@ -203,9 +263,6 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   const int i = (int)r0.x, rel = (int)r0.y, day = (int)r0.z, hourq = (int)r0.w;
   const int popped0 = (int)r1.x, cum_prev = (int)r1.y;
   const unsigned cumT_prev = r1.z;
-  int head = (int)r1.w;
-  int cum_hm1 = (int)r2.x;
-  unsigned cumT_hm1 = r2.y;
   int last_delta = (int)r2.z, consecutive = (int)r2.w, scale = (int)r3.x;
   int hl = (int)r3.y, hpos = (int)r3.z;
   const unsigned fault0 = r4.x;
@@ -221,21 +278,6 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
     if ((unsigned)a_dc > 2u) a_dc = 1;
     if ((unsigned)a_bat > 2u) a_bat = 2;
   }
-  // the queue table ahead of the oldest task
-  constexpr int QA = 16;        // table entries ahead of the oldest task's step requested up front (two per dwordx4)
-  uint4 qa[QA / 2];
-#pragma unroll
-  for (int q = 0; q < QA / 2; q++) qa[q] = make_uint4(0u, 0u, 0u, 0u);
-  const bool may_pop = a_ls == 2 || cumq[0] - popped0 > 0;       // (drain, or overdue tasks to run)
-  if (may_pop) {
-#pragma unroll
-    for (int q = 0; q < QA / 2; q++) {
-      const int t = head + 2 * q;
-      if (t + 1 < rel) qa[q] = *reinterpret_cast<const uint4*>(qt + t);
-      else if (t < rel) { const uint2 e = qt[t]; qa[q] = make_uint4(e.x, e.y, 0u, 0u); }
-    }
-  }
-
   static_assert(SDC_FEAT_W == 10 && SDC_FEAT_T1 == 12 && SDC_FEAT_C == 22 && SDC_FEAT_T == 24 && SDC_FEAT_WB == 28 &&
                 SDC_FEAT_NCNEXT == 30, "feature-row slots of the step's inputs");
   auto row_f64 = [&](const int j) { return __hiloint2double(__float_as_int(row[j + 1]), __float_as_int(row[j])); };
@@ -246,103 +288,26 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
 
   // ---- load shifting: envs/carbon_ls.py:172-324 (pair_dynamics, same expressions) ---------------------------------------------
   if (wl < 0 || wl > 1) fault |= SDC_FAULT_WORKLOAD;
-  const double flex = KC(0.2), nonflex = KC(0.8);
-  const int ns = (int)ceil(wl * nonflex * 100);
-  const int shf = (int)floor(wl * flex * 100);
   const int now = rel;
-  int popped = popped0;
-  const int overdue = max(0, cumq[0] - popped);
-  int avail = 90 - (ns + shf);
-  int od_proc = 0;
-  if (avail > 0 && overdue > 0) od_proc = min(overdue, avail);
-  popped += od_proc;
-  avail = 90 - (ns + shf + od_proc);
-  const int qlen = cum_prev - popped;
-  const bool defer = a_ls == 0, drain = a_ls == 2 && avail >= 1;
-  const int add = defer ? min(shf, S.queue_max - qlen) : 0;
-  const int dropped = defer ? shf - add : 0;
-  const int processed = drain ? min(min(shf, avail), qlen) : 0;
-  popped += processed;
-  const int util_tasks = od_proc + (defer ? shf - add : shf + processed);
-  double util = KDIV((double)util_tasks, 100);
+  const WideLs ls = wide_ls_algebra(S, wl, a_ls, popped0, cum_prev, cumT_prev, now, cumq);
+  const int ns = ls.ns, overdue = ls.overdue, popped = ls.popped, dropped = ls.dropped, processed = ls.processed;
+  const int cum_now = ls.cum_now, total = ls.total;
+  const unsigned cumT_now = ls.cumT_now;
+  double util = KDIV((double)ls.util_tasks, 100);
   util += KDIV((double)ns, 100);
-  const int cum_now = cum_prev + add;
-  const unsigned cumT_now = cumT_prev + (unsigned)add * (unsigned)now;
-  const int total = cum_now - popped;
-  const int a24 = max(0, cumq[1] - popped), a48 = max(0, cumq[2] - popped);
-  const int a72 = max(0, cumq[3] - popped), a96 = max(0, cumq[4] - popped);
   double hist[5];
   const double den = (double)max(total, 1), rden = 1.0 / den;
-  hist[0] = sdc_div_const((double)(total - a24), den, rden);
-  hist[1] = sdc_div_const((double)(a24 - a48), den, rden);
-  hist[2] = sdc_div_const((double)(a48 - a72), den, rden);
-  hist[3] = sdc_div_const((double)(a72 - a96), den, rden);
-  hist[4] = a96 > 0 ? 1.0 : 0.0;
-  // oldest task: smallest step hd in [head, now] with cum[hd] > popped; it only moves when tasks were popped
-  double oldest = 0.0, avg = 0.0;
-  {
-    const bool was_empty = (cum_prev - popped0) == 0;
-    bool need = total > 0 && !was_empty && popped != popped0;
-    if (need) {
-      // among the QA entries requested up front (entry j = step head + j)?
-      int f = -1;
-      unsigned cm1 = 0u, ctm1 = 0u;     // cum / cumT of the entry before the first hit
-#pragma unroll
-      for (int j = QA - 1; j >= 0; j--) {
-        const int t = head + j;
-        const unsigned cx = (j & 1) ? qa[j / 2].z : qa[j / 2].x;
-        const int c = (t == now) ? cum_now : (int)cx;
-        if (t <= now && c > popped) f = j;
-      }
-#pragma unroll
-      for (int j = 0; j < QA - 1; j++) {
-        if (f == j + 1) {
-          cm1 = (j & 1) ? qa[j / 2].z : qa[j / 2].x;
-          ctm1 = (j & 1) ? qa[j / 2].w : qa[j / 2].y;
-        }
-      }
-      if (f >= 0) {
-        need = false;
-        if (f > 0) {
-          head += f;
-          cum_hm1 = (int)cm1;
-          cumT_hm1 = ctm1;
-        }
-      }
-    }
-    if (need) {
-      // further ahead than that (rare): walk the table
-      int t = head + QA;
-      while (t < now && (int)qt[t].x <= popped) t++;      // (cum[now] > popped: the walk ends at `now` at the latest)
-      head = t;
-      if (head == now) {
-        cum_hm1 = cum_prev;
-        cumT_hm1 = cumT_prev;
-      } else {
-        const uint2 e = qt[head - 1];
-        cum_hm1 = (int)e.x;
-        cumT_hm1 = e.y;
-      }
-    }
-    if (total > 0) {
-      if (was_empty) {
-        head = now;
-        cum_hm1 = cum_prev;
-        cumT_hm1 = cumT_prev;
-      }
-      const long long sum_t = (long long)cumT_now - (long long)cumT_hm1 - (long long)(popped - cum_hm1) * head;
-      const long long sum_age_steps = (long long)total * now - sum_t;
-      oldest = (double)(now - head) * 0.25;
-      avg = sdc_div_const((double)sum_age_steps * 0.25, den, rden);
-    } else {
-      head = now;
-      cum_hm1 = cum_now;
-      cumT_hm1 = cumT_now;
-    }
-  }
+  hist[0] = sdc_div_const((double)(total - ls.a24), den, rden);
+  hist[1] = sdc_div_const((double)(ls.a24 - ls.a48), den, rden);
+  hist[2] = sdc_div_const((double)(ls.a48 - ls.a72), den, rden);
+  hist[3] = sdc_div_const((double)(ls.a72 - ls.a96), den, rden);
+  hist[4] = ls.a96 > 0 ? 1.0 : 0.0;
   const double normq = sdc_div_const((double)total, S.queue_max_d, S.rc_queue_max);
-  const double oldest_norm = KDIV(oldest, 24), avg_norm = KDIV(avg, 24);
+  // (the oldest task's step, the cached prefix counts before it and the two ages: from the reward wavefront, behind barrier 2)
 
+  WST_PUT(0, wst0);
+  WST_PUT(1, wst1);
+  WST(2);
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 --------------------------------------------------------------------
   if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
   const int delta = a_dc - 1;
@@ -427,6 +392,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
       s_out.push4(vo[0], vo[1], vo[2], vo[3]);
     }
   }
+  WST(3);
   if (bad_delta) fault |= SDC_FAULT_OUTLET_DELTA;
   const double sum_outlet = s_out.total();
   const double p_it = s_pw.total();
@@ -507,14 +473,20 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
   const unsigned f_all = fault0 | fault;
 
+  WST(4);
   // ---- hand-over to the reward wavefront --------------------------------------------------------------------------------------------
   {
     WideHand& H = *reinterpret_cast<WideHand*>(sh.row + WE * 16);
-    H.e_off[lane] = e_off; H.energy[lane] = energy; H.norm_ci[lane] = norm_ci; H.oldest_norm[lane] = oldest_norm;
-    H.x_new[lane] = x_new; H.hl[lane] = hl; H.slot[lane] = slot; H.overdue[lane] = overdue; H.hourq_n[lane] = hourq_n;
+    H.e_off[lane] = e_off; H.energy[lane] = energy; H.norm_ci[lane] = norm_ci;
+    H.x_new[lane] = x_new; H.hl[lane] = hl; H.slot[lane] = slot;
   }
-  __syncthreads();      // (2) the step's energy is known
+  __syncthreads();      // (2) the step's energy is known; so are the oldest task and the ages
+  const WideBack& B = *reinterpret_cast<const WideBack*>(sh.hdr);
+  const int head = B.head[lane], cum_hm1 = B.cum_hm1[lane];
+  const unsigned cumT_hm1 = B.cumT_hm1[lane];
+  const double oldest_norm = B.oldest_norm[lane], avg_norm = B.avg_norm[lane];
 
+  WST(5);
   // ---- new state: this step's key into the ring, its prefix counts into the queue table, the record's changed chunks into the block and
   // the block out.  (All of the step's stores sit HERE, behind the reward part: this hardware counts loads and stores in one
   // counter and retires them in order, so a wait for a late load -- a window's keys for the whole-wavefront steps above -- is also
@@ -536,6 +508,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   wave_sync();
   block_store16(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane, 0ull);
 
+  WST(6);
   // ---- outputs ----------------------------------------------------------------------------------------------------------------------
   // the observation pool (sdc_device.hpp SDC_P_*): the trace-only entries are the feature row's, nine depend on the step
   float pool[SDC_POOL_DIM];
@@ -642,23 +615,59 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
     }
   }
   done[env] = (unsigned char)(terminal ? 1 : 0);
-#ifdef SDC_WIDE_STAMPS
-  if (lane == 0)
-    for (int q = 0; q < 15; q++) info[(size_t)env0 * SDC_INFO_DIM + q] = (float)(wstamp[q + 1] - wstamp[q]);
-  if (lane == 1) info[(size_t)env0 * SDC_INFO_DIM + 15] = (float)(wstamp[0] & 0xFFFFFull);
-#endif
+  WST(7);
   __syncthreads();      // (3) the info rows are staged (minus the reward-side columns)
 }
 
 // ---- the REWARD wavefront of an env workgroup: lane = env; whole-wavefront steps (lane = key) for what needs a window's keys ----------
-__device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, const int env0, const int lane, float* __restrict__ info,
-                                             float* __restrict__ rew) {
+__device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, const int env0, const int lane, const int rel_hint,
+                                             const int32_t* __restrict__ actions, float* __restrict__ info, float* __restrict__ rew) {
   using namespace sdc_rw;
   const int env = env0 + lane;
   WideLate& late = *reinterpret_cast<WideLate*>(sh.hdr);
+  KLit kt{};
   block_load<16>(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.hdr, lane);
+  int a_ls = actions[(size_t)env * 3];
+  const uint2* qt = S.qtab + (size_t)env * S.qstride;
+  int cumq[5];     // cum[now - 97], cum[now - 24], cum[now - 48], cum[now - 72], cum[now - 96] (0 before the episode's start)
+#pragma unroll
+  for (int s = 0; s < 5; s++) {
+    const int back = s == 0 ? 97 : 24 * s;
+    const int t = rel_hint - back;
+    cumq[s] = t >= 0 ? (int)qt[t].x : 0;
+  }
   dma_wait();
   __syncthreads();      // (1) records, feature rows and headers are in LDS
+  // ---- the oldest queued task and the ages (pair_dynamics, same expressions): the load-shifting algebra once more, then the queue
+  // table ahead of the oldest task -- requested now, looked at after the header work below
+  const uint4 q0 = block_get<16>(sh.rec, lane, 0), q1 = block_get<16>(sh.rec, lane, 1), q2 = block_get<16>(sh.rec, lane, 2);
+  const int rel = (int)q0.y, hourq = (int)q0.w, popped0 = (int)q1.x, cum_prev = (int)q1.y;
+  const unsigned cumT_prev = q1.z;
+  int head = (int)q1.w, cum_hm1 = (int)q2.x;
+  unsigned cumT_hm1 = q2.y;
+  const int now = rel;
+  double wl;
+  {
+    const uint4 v = block_get<8>(sh.row, lane, SDC_FEAT_W / 4);
+    static_assert(SDC_FEAT_W % 4 == 2, "the workload's two floats in one chunk of the row");
+    wl = __hiloint2double((int)v.w, (int)v.z);
+  }
+  if ((unsigned)a_ls > 2u) a_ls = 1;
+  const WideLs ls = wide_ls_algebra(S, wl, a_ls, popped0, cum_prev, cumT_prev, now, cumq);
+  const int overdue = ls.overdue, hourq_n = hourq + 1 >= 96 ? 0 : hourq + 1;
+  constexpr int QA = WIDE_QA;
+  uint4 qa[QA / 2];
+#pragma unroll
+  for (int q = 0; q < QA / 2; q++) qa[q] = make_uint4(0u, 0u, 0u, 0u);
+  if (a_ls == 2 || cumq[0] - popped0 > 0) {       // (drain, or overdue tasks to run: the oldest task may move)
+#pragma unroll
+    for (int q = 0; q < QA / 2; q++) {
+      const int t = head + 2 * q;
+      if (t + 1 < rel) qa[q] = *reinterpret_cast<const uint4*>(qt + t);
+      else if (t < rel) { const uint2 e = qt[t]; qa[q] = make_uint4(e.x, e.y, 0u, 0u); }
+    }
+  }
+  WST_HOLD(wst8);
   // history length and ring position BEFORE the step (the record block is the dynamics wavefront's; read-only here)
   int hl, hpos;
   {
@@ -793,13 +802,88 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     }
   }
 
+  WST_PUT(8, wst8);
+  WST(9);
+
+  // ---- oldest task: smallest step hd in [head, now] with cum[hd] > popped; it only moves when tasks were popped ----------------------
+  double oldest_norm, avg_norm;
+  {
+    const int popped = ls.popped, cum_now = ls.cum_now, total = ls.total;
+    const unsigned cumT_now = ls.cumT_now;
+    const double den = (double)max(total, 1), rden = 1.0 / den;
+    double oldest = 0.0, avg = 0.0;
+    const bool was_empty = (cum_prev - popped0) == 0;
+    bool need = total > 0 && !was_empty && popped != popped0;
+    if (need) {
+      // among the QA entries requested up front (entry j = step head + j)?
+      int f = -1;
+      unsigned cm1 = 0u, ctm1 = 0u;     // cum / cumT of the entry before the first hit
+#pragma unroll
+      for (int j = QA - 1; j >= 0; j--) {
+        const int t = head + j;
+        const unsigned cx = (j & 1) ? qa[j / 2].z : qa[j / 2].x;
+        const int c = (t == now) ? cum_now : (int)cx;
+        if (t <= now && c > popped) f = j;
+      }
+#pragma unroll
+      for (int j = 0; j < QA - 1; j++) {
+        if (f == j + 1) {
+          cm1 = (j & 1) ? qa[j / 2].z : qa[j / 2].x;
+          ctm1 = (j & 1) ? qa[j / 2].w : qa[j / 2].y;
+        }
+      }
+      if (f >= 0) {
+        need = false;
+        if (f > 0) {
+          head += f;
+          cum_hm1 = (int)cm1;
+          cumT_hm1 = ctm1;
+        }
+      }
+    }
+    if (need) {
+      // further ahead than that (rare): walk the table
+      int t = head + QA;
+      while (t < now && (int)qt[t].x <= popped) t++;      // (cum[now] > popped: the walk ends at `now` at the latest)
+      head = t;
+      if (head == now) {
+        cum_hm1 = cum_prev;
+        cumT_hm1 = cumT_prev;
+      } else {
+        const uint2 e = qt[head - 1];
+        cum_hm1 = (int)e.x;
+        cumT_hm1 = e.y;
+      }
+    }
+    if (total > 0) {
+      if (was_empty) {
+        head = now;
+        cum_hm1 = cum_prev;
+        cumT_hm1 = cumT_prev;
+      }
+      const long long sum_t = (long long)cumT_now - (long long)cumT_hm1 - (long long)(popped - cum_hm1) * head;
+      const long long sum_age_steps = (long long)total * now - sum_t;
+      oldest = (double)(now - head) * 0.25;
+      avg = sdc_div_const((double)sum_age_steps * 0.25, den, rden);
+    } else {
+      head = now;
+      cum_hm1 = cum_now;
+      cumT_hm1 = cumT_now;
+    }
+    oldest_norm = KDIV(oldest, 24);
+    avg_norm = KDIV(avg, 24);
+    WideBack& B = *reinterpret_cast<WideBack*>(sh.hdr);      // (the header block is in registers from here to the commit)
+    B.oldest_norm[lane] = oldest_norm; B.avg_norm[lane] = avg_norm;
+    B.head[lane] = head; B.cum_hm1[lane] = cum_hm1; B.cumT_hm1[lane] = cumT_hm1;
+  }
   __syncthreads();      // (2) the step's energy is known
   const WideHand& H = *reinterpret_cast<const WideHand*>(sh.row + WE * 16);
-  const double e_off = H.e_off[lane], energy = H.energy[lane], norm_ci = H.norm_ci[lane], oldest_norm = H.oldest_norm[lane];
+  const double e_off = H.e_off[lane], energy = H.energy[lane], norm_ci = H.norm_ci[lane];
   const unsigned x_new = H.x_new[lane];
-  const int slot = H.slot[lane], overdue = H.overdue[lane], hourq_n = H.hourq_n[lane];
+  const int slot = H.slot[lane];
   hl = H.hl[lane];      // (after the append: == n)
 
+  WST(10);
   // ---- O(1) updates: running sums, the four windows ------------------------------------------------------------------------------------
   const double vn = key_f64(x_new), vo = has_old ? key_f64(x_old) : 0.0;
   A1 += vn - vo;
@@ -894,6 +978,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     const unsigned c0 = opq(ck[w][0]), c1 = opq(ck[w][1]), c2 = opq(ck[w][2]), c3 = opq(ck[w][3]);
     return j <= 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
   };
+  WST(11);
   unsigned a1, b1, a3, b3;
   {
     // keys at ranks k and k + 1 (the second only if it exists): hw_resolve
@@ -985,6 +1070,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   const double tt2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
   double mean, sd, inv_sd;
   clipped_moments(n, b, A1, A2, tt1, tt2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap, S.hist_cap_d);
+  WST(12);
   // ---- a window that the next step could exhaust: file a re-centring request (served by the NEXT launch's sweep wavefronts) -----------
   {
     int k1n, k3n;
@@ -1084,6 +1170,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     rew[(size_t)env * 3 + 1] = (float)r_a[1];
     rew[(size_t)env * 3 + 2] = (float)r_a[2];
   }
+  WST(13);
   // ---- an env whose step needs anything else (no reward state yet, a window that does not cover, several keys across a bound, no
   // room for a request): env_reward() redoes it whole-wavefront from its state in memory -- which this step has not touched, or
   // else is told to rebuild ------------------------------------------------------------------------------------------------------
@@ -1115,6 +1202,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     }
   }
 
+  WST(14);
   // ---- the five reward-side info columns into the staged rows, the wavefronts' 64 info rows out as 11 KB of whole lines ------------------
   __syncthreads();      // (3) the info rows are staged (minus these columns)
   {
@@ -1131,6 +1219,11 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
 #pragma unroll
     for (int k = 0; k < SDC_INFO_DIM / 4; k++) nt_store4(i4 + 4 * (k * WE + lane), s4[k * WE + lane]);
   }
+#ifdef SDC_WIDE_STAMPS
+  WST(15);
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane < 16) info[(size_t)env0 * SDC_INFO_DIM + lane] = (float)((reinterpret_cast<unsigned long long*>(sh.row + WE * 16 + 896)[lane]) & 0xFFFFFFull);
+#endif
 }
 
 }  // namespace
@@ -1163,5 +1256,5 @@ extern "C" __global__ __launch_bounds__(2 * SDC_WAVE) __attribute__((amdgpu_wave
   const int env0 = first_pair_of_block(bx - S.sweep_blocks, nb, 1) * WE;     // (every XCD a contiguous range of envs)
   if (env0 >= S.n_envs) return;
   if (wave == 0) wide_dynamics(S, sh, env0, lane, rel_hint, actions, obs, share_obs, done, final_obs);
-  else wide_rewards(S, sh, env0, lane, info, rew);
+  else wide_rewards(S, sh, env0, lane, rel_hint, actions, info, rew);
 }

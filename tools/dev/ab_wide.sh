@@ -7,7 +7,7 @@ python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 mkdir -p tools/bin
 NAMES=""
 for v in "$@"; do
-  name="${v%%:*}"; flags="${v#*:}"
+  name="${v%%:*}"; flags="${v#*:}"; rm -f tools/bin/lib_$name.so
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -disable-machine-licm $flags -c dc_rl_amd/csrc/sdc_wide.hip -o tools/bin/wide_$name.o 2>/dev/null &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/lib_$name.so $(ls dc_rl_amd/csrc/build/*.o | grep -v sdc_wide.o) tools/bin/wide_$name.o ) &
   NAMES="$NAMES $name"
