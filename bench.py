@@ -68,7 +68,7 @@ N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
 MAX_CLOCK_GHZ = 2.4
 HIST_CAP = 10000
 ALG_BYTES_FIXED = 1540      # B(H) = 4*H + 1540 bytes per env-step
-WIDE_MIN_ENVS = 24576       # sdc_capi.hip SDC_WIDE_MIN_ENVS: single steps of a batch this large run one lane per env (sdc_wide.hip)
+WIDE_MIN_ENVS = 12288       # sdc_capi.hip SDC_WIDE_MIN_ENVS: single steps of a batch this large run one lane per env (sdc_wide.hip)
 STEP_KERNEL = "sdc_dynamics_fast_kernel"   # the step kernel specialised for the common case, which is what this workload is
 STEP_KERNEL_PREFIX = "sdc_dynamics"            # (the general kernel sdc_dynamics_kernel serves every other case)
 MIN_REGION_S = 0.2
@@ -178,7 +178,7 @@ def secondary_rate(n_envs, episode_steps, location, device, timed_steps, month=N
         dt = time.perf_counter() - t0
     faults = int((eng.info[:, 37] != 0).sum().item())
     hl = int(eng.get_state("hist_len").min())
-    out = {"envs": n_envs, "episode_steps": episode_steps, "location": location, "timed_steps": timed_steps,
+    out = {"envs": n_envs, "kernel": eng.last_step_kernel(), "episode_steps": episode_steps, "location": location, "timed_steps": timed_steps,
            "us_per_step": round(dt / timed_steps * 1e6, 2), "value": round(n_envs * timed_steps / dt, 1),
            "unit": "env-steps/s", "history_len": hl, "faults": faults}
     if loops:
@@ -911,11 +911,12 @@ def main():
             except Exception as e:
                 sec["harl_unchanged_loop"] = {"error": repr(e)}
             scan = []
-            for n in (2048, 8192, 16384, 32768):   # (32 768: where one GPU's rate still grows -- eight four-env wavefronts per SIMD)
+            # (2 048 / 8 192: two / four envs per wavefront; from 12 288: one lane per env -- sdc_wide.hip; counters at 8 192 and 32 768)
+            for n in (2048, 8192, 16384, 32768, 65536):
                 try:
                     r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=8192 <= n <= 16384)
                     r["rate_vs_4096_envs"] = round(r["value"] / value, 4)
-                    if 8192 <= n <= 16384 and not args.no_pmc:
+                    if n in (8192, 32768) and not args.no_pmc:
                         r["roofline"] = scan_roofline(n, args.episode_steps, r["us_per_step"], args)
                     scan.append(r)
                 except Exception as e:

@@ -249,9 +249,9 @@ int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 // racks, 16-byte aligned output rows (whole-line stores through the wavefront's staging block); debug_flags bit 11 forces it
 // for any such batch, bit 12 keeps it off
 #ifndef SDC_WIDE_MIN_ENVS
-// (measured, us per step inside an episode, lane-per-env / four per wavefront: 20 480 envs 29.2 / 27.9, 24 576: 31.1 / 33.4,
-// 28 672: 32.6 / 36.6, 32 768: 34.4 / 40.2, 65 536: 55.0 / 72.6)
-#define SDC_WIDE_MIN_ENVS 24576
+// (measured, us per step with the episode boundary inside, lane per env / four per wavefront: 8 192 envs 18.4 / 14.5, 12 288: 20.4 / 21.4,
+// 16 384: 21.7 / 24.8, 20 480: 23.6 / 27.9, 32 768: 29.2 / 40.2, 65 536: 49.3 / 72.6)
+#define SDC_WIDE_MIN_ENVS 12288
 #endif
 bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, const float* info) {
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
