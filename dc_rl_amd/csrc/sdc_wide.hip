@@ -915,9 +915,6 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     unsigned long long um[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) um[w] = __ballot(upd[w]);
-#ifdef SDC_WX_NOUPD      // (timing experiment: results are wrong)
-    um[0] = um[1] = um[2] = um[3] = 0ull;
-#endif
     while (__builtin_expect((um[0] | um[1] | um[2] | um[3]) != 0ull, 0)) {
       int te[4], tw[4];
       bool have[4];

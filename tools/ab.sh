@@ -7,7 +7,7 @@ CMD="$1"; shift
 # the production build's scheduling strategy (dc_rl_amd/_lib.py HIPCC_FLAGS); AB_BASE="" to compare strategies
 BASE="${AB_BASE--mllvm -amdgpu-sched-strategy=max-ilp -mllvm -disable-machine-licm}"
 mkdir -p tools/bin
-SRCS="dc_rl_amd/csrc/sdc_capi.hip dc_rl_amd/csrc/sdc_step.hip dc_rl_amd/csrc/sdc_features.hip dc_rl_amd/csrc/sdc_verify.hip dc_rl_amd/csrc/sdc_reset.hip"
+SRCS="dc_rl_amd/csrc/sdc_capi.hip dc_rl_amd/csrc/sdc_step.hip dc_rl_amd/csrc/sdc_rollout.hip dc_rl_amd/csrc/sdc_wide.hip dc_rl_amd/csrc/sdc_features.hip dc_rl_amd/csrc/sdc_verify.hip dc_rl_amd/csrc/sdc_reset.hip"
 NAMES=""
 for v in "$@"; do
   name="${v%%:*}"; flags="${v#*:}"

@@ -2,7 +2,7 @@
 # One gpurun call that produces everything profiles/ and DESIGN.md quote for a round:  bash tools/profile_round.sh r2
 # (rocprofv3 passes run from /tmp with TMPDIR=/tmp; --pmc passes -- inside bench.py -- use --kernel-trace only)
 set -x
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -22,7 +22,7 @@ timeout 600 python bench.py --mixed-racks --no-cpu-baseline --no-pmc > $O/bench_
 timeout 600 python tools/batch_scan.py > $O/batch_scan.txt 2>&1
 timeout 600 python tools/qb.py > $O/quick_rates.txt 2>&1
 # (the in-kernel clock stamps of the COMMON-CASE kernels need the measurement build: tools/bin/lib_dbg.so, made by
-#  tools/ab.sh ... dbg:'-DSDC_FAST_DEBUG=1'; without it these tools time the general kernels)
+#  tools/profile_prepare.sh; without it these tools time the general kernels)
 if [ -f tools/bin/lib_dbg.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/prod.so; cp tools/bin/lib_dbg.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
 timeout 600 python tools/wave_phases.py > $O/wave_phases.txt 2>&1
 timeout 600 python tools/wave_timeline.py > $O/wave_timeline.txt 2>&1
@@ -46,8 +46,15 @@ timeout 600 python tools/harl_loop_rate.py 48 512 4096 > $O/harl_loop_rate.txt 2
 timeout 600 python bench.py --gpus 2 --single-process --devices 0,0 --steps 200 --warmup 20 > $O/bench_single_process.txt 2>&1
 bash tools/reset_time.sh > $O/reset_kernels.txt 2>&1
 bash tools/reset_pmc.sh > $O/reset_pmc.txt 2>&1
-# (phase stamps of sdc_reset_kernel: the measurement build tools/bin/lib_rt.so = the production sources with -DSDC_RT)
+# (phase stamps of sdc_reset_kernel: the measurement build tools/bin/lib_rt.so = the production sources with -DSDC_RT, tools/profile_prepare.sh)
 if [ -f tools/bin/lib_rt.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/prod.so; cp tools/bin/lib_rt.so dc_rl_amd/csrc/libsustaindc_hip.so; for n in 1024 2048 4096; do timeout 200 python tools/reset_phases.py $n; done > $O/reset_phases.txt 2>&1; cp /tmp/prod.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
+# round 5: the lane-per-env kernel (sdc_dynamics_wide_kernel, 12 288 envs and up): rocprofv3 time + counters at 16 384 / 32 768 envs next to the
+# four-envs-per-wavefront kernel on the same rings, the two wavefronts' timeline (the -DSDC_WIDE_STAMPS build), the crossover
+bash tools/dev/wide_pmc.sh 32768 > $O/wide_pmc_32768.txt 2>&1
+bash tools/dev/wide_pmc.sh 16384 > $O/wide_pmc_16384.txt 2>&1
+SDC_DBG=4096 bash tools/dev/wide_pmc.sh 32768 > $O/quad_pmc_32768.txt 2>&1
+for n in 8192 12288 16384 20480 32768 65536; do timeout 200 python tools/dev/wide_prof.py $n 2000; SDC_DBG=4096 timeout 200 python tools/dev/wide_prof.py $n 2000; SDC_DBG=2048 timeout 200 python tools/dev/wide_prof.py $n 2000; done > $O/wide_crossover.txt 2>&1
+if [ -f tools/bin/lib_wstamps.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/prod.so; cp tools/bin/lib_wstamps.so dc_rl_amd/csrc/libsustaindc_hip.so; for n in 16384 32768 65536; do timeout 200 python tools/dev/wide_timeline.py $n; done > $O/wide_timeline.txt 2>&1; cp /tmp/prod.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
 hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o /tmp/valu_rates 2>/dev/null && timeout 200 /tmp/valu_rates > $O/valu_rates.txt 2>&1
 grep -v amdgpu.ids $O/*.txt | tail -60
 cut -c1-600 $O/bench.json
