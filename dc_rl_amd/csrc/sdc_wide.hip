@@ -88,7 +88,7 @@ static_assert(sizeof(WideLate) <= sizeof(unsigned) * WE * 64, "");
 // so the rotation is applied to the SOURCE address; with it the lanes' reads of "their chunk c" spread over all banks.
 typedef __attribute__((address_space(1))) const void* sdc_gptr;
 typedef __attribute__((address_space(3))) void* sdc_lptr;
-template <int CPR>     // 16-byte chunks per record: 16 (256-byte records / headers), 8 (128-byte feature rows)
+template <int CPR, int NC = CPR>     // 16-byte chunks per record: 16 (256-byte records / headers), 8 (128-byte feature rows); the first NC of them
 __device__ __forceinline__ void block_load(const void* gbase, unsigned* lds, const int lane) {
   static_assert(CPR == 16 || CPR == 8, "");
 #pragma unroll
@@ -96,9 +96,12 @@ __device__ __forceinline__ void block_load(const void* gbase, unsigned* lds, con
     const int sl = k * WE + lane;
     const int e = sl / CPR, c = ((sl % CPR) - e) & (CPR - 1);
     const char* g = reinterpret_cast<const char*>(gbase) + (size_t)(e * CPR + c) * 16;
-    __builtin_amdgcn_global_load_lds((sdc_gptr)g, (sdc_lptr)(lds + k * WE * 4), 16, 0, 0);
+    if (NC == CPR || c < NC) __builtin_amdgcn_global_load_lds((sdc_gptr)g, (sdc_lptr)(lds + k * WE * 4), 16, 0, 0);
   }
 }
+// a state record's used part: R_END = 42 dwords = chunks 0..10; 12 chunks = whole 64-byte sectors.  The padding is neither loaded nor stored.
+#define WIDE_REC_CHUNKS 12
+static_assert(R_END <= WIDE_REC_CHUNKS * 4, "");
 template <int CPR>
 __device__ __forceinline__ uint4 block_get(const unsigned* lds, const int e, const int c) {
   return reinterpret_cast<const uint4*>(lds)[e * CPR + ((c + e) & (CPR - 1))];
@@ -109,13 +112,14 @@ __device__ __forceinline__ void block_put(unsigned* lds, const int e, const int 
 }
 // the block back to memory in whole lines; records whose bit is set in `skip` are left alone (their env's state was written by
 // the whole-wavefront fallback)
+template <int NC = 16>      // (the first NC chunks of every record)
 __device__ __forceinline__ void block_store16(void* gbase, const unsigned* lds, const int lane, const unsigned long long skip) {
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int sl = k * WE + lane;
     const int e = sl >> 4, c = ((sl & 15) - e) & 15;
     const uint4 v = reinterpret_cast<const uint4*>(lds)[sl];
-    if (!((skip >> e) & 1ull)) reinterpret_cast<uint4*>(gbase)[e * 16 + c] = v;
+    if (!((skip >> e) & 1ull) && (NC == 16 || c < NC)) reinterpret_cast<uint4*>(gbase)[e * 16 + c] = v;
   }
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -231,7 +235,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   const unsigned tab0 = reinterpret_cast<const unsigned*>(&D.rc)[lane], tab1 = reinterpret_cast<const unsigned*>(&D.rc)[lane + 64];
   auto PRM = [&](const int j) { return readlane_f64(prm_l, j); };
   // the wavefront's 64 records and 64 feature rows: two contiguous blocks, in through the LDS (block I/O above)
-  block_load<16>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane);
+  block_load<16, WIDE_REC_CHUNKS>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane);
   block_load<8>(S.feat + feat_row_offset(S, env0, rel_hint + 1), sh.row, lane);
   static_assert(R_CURSOR == 0 && R_TREL == 1 && R_DAY == 2 && R_HOURQ == 3 && R_QPOPPED == 4 && R_QCUM == 5 && R_QCUMT == 6 &&
                 R_QHEAD == 7 && R_QCUM_HM1 == 8 && R_QCUMT_HM1 == 9 && R_LAST_DELTA == 10 && R_CONSEC == 11 && R_SCALE == 12 &&
@@ -506,7 +510,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
     block_put<16>(sh.rec, lane, 10, make_uint4((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet), r10.z, r10.w));
   }
   wave_sync();
-  block_store16(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane, 0ull);
+  block_store16<WIDE_REC_CHUNKS>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane, 0ull);
 
   WST(6);
   // ---- outputs ----------------------------------------------------------------------------------------------------------------------
@@ -628,6 +632,9 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   KLit kt{};
   block_load<16>(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.hdr, lane);
   int a_ls = actions[(size_t)env * 3];
+  // the step's workload straight from its feature row: the row BLOCK in LDS is the dynamics wavefront's, which parks its rack-class
+  // results over it once it has read it
+  const float2 wl2 = *reinterpret_cast<const float2*>(S.feat + feat_row_offset(S, env0, rel_hint + 1) + (size_t)lane * SDC_FEAT_ROW + SDC_FEAT_W);
   const uint2* qt = S.qtab + (size_t)env * S.qstride;
   int cumq[5];     // cum[now - 97], cum[now - 24], cum[now - 48], cum[now - 72], cum[now - 96] (0 before the episode's start)
 #pragma unroll
@@ -646,12 +653,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   int head = (int)q1.w, cum_hm1 = (int)q2.x;
   unsigned cumT_hm1 = q2.y;
   const int now = rel;
-  double wl;
-  {
-    const uint4 v = block_get<8>(sh.row, lane, SDC_FEAT_W / 4);
-    static_assert(SDC_FEAT_W % 4 == 2, "the workload's two floats in one chunk of the row");
-    wl = __hiloint2double((int)v.w, (int)v.z);
-  }
+  const double wl = __hiloint2double(__float_as_int(wl2.y), __float_as_int(wl2.x));
   if ((unsigned)a_ls > 2u) a_ls = 1;
   const WideLs ls = wide_ls_algebra(S, wl, a_ls, popped0, cum_prev, cumT_prev, now, cumq);
   const int overdue = ls.overdue, hourq_n = hourq + 1 >= 96 ? 0 : hourq + 1;
@@ -1131,6 +1133,10 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     for (int a = 0; a < 3; a++) ret_a[a] = hd_f64(H_RET + 2 * a) + r_a[a];
   }
   float z_f = (float)z, path_f = arrived ? 2.0f : 0.0f, ret_f[3] = {(float)ret_a[0], (float)ret_a[1], (float)ret_a[2]};
+  // (3) the dynamics wavefront has staged the info rows (minus the reward-side columns) -- and has long read the hand-back, which sits
+  // in the header block's LDS: from here on that block is rewritten (the headers out, the fallback's scratch).  This wavefront is the
+  // later one at this barrier: placing it here rather than in front of the info rows costs nothing.
+  __syncthreads();
   if (ok) {
     auto put64 = [&](const int j, const double v) { hd[j] = (unsigned)__double2loint(v); hd[j + 1] = (unsigned)__double2hiint(v); };
     hd[H_KB] = kb0;
@@ -1200,8 +1206,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   }
 
   WST(14);
-  // ---- the five reward-side info columns into the staged rows, the wavefronts' 64 info rows out as 11 KB of whole lines ------------------
-  __syncthreads();      // (3) the info rows are staged (minus these columns)
+  // ---- the five reward-side info columns into the staged rows (behind barrier 3), the wavefronts' 64 info rows out as 11 KB of whole lines
   {
     float* const stage = reinterpret_cast<float*>(&sh.rec[0]);
     float* irow = stage + lane * SDC_INFO_DIM;
