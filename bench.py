@@ -615,7 +615,9 @@ def main():
     dc_files = ("dc_config.json", "dc_config_r16.json", "dc_config_r25.json") if args.mixed_racks else ("dc_config.json",)
     # one job seed; the reset RNG is keyed on the GLOBAL env index, so the job is the same set of environments
     # whatever the number of GPUs it is sharded over
-    eng, tb, params = build_engine(N, args.episode_steps, dev, seed=1234, dc_files=dc_files, env_index_base=rank * N)
+    # (kernel-selection flags only for the counter passes a tool wraps -- tools/dev/wide_pmc.sh -- never for a reported line)
+    dbg = int(os.environ.get("SDC_DEBUG_FLAGS", "0")) if args.pmc_inner else 0
+    eng, tb, params = build_engine(N, args.episode_steps, dev, seed=1234, dc_files=dc_files, env_index_base=rank * N, debug_flags=dbg)
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)   # seed 1234
     # actions: i.i.d. uniform per env and step.  A pool of 1024 pre-generated steps indexed by a GLOBAL step counter --

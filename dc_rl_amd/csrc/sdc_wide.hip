@@ -101,6 +101,9 @@ __device__ __forceinline__ void block_load(const void* gbase, unsigned* lds, con
 }
 // a state record's used part: R_END = 42 dwords = chunks 0..10; 12 chunks = whole 64-byte sectors.  The padding is neither loaded nor stored.
 #define WIDE_REC_CHUNKS 12
+#ifndef WIDE_ROOMY_WGS
+#define WIDE_ROOMY_WGS SDC_CUS      // env workgroups up to which the sweeps run BELOW the env wavefronts (one workgroup per CU: see the kernel)
+#endif
 static_assert(R_END <= WIDE_REC_CHUNKS * 4, "");
 template <int CPR>
 __device__ __forceinline__ uint4 block_get(const unsigned* lds, const int e, const int c) {
@@ -1243,13 +1246,18 @@ extern "C" __global__ __launch_bounds__(2 * SDC_WAVE) __attribute__((amdgpu_wave
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
   const int lane = threadIdx.x % SDC_WAVE;
   const int bx = (int)blockIdx.x;
+  // Issue priorities.  An env wavefront placed beside an ACTIVE sweep wavefront loses ~2 us of its ~12 us at the sweeps' raised
+  // priority (the other kernels' choice; measured at 16 384 envs: the rack-model segment 5.6 instead of 3.7 us in the same 8 % of
+  // the workgroups every launch -- and the launch ends with its slowest workgroup).  Up to one env workgroup per CU a sweep is ~5 us
+  // of a launch that lasts ~18 us anyway: there it runs BELOW the env wavefronts (12 288 / 16 384 envs: -0.7 us per step).  With
+  // more workgroups than that it made no difference or cost a little (24 576 envs +0.2, 65 536 +1.5 us at <= 1024): raised, as before.
   if (bx < S.sweep_blocks) {
     // one wavefront per request: a sweep is 40 KB through one wavefront, ~5 us -- shorter than the step it runs beside
     sdc_rw::TailLds& tl = reinterpret_cast<WideLate*>(wave == 0 ? sh.rec : sh.hdr)->tl;
     const int set = S.step_no % 3;
     const int cnt = min(S.rq_count[set], S.rq_max);
     if (bx == 0 && wave == 0 && lane == 0) S.rq_count[(S.step_no + 2) % 3] = 0;     // the set the NEXT step's requests go to
-    if (2 * bx + wave < cnt) __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
+    if (2 * bx + wave < cnt && (int)gridDim.x - S.sweep_blocks > WIDE_ROOMY_WGS) __builtin_amdgcn_s_setprio(SDC_SWEEP_PRIO);
 #pragma unroll 1
     for (int j = 2 * bx + wave; j < cnt; j += 2 * S.sweep_blocks) serve_recentring_request(S, set, j, lane, tl);
     return;
@@ -1257,6 +1265,7 @@ extern "C" __global__ __launch_bounds__(2 * SDC_WAVE) __attribute__((amdgpu_wave
   const int nb = (int)gridDim.x - S.sweep_blocks;
   const int env0 = first_pair_of_block(bx - S.sweep_blocks, nb, 1) * WE;     // (every XCD a contiguous range of envs)
   if (env0 >= S.n_envs) return;
+  if (nb <= WIDE_ROOMY_WGS) __builtin_amdgcn_s_setprio(2);
   if (wave == 0) wide_dynamics(S, sh, env0, lane, rel_hint, actions, obs, share_obs, done, final_obs);
   else wide_rewards(S, sh, env0, lane, rel_hint, actions, info, rew);
 }

@@ -26,6 +26,7 @@ timeout 600 python tools/qb.py > $O/quick_rates.txt 2>&1
 if [ -f tools/bin/lib_dbg.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/prod.so; cp tools/bin/lib_dbg.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
 timeout 600 python tools/wave_phases.py > $O/wave_phases.txt 2>&1
 timeout 600 python tools/wave_timeline.py > $O/wave_timeline.txt 2>&1
+timeout 600 python tools/wave_timeline.py 2048 > $O/wave_timeline_2048.txt 2>&1     # one wavefront per SIMD: a wavefront's life without a neighbour
 timeout 600 python tools/wave_tail.py > $O/wave_tail.txt 2>&1
 if [ -f /tmp/prod.so ]; then cp /tmp/prod.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
 timeout 600 python tools/rollout_rate.py > $O/rollout_rate.txt 2>&1
@@ -52,8 +53,8 @@ if [ -f tools/bin/lib_rt.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/p
 # four-envs-per-wavefront kernel on the same rings, the two wavefronts' timeline (the -DSDC_WIDE_STAMPS build), the crossover
 bash tools/dev/wide_pmc.sh 32768 > $O/wide_pmc_32768.txt 2>&1
 bash tools/dev/wide_pmc.sh 16384 > $O/wide_pmc_16384.txt 2>&1
-SDC_DBG=4096 bash tools/dev/wide_pmc.sh 32768 > $O/quad_pmc_32768.txt 2>&1
-for n in 8192 12288 16384 20480 32768 65536; do timeout 200 python tools/dev/wide_prof.py $n 2000; SDC_DBG=4096 timeout 200 python tools/dev/wide_prof.py $n 2000; SDC_DBG=2048 timeout 200 python tools/dev/wide_prof.py $n 2000; done > $O/wide_crossover.txt 2>&1
+SDC_DEBUG_FLAGS=4096 bash tools/dev/wide_pmc.sh 32768 > $O/quad_pmc_32768.txt 2>&1
+for f in 0 4096 2048; do echo "debug_flags $f (4096: lane-per-env kernel off, 2048: forced)"; SDC_DBG=$f timeout 300 python tools/batch_scan.py 8192 12288 16384 20480 32768 65536; done > $O/wide_crossover.txt 2>&1
 if [ -f tools/bin/lib_wstamps.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/prod.so; cp tools/bin/lib_wstamps.so dc_rl_amd/csrc/libsustaindc_hip.so; for n in 16384 32768 65536; do timeout 200 python tools/dev/wide_timeline.py $n; done > $O/wide_timeline.txt 2>&1; cp /tmp/prod.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
 hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o /tmp/valu_rates 2>/dev/null && timeout 200 /tmp/valu_rates > $O/valu_rates.txt 2>&1
 grep -v amdgpu.ids $O/*.txt | tail -60

@@ -3,7 +3,7 @@ entry, inputs staged, end; which wavefronts end last, and what the launch span w
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
-N = 4096
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng, tb, params = bench.build_engine(N, 672, 0, seed=1234, debug_flags=24)
 g = torch.Generator(device="cpu").manual_seed(1234)
 pool = torch.randint(0, 3, (256, N, 3), dtype=torch.int32, generator=g).to("cuda:0")
