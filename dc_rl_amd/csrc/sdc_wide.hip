@@ -101,6 +101,9 @@ __device__ __forceinline__ void block_load(const void* gbase, unsigned* lds, con
 }
 // a state record's used part: R_END = 42 dwords = chunks 0..10; 12 chunks = whole 64-byte sectors.  The padding is neither loaded nor stored.
 #define WIDE_REC_CHUNKS 12
+// window-update tasks of a step: their windows in the header block's LDS behind the hand-back (wide_rewards)
+#define WIDE_TASK_OFF 512
+#define WIDE_TASK_SLOTS 8
 #ifndef WIDE_ROOMY_WGS
 #define WIDE_ROOMY_WGS SDC_CUS      // env workgroups up to which the sweeps run BELOW the env wavefronts (one workgroup per CU: see the kernel)
 #endif
@@ -915,59 +918,45 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
       }
     }
     // a key lands INSIDE a window of some env (or the window starts / ends the history where it would land): the whole wavefront
-    // updates that window, lane = key.  ~3 such (env, window) tasks per wavefront and step: their windows are requested four at
-    // a time (each is a memory round trip that nothing else of this wavefront could hide).
+    // updates that window, lane = key.  ~3 such (env, window) tasks per wavefront and step, 8-10 in the busiest workgroup of a launch
+    // -- which is the one the launch waits for: ALL their windows are requested at once, by LDS-DMA into the header block's free
+    // part (one memory round trip, which nothing else of this wavefront could hide), then taken one after the other.
     unsigned long long um[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) um[w] = __ballot(upd[w]);
+    unsigned* const wbuf = sh.hdr + WIDE_TASK_OFF;      // [slot][key]
     while (__builtin_expect((um[0] | um[1] | um[2] | um[3]) != 0ull, 0)) {
-      int te[4], tw[4];
-      bool have[4];
-      unsigned tkey[4];
+      {
+        int k = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        have[j] = false;
-        te[j] = 0; tw[j] = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++)
-          if (!have[j] && um[w] != 0ull) {
-            te[j] = __ffsll((long long)um[w]) - 1;
-            um[w] &= um[w] - 1;
-            tw[j] = w;
-            have[j] = true;
+        for (int w = 0; w < 4; w++) {
+          unsigned long long m = um[w];
+          while (m != 0ull && k < WIDE_TASK_SLOTS) {
+            const int e = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            __builtin_amdgcn_global_load_lds((sdc_gptr)(qwin_env0 + ((size_t)e * SDC_WIN + lane) * 4 + w), (sdc_lptr)(wbuf + k * SDC_WIN), 4, 0, 0);
+            k++;
           }
-        tkey[j] = KEY_NONE;
-        if (have[j]) tkey[j] = qwin_env0[((size_t)te[j] * SDC_WIN + lane) * 4 + tw[j]];
+        }
       }
+      dma_wait();
+      int k = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (!have[j]) continue;
-        const int e = te[j], w = tw[j];
-        const unsigned e_new = lane_key(x_new, e), e_old = lane_key(x_old, e);
-        const bool e_has_old = e_old != KEY_NONE;
-        const int e_nprev = (int)lane_key((unsigned)n_prev, e);
+      for (int w = 0; w < 4; w++) {
         const unsigned flip = w == 3 ? KEY_NONE : 0u;
-        const int q_r0 = (int)lane_key((unsigned)(w == 0 ? wr0[0] : (w == 1 ? wr0[1] : (w == 2 ? wr0[2] : wr0[3]))), e);
-        const int q_hi = (int)lane_key((unsigned)(w == 0 ? whi[0] : (w == 1 ? whi[1] : (w == 2 ? whi[2] : whi[3]))), e);
-        QTrack q = {tkey[j], q_r0, q_hi};
-        const bool wd = qt_update(q, e_new ^ flip, e_old ^ flip, e_has_old, e_nprev, lane);
-        if (wd) qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w] = q.w;
-        const int kw = w == 0 ? (int)lane_key((unsigned)k1, e) : (int)lane_key((unsigned)k3, e);
-        const int base = look_base(w, q, kw, lane_key(kbl[w == 3 ? 1 : 0], e));
-        // (deliver(): w is a run-time value here)
-        const unsigned first = lane_key(q.w, 0), last = lane_key(q.w, max(q.hi - 1, 0));
-        unsigned c[4];
-#pragma unroll
-        for (int x = 0; x < 4; x++) c[x] = lane_key(q.w, min(max(base + x, 0), SDC_WIN - 1));
-        if (lane == e) {
-#pragma unroll
-          for (int x = 0; x < 4; x++)
-            if (x == w) {
-              wr0[x] = q.r0; whi[x] = q.hi; wf[x] = first; wlast[x] = last; cb[x] = base;
-#pragma unroll
-              for (int y = 0; y < 4; y++) ck[x][y] = c[y];
-            }
-          if (wd) touched = true;
+        while (um[w] != 0ull && k < WIDE_TASK_SLOTS) {
+          const int e = __ffsll((long long)um[w]) - 1;
+          um[w] &= um[w] - 1;
+          const unsigned e_new = lane_key(x_new, e), e_old = lane_key(x_old, e);
+          const bool e_has_old = e_old != KEY_NONE;
+          const int e_nprev = (int)lane_key((unsigned)n_prev, e);
+          QTrack q = {wbuf[k * SDC_WIN + lane], (int)lane_key((unsigned)wr0[w], e), (int)lane_key((unsigned)whi[w], e)};
+          k++;
+          const bool wd = qt_update(q, e_new ^ flip, e_old ^ flip, e_has_old, e_nprev, lane);
+          if (wd) qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w] = q.w;
+          const int kw = w == 0 ? (int)lane_key((unsigned)k1, e) : (int)lane_key((unsigned)k3, e);
+          deliver(e, w, q, look_base(w, q, kw, lane_key(kbl[w == 3 ? 1 : 0], e)));
+          if (lane == e && wd) touched = true;
         }
       }
     }
