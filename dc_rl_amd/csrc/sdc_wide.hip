@@ -19,6 +19,7 @@
 //
 // The host picks this kernel for a lock-step, single-config, default-reward batch of a multiple of 64 envs above
 // SDC_WIDE_MIN_ENVS (sdc_capi.hip wide_case).  Reference: sustaindc_env.py:533-737 (per-block citations: sdc_pairstep.hpp).
+#include <type_traits>
 #include "sdc_pairstep.hpp"
 #include "sdc_sweep.hpp"
 
@@ -810,6 +811,72 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     }
   }
 
+  // ---- O(1) window updates, the two halves of a step's qt_update on every window: the EVICTION (the ring key this step overwrites:
+  // known now) before barrier 2, in the time this wavefront would wait for the energy; the INSERTION behind it.  Per lane: a key that
+  // lands below / above a window only moves its ranks.  A key that lands INSIDE a window of some env (or where the window starts /
+  // ends the history): the whole wavefront updates that window, lane = key -- ~3 such (env, window) tasks per wavefront and step,
+  // 8-10 in the busiest workgroup of a launch, which is the one the launch waits for: ALL the windows of a phase are requested at
+  // once, by LDS-DMA into the header block's free part (one memory round trip), then taken one after the other.
+  unsigned x_new_late = 0u;      // (this step's key: known behind barrier 2)
+  auto window_tasks = [&](const bool (&upd)[4], auto EVICT) __attribute__((always_inline)) {
+    constexpr bool evict = decltype(EVICT)::value;
+    unsigned long long um[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) um[w] = __ballot(upd[w]);
+    unsigned* const wbuf = sh.hdr + WIDE_TASK_OFF;      // [slot][key]
+    while (__builtin_expect((um[0] | um[1] | um[2] | um[3]) != 0ull, 0)) {
+      {
+        int k = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          unsigned long long m = um[w];
+          while (m != 0ull && k < WIDE_TASK_SLOTS) {
+            const int e = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            __builtin_amdgcn_global_load_lds((sdc_gptr)(qwin_env0 + ((size_t)e * SDC_WIN + lane) * 4 + w), (sdc_lptr)(wbuf + k * SDC_WIN), 4, 0, 0);
+            k++;
+          }
+        }
+      }
+      dma_wait();
+      int k = 0;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const unsigned flip = w == 3 ? KEY_NONE : 0u;
+        while (um[w] != 0ull && k < WIDE_TASK_SLOTS) {
+          const int e = __ffsll((long long)um[w]) - 1;
+          um[w] &= um[w] - 1;
+          QTrack q = {wbuf[k * SDC_WIN + lane], (int)lane_key((unsigned)wr0[w], e), (int)lane_key((unsigned)whi[w], e)};
+          k++;
+          bool wd;
+          if (evict) {
+            wd = qt_evict(q, lane_key(x_old, e) ^ flip, lane);
+          } else {
+            const bool e_has_old = lane_key(x_old, e) != KEY_NONE;
+            const int e_nprev = (int)lane_key((unsigned)n_prev, e);
+            wd = qt_insert(q, lane_key(x_new_late, e) ^ flip, e_has_old ? e_nprev - 1 : e_nprev, lane);
+          }
+          if (wd) qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w] = q.w;
+          const int kw = w == 0 ? (int)lane_key((unsigned)k1, e) : (int)lane_key((unsigned)k3, e);
+          deliver(e, w, q, look_base(w, q, kw, lane_key(kbl[w == 3 ? 1 : 0], e)));
+          if (lane == e && wd) touched = true;
+        }
+      }
+    }
+  };
+  {
+    bool upd[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const unsigned y = x_old ^ (w == 3 ? KEY_NONE : 0u);
+      const bool e_below = has_old && y < wf[w];
+      const bool e_ok = !has_old || y > wlast[w] || e_below;          // (evicted key above the window / below it)
+      upd[w] = ok && !e_ok;
+      if (e_ok && e_below) wr0[w] -= 1;
+    }
+    window_tasks(upd, std::true_type{});
+  }
+
   WST_PUT(8, wst8);
   WST(9);
 
@@ -888,6 +955,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   const WideHand& H = *reinterpret_cast<const WideHand*>(sh.row + WE * 16);
   const double e_off = H.e_off[lane], energy = H.energy[lane], norm_ci = H.norm_ci[lane];
   const unsigned x_new = H.x_new[lane];
+  x_new_late = x_new;
   const int slot = H.slot[lane];
   hl = H.hl[lane];      // (after the append: == n)
 
@@ -897,69 +965,19 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   A1 += vn - vo;
   A2 += vn * vn - vo * vo;
   {
+    // the appended key against every window as the eviction left it (qt_update = qt_evict, then qt_insert: the eviction half ran
+    // before barrier 2)
     bool upd[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-      const unsigned flip = w == 3 ? KEY_NONE : 0u;
-      const unsigned y = x_old ^ flip, x = x_new ^ flip;
-      const bool e_below = has_old && y < wf[w];
-      const bool e_ok = !has_old || y > wlast[w] || e_below;          // (evicted key above the window / below it)
-      const int r0e = wr0[w] - (e_below ? 1 : 0);
-      const bool ends = r0e + whi[w] == m_hist;
-      const bool i_below = x < wf[w] && r0e != 0;
+      const unsigned x = x_new ^ (w == 3 ? KEY_NONE : 0u);
+      const bool ends = wr0[w] + whi[w] == m_hist;
+      const bool i_below = x < wf[w] && wr0[w] != 0;
       const bool i_ok = i_below || (x >= wlast[w] && !ends);          // (appended key below the window / above it)
-      const bool out = e_ok && i_ok;
-      upd[w] = ok && !out;
-      if (out) {
-        // the window's keys stay where they are, its ranks move: so do the positions this lane looks at
-        const int r0n = r0e + (i_below ? 1 : 0);
-        if (w < 2) cb[w] += 0;
-        wr0[w] = r0n;
-      }
+      upd[w] = ok && !i_ok && whi[w] > 0;
+      if (i_ok && i_below) wr0[w] += 1;      // (the window's keys stay where they are, its ranks move)
     }
-    // a key lands INSIDE a window of some env (or the window starts / ends the history where it would land): the whole wavefront
-    // updates that window, lane = key.  ~3 such (env, window) tasks per wavefront and step, 8-10 in the busiest workgroup of a launch
-    // -- which is the one the launch waits for: ALL their windows are requested at once, by LDS-DMA into the header block's free
-    // part (one memory round trip, which nothing else of this wavefront could hide), then taken one after the other.
-    unsigned long long um[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) um[w] = __ballot(upd[w]);
-    unsigned* const wbuf = sh.hdr + WIDE_TASK_OFF;      // [slot][key]
-    while (__builtin_expect((um[0] | um[1] | um[2] | um[3]) != 0ull, 0)) {
-      {
-        int k = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-          unsigned long long m = um[w];
-          while (m != 0ull && k < WIDE_TASK_SLOTS) {
-            const int e = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            __builtin_amdgcn_global_load_lds((sdc_gptr)(qwin_env0 + ((size_t)e * SDC_WIN + lane) * 4 + w), (sdc_lptr)(wbuf + k * SDC_WIN), 4, 0, 0);
-            k++;
-          }
-        }
-      }
-      dma_wait();
-      int k = 0;
-#pragma unroll
-      for (int w = 0; w < 4; w++) {
-        const unsigned flip = w == 3 ? KEY_NONE : 0u;
-        while (um[w] != 0ull && k < WIDE_TASK_SLOTS) {
-          const int e = __ffsll((long long)um[w]) - 1;
-          um[w] &= um[w] - 1;
-          const unsigned e_new = lane_key(x_new, e), e_old = lane_key(x_old, e);
-          const bool e_has_old = e_old != KEY_NONE;
-          const int e_nprev = (int)lane_key((unsigned)n_prev, e);
-          QTrack q = {wbuf[k * SDC_WIN + lane], (int)lane_key((unsigned)wr0[w], e), (int)lane_key((unsigned)whi[w], e)};
-          k++;
-          const bool wd = qt_update(q, e_new ^ flip, e_old ^ flip, e_has_old, e_nprev, lane);
-          if (wd) qwin_env0[((size_t)e * SDC_WIN + lane) * 4 + w] = q.w;
-          const int kw = w == 0 ? (int)lane_key((unsigned)k1, e) : (int)lane_key((unsigned)k3, e);
-          deliver(e, w, q, look_base(w, q, kw, lane_key(kbl[w == 3 ? 1 : 0], e)));
-          if (lane == e && wd) touched = true;
-        }
-      }
-    }
+    window_tasks(upd, std::false_type{});
   }
   ok = ok && whi[0] > 0 && whi[1] > 0 && whi[2] > 0 && whi[3] > 0;
   // key at position p of window w, if it is one of the four this lane holds
