@@ -68,7 +68,7 @@ N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
 MAX_CLOCK_GHZ = 2.4
 HIST_CAP = 10000
 ALG_BYTES_FIXED = 1540      # B(H) = 4*H + 1540 bytes per env-step
-WIDE_MIN_ENVS = 12288       # sdc_capi.hip SDC_WIDE_MIN_ENVS: single steps of a batch this large run one lane per env (sdc_wide.hip)
+WIDE_MIN_ENVS = 9216        # sdc_capi.hip SDC_WIDE_MIN_ENVS: single steps of a batch this large run one lane per env (sdc_wide.hip)
 STEP_KERNEL = "sdc_dynamics_fast_kernel"   # the step kernel specialised for the common case, which is what this workload is
 STEP_KERNEL_PREFIX = "sdc_dynamics"            # (the general kernel sdc_dynamics_kernel serves every other case)
 MIN_REGION_S = 0.2
@@ -913,7 +913,7 @@ def main():
             except Exception as e:
                 sec["harl_unchanged_loop"] = {"error": repr(e)}
             scan = []
-            # (2 048 / 8 192: two / four envs per wavefront; from 12 288: one lane per env -- sdc_wide.hip; counters at 8 192 and 32 768)
+            # (2 048 / 8 192: two / four envs per wavefront; from 9 216: one lane per env -- sdc_wide.hip; counters at 8 192 and 32 768)
             for n in (2048, 8192, 16384, 32768, 65536):
                 try:
                     r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=8192 <= n <= 16384)

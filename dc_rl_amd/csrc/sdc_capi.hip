@@ -249,9 +249,9 @@ int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 // racks, 16-byte aligned output rows (whole-line stores through the wavefront's staging block); debug_flags bit 11 forces it
 // for any such batch, bit 12 keeps it off
 #ifndef SDC_WIDE_MIN_ENVS
-// (measured, us per step with the episode boundary inside, lane per env / four per wavefront: 8 192 envs 18.4 / 14.5, 12 288: 20.4 / 21.4,
-// 16 384: 21.7 / 24.8, 20 480: 23.6 / 27.9, 32 768: 29.2 / 40.2, 65 536: 49.3 / 72.6)
-#define SDC_WIDE_MIN_ENVS 12288
+// (measured, us per step with the episode boundary inside, lane per env / four per wavefront: 7 168 envs 14.8 / 13.8, 8 192: 15.1 / 14.5,
+// 9 216: 15.6 / 15.7, 10 240: 15.9 / 16.0, 11 264: 16.2 / 16.3, 12 288: 16.4 / 21.4, 16 384: 17.6 / 24.8, 32 768: 26.2 / 40.2, 65 536: 47 / 72.6)
+#define SDC_WIDE_MIN_ENVS 9216
 #endif
 bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, const float* info) {
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };

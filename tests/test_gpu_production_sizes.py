@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("N", [12288, 16384, 32768])
 def test_quad_step_kernel_production_vs_oracle(N):
-    """The default kernel of a large batch (debug_flags = 0) -- since round 5 ONE LANE PER ENV (sdc_wide.hip) from 12 288 envs -- at
+    """The default kernel of a large batch (debug_flags = 0) -- since round 5 ONE LANE PER ENV (sdc_wide.hip) from 9 216 envs -- at
     12 288 / 16 384 / 32 768 envs (the largest batch a rate is quoted for): 330 single steps over two auto-resets, the first / last
     wavefronts and both sides of every occupancy round sampled, every reward-state path."""
     rig = ProductionRig(N, debug_flags=0, episode_steps=120, seed=1000 + N, envs_per_wave=4)

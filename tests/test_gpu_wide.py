@@ -125,11 +125,11 @@ def test_lane_per_env_kernel_full_rings_whole_state():
 
 def test_the_host_picks_the_kernel_by_batch_size():
     """Single steps of a lock-step, single-config batch: two envs per wavefront up to 5 632 envs, four above, one lane per env from
-    12 288 (sdc_capi.hip fast_case / quad_case / wide_case); debug_flags bit 12 keeps the lane-per-env kernel off."""
+    9 216 (sdc_capi.hip fast_case / quad_case / wide_case); debug_flags bit 12 keeps the lane-per-env kernel off."""
     import torch
     for N, flags, want in ((4096, 0, "sdc_dynamics_fast_kernel"), (8192, 0, "sdc_dynamics_quad_kernel"),
-                           (12288, 0, "sdc_dynamics_wide_kernel"), (12288, 4096, "sdc_dynamics_quad_kernel"),
-                           (12300, 0, "sdc_dynamics_quad_kernel")):
+                           (9216, 0, "sdc_dynamics_wide_kernel"), (9216, 4096, "sdc_dynamics_quad_kernel"),
+                           (9220, 0, "sdc_dynamics_quad_kernel")):
         (e,) = _engines(N, 96, flags=(flags,))
         e.step(torch.ones((N, 3), dtype=torch.int32, device="cuda"))
         assert e.last_step_kernel() == want, (N, flags, e.last_step_kernel())
