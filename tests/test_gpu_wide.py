@@ -134,3 +134,33 @@ def test_the_host_picks_the_kernel_by_batch_size():
         e.step(torch.ones((N, 3), dtype=torch.int32, device="cuda"))
         assert e.last_step_kernel() == want, (N, flags, e.last_step_kernel())
         e.close()
+
+
+def test_rollout_of_a_large_batch_is_single_step_launches_of_the_lane_per_env_kernel():
+    """`sdc_rollout` over a batch the lane-per-env kernel serves (9 216 envs and up): K launches of it inside the call, the same bits
+    as K calls of step() on a twin engine and as the multi-step kernel of four envs per wavefront (debug_flags bit 12), across an
+    episode end (auto-reset inside the last step)."""
+    import torch
+    N, steps, K = 9216, 48, 24
+    a, b, c = _engines(N, steps, flags=(0, 0, 4096))
+    g = torch.Generator(device="cpu").manual_seed(21)
+    acts = torch.randint(0, 3, (2 * K, N, 3), dtype=torch.int32, generator=g).cuda()
+    rsv = L.INFO_IDX["reserved"]
+    for half in range(2):                       # the second rollout ends the episode
+        seq = acts[half * K:(half + 1) * K].contiguous()
+        ro = a.rollout(seq)
+        rc = c.rollout(seq)
+        assert a.last_step_kernel() == "sdc_dynamics_wide_kernel"
+        for k in range(K):
+            st = b.step(seq[k])
+            for u, v, w, nm in zip(ro, st, rc, ("obs", "share_obs", "rew", "done", "info")):
+                u, w = u[k], w[k]
+                if nm == "info":
+                    u, v, w = u.clone(), v.clone(), w.clone()
+                    u[:, rsv] = 0; v[:, rsv] = 0; w[:, rsv] = 0
+                assert torch.equal(u, v.reshape(u.shape)), (half, k, nm, "rollout vs step")
+                assert torch.equal(u, w), (half, k, nm, "lane per env vs four per wavefront")
+    assert bool(ro[3][-1].all())                # the episode ended in the last step of the second rollout
+    for e in (a, b, c):
+        assert (e.info[:, L.INFO_IDX["fault"]] == 0).all()
+        e.close()

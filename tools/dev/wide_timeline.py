@@ -48,3 +48,8 @@ print("  slowest rack by workgroup index (mean over launches):", [(int(i), round
 ls_seg = seg[0][..., 1]; hv = seg[0][..., 3]
 slow = rack > np.percentile(rack, 95)
 print("  workgroup-launches in the top 5 %% of rack time: rack %.2f, load shifting %.2f (all %.2f), HVAC+battery %.2f (all %.2f), R updates %.2f (all %.2f)" % (rack[slow].mean(), ls_seg[slow].mean(), ls_seg.mean(), hv[slow].mean(), hv.mean(), upd[slow].mean(), upd.mean()))
+# entry of the workgroups by position in the grid (env workgroup index = blockIdx.x - sweep blocks; first_pair_of_block maps it to envs):
+# a[..., 0] is indexed by ENV block; print by env block in groups of 32
+grp = 32
+print("  entry after the launch's first entry (us), mean by env block / %d:" % grp, " ".join("%.1f" % sp[:, i:i + grp].mean() for i in range(0, sp.shape[1], grp)))
+print("  entry percentiles over workgroups (us): " + " ".join("p%d %.2f" % (q, np.percentile(sp, q)) for q in (10, 25, 50, 75, 90, 99)))
