@@ -1,12 +1,17 @@
-// sdc_wide.hip -- the step kernel for the LARGEST batches: ONE LANE PER ENVIRONMENT (a wavefront = 64 consecutive envs).
+// sdc_wide.hip -- the step kernel for the LARGEST batches: ONE LANE PER ENVIRONMENT, 64 envs = a workgroup of TWO wavefronts.
 //
 // The pair / quad kernels (sdc_pairstep.hpp) carry an env on 32 / 16 lanes: the rack model runs lane = rack, and every per-env
 // scalar instruction -- most of the step -- is issued once per 2 / 4 envs.  That is the right trade while the batch is small
-// enough that a launch is a latency chain per wavefront (4096 envs).  At 32 768 envs the quad kernel issues 363 VALU instructions
-// per env-step and the SIMDs are the bound.  Here an env is ONE lane: the scalar physics is issued once per 64 envs, the rack
-// model is a per-lane loop over the config's racks (its parameters wave-uniform: scalar operands), and nothing in the dynamics
-// crosses lanes.  ~55 VALU instructions per env-step; what bounds the kernel is then what SURVEY.md section 8(d) says bounds
-// the path: the bytes of state, traces and outputs it moves.
+// enough that a launch is a latency chain per wavefront (4096 envs).  At 32 768 envs the quad kernel issues 410 VALU instructions
+// per env-step and the SIMDs are the bound.  Here an env is ONE lane: the scalar physics is issued once per 64 envs (57 VALU
+// instructions per env-step, counters), the rack model runs once per distinct rack (its parameters wave-uniform: scalar operands),
+// and nothing in the dynamics crosses lanes.
+//
+// A lone wavefront runs its instruction stream at ~6 cycles per instruction whatever the dependences, so a workgroup's time is the
+// number of instructions on its critical path: wavefront 0 (DYNAMICS) computes the step's energy and writes observations and state,
+// wavefront 1 (REWARDS) meanwhile reads the reward-side state, serves arriving re-centred windows, applies the step's EVICTION
+// to the rank windows (the ring key the step overwrites is known from the start), finds the oldest queued task for the other
+// wavefront -- and does the insertion, the moments and the rewards once the energy is handed over.  Three barriers.
 //
 // The arithmetic is pair_dynamics' / pair_reward_fast's, expression for expression in the same order (the rack sums in the
 // half-wave reduction's tree order), so the outputs and the state are the same bits whichever kernel steps a batch.
@@ -15,10 +20,12 @@
 // from the header, the few keys around the wanted ranks gathered from the windows in memory (sdc_trackers.hpp: a window lists 64
 // of the 10 000 keys, a step's keys land inside one on ~5 % of the env-steps).  What needs a window's 64 keys side by side -- a key
 // landing inside it, a re-centred window arriving, a re-centring request to file -- is done by the WHOLE wavefront for that one
-// env (lane = key, the sdc_trackers.hpp primitives), env after env; anything unusual falls back to env_reward() (sdc_pairstep.hpp).
+// env (lane = key, the sdc_trackers.hpp primitives), all such windows of a phase fetched together; anything unusual falls back to
+// env_reward() (sdc_pairstep.hpp).
 //
-// The host picks this kernel for a lock-step, single-config, default-reward batch of a multiple of 64 envs above
+// The host picks this kernel for a lock-step, single-config, default-reward batch of a multiple of 64 envs from
 // SDC_WIDE_MIN_ENVS (sdc_capi.hip wide_case).  Reference: sustaindc_env.py:533-737 (per-block citations: sdc_pairstep.hpp).
+// Measurements behind every choice: profiles/r5_wide_experiments.txt, r5_wide_timeline.txt.
 #include <type_traits>
 #include "sdc_pairstep.hpp"
 #include "sdc_sweep.hpp"
