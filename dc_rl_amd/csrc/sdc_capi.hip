@@ -255,7 +255,7 @@ int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 #endif
 bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, const float* info) {
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-  return (h->cfg.n_envs & 63) == 0 && h->d.n_cfg == 1 && h->racks_cfg0 <= 31 && h->rack_cls_cfg0 > 0 && (h->d.debug_flags & (512 | 1024 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
+  return (h->cfg.n_envs & 63) == 0 && h->d.qcum_t != nullptr && h->d.n_cfg == 1 && h->racks_cfg0 <= 31 && h->rack_cls_cfg0 > 0 && (h->d.debug_flags & (512 | 1024 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
          (h->cfg.n_envs >= SDC_WIDE_MIN_ENVS || (h->d.debug_flags & 2048)) && al16(obs) && al16(share_obs) && al16(info);
 }
 int wide_sweep_blocks(const sdc_handle* h) { return std::min(h->d.rq_max, 256) / 2; }     // (two wavefronts each, a request per wavefront)
@@ -426,6 +426,14 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   d.tabW = tabW; d.tabC = tabC; d.tabT = tabT; d.tabWB = tabWB; d.hour_lut = hour_lut; d.dc = dcp; d.n_cfg = cfg->n_dc_configs;
   A(d.rec, (size_t)N * SDC_REC_DWORDS);
   A(d.qtab, (size_t)N * d.qstride);
+  d.qcum_t = nullptr;
+  if ((N & 63) == 0 && (N >= SDC_WIDE_MIN_ENVS || (cfg->debug_flags & 2048))) {      // (batches the lane-per-env kernel can serve: wide_case)
+    A(d.qcum_t, (size_t)N * d.qstride);
+    if (hipMemset(d.qcum_t, 0, sizeof(unsigned) * (size_t)N * d.qstride) != hipSuccess) {
+      sdc_destroy(h);
+      return fail_msg("sdc_create: clearing the queue table's mirror failed");
+    }
+  }
   A(d.t_win, (size_t)N * d.lw);
   A(d.wb_win, (size_t)N * d.lw);
   A(d.hist, (size_t)N * SDC_HIST_STRIDE);
@@ -1089,6 +1097,12 @@ int sdc_get_state(sdc_handle* h, const char* field, void* host_buf, size_t bytes
   return 0;
 }
 
+// the queue table's time-major mirror rebuilt from the table (after a host write to it)
+__global__ void sdc_qcum_mirror_kernel(SdcDev S) {
+  const int t = (int)blockIdx.x, env = (int)(blockIdx.y * blockDim.x + threadIdx.x);
+  if (env < S.n_envs) S.qcum_t[(size_t)t * S.n_envs + env] = S.qtab[(size_t)env * S.qstride + t].x;
+}
+
 int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t bytes) {
   if (!h || !field || !host_buf) return fail_msg("sdc_set_state: null argument");
   const Field* f = find_field(h, field);
@@ -1134,6 +1148,11 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
       for (int e = 0; e < h->cfg.n_envs; e++) h->cfg_host[e] = (int)r[(size_t)e * SDC_REC_DWORDS + R_CFG];
       if (rebuild_prm_env(h)) return -1;
     }
+  }
+  if (h->d.qcum_t && std::strcmp(field, "qtab") == 0) {
+    hipLaunchKernelGGL(sdc_qcum_mirror_kernel, dim3(h->d.qstride, (h->cfg.n_envs + 255) / 256), dim3(256), 0, 0, h->d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
   }
   h->latch_valid = false;                  // (closed loop: the library's copy of the latest observations describes the state before this write)
   if (invalidate_features(h)) return -1;   // whatever was written, the precomputed observation rows may no longer match it

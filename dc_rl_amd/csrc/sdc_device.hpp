@@ -204,6 +204,9 @@ struct SdcDev {
   // per-env state
   unsigned* rec;     // [N][SDC_REC_DWORDS] state records (see SdcRec)
   uint2* qtab;       // [N][qstride] {cum, cumT} per enqueue step of the episode
+  unsigned* qcum_t;  // [qstride][N] TIME-MAJOR mirror of qtab's `cum` column, or nullptr (batches the lane-per-env kernel cannot serve): its five
+                     // queue-history probes per env are then 64 consecutive dwords per wavefront instead of 64 scattered 64-byte bursts.
+                     // Every kernel that appends to qtab appends here too (qcum_append); sdc_set_state("qtab") rebuilds it
   double* t_win;     // [N][lw] dry bulb after noise + roll + clip, from the episode's first cursor
   double* wb_win;    // [N][lw] wet bulb likewise
   unsigned* hist;    // [N][SDC_HIST_STRIDE]  order-preserving uint32 key of fp32(energy - hist_ref); 0xFFFFFFFF = empty
@@ -326,6 +329,10 @@ enum { SDC_P_COS = 0, SDC_P_SIN, SDC_P_NC, SDC_P_CI7 = 3, SDC_P_OLDEST = 10, SDC
 #define SDC_FEAT_ROW 32      // floats per feature row (128 bytes)
 // feature rows are kept step-major: the rows all envs read in one launch (envs in lock-step) are adjacent -- 512 KB at
 // 4096 envs, a handful of pages -- instead of one row per 86 KB
+// the time-major mirror of the queue table's `cum` column (SdcDev::qcum_t), kept by whoever appends to the table
+__device__ __forceinline__ void qcum_append(const SdcDev& S, const int env, const int t, const unsigned cum) {
+  if (S.qcum_t) S.qcum_t[(size_t)t * S.n_envs + env] = cum;
+}
 __device__ __forceinline__ size_t feat_row_offset(const SdcDev& S, const int env, const int s) {
   return ((size_t)s * (size_t)S.n_envs + (size_t)env) * SDC_FEAT_ROW;
 }

@@ -255,13 +255,12 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
                 R_QHEAD == 7 && R_QCUM_HM1 == 8 && R_QCUMT_HM1 == 9 && R_LAST_DELTA == 10 && R_CONSEC == 11 && R_SCALE == 12 &&
                 R_HIST_LEN == 13 && R_HIST_POS == 14 && R_FAULT == 16 && R_STPT == 24 && R_BAT == 26 && R_HIST_REF == 36 &&
                 R_LAST_ROOM == 40, "record layout the chunk reads assume");
-  const uint2* qt = S.qtab + (size_t)env * S.qstride;
   int cumq[5];     // cum[now - 97], cum[now - 24], cum[now - 48], cum[now - 72], cum[now - 96] (0 before the episode's start)
 #pragma unroll
   for (int s = 0; s < 5; s++) {
     const int back = s == 0 ? 97 : 24 * s;
     const int t = rel_hint - back;
-    cumq[s] = t >= 0 ? (int)qt[t].x : 0;
+    cumq[s] = t >= 0 ? (int)S.qcum_t[(size_t)t * S.n_envs + env] : 0;      // (the table's time-major mirror: 64 consecutive dwords)
   }
 
   WST_HOLD(wst1);
@@ -511,6 +510,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   // a wait for every store issued before it.)
   S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
   S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
+  S.qcum_t[(size_t)now * S.n_envs + env] = (unsigned)cum_now;
   block_put<16>(sh.rec, lane, 0, make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n));
   block_put<16>(sh.rec, lane, 1, make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head));
   block_put<16>(sh.rec, lane, 2, make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive));
@@ -655,7 +655,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   for (int s = 0; s < 5; s++) {
     const int back = s == 0 ? 97 : 24 * s;
     const int t = rel_hint - back;
-    cumq[s] = t >= 0 ? (int)qt[t].x : 0;
+    cumq[s] = t >= 0 ? (int)S.qcum_t[(size_t)t * S.n_envs + env] : 0;      // (the table's time-major mirror: 64 consecutive dwords)
   }
   dma_wait();
   __syncthreads();      // (1) records, feature rows and headers are in LDS

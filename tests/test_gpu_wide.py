@@ -164,3 +164,49 @@ def test_rollout_of_a_large_batch_is_single_step_launches_of_the_lane_per_env_ke
     for e in (a, b, c):
         assert (e.info[:, L.INFO_IDX["fault"]] == 0).all()
         e.close()
+
+
+def test_the_queue_tables_time_major_mirror_is_kept_by_every_kernel():
+    """The lane-per-env kernel reads its five queue-history probes from a time-major mirror of the queue table's `cum` column
+    (SdcDev::qcum_t), which every kernel that appends to the table keeps.  (1) Engine A (lane per env) with a profiled step every
+    third launch -- those run the general kernel (sdc_dynamics_kernel), which appends through pair_dynamics -- against a
+    two-envs-per-wavefront engine: 150 steps of a 200-step episode (all probe lags live) bit-identical.  (2) A's state_dict() into a
+    FRESH lane-per-env engine (a host write to the table rebuilds the mirror; the restored engine steps the general kernel until
+    its next reset has recomputed the feature rows, then the lane-per-env kernel) and into a pair engine: all continue
+    bit-identically over the episode end."""
+    import torch
+    N, steps = 256, 200
+    a, b, c = _engines(N, steps, flags=(WIDE, WIDE, PAIR))
+    g = torch.Generator(device="cpu").manual_seed(33)
+    acts = torch.randint(0, 3, (260, N, 3), dtype=torch.int32, generator=g).cuda()
+    rsv = L.INFO_IDX["reserved"]
+
+    def same(outs, t, what):
+        for nm, *xs in zip(("obs", "share_obs", "rew", "done", "info"), *outs):
+            xs = [x.clone() for x in xs]
+            if nm == "info":
+                for x in xs:
+                    x[:, rsv] = 0
+            for x in xs[1:]:
+                assert torch.equal(xs[0], x), (t, nm, what)
+
+    a.profile(3)
+    seen = set()
+    for t in range(150):
+        same([a.step(acts[t]), c.step(acts[t])], t, "profiled lane-per-env engine vs pair engine")
+        seen.add(a.last_step_kernel())
+    assert seen == {"sdc_dynamics_wide_kernel", "sdc_dynamics_kernel"}, seen
+    a.profile(0)
+    sd = a.state_dict()
+    assert int(sd["qtab"].view(np.uint32).reshape(N, -1, 2)[:, 50:150, 0].max()) > 0      # (the table has content to mirror)
+    b.load_state_dict(sd)
+    c.load_state_dict(sd)
+    kb = set()
+    for t in range(150, 260):
+        same([a.step(acts[t]), b.step(acts[t]), c.step(acts[t])], t, "restored engines")
+        kb.add(b.last_step_kernel())
+    assert kb == {"sdc_dynamics_kernel", "sdc_dynamics_wide_kernel"}, kb
+    assert c.last_step_kernel() == "sdc_dynamics_fast_kernel"
+    for e in (a, b, c):
+        assert (e.info[:, L.INFO_IDX["fault"]] == 0).all()
+        e.close()
