@@ -644,6 +644,10 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   const int env = env0 + lane;
   WideLate& late = *reinterpret_cast<WideLate*>(sh.hdr);
   KLit kt{};
+  // history length and ring position BEFORE the step, straight from the record in memory (the record BLOCK is on its way into LDS
+  // for the dynamics wavefront): they address the ring key this step evicts, and that load starts one round trip earlier this way
+  const uint4 r3g = *reinterpret_cast<const uint4*>(S.rec + (size_t)env * SDC_REC_DWORDS + 12);
+  static_assert(R_HIST_LEN == 13 && R_HIST_POS == 14, "dwords 1 and 2 of the record's fourth chunk");
   block_load<16>(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.hdr, lane);
   int a_ls = actions[(size_t)env * 3];
   // the step's workload straight from its feature row: the row BLOCK in LDS is the dynamics wavefront's, which parks its rack-class
@@ -657,6 +661,12 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     const int t = rel_hint - back;
     cumq[s] = t >= 0 ? (int)S.qcum_t[(size_t)t * S.n_envs + env] : 0;      // (the table's time-major mirror: 64 consecutive dwords)
   }
+  // the evicted ring key (read BEFORE this step's key goes into that slot: the dynamics wavefront stores it behind barrier 2)
+  int hl = (int)r3g.y;
+  const int hpos = (int)r3g.z;
+  const int slot0 = hl < S.hist_cap ? hl : hpos;
+  unsigned x_old = 0xFFFFFFFFu;
+  if (hl >= S.hist_cap) x_old = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
   dma_wait();
   __syncthreads();      // (1) records, feature rows and headers are in LDS
   // ---- the oldest queued task and the ages (pair_dynamics, same expressions): the load-shifting algebra once more, then the queue
@@ -684,16 +694,6 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     }
   }
   WST_HOLD(wst8);
-  // history length and ring position BEFORE the step (the record block is the dynamics wavefront's; read-only here)
-  int hl, hpos;
-  {
-    const uint4 r3 = block_get<16>(sh.rec, lane, 3);
-    hl = (int)r3.y; hpos = (int)r3.z;
-  }
-  // the evicted ring key (read BEFORE this step's key goes into that slot: the dynamics wavefront stores it behind barrier 2)
-  const int slot0 = hl < S.hist_cap ? hl : hpos;
-  unsigned x_old = 0xFFFFFFFFu;
-  if (hl >= S.hist_cap) x_old = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
 
   // ---- reward-side state: the env's header (its 64 dwords in this lane's registers), then the few window keys a step usually needs
   unsigned hd[SDC_HDR_DWORDS];
