@@ -210,3 +210,24 @@ def test_the_queue_tables_time_major_mirror_is_kept_by_every_kernel():
     for e in (a, b, c):
         assert (e.info[:, L.INFO_IDX["fault"]] == 0).all()
         e.close()
+
+
+def test_lane_per_env_kernel_in_verify_mode_from_empty_rings():
+    """9 216 envs (the smallest batch the host gives to the lane-per-env kernel by itself) from EMPTY rings for 1 300 steps with
+    debug_flags bit 0: after every step sdc_reward_verify_kernel checks every key of all four rank windows against its rank in the
+    ring, the quartiles against an exact bisection and z against a direct fp64 pass.  Covers the young histories (fallback path for
+    all 64 envs of a wavefront), the first rebuilds, the flood of re-centring requests around steps 64-100 and an auto-reset."""
+    import torch
+    N = 9216
+    (e,) = _engines(N, 672, flags=(1,))
+    g = torch.Generator(device="cpu").manual_seed(12)
+    pool = torch.randint(0, 3, (64, N, 3), dtype=torch.int32, generator=g).cuda()
+    for t in range(1300):
+        o, s, r, d, info = e.step(pool[t & 63])
+        if t % 100 == 99:
+            assert (info[:, L.INFO_IDX["fault"]] == 0).all(), t
+            assert torch.isfinite(r).all(), t
+    assert e.last_step_kernel() == "sdc_dynamics_wide_kernel"
+    assert (e.get_state("order_stat_sticky") == 0).all()
+    assert (e.info[:, L.INFO_IDX["fault"]] == 0).all()
+    e.close()
