@@ -395,13 +395,25 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
     wave_sync();
     // (four slots per trip: the values come from LDS together, the tree's two bottom levels need no bookkeeping; a slot beyond the
     // last rack adds the 0.0 the other mappings' idle lanes add)
+    int rk = 0;
 #pragma unroll 2
-    for (int rk = 0; rk < R; rk += 4) {
+    for (; rk + 4 <= R; rk += 4) {      // (whole trips: no slot to blank)
       double vp[4], vo[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int c = tab_i32(11 + rk + j);
+        vp[j] = cls_pw[c * WE + lane];
+        vo[j] = cls_out[c * WE + lane];
+      }
+      s_pw.push4(vp[0], vp[1], vp[2], vp[3]);
+      s_out.push4(vo[0], vo[1], vo[2], vo[3]);
+    }
+    if (rk < R) {
+      double vp[4], vo[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
         const bool in = rk + j < R;
+        const int c = in ? tab_i32(11 + rk + j) : 0;
         vp[j] = in ? cls_pw[c * WE + lane] : 0.0;
         vo[j] = in ? cls_out[c * WE + lane] : 0.0;
       }
