@@ -128,12 +128,26 @@ __device__ __forceinline__ void block_put(unsigned* lds, const int e, const int 
 // the whole-wavefront fallback)
 template <int NC = 16>      // (the first NC chunks of every record)
 __device__ __forceinline__ void block_store16(void* gbase, const unsigned* lds, const int lane, const unsigned long long skip) {
+  // all sixteen LDS reads in flight together (a read inside each store's condition would be waited for one at a time)
+  uint4 v[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int sl = k * WE + lane;
-    const int e = sl >> 4, c = ((sl & 15) - e) & 15;
-    const uint4 v = reinterpret_cast<const uint4*>(lds)[sl];
-    if (!((skip >> e) & 1ull) && (NC == 16 || c < NC)) reinterpret_cast<uint4*>(gbase)[e * 16 + c] = v;
+  for (int k = 0; k < 16; k++) v[k] = reinterpret_cast<const uint4*>(lds)[k * WE + lane];
+  // slot k * 64 + lane holds chunk c of record e = 4 k + lane / 16; e's skip bit is bit 4 k of `skip >> (lane / 16)`
+  const int e0 = lane >> 4, l15 = lane & 15;
+  const unsigned long long s = skip >> e0;
+  uint4* const g = reinterpret_cast<uint4*>(gbase);
+  if (skip == 0ull) {      // (wave-uniform: the usual case)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int e = 4 * k + e0, c = (l15 - e) & 15;
+      if (NC == 16 || c < NC) g[e * 16 + c] = v[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int e = 4 * k + e0, c = (l15 - e) & 15;
+      if (!((s >> (4 * k)) & 1ull) && (NC == 16 || c < NC)) g[e * 16 + c] = v[k];
+    }
   }
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
