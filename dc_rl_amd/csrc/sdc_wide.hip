@@ -62,12 +62,9 @@ struct WideHand {
   unsigned x_new[WE];
   int hl[WE], slot[WE];
 };
-// ... and what the reward wavefront hands back (in `hdr`, which it keeps in registers between its first read and the commit)
-struct WideBack {
-  double oldest_norm[WE], avg_norm[WE];
-  int head[WE], cum_hm1[WE];
-  unsigned cumT_hm1[WE];
-};
+// ... and what the reward wavefront hands BACK -- the oldest queued task's step, the cached prefix counts before it, the two normalised
+// ages -- sits in two chunks of the lane's record image that hold no record data (the records' padding is neither loaded nor stored):
+// written before barrier 2, read by the dynamics wavefront right behind it, rewritten by nobody
 static_assert(sizeof(WideHand) <= sizeof(unsigned) * WE * 16, "the hand-over sits in the upper half of `row`");
 // (measurement build -DSDC_WIDE_STAMPS: lane 0 of both wavefronts stamps the wall clock (100 MHz) at the marks WST(i); the reward wavefront
 // leaves them in columns 0..15 of its first env's info row -- tools/dev/wide_timeline.py)
@@ -109,13 +106,13 @@ __device__ __forceinline__ void block_load(const void* gbase, unsigned* lds, con
 }
 // a state record's used part: R_END = 42 dwords = chunks 0..10; 12 chunks = whole 64-byte sectors.  The padding is neither loaded nor stored.
 #define WIDE_REC_CHUNKS 12
-// window-update tasks of a step: their windows in the header block's LDS behind the hand-back (wide_rewards)
+// window-update tasks of a step: their windows in the header block's LDS (the headers are in registers by then: wide_rewards)
 #define WIDE_TASK_OFF 512
 #define WIDE_TASK_SLOTS 8
 #ifndef WIDE_ROOMY_WGS
 #define WIDE_ROOMY_WGS SDC_CUS      // env workgroups up to which the sweeps run BELOW the env wavefronts (one workgroup per CU: see the kernel)
 #endif
-static_assert(R_END <= WIDE_REC_CHUNKS * 4, "");
+static_assert(R_END <= WIDE_REC_CHUNKS * 4 && WIDE_REC_CHUNKS + 2 <= 16, "the record's chunks, then two for the hand-back");
 template <int CPR>
 __device__ __forceinline__ uint4 block_get(const unsigned* lds, const int e, const int c) {
   return reinterpret_cast<const uint4*>(lds)[e * CPR + ((c + e) & (CPR - 1))];
@@ -524,10 +521,10 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
     H.x_new[lane] = x_new; H.hl[lane] = hl; H.slot[lane] = slot;
   }
   __syncthreads();      // (2) the step's energy is known; so are the oldest task and the ages
-  const WideBack& B = *reinterpret_cast<const WideBack*>(sh.hdr);
-  const int head = B.head[lane], cum_hm1 = B.cum_hm1[lane];
-  const unsigned cumT_hm1 = B.cumT_hm1[lane];
-  const double oldest_norm = B.oldest_norm[lane], avg_norm = B.avg_norm[lane];
+  const uint4 hb0 = block_get<16>(sh.rec, lane, WIDE_REC_CHUNKS), hb1 = block_get<16>(sh.rec, lane, WIDE_REC_CHUNKS + 1);
+  const int head = (int)hb1.x, cum_hm1 = (int)hb1.y;
+  const unsigned cumT_hm1 = hb1.z;
+  const double oldest_norm = __hiloint2double((int)hb0.y, (int)hb0.x), avg_norm = __hiloint2double((int)hb0.w, (int)hb0.z);
 
   WST(5);
   // ---- new state: this step's key into the ring, its prefix counts into the queue table, the record's changed chunks into the block and
@@ -980,9 +977,9 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     }
     oldest_norm = KDIV(oldest, 24);
     avg_norm = KDIV(avg, 24);
-    WideBack& B = *reinterpret_cast<WideBack*>(sh.hdr);      // (the header block is in registers from here to the commit)
-    B.oldest_norm[lane] = oldest_norm; B.avg_norm[lane] = avg_norm;
-    B.head[lane] = head; B.cum_hm1[lane] = cum_hm1; B.cumT_hm1[lane] = cumT_hm1;
+    block_put<16>(sh.rec, lane, WIDE_REC_CHUNKS, make_uint4((unsigned)__double2loint(oldest_norm), (unsigned)__double2hiint(oldest_norm),
+                                                          (unsigned)__double2loint(avg_norm), (unsigned)__double2hiint(avg_norm)));
+    block_put<16>(sh.rec, lane, WIDE_REC_CHUNKS + 1, make_uint4((unsigned)head, (unsigned)cum_hm1, cumT_hm1, 0u));
   }
   __syncthreads();      // (2) the step's energy is known
   const WideHand& H = *reinterpret_cast<const WideHand*>(sh.row + WE * 16);
@@ -1176,10 +1173,6 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     for (int a = 0; a < 3; a++) ret_a[a] = hd_f64(H_RET + 2 * a) + r_a[a];
   }
   float z_f = (float)z, path_f = arrived ? 2.0f : 0.0f, ret_f[3] = {(float)ret_a[0], (float)ret_a[1], (float)ret_a[2]};
-  // (3) the dynamics wavefront has staged the info rows (minus the reward-side columns) -- and has long read the hand-back, which sits
-  // in the header block's LDS: from here on that block is rewritten (the headers out, the fallback's scratch).  This wavefront is the
-  // later one at this barrier: placing it here rather than in front of the info rows costs nothing.
-  __syncthreads();
   if (ok) {
     auto put64 = [&](const int j, const double v) { hd[j] = (unsigned)__double2loint(v); hd[j + 1] = (unsigned)__double2hiint(v); };
     hd[H_KB] = kb0;
@@ -1249,7 +1242,8 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   }
 
   WST(14);
-  // ---- the five reward-side info columns into the staged rows (behind barrier 3), the wavefronts' 64 info rows out as 11 KB of whole lines
+  // ---- the five reward-side info columns into the staged rows, the wavefronts' 64 info rows out as 11 KB of whole lines ------------------
+  __syncthreads();      // (3) the info rows are staged (minus these columns)
   {
     float* const stage = reinterpret_cast<float*>(&sh.rec[0]);
     float* irow = stage + lane * SDC_INFO_DIM;
