@@ -188,6 +188,12 @@ def secondary_rate(n_envs, episode_steps, location, device, timed_steps, month=N
             eng.reset()
             for i in range(16):
                 eng.step(pool[i])
+            # (one untimed launch first: a rollout returns fresh [K, N, ...] tensors -- half a gigabyte at 16 384 envs -- and the first
+            # call after the scan's empty_cache() pays the device allocations)
+            if name == "rollout":
+                eng.rollout(pool[16:16 + 48])
+            else:
+                eng.rollout_actor(48, sample=True)
             done_steps = 0
             with no_gc():
                 torch.cuda.synchronize()
