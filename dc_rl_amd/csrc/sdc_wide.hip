@@ -45,11 +45,13 @@ __device__ __forceinline__ f4v nt_load4(const float* p) { return __builtin_nonte
 __device__ __forceinline__ void nt_store4(float* p, const f4v v) { __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p)); }
 
 // LDS of an env workgroup (64 envs, two wavefronts), 40 KB -- four workgroups per CU, two wavefronts per SIMD:
-//   rec  16 KB  the 64 state records (dynamics wavefront), from the first loads until the patched block has gone back to memory;
-//               then its output staging: the obs rows (20 KB, running into `row`), the share_obs rows, the info rows
+//   rec  16 KB  the 64 state records (dynamics wavefront), from the first loads until the patched block has gone back to memory (12 of
+//               every record's 16 chunks hold data: two of the others carry the reward wavefront's hand-BACK); then its output
+//               staging: the obs rows (20 KB, running into `row`), the share_obs rows, the info rows
 //   row   8 KB  the 64 feature rows on the way in; during the rack model the rack classes' results {power, outlet} per lane; from the
 //               end of the dynamics its upper half holds the HAND-OVER to the reward wavefront (WideHand)
-//   hdr  16 KB  the 64 headers (reward wavefront), likewise; then the whole-wavefront fallback's scratch (WideLate)
+//   hdr  16 KB  the 64 headers (reward wavefront), likewise: in its registers from its first read to the commit, the LDS meanwhile the
+//               landing place of the window-update tasks' windows; behind the commit the whole-wavefront fallback's scratch (WideLate)
 struct WideShared {
   unsigned rec[WE * 64];
   unsigned row[WE * 32];
