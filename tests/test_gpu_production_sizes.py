@@ -41,6 +41,35 @@ def test_quad_step_kernel_production_vs_oracle(N):
     rig.eng.close()
 
 
+def test_lane_per_env_kernel_equals_four_per_wavefront_for_every_env_16384():
+    """The oracle is run for a sample of the envs; EVERY env of the lane-per-env kernel is held to the four-envs-per-wavefront kernel
+    here: two engines in the production configuration (full rings with duplicates, spread write positions, the same seed), 16 384
+    envs, 260 single steps over two auto-resets under the full load of deferred re-centrings -- every output of every env the same
+    bits (the diagnostics column aside: it says which path served the reward state)."""
+    import torch
+    N = 16384
+    a = ProductionRig(N, debug_flags=0, episode_steps=120, seed=515, envs_per_wave=4, n_random=0)
+    b = ProductionRig(N, debug_flags=4096, episode_steps=120, seed=515, envs_per_wave=4, n_random=0)
+    a.eng.reset()
+    b.eng.reset()
+    g = torch.Generator(device="cpu").manual_seed(515)
+    rsv = L.INFO_IDX["reserved"]
+    for t in range(260):
+        acts = torch.randint(0, 3, (N, 3), dtype=torch.int32, generator=g).cuda()
+        for u, v, nm in zip(a.eng.step(acts), b.eng.step(acts), ("obs", "share_obs", "rew", "done", "info")):
+            if nm == "info":
+                u, v = u.clone(), v.clone()
+                u[:, rsv] = 0
+                v[:, rsv] = 0
+            if not torch.equal(u, v):
+                bad = (u != v).nonzero()
+                raise AssertionError((t, nm, bad[:6].tolist(), u[tuple(bad[0])].item(), v[tuple(bad[0])].item()))
+    assert a.eng.last_step_kernel() == "sdc_dynamics_wide_kernel" and b.eng.last_step_kernel() == "sdc_dynamics_quad_kernel"
+    for r in (a, b):
+        assert (r.eng.info[:, L.INFO_IDX["fault"]] == 0).all()
+        r.eng.close()
+
+
 def test_quad_step_kernel_32768_envs_vs_oracle():
     """... and the four-envs-per-wavefront kernel at 32 768 envs (debug_flags bit 12 keeps the lane-per-env kernel off): what
     `sdc_rollout` and the closed loop still run at that size."""
