@@ -348,19 +348,23 @@ def pmc_summary(c):
     return out
 
 
-def scan_kernel_name(n_envs):
-    """Which step kernel the host picks for a single-config lock-step batch of this size (sdc_capi.hip)."""
-    if n_envs >= WIDE_MIN_ENVS and n_envs % 64 == 0:
-        return "sdc_dynamics_wide_kernel"
-    return "sdc_dynamics_quad_kernel" if n_envs >= 5636 and n_envs % 4 == 0 else STEP_KERNEL
+def what_bounds(issue_frac, hbm_frac):
+    """What the measurements say bounds a kernel: "hbm" (physical HBM traffic at >= half of the 8 TB/s peak), "issue" (the SIMDs'
+    issue ports busy for >= half of the launch) or "latency" (neither: a wavefront's dependent chain + dispatch).  SURVEY 8(d)'s
+    roofline for the PATH is HBM whatever this says: `roofline.roofline`, `frac`."""
+    if hbm_frac is not None and hbm_frac >= 0.5:
+        return "hbm"
+    if issue_frac is not None and issue_frac >= 0.5:
+        return "issue"
+    return "latency" if (issue_frac is not None or hbm_frac is not None) else None
 
 
-def scan_roofline(n_envs, episode_steps, us_per_step, args):
+def scan_roofline(n_envs, episode_steps, us_per_step, args, kernel, mixed_racks=False):
     """The counter passes of `pmc_collect` at another batch size (the four-envs-per-wavefront kernel above 5632 envs):
     the same physical figures as the headline's `roofline`, against the wall-clock time per step of that batch."""
     import argparse as _ap
     a2 = _ap.Namespace(**vars(args))
-    a2.envs_per_gpu, a2.episode_steps, a2.mixed_racks = n_envs, episode_steps, False
+    a2.envs_per_gpu, a2.episode_steps, a2.mixed_racks = n_envs, episode_steps, mixed_racks
     c, err = pmc_collect(a2, timeout_s=150)
     if c is None:
         return {"error": err}
@@ -370,7 +374,9 @@ def scan_roofline(n_envs, episode_steps, us_per_step, args):
     traffic = pm.get("hbm_bytes_per_launch")
     valu = pm.get("valu_active_simd_cycles_per_launch")
     alg = ALG_BYTES_FIXED * n_envs
-    out = {"bound": "hbm", "kernel": scan_kernel_name(n_envs),
+    issue = (pm["issue_active_simd_cycles_per_launch"] / simd_cycles) if pm.get("issue_active_simd_cycles_per_launch") else None
+    out = {"roofline": "hbm", "bound": what_bounds(issue, traffic / t / 1e9 / HBM_PEAK_GBPS if traffic else None),
+           "kernel": kernel,      # (what sdc_last_step_kernel() reported for the timed batch)
            "achieved": round(alg / t / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": round(alg / t / 1e9 / HBM_PEAK_GBPS, 5), "frac_hbm_algorithmic": round(alg / t / 1e9 / HBM_PEAK_GBPS, 5),
            "valu_busy_frac": round(valu / simd_cycles, 4) if valu else None,
@@ -793,8 +799,12 @@ def main():
         valu_busy = (valu_cyc / simd_cycles) if valu_cyc else None
         eff = b * N / k_evt / 1e9
         alg_fixed = ALG_BYTES_FIXED * N
+        issue_frac = (pmc["issue_active_simd_cycles_per_launch"] / simd_cycles
+                      if pmc and pmc.get("issue_active_simd_cycles_per_launch") else None)
         roof = {
-            "bound": "hbm", "kernel": STEP_KERNEL,
+            # `roofline`: the roofline SURVEY 8(d) prices the path against (`frac`); `bound`: what the counters say bounds THIS kernel
+            "roofline": "hbm", "bound": what_bounds(issue_frac, traffic / k_evt / 1e9 / HBM_PEAK_GBPS if traffic else None) or "issue",
+            "kernel": eng.last_step_kernel(),
             # algorithmic bytes per launch (WITHOUT the history term: the kernel keeps the order statistics
             # incrementally) / the kernel's average launch duration, against the 8 TB/s HBM peak
             "achieved": round(alg_fixed / k_evt / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -812,8 +822,7 @@ def main():
             "available_M_simd_cycles_per_launch": round(simd_cycles / 1e6, 3),
             # every instruction class (VALU, scalar, LDS, memory, branch) against the same SIMD-cycles: what the two wavefronts
             # of a SIMD keep its issue port busy with over the whole launch, launch gap and dispatch ramp included
-            "issue_frac": (round(pmc["issue_active_simd_cycles_per_launch"] / simd_cycles, 4)
-                           if pmc and pmc.get("issue_active_simd_cycles_per_launch") else None),
+            "issue_frac": round(issue_frac, 4) if issue_frac else None,
             "wave_issue_frac": pmc.get("wave_issue_frac") if pmc else None,
             "kernel_avg_us": round(k_evt * 1e6, 2),
             "kernel_first_entry_to_last_exit_us": round(k_dyn * 1e6, 2),
@@ -925,7 +934,7 @@ def main():
                     r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=8192 <= n <= 16384)
                     r["rate_vs_4096_envs"] = round(r["value"] / value, 4)
                     if n in (8192, 32768) and not args.no_pmc:
-                        r["roofline"] = scan_roofline(n, args.episode_steps, r["us_per_step"], args)
+                        r["roofline"] = scan_roofline(n, args.episode_steps, r["us_per_step"], args, r.get("kernel"))
                     scan.append(r)
                 except Exception as e:
                     scan.append({"envs": n, "error": repr(e)})

@@ -154,7 +154,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     stamp = os.path.join(objdir, "flags.txt")
-    flag_text = " ".join(cflags)
+    # (the compiler is part of the stamp: objects of another hipcc are not reused)
+    try:
+        cc_id = subprocess.run([hipcc, "--version"], capture_output=True, text=True, check=True).stdout.strip().replace("\n", " | ")
+    except Exception:
+        cc_id = "unknown"
+    flag_text = hipcc + " [" + cc_id + "] " + " ".join(cflags)
     if not os.path.exists(stamp) or open(stamp).read() != flag_text:
         force = True
     hdr_time = max(os.path.getmtime(d) for d in deps if not d.endswith(".hip"))
@@ -163,10 +168,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
             return obj
-        cmd = [hipcc] + cflags + ["-c", src, "-o", obj]
+        # (several ranks / test workers may build at once: each writes its own file, the rename is atomic)
+        tmp_obj = obj + f".{os.getpid()}.tmp"
+        cmd = [hipcc] + cflags + ["-c", src, "-o", tmp_obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd, cwd=CSRC)
+        try:
+            subprocess.check_call(cmd, cwd=CSRC)
+            os.replace(tmp_obj, obj)
+        finally:
+            if os.path.exists(tmp_obj):
+                os.remove(tmp_obj)
         return obj
 
     from concurrent.futures import ThreadPoolExecutor

@@ -428,11 +428,7 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   A(d.qtab, (size_t)N * d.qstride);
   d.qcum_t = nullptr;
   if ((N & 63) == 0 && (N >= SDC_WIDE_MIN_ENVS || (cfg->debug_flags & 2048))) {      // (batches the lane-per-env kernel can serve: wide_case)
-    A(d.qcum_t, (size_t)N * d.qstride);
-    if (hipMemset(d.qcum_t, 0, sizeof(unsigned) * (size_t)N * d.qstride) != hipSuccess) {
-      sdc_destroy(h);
-      return fail_msg("sdc_create: clearing the queue table's mirror failed");
-    }
+    A(d.qcum_t, (size_t)N * d.qstride);      // (zeroed by the allocation)
   }
   A(d.t_win, (size_t)N * d.lw);
   A(d.wb_win, (size_t)N * d.lw);
@@ -866,6 +862,8 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
     d.step_no = h->step_no;
     h->step_no = next_step_no(h->step_no, n_steps + 3);
     HIP_TRY(hipMemsetAsync(d.rq_count, 0, sizeof(int) * 4, st));
+    const bool r_fast = fast_case(h, actions, share_obs, info, false) && !actions_out;
+    h->last_step_kernel = r_fast ? (quad_case(h, true) ? "sdc_rollout_quad_kernel" : "sdc_rollout_fast_kernel") : "sdc_rollout_kernel";
     if (fast_case(h, actions, share_obs, info, false) && !actions_out && quad_case(h, true))
       hipLaunchKernelGGL(sdc_rollout_quad_kernel, dim3(quad_blocks(N)), dim3(SDC_WAVE * STEP_WPB), 0, st, d, n_steps, h->rel_hint,
                          actions, obs, share_obs, done, info, final_obs, rew);

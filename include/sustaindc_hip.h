@@ -297,7 +297,7 @@ int sdc_steps_to_episode_end(const sdc_handle* h);
  * about episode boundaries (harl/envs/env_wrappers.py:176-190: "original_obs" bookkeeping) without a device->host
  * read.  Returns the number of finished envs; done_host [N] (host, may be NULL) is filled only when it is > 0. */
 int sdc_last_done(const sdc_handle* h, uint8_t* done_host);
-/* name of the step kernel the last sdc_step launched ("" before the first): the host picks by batch size and configuration
+/* name of the kernel the last sdc_step / sdc_rollout launched ("" before the first): the host picks by batch size and configuration
  * between the general kernel, the common-case kernels with two / four envs per wavefront and the lane-per-env kernel of the
  * largest batches (sdc_capi.hip fast_case / quad_case / wide_case) -- all give the same results; tests and benchmarks name
  * what they measured with this. */

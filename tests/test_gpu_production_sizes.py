@@ -71,8 +71,8 @@ def test_lane_per_env_kernel_equals_four_per_wavefront_for_every_env_16384():
 
 
 def test_quad_step_kernel_32768_envs_vs_oracle():
-    """... and the four-envs-per-wavefront kernel at 32 768 envs (debug_flags bit 12 keeps the lane-per-env kernel off): what
-    `sdc_rollout` and the closed loop still run at that size."""
+    """... and the four-envs-per-wavefront kernel at 32 768 envs (debug_flags bit 12 keeps the lane-per-env kernel off): the mapping
+    the closed loop (and `sdc_rollout` with `actions_out` / unaligned outputs) still runs at that size."""
     rig = ProductionRig(32768, debug_flags=4096, episode_steps=120, seed=33768, envs_per_wave=4)
     obs, _ = rig.eng.reset()
     rig.begin_all(obs)
@@ -99,13 +99,15 @@ def test_config3_mixed_racks_4096_production():
     rig.eng.close()
 
 
-def test_rollout_16384_envs_full_rings_vs_oracle():
-    """`sdc_rollout` at 16 384 envs (sdc_rollout_quad_kernel), rings full: 10 single steps (their deferred requests are still in
-    flight when the multi-step launch starts), then 48 + 48 + the episode's last 14 steps in three launches, across an
-    auto-reset, vs the oracle."""
+@pytest.mark.parametrize("flags,kernel", [(0, "sdc_dynamics_wide_kernel"), (4096, "sdc_rollout_quad_kernel")])
+def test_rollout_16384_envs_full_rings_vs_oracle(flags, kernel):
+    """`sdc_rollout` at 16 384 envs, rings full: 10 single steps (their deferred requests are still in flight when the multi-step
+    call starts), then 48 + 48 + the episode's last 14 steps in three calls, across an auto-reset, vs the oracle.  debug_flags 0:
+    what the call does at this size since round 5 -- K single-step launches of the lane-per-env kernel; bit 12 (4096) keeps that
+    kernel off: ONE launch of `sdc_rollout_quad_kernel` per call (still what serves unaligned outputs / `actions_out`)."""
     import torch
     N = 16384
-    rig = ProductionRig(N, debug_flags=0, episode_steps=120, seed=555, envs_per_wave=4)
+    rig = ProductionRig(N, debug_flags=flags, episode_steps=120, seed=555, envs_per_wave=4)
     eng = rig.eng
     obs, _ = eng.reset()
     rig.begin_all(obs)
@@ -122,7 +124,8 @@ def test_rollout_16384_envs_full_rings_vs_oracle():
     k = 24
     acts = torch.randint(0, 3, (k, N, 3), dtype=torch.int32, generator=g).cuda()
     rig.check_rollout(acts, eng.rollout(acts))
-    print("sdc_rollout, 16384 envs:", rig.worst, "reward-state paths:", rig.paths[:4])
+    print("sdc_rollout, 16384 envs:", eng.last_step_kernel(), rig.worst, "reward-state paths:", rig.paths[:4])
+    assert eng.last_step_kernel() == kernel
     rig.assert_ok()
     rig.eng.close()
 
