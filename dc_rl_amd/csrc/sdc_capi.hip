@@ -26,6 +26,8 @@ extern "C" __global__ void sdc_dynamics_quad_kernel(SdcDev S, int rel_hint, cons
                                                     unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_dynamics_wide_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
                                                     unsigned char* done, float* info, float* final_obs, float* rew);
+extern "C" __global__ void sdc_dynamics_wide_gen_kernel(SdcDev S, int rel_hint, const int32_t* actions, float* obs, float* share_obs,
+                                                        unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_rollout_quad_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs,
                                                    float* share_obs, unsigned char* done, float* info, float* final_obs, float* rew);
 extern "C" __global__ void sdc_rollout_fast_kernel(SdcDev S, int K, int rel_hint, const int32_t* actions, float* obs,
@@ -120,6 +122,9 @@ struct sdc_handle {
   double* prm_env_dev = nullptr;
   bool prm_env_ok = false;
   int racks_max = 0;
+  // the lane-per-env kernel's general form (sdc_wide.hip GEN): one SdcWideCfg per config, when the batch's configs qualify
+  SdcWideCfg* wcfg_dev = nullptr;
+  bool wide_gen_ok = false;
   std::vector<unsigned char> last_done;   // which envs finished in the last sdc_step / sdc_rollout call (host mirror)
   int n_last_done = 0;
   bool tables_set = false, assigned = false, started = false;
@@ -253,20 +258,42 @@ int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 // 9 216: 15.6 / 15.7, 10 240: 15.9 / 16.0, 11 264: 16.2 / 16.3, 12 288: 16.4 / 21.4, 16 384: 17.6 / 24.8, 32 768: 26.2 / 40.2, 65 536: 47 / 72.6)
 #define SDC_WIDE_MIN_ENVS 9216
 #endif
-bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, const float* info) {
+// the structural conditions of the lane-per-env kernel (either form): a multiple of 64 envs, the queue table's time-major mirror,
+// whole-line stores through the workgroup's staging block (16-byte aligned output rows)
+bool wide_shape(const sdc_handle* h, const float* obs, const float* share_obs, const float* info, const float* final_obs) {
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-  return (h->cfg.n_envs & 63) == 0 && h->d.qcum_t != nullptr && h->d.n_cfg == 1 && h->racks_cfg0 <= 31 && h->rack_cls_cfg0 > 0 && (h->d.debug_flags & (512 | 1024 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
-         (h->cfg.n_envs >= SDC_WIDE_MIN_ENVS || (h->d.debug_flags & 2048)) && al16(obs) && al16(share_obs) && al16(info);
+  return (h->cfg.n_envs & 63) == 0 && h->d.qcum_t != nullptr && (h->d.debug_flags & (512 | 1024 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
+         (h->cfg.n_envs >= SDC_WIDE_MIN_ENVS || (h->d.debug_flags & 2048)) && al16(obs) && al16(share_obs) && al16(info) && al16(final_obs);
+}
+// ... its common-case form (one config of <= 32 racks in <= 8 classes; fast_case holds as well: the caller checks both)
+bool wide_case(const sdc_handle* h, const float* obs, const float* share_obs, const float* info, const float* final_obs) {
+  return wide_shape(h, obs, share_obs, info, final_obs) && h->d.n_cfg == 1 && h->racks_cfg0 <= 32 && h->rack_cls_cfg0 > 0;
 }
 int wide_sweep_blocks(const sdc_handle* h) { return std::min(h->d.rq_max, 256) / 2; }     // (two wavefronts each, a request per wavefront)
+// what every specialised kernel needs: all envs in lock-step with valid feature rows, every output array present, no profiling
+bool lockstep_case(const sdc_handle* h, const float* share_obs, const float* info, bool timed) {
+  const SdcDev& d = h->d;
+  return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs && share_obs && info && !timed &&
+         (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | 512 | 1024 | 2048 | 4096 | FAST_DEBUG_FLAGS)) == 0;
+}
 bool fast_case(const sdc_handle* h, const int32_t* actions, const float* share_obs, const float* info, bool timed) {
   const SdcDev& d = h->d;
-  return h->rel_hint >= 0 && d.feat != nullptr && h->n_feat_host == h->cfg.n_envs &&
-         (d.n_cfg == 1 ? (h->racks_cfg0 > 0 && h->racks_cfg0 <= 32) : (h->prm_env_ok && h->racks_max <= 32)) && actions && share_obs &&
-         info && !timed && (h->cfg.n_envs & 1) == 0 && (d.debug_flags & ~(1 | 64 | 512 | 1024 | 2048 | 4096 | FAST_DEBUG_FLAGS)) == 0 &&
+  return lockstep_case(h, share_obs, info, timed) &&
+         (d.n_cfg == 1 ? (h->racks_cfg0 > 0 && h->racks_cfg0 <= 32) : (h->prm_env_ok && h->racks_max <= 32)) && actions &&
          d.policy[0] == SDC_POLICY_EXTERNAL && d.policy[1] == SDC_POLICY_EXTERNAL && d.policy[2] == SDC_POLICY_EXTERNAL &&
          d.reward_method[0] == SDC_REWARD_DEFAULT && d.reward_method[1] == SDC_REWARD_DEFAULT &&
          d.reward_method[2] == SDC_REWARD_DEFAULT;
+}
+// ... and the lane-per-env kernel's GENERAL form (sdc_wide.hip GEN): several configs (SdcWideCfg: rebuild_wide_cfg), rule-based
+// policies on any slot, any reward function for the dc / battery agents.  The ls agent keeps default_ls_reward -- with another one
+// the history is not appended to (utils/reward_creator.py:63), a mode the per-lane reward path does not have.
+bool wide_gen_case(const sdc_handle* h, const int32_t* actions, const float* obs, const float* share_obs, const float* info,
+                   const float* final_obs, bool timed) {
+  const SdcDev& d = h->d;
+  const bool acts = actions != nullptr || (d.policy[0] != SDC_POLICY_EXTERNAL && d.policy[1] != SDC_POLICY_EXTERNAL &&
+                                           d.policy[2] != SDC_POLICY_EXTERNAL);
+  return lockstep_case(h, share_obs, info, timed) && wide_shape(h, obs, share_obs, info, final_obs) && h->wide_gen_ok && acts &&
+         d.reward_method[0] == SDC_REWARD_DEFAULT;
 }
 
 // several configs: (re)build every env's copy of its config's scalars once all configs and the assignment are known
@@ -291,6 +318,60 @@ int rebuild_prm_env(sdc_handle* h) {
   HIP_TRY(hipMemcpy(h->prm_env_dev, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
   h->d.prm_env = h->prm_env_dev;
   h->prm_env_ok = true;
+  return 0;
+}
+
+// the lane-per-env kernel's general form: one SdcWideCfg per config, if every config is set, has <= 32 racks in <= SDC_WIDE_MAX_CLS
+// classes, and the scalars the kernel keeps wave-uniform are the same bits in all of them
+int rebuild_wide_cfg(sdc_handle* h) {
+  h->wide_gen_ok = false;
+  h->d.wcfg = nullptr;
+  const int C = h->cfg.n_dc_configs;
+  if (C > SDC_WIDE_MAX_CFG || (int)h->dc_set.size() != C || (int)h->dc_host.size() != C) return 0;
+  for (int c = 0; c < C; c++)
+    if (!h->dc_set[c]) return 0;
+  std::vector<SdcWideCfg> tab((size_t)C);
+  std::memset(tab.data(), 0, sizeof(SdcWideCfg) * tab.size());
+  int max_cls = 0, max_racks = 0;
+  for (int c = 0; c < C; c++) {
+    const SdcDcDev& e = h->dc_host[c];
+    const sdc_dc_params& p = e.p;
+    const SdcDcDev& e0 = h->dc_host[0];
+    // wave-uniform in the kernel (read from config 0): must not differ
+    const double shared_c[] = {p.m_cpu, p.c_cpu, p.rs_cpu, p.m_fan, p.c_fan, p.rs_fan, p.itfan_ref_p, p.itfan_ref_v_ratio, p.it_fan_full_load_v,
+                               p.c_air, p.rho_air, p.crac_supply_pu, p.min_temp, p.max_temp, e.rc_itfan_ref_v_ratio, e.rc_rho_air, e.k_outlet};
+    const sdc_dc_params& p0 = e0.p;
+    const double shared_0[] = {p0.m_cpu, p0.c_cpu, p0.rs_cpu, p0.m_fan, p0.c_fan, p0.rs_fan, p0.itfan_ref_p, p0.itfan_ref_v_ratio, p0.it_fan_full_load_v,
+                               p0.c_air, p0.rho_air, p0.crac_supply_pu, p0.min_temp, p0.max_temp, e0.rc_itfan_ref_v_ratio, e0.rc_rho_air, e0.k_outlet};
+    if (std::memcmp(shared_c, shared_0, sizeof(shared_c)) != 0) return 0;
+    if (p.n_racks > 32) return 0;
+    SdcWideCfg& w = tab[(size_t)c];
+    int n = 0;
+    for (int r = 0; r < p.n_racks; r++) {
+      int k = -1;
+      for (int j = 0; j < n; j++)
+        if (w.cls[j][0] == p.rack_n[r] && w.cls[j][1] == p.rack_supply[r] && w.cls[j][2] == p.rack_full[r] && w.cls[j][3] == p.rack_idle[r]) k = j;
+      if (k < 0) {
+        if (n == SDC_WIDE_MAX_CLS) return 0;
+        k = n++;
+        w.cls[k][0] = p.rack_n[r]; w.cls[k][1] = p.rack_supply[r]; w.cls[k][2] = p.rack_full[r]; w.cls[k][3] = p.rack_idle[r];
+      }
+      w.map[r >> 3] |= (unsigned)k << (4 * (r & 7));
+    }
+    w.n_cls = n;
+    w.n_racks = p.n_racks;
+    w.scal[WC_RET_SUM] = e.ret_sum; w.scal[WC_RC_N_RACKS] = e.rc_n_racks; w.scal[WC_CT_FAN_REF_P] = p.ct_fan_ref_p;
+    w.scal[WC_RC_CTAFR] = e.rc_ctafr; w.scal[WC_BAT_CAP] = p.bat_capacity_mwh; w.scal[WC_RC_BAT_CAP] = e.rc_bat_capacity;
+    max_cls = std::max(max_cls, n);
+    max_racks = std::max(max_racks, p.n_racks);
+  }
+  if (!h->wcfg_dev && dev_alloc(h, &h->wcfg_dev, (size_t)SDC_WIDE_MAX_CFG) != 0) return -1;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->wcfg_dev, tab.data(), sizeof(SdcWideCfg) * tab.size(), hipMemcpyHostToDevice));
+  h->d.wcfg = h->wcfg_dev;
+  h->d.wide_max_cls = max_cls;
+  h->d.wide_max_racks4 = (max_racks + 3) / 4 * 4;
+  h->wide_gen_ok = true;
   return 0;
 }
 
@@ -569,7 +650,7 @@ int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
     std::vector<Cls> cls;
     std::vector<std::pair<double, double>> grp;
     std::vector<int> of_rack((size_t)p->n_racks, 0);
-    bool fits = p->n_racks <= 31;
+    bool fits = p->n_racks <= 32;
     for (int r = 0; r < p->n_racks && fits; r++) {
       const Cls c = {p->rack_n[r], p->rack_full[r], p->rack_idle[r], p->rack_supply[r], 0};
       int k = -1;
@@ -619,7 +700,8 @@ int sdc_set_dc_params(sdc_handle* h, int cfg_id, const sdc_dc_params* p) {
   h->dc_set.resize((size_t)h->cfg.n_dc_configs, 0);
   h->dc_host[cfg_id] = e;
   h->dc_set[cfg_id] = 1;
-  return rebuild_prm_env(h);
+  if (rebuild_prm_env(h)) return -1;
+  return rebuild_wide_cfg(h);
 }
 
 int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id, const int32_t* day_lo,
@@ -647,7 +729,8 @@ int sdc_assign_envs(sdc_handle* h, const int32_t* loc_id, const int32_t* cfg_id,
   h->assigned = true;
   h->cfg_host.assign(cfg_id, cfg_id + N);
   h->dc_set.resize((size_t)h->cfg.n_dc_configs, 0);
-  return rebuild_prm_env(h);
+  if (rebuild_prm_env(h)) return -1;
+  return rebuild_wide_cfg(h);
 }
 
 int sdc_reset(sdc_handle* h, const uint8_t* mask_host, const sdc_reset_override* ovr, float* obs, float* share_obs,
@@ -776,10 +859,16 @@ int sdc_step(sdc_handle* h, const int32_t* actions, float* obs, float* share_obs
   }
   d.step_no = h->step_no;
   h->step_no = next_step_no(h->step_no, 1);
-  if (fast_case(h, actions, share_obs, info, timed) && wide_case(h, obs, share_obs, info)) {
+  if (fast_case(h, actions, share_obs, info, timed) && wide_case(h, obs, share_obs, info, final_obs)) {
     d.sweep_blocks = wide_sweep_blocks(h);
     h->last_step_kernel = "sdc_dynamics_wide_kernel";
     hipLaunchKernelGGL(sdc_dynamics_wide_kernel, dim3(d.sweep_blocks + N / SDC_WAVE), dim3(2 * SDC_WAVE), 0, st, d, h->rel_hint, actions,
+                       obs, share_obs, done, info, final_obs, rew);
+  } else if (wide_gen_case(h, actions, obs, share_obs, info, final_obs, timed)) {
+    // a large batch of SEVERAL configs, or with rule-based policies / other reward functions: the lane-per-env kernel's general form
+    d.sweep_blocks = wide_sweep_blocks(h);
+    h->last_step_kernel = "sdc_dynamics_wide_gen_kernel";
+    hipLaunchKernelGGL(sdc_dynamics_wide_gen_kernel, dim3(d.sweep_blocks + N / SDC_WAVE), dim3(2 * SDC_WAVE), 0, st, d, h->rel_hint, actions,
                        obs, share_obs, done, info, final_obs, rew);
   } else if (fast_case(h, actions, share_obs, info, timed) && quad_case(h, false)) {
     h->last_step_kernel = "sdc_dynamics_quad_kernel";
@@ -841,19 +930,31 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
   const int N = h->cfg.n_envs;
   SdcDev d = h->d;
   d.actions_out = actions_out;
-  if (actions && !actions_out && fast_case(h, actions, share_obs, info, false) && wide_case(h, obs, share_obs, info)) {
+  const bool w_common = actions && !actions_out && fast_case(h, actions, share_obs, info, false) && wide_case(h, obs, share_obs, info, final_obs);
+  // (the slices of step k start k * N rows in: aligned like the arrays themselves for the batches this kernel takes, N % 64 == 0)
+  const bool w_gen = !w_common && wide_gen_case(h, actions, obs, share_obs, info, final_obs, false) &&
+                     (!actions_out || (reinterpret_cast<uintptr_t>(actions_out) & 3u) == 0);
+  if (w_common || w_gen) {
     // A batch the lane-per-env kernel serves (sdc_wide.hip: from SDC_WIDE_MIN_ENVS envs): n_steps single-step launches of it, the
     // deferred re-centrings running between them as in sdc_step -- faster than one n_steps launch of four envs per wavefront
-    // (16 384 envs: 17.7 against 23.4 us per step), the same outputs to the bit
+    // (16 384 envs: 17.7 against 23.4 us per step), the same outputs to the bit.  Its general form likewise: several configs,
+    // rule-based policies (a step's policy reads the state the previous launch left), other reward functions.
     d.sweep_blocks = wide_sweep_blocks(h);
-    h->last_step_kernel = "sdc_dynamics_wide_kernel";
+    h->last_step_kernel = w_common ? "sdc_dynamics_wide_kernel" : "sdc_dynamics_wide_gen_kernel";
     for (int k = 0; k < n_steps; k++) {
       d.step_no = h->step_no;
       h->step_no = next_step_no(h->step_no, 1);
       const size_t o = (size_t)k * N;
-      hipLaunchKernelGGL(sdc_dynamics_wide_kernel, dim3(d.sweep_blocks + N / SDC_WAVE), dim3(2 * SDC_WAVE), 0, st, d,
-                         h->rel_hint >= 0 ? h->rel_hint + k : h->rel_hint, actions + o * 3, obs + o * SDC_OBS_OUT,
-                         share_obs + o * SDC_SHARE_OBS_DIM, done + o, info + o * SDC_INFO_DIM, final_obs, rew + o * 3);
+      d.actions_out = actions_out ? actions_out + o * 3 : nullptr;
+      const int rel_k = h->rel_hint >= 0 ? h->rel_hint + k : h->rel_hint;
+      if (w_common)
+        hipLaunchKernelGGL(sdc_dynamics_wide_kernel, dim3(d.sweep_blocks + N / SDC_WAVE), dim3(2 * SDC_WAVE), 0, st, d, rel_k,
+                           actions + o * 3, obs + o * SDC_OBS_OUT, share_obs + o * SDC_SHARE_OBS_DIM, done + o,
+                           info + o * SDC_INFO_DIM, final_obs, rew + o * 3);
+      else
+        hipLaunchKernelGGL(sdc_dynamics_wide_gen_kernel, dim3(d.sweep_blocks + N / SDC_WAVE), dim3(2 * SDC_WAVE), 0, st, d, rel_k,
+                           actions ? actions + o * 3 : nullptr, obs + o * SDC_OBS_OUT, share_obs + o * SDC_SHARE_OBS_DIM, done + o,
+                           info + o * SDC_INFO_DIM, final_obs, rew + o * 3);
     }
   } else {
     // (a multi-step launch has no spare wavefronts between its steps: it re-centres inline, and requests left by the

@@ -149,6 +149,26 @@ struct SdcDcDev {
   SdcRackClasses rc;
 };
 
+// THE LANE-PER-ENV KERNEL'S GENERAL FORM (sdc_wide.hip, template GEN: several configs in one batch, rule-based policies, alternate
+// reward functions of the dc / battery agents): every LANE carries its own config.  What differs between the configs of a batch the
+// kernel serves -- the rack table and the quantities sized from it and from the location (utils/make_envs_pyenv.py:139-218) -- is one
+// SdcWideCfg per config, staged into LDS by every workgroup (LDS-DMA) and read per lane; the scalars of the server / HVAC
+// characteristics (CPU and fan curves, air constants, set-point limits) must be the same bits in every config (the reference's
+// dc_config_dc{1,2,3}.json differ in their rack lists only) and stay wave-uniform.  59 doubles per config: an ODD number of 8-byte
+// words, so lanes of different configs read different LDS banks.
+#define SDC_WIDE_MAX_CLS 12    // rack classes per config (the shipped 16 / 20 / 25-rack configs: 8 / 7 / 11)
+#define SDC_WIDE_MAX_CFG 16
+enum { WC_RET_SUM = 0, WC_RC_N_RACKS, WC_CT_FAN_REF_P, WC_RC_CTAFR, WC_BAT_CAP, WC_RC_BAT_CAP, WC_SCAL_COUNT };
+struct SdcWideCfg {
+  double cls[SDC_WIDE_MAX_CLS][4];     // class c: {cpus, supply approach, full load, idle} (unused classes: zeros)
+  double scal[WC_SCAL_COUNT];          // the per-config scalars, WC_*
+  unsigned map[4];                     // rack slot r -> class: 4 bits each, slot r in bits 4 (r % 8) of map[r / 8]
+  int n_cls, n_racks;
+  double pad[2];
+};
+static_assert(sizeof(SdcWideCfg) == 59 * 8, "an odd number of 8-byte words per config");
+#define SDC_WIDE_CFG_DOUBLES 59
+
 // DEFERRED WINDOW RE-CENTRING.  A rank window that the next step could exhaust has to be re-centred with one sweep over
 // the env's 40 KB ring (sdc_ringpath.hpp qt_refill, ~5 us) -- done inline that sweep made its wavefront the straggler of
 // nearly every launch.  Instead the step that sees the need (step t) files a REQUEST with a snapshot of the window;
@@ -197,6 +217,8 @@ struct SdcDev {
   int n_cfg;
   const double* prm_env;   // [N][32] (several configs only, else null): every env's own copy of its config's scalars (P_*), so
                            // that the common-case kernels can request them WITH the record -- the config id is inside it
+  const SdcWideCfg* wcfg;  // [n_cfg] (or null: a batch the lane-per-env kernel's general form does not serve): see SdcWideCfg
+  int wide_max_cls, wide_max_racks4;   // ... the largest class count of a config; the largest rack count rounded up to four
   double rc_queue_max, rc_hist_cap;   // reciprocals of queue_max / hist_cap (see SdcDcDev)
   double queue_max_d, hist_cap_d;     // ... and the two as doubles (a uniform int -> double conversion inside the multi-step kernels' loop
                                       // is hoisted out of it and held in two VGPRs across the whole step; these stay scalar)

@@ -23,8 +23,12 @@
 // env (lane = key, the sdc_trackers.hpp primitives), all such windows of a phase fetched together; anything unusual falls back to
 // env_reward() (sdc_pairstep.hpp).
 //
-// The host picks this kernel for a lock-step, single-config, default-reward batch of a multiple of 64 envs from
-// SDC_WIDE_MIN_ENVS (sdc_capi.hip wide_case).  Reference: sustaindc_env.py:533-737 (per-block citations: sdc_pairstep.hpp).
+// The host picks this kernel for a lock-step batch of a multiple of 64 envs from SDC_WIDE_MIN_ENVS: its COMMON-CASE form (one
+// config, the caller's actions, default rewards: sdc_capi.hip wide_case) or its GENERAL form (template GEN, wide_gen_case): every
+// lane carries its own config (SdcWideCfg, staged in LDS: BASELINE configs[3]'s 16 / 20 / 25-rack mixes), the rule-based policies of
+// utils/rbc_agents.py:3-47, utils/trim_and_respond.py:8-38 and utils/base_agents.py choose actions inside the step, the dc / battery
+// agents take any of utils/reward_creator.py:154-334.  Same expressions either way: the same bits as the pair kernels.
+// Reference: sustaindc_env.py:533-737 (per-block citations: sdc_pairstep.hpp).
 // Measurements behind every choice: profiles/r5_wide_experiments.txt, r5_wide_timeline.txt.
 #include <type_traits>
 #include "sdc_pairstep.hpp"
@@ -52,11 +56,22 @@ __device__ __forceinline__ void nt_store4(float* p, const f4v v) { __builtin_non
 //               end of the dynamics its upper half holds the HAND-OVER to the reward wavefront (WideHand)
 //   hdr  16 KB  the 64 headers (reward wavefront), likewise: in its registers from its first read to the commit, the LDS meanwhile the
 //               landing place of the window-update tasks' windows; behind the commit the whole-wavefront fallback's scratch (WideLate)
-struct WideShared {
+// The GENERAL form (GEN): `row` holds the results of up to 12 rack classes (12 KB), and behind the three blocks sits the batch's
+// config table (SdcWideCfg x n_cfg <= 16: 7.4 KB) -- 51.4 KB, three workgroups per CU (49 152 envs in one dispatch round).
+template <bool GEN>
+struct WideSharedT {
   unsigned rec[WE * 64];
   unsigned row[WE * 32];
   unsigned hdr[WE * 64];
 };
+template <>
+struct WideSharedT<true> {
+  unsigned rec[WE * 64];
+  unsigned row[WE * 4 * SDC_WIDE_MAX_CLS];
+  unsigned hdr[WE * 64];
+  double cfg[SDC_WIDE_MAX_CFG * SDC_WIDE_CFG_DOUBLES];
+};
+static_assert(sizeof(WideSharedT<true>) * 3 <= 160 * 1024 && sizeof(WideSharedT<false>) * 4 == 160 * 1024, "workgroups per CU");
 static_assert(sizeof(float) * WE * SDC_OBS_OUT <= sizeof(unsigned) * (WE * 64 + WE * 16), "the obs rows are staged across `rec` and the lower half of `row`");
 // what the dynamics hand to the reward part, per env (lane): [field][lane]
 struct WideHand {
@@ -68,6 +83,11 @@ struct WideHand {
 // ages -- sits in two chunks of the lane's record image that hold no record data (the records' padding is neither loaded nor stored):
 // written before barrier 2, read by the dynamics wavefront right behind it, rewritten by nobody
 static_assert(sizeof(WideHand) <= sizeof(unsigned) * WE * 16, "the hand-over sits in the upper half of `row`");
+// ... the general form's extension, behind it (its `row` is 12 KB)
+struct WideHandGen {
+  double p_it[WE], total_kw[WE], water[WE];
+};
+static_assert(sizeof(WideHandGen) <= sizeof(unsigned) * WE * 16 && SDC_WIDE_MAX_CLS >= 12, "dwords 32 WE .. 48 WE of the general form's `row`");
 // (measurement build -DSDC_WIDE_STAMPS: lane 0 of both wavefronts stamps the wall clock (100 MHz) at the marks WST(i); the reward wavefront
 // leaves them in columns 0..15 of its first env's info row -- tools/dev/wide_timeline.py)
 #ifdef SDC_WIDE_STAMPS
@@ -151,42 +171,26 @@ __device__ __forceinline__ void block_store16(void* gbase, const unsigned* lds, 
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// pairwise (binary-tree) sum over rack slots 0..31 in slot order, streamed: push(v) for slot 0, 1, ... ; total() when done.  The tree
+// pairwise (binary-tree) sum over rack slots 0..31 in slot order, streamed four slots at a time; total() when done.  The tree
 // is half_sum_f64's (strides 1, 2, 4, 8 inside the rows, then the two rows), so the sums round as in the other mappings;
 // slots without a rack hold zeros there, which change nothing here.
 struct TreeSum32 {
-  double a1, a2, a4, a8, a16;
+  double a4, a8, a16, a32;
   int k;
-  __device__ __forceinline__ void init() { k = 0; a1 = a2 = a4 = a8 = a16 = 0.0; }
-  // (k is wave-uniform: the branches below are scalar.  Level a_m holds the sum of a complete group of m slots that still waits
-  // for its right-hand neighbour)
-  __device__ __forceinline__ void push(double v) {
-    if (k & 1) {
-      v = a1 + v;
-      if (k & 2) {
-        v = a2 + v;
-        if (k & 4) {
-          v = a4 + v;
-          if (k & 8) a16 = a8 + v;      // (slots 0..15 complete; the host keeps this kernel to <= 31 racks: bit 4 never carries)
-          else a8 = v;
-        } else {
-          a4 = v;
-        }
-      } else {
-        a2 = v;
-      }
-    } else {
-      a1 = v;
-    }
-    k++;
-  }
-  // four slots at once (k a multiple of 4): their two bottom levels are plain adds, (v0 + v1) + (v2 + v3)
+  __device__ __forceinline__ void init() { k = 0; a4 = a8 = a16 = a32 = 0.0; }
+  // four slots at once (k a multiple of 4, wave-uniform: the branches below are scalar): their two bottom levels are plain adds,
+  // (v0 + v1) + (v2 + v3).  Level a_m holds the sum of a complete group of m slots that still waits for its right-hand neighbour.
   __device__ __forceinline__ void push4(const double v0, const double v1, const double v2, const double v3) {
     double v = (v0 + v1) + (v2 + v3);
     if (k & 4) {
       v = a4 + v;
-      if (k & 8) a16 = a8 + v;
-      else a8 = v;
+      if (k & 8) {
+        v = a8 + v;
+        if (k & 16) a32 = a16 + v;      // (slots 0..31: the two rows of the half-wave reduction)
+        else a16 = v;
+      } else {
+        a8 = v;
+      }
     } else {
       a4 = v;
     }
@@ -194,11 +198,10 @@ struct TreeSum32 {
   }
   // the tree's upper levels: a count that is not a power of two leaves partial sums on several levels (lower level = later slots)
   __device__ __forceinline__ double total() const {
+    if (k & 32) return a32;
     double t = 0.0;
     bool have = false;
-    if (k & 1) { t = a1; have = true; }
-    if (k & 2) { t = have ? a2 + t : a2; have = true; }
-    if (k & 4) { t = have ? a4 + t : a4; have = true; }
+    if (k & 4) { t = a4; have = true; }
     if (k & 8) { t = have ? a8 + t : a8; have = true; }
     if (k & 16) { t = have ? a16 + t : a16; }
     return t;
@@ -245,7 +248,8 @@ __device__ __forceinline__ WideLs wide_ls_algebra(const SdcDev& S, const double 
 constexpr int WIDE_QA = 16;        // table entries ahead of the oldest task's step requested up front (two per dwordx4)
 
 // ---- the DYNAMICS wavefront of an env workgroup: lane = env ---------------------------------------------------------------------------
-__device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, const int env0, const int lane, const int rel_hint,
+template <bool GEN>
+__device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>& sh, const int env0, const int lane, const int rel_hint,
                                               const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
                                               unsigned char* __restrict__ done, float* __restrict__ final_obs) {
   using namespace sdc_rw;
@@ -253,8 +257,14 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   KLit kt{};
   WST_HOLD(wst0);
   // ---- loads: actions, state record, feature row, queue-history probes ----------------------------------------------------
-  const int32_t* ap = actions + (size_t)env * 3;
-  int a_ls = ap[0], a_dc = ap[1], a_bat = ap[2];
+  int a_ls = 1, a_dc = 1, a_bat = 2;       // (GEN: rule-based slots never read the caller's array, which may be null)
+  if (!GEN || actions) {
+    const int32_t* ap = actions + (size_t)env * 3;
+    const int t0 = ap[0], t1 = ap[1], t2 = ap[2];
+    if (!GEN || S.policy[0] == SDC_POLICY_EXTERNAL) a_ls = t0;
+    if (!GEN || S.policy[1] == SDC_POLICY_EXTERNAL) a_dc = t1;
+    if (!GEN || S.policy[2] == SDC_POLICY_EXTERNAL) a_bat = t2;
+  }
   // the config's scalars (P_*: double j in lane j) and its rack-class table (dword j in lane j % 64 of two registers), requested with
   // the first loads and read with v_readlane where they are used: wave-uniform operands, no load in the middle of the step
   const SdcDcDev& D = S.dc[0];
@@ -264,6 +274,15 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   // the wavefront's 64 records and 64 feature rows: two contiguous blocks, in through the LDS (block I/O above)
   block_load<16, WIDE_REC_CHUNKS>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane);
   block_load<8>(S.feat + feat_row_offset(S, env0, rel_hint + 1), sh.row, lane);
+  if constexpr (GEN) {
+    // the batch's config table (SdcWideCfg x n_cfg, L2-resident) into LDS: read per lane, by the lane's config id, from barrier 1 on
+    const int bytes = S.n_cfg * (int)sizeof(SdcWideCfg);
+#pragma unroll 1
+    for (int o = 0; o < bytes; o += WE * 16)
+      if (o + lane * 16 < bytes)
+        __builtin_amdgcn_global_load_lds((sdc_gptr)(reinterpret_cast<const char*>(S.wcfg) + o + lane * 16),
+                                         (sdc_lptr)(reinterpret_cast<char*>(sh.cfg) + o), 16, 0, 0);
+  }
   static_assert(R_CURSOR == 0 && R_TREL == 1 && R_DAY == 2 && R_HOURQ == 3 && R_QPOPPED == 4 && R_QCUM == 5 && R_QCUMT == 6 &&
                 R_QHEAD == 7 && R_QCUM_HM1 == 8 && R_QCUMT_HM1 == 9 && R_LAST_DELTA == 10 && R_CONSEC == 11 && R_SCALE == 12 &&
                 R_HIST_LEN == 13 && R_HIST_POS == 14 && R_FAULT == 16 && R_STPT == 24 && R_BAT == 26 && R_HIST_REF == 36 &&
@@ -283,6 +302,14 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   const uint4 r3 = block_get<16>(sh.rec, lane, 3), r4 = block_get<16>(sh.rec, lane, 4), r6 = block_get<16>(sh.rec, lane, 6);
   const uint4 r9q = block_get<16>(sh.rec, lane, 9);
   const uint2 r9 = make_uint2(r9q.x, r9q.y);
+  // GEN: the trim-and-respond counter (chunk 5), the carbon-intensity normalisation (7), last step's room temperature (10)
+  uint4 r5 = make_uint4(0u, 0u, 0u, 0u), r7 = r5, r10p = r5;
+  if constexpr (GEN) {
+    r5 = block_get<16>(sh.rec, lane, 5);
+    r7 = block_get<16>(sh.rec, lane, 7);
+    r10p = block_get<16>(sh.rec, lane, 10);
+  }
+  static_assert(R_LOC == 17 && R_CFG == 18 && R_TR_COUNT == 21 && R_CI_MIN == 28 && R_CI_DEN == 30, "record layout the GEN chunk reads assume");
   float row[SDC_FEAT_ROW];
 #pragma unroll
   for (int q = 0; q < SDC_FEAT_ROW / 4; q++) {
@@ -299,6 +326,16 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   const double stpt0 = __hiloint2double((int)r6.y, (int)r6.x);
   double bat_load = __hiloint2double((int)r6.w, (int)r6.z);
   const double href0 = __hiloint2double((int)r9.y, (int)r9.x);
+  // GEN: this lane's config (SdcWideCfg in LDS: 59 doubles per config -- an odd stride, lanes of different configs read different banks)
+  const double* wc = nullptr;
+  if constexpr (GEN) wc = &sh.cfg[0] + (int)r4.z * SDC_WIDE_CFG_DOUBLES;
+  constexpr int WC_SCAL = 4 * SDC_WIDE_MAX_CLS, WC_MAP = WC_SCAL + WC_SCAL_COUNT;
+  static_assert(offsetof(SdcWideCfg, scal) == 8 * WC_SCAL && offsetof(SdcWideCfg, map) == 8 * WC_MAP && offsetof(SdcWideCfg, n_cls) == 8 * (WC_MAP + 2), "");
+  // a per-config scalar: the lane's own (GEN) or config 0's, wave-uniform
+  auto PCFG = [&](const int wc_j, const int p_j) __attribute__((always_inline)) {
+    if constexpr (GEN) return wc[WC_SCAL + wc_j];
+    else return PRM(p_j);
+  };
 
   unsigned fault = 0;
   if (i + 9 > S.table_len - 1) fault |= SDC_FAULT_TABLE_RANGE;
@@ -338,6 +375,34 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   WST_PUT(0, wst0);
   WST_PUT(1, wst1);
   WST(2);
+  // ---- GEN: rule-based policies choose the dc / battery actions (pair_dynamics, same expressions) ------------------------------------
+  int tr_count = (int)r5.y;
+  if constexpr (GEN) {
+    if (S.policy[1] == SDC_POLICY_TRIM_AND_RESPOND) {
+      // utils/trim_and_respond.py:28-38 on the room temperature the previous step reported (dc_int_temperature)
+      const double room = __hiloint2double((int)r10p.y, (int)r10p.x);
+      if (S.tr_limit >= room) {
+        if (tr_count > 4) {        // response_duration_limit = 4
+          tr_count = 0;
+          a_dc = 2;
+        } else {
+          tr_count += 1;
+          a_dc = 1;
+        }
+      } else {
+        a_dc = 0;
+      }
+    }
+    if (S.policy[2] == SDC_POLICY_RBC) {
+      // utils/rbc_agents.py:21-47 (look_ahead 3, smooth_window 1): charge when the carbon intensity three steps ahead is above the
+      // current one, else discharge -- on the NORMALISED values the reference's agent is given (managers.py:437)
+      const int i3 = min(max(i + 3, 0), S.table_len - 1);
+      const double c3 = S.tabC[(size_t)(int)r4.y * S.table_len + i3];
+      const double cmin = __hiloint2double((int)r7.y, (int)r7.x), cden = __hiloint2double((int)r7.w, (int)r7.z);
+      a_bat = (c3 - cmin) / cden > (ci_i - cmin) / cden ? 0 : 1;
+    }
+  }
+
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 --------------------------------------------------------------------
   if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
   const int delta = a_dc - 1;
@@ -357,13 +422,62 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   // what depends on (cpus, supply approach) once per group -- the results parked per lane in LDS, and the racks' sums then take
   // every slot's class value in slot order (the half-wave reduction's tree).  Same expressions on the same inputs as a pass over
   // all racks: the same bits.
-  const int R = (int)PRM(P_N_RACKS);
   const double load_pct = util * 100;
   bool bad_delta = false;
   TreeSum32 s_out, s_pw;
   s_out.init();
   s_pw.init();
-  {
+  if constexpr (GEN) {
+    // every lane its own config: class j of the lane's config (its four parameters from the config table in LDS), for j up to the
+    // largest class count of the batch's configs; then the lane's racks in slot order, the class of slot r from the config's map
+    const uint2 ncr = *reinterpret_cast<const uint2*>(wc + WC_MAP + 2);
+    const int n_cls = (int)ncr.x, R = (int)ncr.y;
+    double* cls_pw = reinterpret_cast<double*>(sh.row);                 // [class][lane]
+    double* cls_out = cls_pw + SDC_WIDE_MAX_CLS * WE;
+    const double m_cpu = PRM(P_M_CPU), c_cpu = PRM(P_C_CPU), rs_cpu = PRM(P_RS_CPU);
+    const double m_fan = PRM(P_M_FAN), c_fan = PRM(P_C_FAN), rs_fan = PRM(P_RS_FAN);
+    const double cpu_shift = rs_cpu * KDIV(load_pct, 100), fan_shift = rs_fan * KDIV(load_pct, 20);
+    const int max_cls = S.wide_max_cls;
+#pragma unroll 2
+    for (int c = 0; c < max_cls; c++) {
+      const double r_n = wc[4 * c], r_supply = wc[4 * c + 1], r_full = wc[4 * c + 2], r_idle = wc[4 * c + 3];
+      const double sa = fmax(KC(3.8), fmin(r_supply, KC(5.3)));
+      const double inlet = sa + stpt;
+      const double ratio = ((m_cpu + KC(0.05)) * inlet + c_cpu) + cpu_shift;
+      const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
+      const double fan1 = PRM(P_ITFAN_REF_P) * (v * PRM(P_RC_ITFAN_REF_V_RATIO));
+      const double vf1 = PRM(P_IT_FAN_FULL_LOAD_V) * v;
+      const double pf = r_n * fan1;
+      const double vtot = r_n * vf1;
+      const double cpu1 = fmax(r_idle, r_full * ratio);
+      const double pc = r_n * cpu1;
+      const double pw = pc + pf;
+      const bool plain = pw > KC(1e-300) && pw < KC(1e300) && vtot > KC(1e-300) && vtot < KC(1e300);
+      const double rise = exp2_short(KC(1.096) * log2_pos_normal(plain ? pw : 1.0, kt) - KC(0.824) * log2_pos_normal(plain ? vtot : 1.0, kt), kt);
+      const double out = inlet + PRM(P_K_OUTLET) * rise + KC(-14.01);
+      if (c < n_cls && (out - inlet < 2 || !plain)) bad_delta = true;
+      cls_pw[c * WE + lane] = pw;
+      cls_out[c * WE + lane] = out;
+    }
+    wave_sync();
+    const unsigned* wmap = reinterpret_cast<const unsigned*>(wc + WC_MAP);
+    const int r_end = S.wide_max_racks4;
+#pragma unroll 2
+    for (int rk = 0; rk < r_end; rk += 4) {
+      const unsigned mw = wmap[rk >> 3] >> (4 * (rk & 7));      // (slots rk .. rk + 3: four nibbles of one map word)
+      double vp[4], vo[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool in = rk + j < R;      // (a slot beyond the lane's last rack adds the 0.0 the other mappings' idle lanes add)
+        const int c = (int)((mw >> (4 * j)) & 15u);
+        vp[j] = in ? cls_pw[c * WE + lane] : 0.0;
+        vo[j] = in ? cls_out[c * WE + lane] : 0.0;
+      }
+      s_pw.push4(vp[0], vp[1], vp[2], vp[3]);
+      s_out.push4(vo[0], vo[1], vo[2], vo[3]);
+    }
+  } else {
+    const int R = (int)PRM(P_N_RACKS);
     // the class table: dword j in lane j % 64 of two registers, entries read with v_readlane (wave-uniform operands)
     auto tab_f64 = [&](const int j) { return __hiloint2double((int)lane_key(tab0, 2 * j + 1), (int)lane_key(tab0, 2 * j)); };   // double j of the first 32
     auto tab_i32 = [&](const int j) { return (int)lane_key(tab1, j); };                                                        // int j of the second half
@@ -438,11 +552,12 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   if (bad_delta) fault |= SDC_FAULT_OUTLET_DELTA;
   const double sum_outlet = s_out.total();
   const double p_it = s_pw.total();
-  const double avg_ret = (PRM(P_RET_SUM) + sum_outlet) * PRM(P_RC_N_RACKS);
-  const double mean_outlet = sum_outlet * PRM(P_RC_N_RACKS);
+  const double rc_n_racks = PCFG(WC_RC_N_RACKS, P_RC_N_RACKS);
+  const double avg_ret = (PCFG(WC_RET_SUM, P_RET_SUM) + sum_outlet) * rc_n_racks;
+  const double mean_outlet = sum_outlet * rc_n_racks;
 
   // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 -----------------------------------------------------------------------
-  const double c_air = PRM(P_C_AIR), rho_air = PRM(P_RHO_AIR), ct_fan_ref_p = PRM(P_CT_FAN_REF_P);
+  const double c_air = PRM(P_C_AIR), rho_air = PRM(P_RHO_AIR), ct_fan_ref_p = PCFG(WC_CT_FAN_REF_P, P_CT_FAN_REF_P);
   const double m_sys = rho_air * PRM(P_CRAC_SUPPLY_PU) * p_it;
   const double q_cool = m_sys * c_air * fmax(0.0, avg_ret - stpt);
   const double comp = chiller_power(ct_fan_ref_p, q_cool, amb, kt);
@@ -451,7 +566,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
     const double dlt = fmax(50 - (amb - stpt), 1);
     const double m_air = sdc_div_fast(q_cool, c_air * dlt);
     const double v_air = m_air * PRM(P_RC_RHO_AIR);
-    const double x = fmin(v_air * PRM(P_RC_CTAFR), 1);
+    const double x = fmin(v_air * PCFG(WC_RC_CTAFR, P_RC_CTAFR), 1);
     ct = amb < 5 ? 0.0 : ct_fan_ref_p * (x * x * x);
   }
   double water;
@@ -466,13 +581,13 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   const double total_kw = KDIV(p_it + ct + comp, 1e3);
 
   // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ---------------------------------------------------
-  const double cap = PRM(P_BAT_CAP);
+  const double cap = PCFG(WC_BAT_CAP, P_BAT_CAP), rc_cap = PCFG(WC_RC_BAT_CAP, P_RC_BAT_CAP);
   const double dcload = KDIV(total_kw, 1e3);
   const double e_nobat = dcload * 1e3 * 0.25;
   double energy = e_nobat, co2;
   if (a_bat != 2) {
     const bool chg = a_bat == 0;
-    const double soc = sdc_div_const(bat_load - 0, cap - 0, PRM(P_RC_BAT_CAP));
+    const double soc = sdc_div_const(bat_load - 0, cap - 0, rc_cap);
     const double sg = 1 / (1 + exp_plain(-(10 * (soc - (chg ? 0.5 : 0.25))), kt));
     const double rate = chg ? k_round(0.5 * (1 - sg), 1e4) : fmax(0.5, 4 * sg);
     const double tu = KDIV(rate * 15, 60);
@@ -491,7 +606,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
     }
   }
   co2 = (a_bat == 1 ? fmax(energy, 0.0) : energy) * ci_i;
-  const double soc_after = sdc_div_const(bat_load, cap, PRM(P_RC_BAT_CAP));
+  const double soc_after = sdc_div_const(bat_load, cap, rc_cap);
 
   // ---- time: utils/managers.py:127-147 -------------------------------------------------------------------------------------------
   int hourq_n = hourq + 1, day_n = day;
@@ -521,6 +636,10 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
     WideHand& H = *reinterpret_cast<WideHand*>(sh.row + WE * 16);
     H.e_off[lane] = e_off; H.energy[lane] = energy; H.norm_ci[lane] = norm_ci;
     H.x_new[lane] = x_new; H.hl[lane] = hl; H.slot[lane] = slot;
+    if constexpr (GEN) {      // (inputs of the other reward functions: utils/reward_creator.py:154-334)
+      WideHandGen& G = *reinterpret_cast<WideHandGen*>(sh.row + WE * 32);
+      G.p_it[lane] = p_it; G.total_kw[lane] = total_kw; G.water[lane] = water;
+    }
   }
   __syncthreads();      // (2) the step's energy is known; so are the oldest task and the ages
   const uint4 hb0 = block_get<16>(sh.rec, lane, WIDE_REC_CHUNKS), hb1 = block_get<16>(sh.rec, lane, WIDE_REC_CHUNKS + 1);
@@ -541,6 +660,13 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
   block_put<16>(sh.rec, lane, 2, make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive));
   block_put<16>(sh.rec, lane, 3, make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, r3.w));
   block_put<16>(sh.rec, lane, 4, make_uint4(f_all, r4.y, r4.z, r4.w));
+  if constexpr (GEN) {
+    block_put<16>(sh.rec, lane, 5, make_uint4(r5.x, (unsigned)tr_count, r5.z, r5.w));
+    if (S.actions_out) {     // the actions the step applied (rule-based policies: what they chose)
+      int32_t* ao = S.actions_out + (size_t)env * 3;
+      ao[0] = a_ls; ao[1] = a_dc; ao[2] = a_bat;
+    }
+  }
   block_put<16>(sh.rec, lane, 6, make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
                                                (unsigned)__double2hiint(bat_load)));
   block_put<16>(sh.rec, lane, 9, make_uint4((unsigned)__double2loint(href), (unsigned)__double2hiint(href), r9q.z, r9q.w));
@@ -663,7 +789,8 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideShared& sh, c
 }
 
 // ---- the REWARD wavefront of an env workgroup: lane = env; whole-wavefront steps (lane = key) for what needs a window's keys ----------
-__device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, const int env0, const int lane, const int rel_hint,
+template <bool GEN>
+__device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& sh, const int env0, const int lane, const int rel_hint,
                                              const int32_t* __restrict__ actions, float* __restrict__ info, float* __restrict__ rew) {
   using namespace sdc_rw;
   const int env = env0 + lane;
@@ -674,7 +801,8 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
   const uint4 r3g = *reinterpret_cast<const uint4*>(S.rec + (size_t)env * SDC_REC_DWORDS + 12);
   static_assert(R_HIST_LEN == 13 && R_HIST_POS == 14, "dwords 1 and 2 of the record's fourth chunk");
   block_load<16>(S.hdr + (size_t)env0 * SDC_HDR_DWORDS, sh.hdr, lane);
-  int a_ls = actions[(size_t)env * 3];
+  int a_ls = 1;      // (GEN: a do-nothing ls slot never reads the caller's array, which may be null)
+  if (!GEN || (actions && S.policy[0] == SDC_POLICY_EXTERNAL)) a_ls = actions[(size_t)env * 3];
   // the step's workload straight from its feature row: the row BLOCK in LDS is the dynamics wavefront's, which parks its rack-class
   // results over it once it has read it
   const float2 wl2 = *reinterpret_cast<const float2*>(S.feat + feat_row_offset(S, env0, rel_hint + 1) + (size_t)lane * SDC_FEAT_ROW + SDC_FEAT_W);
@@ -1171,6 +1299,26 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
     double rls = foot + overdue_pen + age_pen;
     rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
     r_a[0] = rls; r_a[1] = foot; r_a[2] = foot;
+    if constexpr (GEN) {
+      // the dc / battery agents' reward functions (utils/reward_creator.py:154-334; pair_reward_fast, same expressions); the ls agent
+      // keeps default_ls_reward here (wide_gen_case)
+      const WideHandGen& G = *reinterpret_cast<const WideHandGen*>(sh.row + WE * 32);
+      const double ite_kw = SDC_DIV_CONST(G.p_it[lane], 1e3), total_kw = G.total_kw[lane], hour = (double)hourq_n * 0.25;
+#pragma unroll
+      for (int a = 1; a < 3; a++) {
+        double v;
+        switch (S.reward_method[a]) {   // wave-uniform
+          case SDC_REWARD_DEFAULT: v = foot; break;
+          case SDC_REWARD_FOOTPRINT: v = foot; break;
+          case SDC_REWARD_TOU: v = -1.0 * energy * tou_price((int)hour % 24); break;
+          case SDC_REWARD_ENERGY_EFFICIENCY: v = ite_kw / total_kw; break;
+          case SDC_REWARD_PUE: v = -fabs((ite_kw != 0 ? total_kw / ite_kw : (double)INFINITY) - 1); break;
+          case SDC_REWARD_WATER: v = -0.01 * G.water[lane]; break;
+          default: v = 0.0;   // SDC_REWARD_CUSTOM: custom_agent_reward returns 0
+        }
+        r_a[a] = v;
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 3; a++) ret_a[a] = hd_f64(H_RET + 2 * a) + r_a[a];
   }
@@ -1231,9 +1379,14 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
         unsigned hd_e = S.hdr[(size_t)env_e * SDC_HDR_DWORDS + lane];
         if (pi(touched ? 1 : 0)) put_u32(hd_e, H_VALID, 0u);
         const uint4 qw_e = reinterpret_cast<const uint4*>(S.qwin)[(size_t)env_e * SDC_WIN + lane];
+        // (ITE / total power, water: inputs of the other reward functions, which only the general form is launched with)
+        double e_pit = 0.0, e_tkw = 0.0, e_wat = 0.0;
+        if constexpr (GEN) {
+          const WideHandGen& G = *reinterpret_cast<const WideHandGen*>(sh.row + WE * 32);
+          e_pit = G.p_it[e]; e_tkw = G.total_kw[e]; e_wat = G.water[e];
+        }
         env_reward(S, env_e, lane, hd_e, qw_e, pi(hl), pi(slot), (unsigned)pi((int)x_new), (unsigned)pi((int)x_old), pf(e_off), pf(energy),
-                   pf(norm_ci), pf(oldest_norm), pi(overdue), pi(hourq_n), 0.0, 0.0, 0.0, rew,      // (ITE / total power, water: inputs of alternate reward functions, which this kernel is never launched with)
-                  
+                   pf(norm_ci), pf(oldest_norm), pi(overdue), pi(hourq_n), e_pit, e_tkw, e_wat, rew,
                    &late.back[0][0] + e * 8 - SDC_INFO_ENERGY_Z, late.tl);
       }
       wave_sync();
@@ -1275,10 +1428,10 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideShared& sh, co
 // wavefronts: wavefront 0 integrates the 64 envs' dynamics, wavefront 1 keeps their reward state -- its loads, the windows that
 // arrive, everything that does not need the step's energy run BESIDE the dynamics on another SIMD, and once the energy is handed
 // over (LDS, one barrier) the dynamics wavefront's outputs and the reward wavefront's normalisation run side by side again.
-extern "C" __global__ __launch_bounds__(2 * SDC_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) void sdc_dynamics_wide_kernel(
-    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
-    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
-  __shared__ WideShared sh;
+template <bool GEN>
+__device__ __forceinline__ void wide_kernel_body(const SdcDev& S, WideSharedT<GEN>& sh, const int rel_hint, const int32_t* __restrict__ actions,
+                                                 float* __restrict__ obs, float* __restrict__ share_obs, unsigned char* __restrict__ done,
+                                                 float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
   const int lane = threadIdx.x % SDC_WAVE;
   const int bx = (int)blockIdx.x;
@@ -1302,6 +1455,22 @@ extern "C" __global__ __launch_bounds__(2 * SDC_WAVE) __attribute__((amdgpu_wave
   const int env0 = first_pair_of_block(bx - S.sweep_blocks, nb, 1) * WE;     // (every XCD a contiguous range of envs)
   if (env0 >= S.n_envs) return;
   if (nb <= WIDE_ROOMY_WGS) __builtin_amdgcn_s_setprio(2);
-  if (wave == 0) wide_dynamics(S, sh, env0, lane, rel_hint, actions, obs, share_obs, done, final_obs);
-  else wide_rewards(S, sh, env0, lane, rel_hint, actions, info, rew);
+  if (wave == 0) wide_dynamics<GEN>(S, sh, env0, lane, rel_hint, actions, obs, share_obs, done, final_obs);
+  else wide_rewards<GEN>(S, sh, env0, lane, rel_hint, actions, info, rew);
+}
+
+extern "C" __global__ __launch_bounds__(2 * SDC_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) void sdc_dynamics_wide_kernel(
+    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
+    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+  __shared__ WideSharedT<false> sh;
+  wide_kernel_body<false>(S, sh, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
+}
+
+// ... and its GENERAL form: every lane its own config, rule-based policies, any reward function for the dc / battery agents
+// (sdc_capi.hip wide_gen_case).  51 KB of LDS: three workgroups per CU.
+extern "C" __global__ __launch_bounds__(2 * SDC_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2))) void sdc_dynamics_wide_gen_kernel(
+    SdcDev S, const int rel_hint, const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
+    unsigned char* __restrict__ done, float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+  __shared__ WideSharedT<true> sh;
+  wide_kernel_body<true>(S, sh, rel_hint, actions, obs, share_obs, done, info, final_obs, rew);
 }

@@ -50,8 +50,8 @@ def test_lane_per_env_kernel_equals_the_pair_kernel(cfg):
     acts = torch.randint(0, 3, (230, N, 3), dtype=torch.int32, generator=g).cuda()
     for t in range(230):
         _same_step(a, b, acts[t], t, cfg)
-    # (25 racks: 12 distinct racks, more than the lane-per-env kernel's class tables hold -- the host keeps that config off it)
-    assert a.last_step_kernel() == ("sdc_dynamics_wide_kernel" if cfg != "dc_config_r25.json" else "sdc_dynamics_fast_kernel")
+    # (25 racks: 11 distinct racks, more than the common-case form's class tables hold -- the kernel's general form takes that config)
+    assert a.last_step_kernel() == ("sdc_dynamics_wide_kernel" if cfg != "dc_config_r25.json" else "sdc_dynamics_wide_gen_kernel")
     assert b.last_step_kernel() == "sdc_dynamics_fast_kernel"
     for name in ("record", "hist", "qtab"):
         np.testing.assert_array_equal(a.get_state(name), b.get_state(name), err_msg=name)
