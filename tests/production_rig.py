@@ -44,7 +44,8 @@ def sample_envs(N, envs_per_wave, rng, n_random=56):
 class ProductionRig:
     """N envs on one engine in the production configuration + oracles for a sample of them."""
 
-    def __init__(self, N, debug_flags=0, mixed=False, episode_steps=120, seed=77, envs_per_wave=2, n_random=56):
+    def __init__(self, N, debug_flags=0, mixed=False, episode_steps=120, seed=77, envs_per_wave=2, n_random=56,
+                 reward_method=(0, 0, 0), policy=(0, 0, 0), trim_and_respond_limit=27.0):
         self.N, self.steps = N, episode_steps
         rng = self.rng = np.random.default_rng(seed)
         locs = MIXED_LOCATIONS if mixed else ("ny",)
@@ -54,7 +55,8 @@ class ProductionRig:
         self.params = [dc_config.size_datacenter(f, 1, traces.max_ambient_for_sizing(traces.obtain_paths(locs[li])[0]))
                        for li, f in combos]
         eng = self.eng = SdcEngine(N, episode_steps=episode_steps, auto_reset=True, seed=seed, debug_flags=debug_flags,
-                                   n_locations=len(locs), n_dc_configs=len(combos))
+                                   n_locations=len(locs), n_dc_configs=len(combos), reward_method=reward_method, policy=policy,
+                                   trim_and_respond_limit=trim_and_respond_limit)
         for li, tb in enumerate(self.tables):
             eng.set_tables(li, tb["W"], tb["C"], tb["T"], tb["WB"])
         for ci, p in enumerate(self.params):
@@ -78,7 +80,7 @@ class ProductionRig:
         self.sample = sample_envs(N, envs_per_wave, rng, n_random)
         self.orcs = {}
         for i in self.sample:
-            p = self.params[self.cfg_id[i]]
+            p = dict(self.params[self.cfg_id[i]], reward_method=tuple(int(m) for m in reward_method))
             o = po.OracleEnv(G.oracle_params_from_dict(p))
             o.e.stpt = float(p["init_setpoint"])
             o.e.hist_len = CAP

@@ -41,13 +41,13 @@ def test_quad_step_kernel_production_vs_oracle(N):
     rig.eng.close()
 
 
-def test_lane_per_env_kernel_equals_four_per_wavefront_for_every_env_16384():
+@pytest.mark.parametrize("N", [16384, 32768])
+def test_lane_per_env_kernel_equals_four_per_wavefront_for_every_env(N):
     """The oracle is run for a sample of the envs; EVERY env of the lane-per-env kernel is held to the four-envs-per-wavefront kernel
     here: two engines in the production configuration (full rings with duplicates, spread write positions, the same seed), 16 384
-    envs, 260 single steps over two auto-resets under the full load of deferred re-centrings -- every output of every env the same
-    bits (the diagnostics column aside: it says which path served the reward state)."""
+    and 32 768 envs, 260 single steps over two auto-resets under the full load of deferred re-centrings -- every output of every env
+    the same bits (the diagnostics column aside: it says which path served the reward state)."""
     import torch
-    N = 16384
     a = ProductionRig(N, debug_flags=0, episode_steps=120, seed=515, envs_per_wave=4, n_random=0)
     b = ProductionRig(N, debug_flags=4096, episode_steps=120, seed=515, envs_per_wave=4, n_random=0)
     a.eng.reset()
@@ -78,6 +78,88 @@ def test_quad_step_kernel_32768_envs_vs_oracle():
     rig.begin_all(obs)
     rig.single_steps(150)
     assert rig.eng.last_step_kernel() == "sdc_dynamics_quad_kernel" and rig.resets >= 1
+    rig.assert_ok()
+    rig.eng.close()
+
+
+def test_65536_envs_production_vs_oracle():
+    """The largest batch a rate is quoted for (`secondary.batch_scan`): 65 536 envs on the lane-per-env kernel, production
+    configuration, 150 single steps over an auto-reset; first / last wavefronts, both sides of every occupancy round and a random
+    spread sampled against the oracle."""
+    rig = ProductionRig(65536, debug_flags=0, episode_steps=120, seed=65536, envs_per_wave=4, n_random=40)
+    obs, _ = rig.eng.reset()
+    rig.begin_all(obs)
+    rig.single_steps(150)
+    print("65536 envs:", rig.worst, "reward-state paths:", rig.paths[:4], "sampled envs:", len(rig.sample))
+    assert rig.eng.last_step_kernel() == "sdc_dynamics_wide_kernel" and rig.resets >= 1
+    rig.assert_ok()
+    rig.assert_all_reward_state_paths_seen()
+    rig.eng.close()
+
+
+def test_config3_mixed_racks_32768_production():
+    """BASELINE configs[3] at the size of configs[4]: 32 768 envs, rack count 20 / 16 / 25 by env_id % 3, three locations -- nine
+    configs in every wavefront -- on the lane-per-env kernel's general form (what `secondary.mixed_racks_32768` times), full rings,
+    debug_flags = 0, 330 steps over two auto-resets vs the oracle."""
+    rig = ProductionRig(32768, debug_flags=0, mixed=True, episode_steps=120, seed=3303, envs_per_wave=4)
+    combos = {(int(rig.loc_id[i]), int(rig.cfg_id[i])) for i in rig.sample}
+    assert len(combos) == 9, combos
+    obs, _ = rig.eng.reset()
+    rig.begin_all(obs)
+    rig.single_steps(330)
+    print("mixed racks, 32768 envs:", rig.worst, "reward-state paths:", rig.paths[:4], "auto-resets:", rig.resets)
+    assert rig.eng.last_step_kernel() == "sdc_dynamics_wide_gen_kernel" and rig.resets >= 2
+    rig.assert_ok()
+    rig.assert_all_reward_state_paths_seen()
+    rig.eng.close()
+
+
+def test_policy_and_tou_rollouts_16384_on_the_general_form_vs_oracle():
+    """`sdc_rollout` with the rule-based policies (do-nothing ls agent, trim-and-respond on the CRAC set-point, RBCBatteryAgent) and
+    `tou_reward` / `water_usage_efficiency_reward` for the dc / battery agents, 16 384 envs x the configs[3] mix, full rings: K
+    launches of the lane-per-env kernel's general form per call, no action array.  The oracle steps the sampled envs under the
+    actions the policies chose (`actions_out`); the choices themselves are checked for EVERY env against the rules
+    (utils/rbc_agents.py:21-47: charge when the carbon intensity three steps ahead is above the current one;
+    utils/trim_and_respond.py:28-38 on the room temperature the previous step reported)."""
+    import torch
+    N, limit = 16384, 34.9
+    rig = ProductionRig(N, debug_flags=0, mixed=True, episode_steps=120, seed=1616, envs_per_wave=4, reward_method=(0, 3, 6),
+                        policy=(1, 3, 2), trim_and_respond_limit=limit)
+    eng = rig.eng
+    obs, _ = eng.reset()
+    rig.begin_all(obs)
+    room_prev = np.full(N, np.nan)          # dc_int_temperature of the previous step (the first step of a run reads the record's)
+    counter = np.zeros(N, np.int64)
+    ROOM = L.INFO_IDX["dc_int_temperature"]
+    n_calls = 0
+    while rig.resets < 1 or n_calls < 4:
+        k = min(40, eng.steps_to_episode_end())
+        cur = eng.get_state("cursor")
+        loc = rig.loc_id
+        out = eng.rollout_policy(k)
+        n_calls += 1
+        assert eng.last_step_kernel() == "sdc_dynamics_wide_gen_kernel"
+        A = out[5].cpu().numpy()
+        info = out[4].cpu().numpy()
+        assert (A[:, :, 0] == 1).all()
+        C = np.stack([rig.tables[li]["C"] for li in range(len(rig.tables))])
+        for t in range(k):
+            i = cur + t
+            want_bat = np.where(C[loc, np.minimum(i + 3, C.shape[1] - 1)] > C[loc, i], 0, 1)
+            assert (A[t, :, 2] == want_bat).mean() > 0.999      # (ties of the NORMALISED values aside)
+            # (the controller reads the fp64 room temperature of the record, the test the fp32 info column: envs within 1e-3 of the
+            # limit are not judged; neither is the very first step, whose "previous" temperature is the record's initial 0)
+            sure = ~np.isnan(room_prev) & (np.abs(room_prev - limit) > 1e-3)
+            want_dc = np.where(limit >= room_prev, np.where(counter > 4, 2, 1), 0)
+            assert (A[t, sure, 1] == want_dc[sure]).all()
+            counter = np.where(A[t, :, 1] == 2, 0, np.where(A[t, :, 1] == 1, counter + 1, counter))
+            room_prev = info[t, :, ROOM].astype(np.float64)
+        rig.check_rollout(torch.from_numpy(A), out)
+        if eng.steps_to_episode_end() == rig.steps:
+            rig.resets += 1
+            rig.begin_all(out[0][-1])
+    print("policy rollouts, 16384 envs:", rig.worst, "reward-state paths:", rig.paths[:4], "calls:", n_calls)
+    assert len(np.unique(A[:, :, 1])) >= 2
     rig.assert_ok()
     rig.eng.close()
 
