@@ -111,12 +111,12 @@ def csrc_hash():
 
 
 def build_engine(n_envs, episode_steps, device, seed, dc_files=("dc_config.json",), debug_flags=0, env_index_base=0,
-                 location="ny"):
+                 location="ny", **engine_kw):
     from dc_rl_amd import dc_config, traces
     from dc_rl_amd.engine import SdcEngine
     tb = traces.synthetic_tables(location, seed=0)
     eng = SdcEngine(n_envs, episode_steps=episode_steps, device=device, auto_reset=True, seed=seed,
-                    n_dc_configs=len(dc_files), debug_flags=debug_flags, env_index_base=env_index_base)
+                    n_dc_configs=len(dc_files), debug_flags=debug_flags, env_index_base=env_index_base, **engine_kw)
     eng.set_tables(0, tb["W"], tb["C"], tb["T"], tb["WB"])
     params = [dc_config.size_datacenter(f, 1, traces.max_ambient_for_sizing(location.upper())) for f in dc_files]
     for i, p in enumerate(params):
@@ -213,6 +213,40 @@ def secondary_rate(n_envs, episode_steps, location, device, timed_steps, month=N
     del pool
     torch.cuda.empty_cache()
     return out
+
+
+def policy_rollout_rate(n_envs, episode_steps, device, dc_files, timed_steps=960):
+    """`sdc_rollout` with the built-in rule-based policies on every agent slot (do-nothing ls agent, trim-and-respond, RBCBatteryAgent:
+    utils/base_agents.py, utils/trim_and_respond.py:8-38, utils/rbc_agents.py:3-47) and tou_reward for the dc agent: no action
+    array, 48 env-steps per call, rings filled to 10 000 by real steps of the same policies."""
+    import torch
+    eng, _, _ = build_engine(n_envs, episode_steps, device, seed=4322, dc_files=dc_files, policy=(1, 3, 2), reward_method=(0, 3, 0),
+                             trim_and_respond_limit=34.9)
+    eng.reset()
+    filled = 0
+    while filled < HIST_CAP + 64:
+        k = min(48, eng.steps_to_episode_end())
+        eng.rollout_policy(k, want_info=False)
+        filled += k
+    done_steps = 0
+    with no_gc():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while done_steps < timed_steps:
+            k = min(48, eng.steps_to_episode_end())
+            out = eng.rollout_policy(k)
+            done_steps += k
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    acts = torch.stack([torch.bincount(out[5][:, :, j].reshape(-1).long(), minlength=3) for j in range(3)]).cpu().tolist()
+    r = {"envs": n_envs, "kernel": eng.last_step_kernel(), "dc_configs": len(dc_files), "steps_per_call": 48,
+         "us_per_step": round(dt / done_steps * 1e6, 2), "value": round(n_envs * done_steps / dt, 1), "unit": "env-steps/s",
+         "policy": "ls do-nothing, dc trim-and-respond (limit 34.9), bat RBC; dc reward tou_reward",
+         "actions_last_call_by_slot": acts, "history_len": int(eng.get_state("hist_len").min()),
+         "faults": int((eng.info[:, 37] != 0).sum().item())}
+    eng.close()
+    torch.cuda.empty_cache()
+    return r
 
 
 def cpu_baseline(tb, params, episode_steps, budget_s=12.0):
@@ -917,6 +951,22 @@ def main():
                 sec["mixed_racks"]["vs_headline"] = round(sec["mixed_racks"]["value"] / value, 4)
             except Exception as e:
                 sec["mixed_racks"] = {"error": repr(e)}
+            MIX = ("dc_config.json", "dc_config_r16.json", "dc_config_r25.json")
+            try:
+                # ... and the same mix at the size of configs[4] (32 768 envs on one GPU): round 6, the lane-per-env kernel's general
+                # form -- every lane its own config (sdc_wide.hip GEN); parity: tests/test_gpu_production_sizes.py
+                r = secondary_rate(32768, args.episode_steps, "ny", dev, 2016, dc_files=MIX)
+                r["workload"] = "BASELINE configs[3] at 32 768 envs: mixed 16/20/25-rack dc configs by env_id % 3"
+                if not args.no_pmc:
+                    r["roofline"] = scan_roofline(32768, args.episode_steps, r["us_per_step"], args, r.get("kernel"), mixed_racks=True)
+                sec["mixed_racks_32768"] = r
+            except Exception as e:
+                sec["mixed_racks_32768"] = {"error": repr(e)}
+            try:
+                # rule-based policies inside the step + tou_reward, no action array: K launches of the general form per sdc_rollout call
+                sec["policy_rollout_16384"] = policy_rollout_rate(16384, args.episode_steps, dev, MIX)
+            except Exception as e:
+                sec["policy_rollout_16384"] = {"error": repr(e)}
             try:
                 # what an UNCHANGED single-process HARL runner gets: its per-step walk over `infos` and its buffer inserts
                 # restated around envs.step (tools/harl_loop_rate.py), NumPy in / out; env_side_share = the part of the

@@ -34,6 +34,8 @@
 // out with v_readlane.  (Struct-of-arrays would make every field of a one-wavefront-per-env kernel a separate
 // wave-uniform scalar load -- ~30 dependent cache misses per step.)
 enum SdcRec {
+  // ---- the first 128-byte line: everything a step reads or writes (the lane-per-env kernel moves this line only; round 6 -- before,
+  // the fields were in order of appearance and a step touched both lines of the record)
   R_CURSOR = 0,   // trace-table index i = day*96 + hour*4 (utils/managers.py:122)
   R_TREL,         // steps since the episode started
   R_DAY,
@@ -49,25 +51,26 @@ enum SdcRec {
   R_SCALE,
   R_HIST_LEN,
   R_HIST_POS,
-  R_EPISODE,
   R_FAULT,
-  R_LOC,          // assignment: trace-table set
-  R_CFG,          //             data-centre parameter set
-  R_DAY_LO,       //             inclusive range of the random start day
-  R_DAY_HI,
+  R_F64 = 16,     // doubles, two dwords each
+  R_STPT = 16,
+  R_BAT = 18,
+  R_HIST_REF = 20,
+  R_LAST_ROOM = 22,  // f64: dc_int_temperature the previous step reported (what the trim-and-respond policy monitors)
+  R_CFG = 24,     // assignment: data-centre parameter set
+  R_LOC,          //             trace-table set
   R_TR_COUNT,     // trim-and-respond policy: response_duration_counter (utils/trim_and_respond.py:22)
-  R_F64 = 24,     // doubles from here, two dwords each
-  R_STPT = 24,
-  R_BAT = 26,
-  R_CI_MIN = 28,
+  R_EPISODE,
+  R_CI_MIN = 28,  // f64 x 2: the episode's carbon-intensity normalisation (what the rule-based battery policy compares in)
   R_CI_DEN = 30,
-  R_T_MIN = 32,
-  R_T_DEN = 34,
-  R_HIST_REF = 36,
-  R_FEAT_OK = 38,    // 1: the episode's observation feature rows (SdcDev::feat) are valid (sdc_features.hip); cleared by
-                     // a reset (whose features kernel sets it again) and by any host write to the env's state
-  R_LAST_ROOM = 40,  // f64: dc_int_temperature the previous step reported (what the trim-and-respond policy monitors)
-  R_END = 42,
+  // ---- the second line: written by resets and host writes only
+  R_DAY_LO = 32,  // assignment: inclusive range of the random start day
+  R_DAY_HI,
+  R_FEAT_OK,      // 1: the episode's observation feature rows (SdcDev::feat) are valid (sdc_features.hip); cleared by
+                  // a reset (whose features kernel sets it again) and by any host write to the env's state
+  R_T_MIN = 36,   // f64 x 2
+  R_T_DEN = 38,
+  R_END = 40,
   SDC_REC_DWORDS = 64
 };
 

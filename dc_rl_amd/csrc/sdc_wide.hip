@@ -89,7 +89,8 @@ struct WideHandGen {
 };
 static_assert(sizeof(WideHandGen) <= sizeof(unsigned) * WE * 16 && SDC_WIDE_MAX_CLS >= 12, "dwords 32 WE .. 48 WE of the general form's `row`");
 // (measurement build -DSDC_WIDE_STAMPS: lane 0 of both wavefronts stamps the wall clock (100 MHz) at the marks WST(i); the reward wavefront
-// leaves them in columns 0..15 of its first env's info row -- tools/dev/wide_timeline.py)
+// leaves them in columns 0..23 of its first env's info row -- tools/dev/wide_timeline.py, wide_entry.py, wide_tail.py; stamp 16 = the
+// workgroup's first instruction, 17 / 19 = arriving windows served / the oldest task found)
 #ifdef SDC_WIDE_STAMPS
 #define WST(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(sh.row + WE * 16 + 896)[i] = wall_clock64(); } while (0)
 // (the first stamps are taken while the feature rows are still streaming into `row`: kept in a register, written later)
@@ -126,7 +127,10 @@ __device__ __forceinline__ void block_load(const void* gbase, unsigned* lds, con
     if (NC == CPR || c < NC) __builtin_amdgcn_global_load_lds((sdc_gptr)g, (sdc_lptr)(lds + k * WE * 4), 16, 0, 0);
   }
 }
-// a state record's used part: R_END = 42 dwords = chunks 0..10; 12 chunks = whole 64-byte sectors.  The padding is neither loaded nor stored.
+// A state record's FIRST 128-byte line (chunks 0..7) holds everything a step reads or writes (sdc_device.hpp SdcRec): that line comes
+// in; the chunks the step changes go back -- 0..5 (96 bytes: cursor .. last room temperature), the general form 0..7 (its
+// trim-and-respond counter sits in chunk 6).  The record's second line is the reset's.  Chunks 12, 13 of the LDS image: the hand-back.
+#define WIDE_REC_LOAD 8
 #define WIDE_REC_CHUNKS 12
 // window-update tasks of a step: their windows in the header block's LDS (the headers are in registers by then: wide_rewards)
 #define WIDE_TASK_OFF 512
@@ -134,7 +138,7 @@ __device__ __forceinline__ void block_load(const void* gbase, unsigned* lds, con
 #ifndef WIDE_ROOMY_WGS
 #define WIDE_ROOMY_WGS SDC_CUS      // env workgroups up to which the sweeps run BELOW the env wavefronts (one workgroup per CU: see the kernel)
 #endif
-static_assert(R_END <= WIDE_REC_CHUNKS * 4 && WIDE_REC_CHUNKS + 2 <= 16, "the record's chunks, then two for the hand-back");
+static_assert(R_CI_DEN + 2 == WIDE_REC_LOAD * 4 && WIDE_REC_LOAD <= WIDE_REC_CHUNKS && WIDE_REC_CHUNKS + 2 <= 16, "the record's first line, then two chunks for the hand-back");
 template <int CPR>
 __device__ __forceinline__ uint4 block_get(const unsigned* lds, const int e, const int c) {
   return reinterpret_cast<const uint4*>(lds)[e * CPR + ((c + e) & (CPR - 1))];
@@ -145,7 +149,8 @@ __device__ __forceinline__ void block_put(unsigned* lds, const int e, const int 
 }
 // the block back to memory in whole lines; records whose bit is set in `skip` are left alone (their env's state was written by
 // the whole-wavefront fallback)
-template <int NC = 16>      // (the first NC chunks of every record)
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+template <int NC = 16, bool NT = false>      // (the first NC chunks of every record; NT: non-temporal)
 __device__ __forceinline__ void block_store16(void* gbase, const unsigned* lds, const int lane, const unsigned long long skip) {
   // all sixteen LDS reads in flight together (a read inside each store's condition would be waited for one at a time)
   uint4 v[16];
@@ -159,7 +164,14 @@ __device__ __forceinline__ void block_store16(void* gbase, const unsigned* lds, 
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int e = 4 * k + e0, c = (l15 - e) & 15;
-      if (NC == 16 || c < NC) g[e * 16 + c] = v[k];
+      if (NC == 16 || c < NC) {
+        if (NT) {
+          const u4v t = {v[k].x, v[k].y, v[k].z, v[k].w};
+          __builtin_nontemporal_store(t, reinterpret_cast<u4v*>(g + e * 16 + c));
+        } else {
+          g[e * 16 + c] = v[k];
+        }
+      }
     }
   } else {
 #pragma unroll
@@ -251,7 +263,8 @@ constexpr int WIDE_QA = 16;        // table entries ahead of the oldest task's s
 template <bool GEN>
 __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>& sh, const int env0, const int lane, const int rel_hint,
                                               const int32_t* __restrict__ actions, float* __restrict__ obs, float* __restrict__ share_obs,
-                                              unsigned char* __restrict__ done, float* __restrict__ final_obs) {
+                                              unsigned char* __restrict__ done, float* __restrict__ final_obs,
+                                              const unsigned long long wst_top = 0ull) {
   using namespace sdc_rw;
   const int env = env0 + lane;
   KLit kt{};
@@ -272,7 +285,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   const unsigned tab0 = reinterpret_cast<const unsigned*>(&D.rc)[lane], tab1 = reinterpret_cast<const unsigned*>(&D.rc)[lane + 64];
   auto PRM = [&](const int j) { return readlane_f64(prm_l, j); };
   // the wavefront's 64 records and 64 feature rows: two contiguous blocks, in through the LDS (block I/O above)
-  block_load<16, WIDE_REC_CHUNKS>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane);
+  block_load<16, WIDE_REC_LOAD>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane);
   block_load<8>(S.feat + feat_row_offset(S, env0, rel_hint + 1), sh.row, lane);
   if constexpr (GEN) {
     // the batch's config table (SdcWideCfg x n_cfg, L2-resident) into LDS: read per lane, by the lane's config id, from barrier 1 on
@@ -285,8 +298,8 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   }
   static_assert(R_CURSOR == 0 && R_TREL == 1 && R_DAY == 2 && R_HOURQ == 3 && R_QPOPPED == 4 && R_QCUM == 5 && R_QCUMT == 6 &&
                 R_QHEAD == 7 && R_QCUM_HM1 == 8 && R_QCUMT_HM1 == 9 && R_LAST_DELTA == 10 && R_CONSEC == 11 && R_SCALE == 12 &&
-                R_HIST_LEN == 13 && R_HIST_POS == 14 && R_FAULT == 16 && R_STPT == 24 && R_BAT == 26 && R_HIST_REF == 36 &&
-                R_LAST_ROOM == 40, "record layout the chunk reads assume");
+                R_HIST_LEN == 13 && R_HIST_POS == 14 && R_FAULT == 15 && R_STPT == 16 && R_BAT == 18 && R_HIST_REF == 20 &&
+                R_LAST_ROOM == 22, "record layout the chunk reads assume");
   int cumq[5];     // cum[now - 97], cum[now - 24], cum[now - 48], cum[now - 72], cum[now - 96] (0 before the episode's start)
 #pragma unroll
   for (int s = 0; s < 5; s++) {
@@ -299,17 +312,14 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   dma_wait();
   __syncthreads();      // (1) records, feature rows and headers are in LDS
   const uint4 r0 = block_get<16>(sh.rec, lane, 0), r1 = block_get<16>(sh.rec, lane, 1), r2 = block_get<16>(sh.rec, lane, 2);
-  const uint4 r3 = block_get<16>(sh.rec, lane, 3), r4 = block_get<16>(sh.rec, lane, 4), r6 = block_get<16>(sh.rec, lane, 6);
-  const uint4 r9q = block_get<16>(sh.rec, lane, 9);
-  const uint2 r9 = make_uint2(r9q.x, r9q.y);
-  // GEN: the trim-and-respond counter (chunk 5), the carbon-intensity normalisation (7), last step's room temperature (10)
-  uint4 r5 = make_uint4(0u, 0u, 0u, 0u), r7 = r5, r10p = r5;
+  const uint4 r3 = block_get<16>(sh.rec, lane, 3), r4 = block_get<16>(sh.rec, lane, 4), r5 = block_get<16>(sh.rec, lane, 5);
+  // GEN: config, location, trim-and-respond counter (chunk 6), the carbon-intensity normalisation (7)
+  uint4 r6 = make_uint4(0u, 0u, 0u, 0u), r7 = r6;
   if constexpr (GEN) {
-    r5 = block_get<16>(sh.rec, lane, 5);
+    r6 = block_get<16>(sh.rec, lane, 6);
     r7 = block_get<16>(sh.rec, lane, 7);
-    r10p = block_get<16>(sh.rec, lane, 10);
   }
-  static_assert(R_LOC == 17 && R_CFG == 18 && R_TR_COUNT == 21 && R_CI_MIN == 28 && R_CI_DEN == 30, "record layout the GEN chunk reads assume");
+  static_assert(R_CFG == 24 && R_LOC == 25 && R_TR_COUNT == 26 && R_CI_MIN == 28 && R_CI_DEN == 30, "record layout the GEN chunk reads assume");
   float row[SDC_FEAT_ROW];
 #pragma unroll
   for (int q = 0; q < SDC_FEAT_ROW / 4; q++) {
@@ -322,13 +332,13 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   const unsigned cumT_prev = r1.z;
   int last_delta = (int)r2.z, consecutive = (int)r2.w, scale = (int)r3.x;
   int hl = (int)r3.y, hpos = (int)r3.z;
-  const unsigned fault0 = r4.x;
-  const double stpt0 = __hiloint2double((int)r6.y, (int)r6.x);
-  double bat_load = __hiloint2double((int)r6.w, (int)r6.z);
-  const double href0 = __hiloint2double((int)r9.y, (int)r9.x);
+  const unsigned fault0 = r3.w;
+  const double stpt0 = __hiloint2double((int)r4.y, (int)r4.x);
+  double bat_load = __hiloint2double((int)r4.w, (int)r4.z);
+  const double href0 = __hiloint2double((int)r5.y, (int)r5.x);
   // GEN: this lane's config (SdcWideCfg in LDS: 59 doubles per config -- an odd stride, lanes of different configs read different banks)
   const double* wc = nullptr;
-  if constexpr (GEN) wc = &sh.cfg[0] + (int)r4.z * SDC_WIDE_CFG_DOUBLES;
+  if constexpr (GEN) wc = &sh.cfg[0] + (int)r6.x * SDC_WIDE_CFG_DOUBLES;
   constexpr int WC_SCAL = 4 * SDC_WIDE_MAX_CLS, WC_MAP = WC_SCAL + WC_SCAL_COUNT;
   static_assert(offsetof(SdcWideCfg, scal) == 8 * WC_SCAL && offsetof(SdcWideCfg, map) == 8 * WC_MAP && offsetof(SdcWideCfg, n_cls) == 8 * (WC_MAP + 2), "");
   // a per-config scalar: the lane's own (GEN) or config 0's, wave-uniform
@@ -374,13 +384,14 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
 
   WST_PUT(0, wst0);
   WST_PUT(1, wst1);
+  WST_PUT(16, wst_top);      // (the workgroup's first instruction, before it has read a kernel argument)
   WST(2);
   // ---- GEN: rule-based policies choose the dc / battery actions (pair_dynamics, same expressions) ------------------------------------
-  int tr_count = (int)r5.y;
+  int tr_count = (int)r6.z;
   if constexpr (GEN) {
     if (S.policy[1] == SDC_POLICY_TRIM_AND_RESPOND) {
       // utils/trim_and_respond.py:28-38 on the room temperature the previous step reported (dc_int_temperature)
-      const double room = __hiloint2double((int)r10p.y, (int)r10p.x);
+      const double room = __hiloint2double((int)r5.w, (int)r5.z);
       if (S.tr_limit >= room) {
         if (tr_count > 4) {        // response_duration_limit = 4
           tr_count = 0;
@@ -397,7 +408,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
       // utils/rbc_agents.py:21-47 (look_ahead 3, smooth_window 1): charge when the carbon intensity three steps ahead is above the
       // current one, else discharge -- on the NORMALISED values the reference's agent is given (managers.py:437)
       const int i3 = min(max(i + 3, 0), S.table_len - 1);
-      const double c3 = S.tabC[(size_t)(int)r4.y * S.table_len + i3];
+      const double c3 = S.tabC[(size_t)(int)r6.y * S.table_len + i3];
       const double cmin = __hiloint2double((int)r7.y, (int)r7.x), cden = __hiloint2double((int)r7.w, (int)r7.z);
       a_bat = (c3 - cmin) / cden > (ci_i - cmin) / cden ? 0 : 1;
     }
@@ -658,24 +669,20 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   block_put<16>(sh.rec, lane, 0, make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n));
   block_put<16>(sh.rec, lane, 1, make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head));
   block_put<16>(sh.rec, lane, 2, make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive));
-  block_put<16>(sh.rec, lane, 3, make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, r3.w));
-  block_put<16>(sh.rec, lane, 4, make_uint4(f_all, r4.y, r4.z, r4.w));
+  block_put<16>(sh.rec, lane, 3, make_uint4((unsigned)scale, (unsigned)hl, (unsigned)hpos, f_all));
   if constexpr (GEN) {
-    block_put<16>(sh.rec, lane, 5, make_uint4(r5.x, (unsigned)tr_count, r5.z, r5.w));
+    block_put<16>(sh.rec, lane, 6, make_uint4(r6.x, r6.y, (unsigned)tr_count, r6.w));
     if (S.actions_out) {     // the actions the step applied (rule-based policies: what they chose)
       int32_t* ao = S.actions_out + (size_t)env * 3;
       ao[0] = a_ls; ao[1] = a_dc; ao[2] = a_bat;
     }
   }
-  block_put<16>(sh.rec, lane, 6, make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
+  block_put<16>(sh.rec, lane, 4, make_uint4((unsigned)__double2loint(stpt), (unsigned)__double2hiint(stpt), (unsigned)__double2loint(bat_load),
                                                (unsigned)__double2hiint(bat_load)));
-  block_put<16>(sh.rec, lane, 9, make_uint4((unsigned)__double2loint(href), (unsigned)__double2hiint(href), r9q.z, r9q.w));
-  {
-    const uint4 r10 = block_get<16>(sh.rec, lane, 10);
-    block_put<16>(sh.rec, lane, 10, make_uint4((unsigned)__double2loint(mean_outlet), (unsigned)__double2hiint(mean_outlet), r10.z, r10.w));
-  }
+  block_put<16>(sh.rec, lane, 5, make_uint4((unsigned)__double2loint(href), (unsigned)__double2hiint(href), (unsigned)__double2loint(mean_outlet),
+                                               (unsigned)__double2hiint(mean_outlet)));
   wave_sync();
-  block_store16<WIDE_REC_CHUNKS>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane, 0ull);
+  block_store16<GEN ? 8 : 6>(S.rec + (size_t)env0 * SDC_REC_DWORDS, sh.rec, lane, 0ull);
 
   WST(6);
   // ---- outputs ----------------------------------------------------------------------------------------------------------------------
@@ -971,6 +978,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
     }
   }
 
+  WST_HOLD(wst17);
   // ---- O(1) window updates, the two halves of a step's qt_update on every window: the EVICTION (the ring key this step overwrites:
   // known now) before barrier 2, in the time this wavefront would wait for the energy; the INSERTION behind it.  Per lane: a key that
   // lands below / above a window only moves its ranks.  A key that lands INSIDE a window of some env (or where the window starts /
@@ -1038,6 +1046,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
   }
 
   WST_PUT(8, wst8);
+  WST_PUT(17, wst17);
   WST(9);
 
   // ---- oldest task: smallest step hd in [head, now] with cum[hd] > popped; it only moves when tasks were popped ----------------------
@@ -1111,6 +1120,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
                                                           (unsigned)__double2loint(avg_norm), (unsigned)__double2hiint(avg_norm)));
     block_put<16>(sh.rec, lane, WIDE_REC_CHUNKS + 1, make_uint4((unsigned)head, (unsigned)cum_hm1, cumT_hm1, 0u));
   }
+  WST(19);
   __syncthreads();      // (2) the step's energy is known
   const WideHand& H = *reinterpret_cast<const WideHand*>(sh.row + WE * 16);
   const double e_off = H.e_off[lane], energy = H.energy[lane], norm_ci = H.norm_ci[lane];
@@ -1416,7 +1426,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
 #ifdef SDC_WIDE_STAMPS
   WST(15);
   __builtin_amdgcn_s_waitcnt(0);
-  if (lane < 16) info[(size_t)env0 * SDC_INFO_DIM + lane] = (float)((reinterpret_cast<unsigned long long*>(sh.row + WE * 16 + 896)[lane]) & 0xFFFFFFull);
+  if (lane < 24) info[(size_t)env0 * SDC_INFO_DIM + lane] = (float)((reinterpret_cast<unsigned long long*>(sh.row + WE * 16 + 896)[lane]) & 0xFFFFFFull);
 #endif
 }
 
@@ -1432,6 +1442,11 @@ template <bool GEN>
 __device__ __forceinline__ void wide_kernel_body(const SdcDev& S, WideSharedT<GEN>& sh, const int rel_hint, const int32_t* __restrict__ actions,
                                                  float* __restrict__ obs, float* __restrict__ share_obs, unsigned char* __restrict__ done,
                                                  float* __restrict__ info, float* __restrict__ final_obs, float* __restrict__ rew) {
+#ifdef SDC_WIDE_STAMPS
+  const unsigned long long wst_top = wall_clock64();
+#else
+  constexpr unsigned long long wst_top = 0ull;
+#endif
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
   const int lane = threadIdx.x % SDC_WAVE;
   const int bx = (int)blockIdx.x;
@@ -1455,7 +1470,7 @@ __device__ __forceinline__ void wide_kernel_body(const SdcDev& S, WideSharedT<GE
   const int env0 = first_pair_of_block(bx - S.sweep_blocks, nb, 1) * WE;     // (every XCD a contiguous range of envs)
   if (env0 >= S.n_envs) return;
   if (nb <= WIDE_ROOMY_WGS) __builtin_amdgcn_s_setprio(2);
-  if (wave == 0) wide_dynamics<GEN>(S, sh, env0, lane, rel_hint, actions, obs, share_obs, done, final_obs);
+  if (wave == 0) wide_dynamics<GEN>(S, sh, env0, lane, rel_hint, actions, obs, share_obs, done, final_obs, wst_top);
   else wide_rewards<GEN>(S, sh, env0, lane, rel_hint, actions, info, rew);
 }
 
