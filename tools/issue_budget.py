@@ -57,8 +57,8 @@ w(f"   ONE wavefront per SIMD (2048 envs): life after staging {d1_mean:.2f} -- {
 w(f"   TWO per SIMD (4096 envs): life {d_mean:.2f} each; the pair needs the SIMD's issue port for up to 2 x {q2us(any_q):.2f} = {2 * q2us(any_q):.2f} us (no two classes overlapping)")
 w(f"   and at least 2 x {q2us(valu_q):.2f} = {2 * q2us(valu_q):.2f} us (VALU alone, everything else hidden under it).  Measured {d_mean:.2f}: the second wavefront's whole {d1_mean:.2f} us")
 w(f"   of work costs the first {d_mean - d1_mean:.2f} us -- it already runs in the first one's gaps.  The two wavefronts' active cycles add up to {2 * q2us(any_q):.2f} us inside a")
-w(f"   {d_mean:.2f} us window: {(2 * q2us(any_q) / d_mean - 1) * 100:.0f} % of them overlap (a scalar / LDS instruction of one under a VALU instruction of the other) and NO cycle of the window is")
-w("   left without an instruction executing -- the SIMD's issue is saturated while both wavefronts are alive.")
+w(f"   {d_mean:.2f} us window: at least {(2 * q2us(any_q) / d_mean - 1) * 100:.0f} % of them overlap (a scalar / LDS instruction of one under a VALU instruction of the other); every further")
+w(f"   idle cycle of the window is matched by one more overlapped one.  bench.py's issue_frac ({roof['issue_frac']:.2f}) is the same sum over the WHOLE launch, ramp and tail included.")
 w("")
 w("4. What is left, and why the 4096-env kernel is frozen here")
 w(f"   * a: {a:.2f} us -- the command processor's; an EMPTY kernel of this grid launched back to back takes 2.9-4.2 us per launch")
