@@ -756,9 +756,31 @@ def main():
             one_step(i)
         prof = eng.profile_read(reset=True)
     eng.profile(0)
-    if dist_on:
-        dt = float(all_reduce(torch.tensor([dt], dtype=torch.float64, device=cdev), dist.ReduceOp.MAX).item())
     faults = int((eng.info[:, 37] != 0).sum().item())
+    # every rank's own clock, device and slowest-rank bookkeeping (so that a SCALE record explains itself): gathered as numbers
+    props = torch.cuda.get_device_properties(cdev)
+    mine = torch.tensor([float(rank), dt, ev_ms * 1e-3, float(props.multi_processor_count), props.total_memory / 2.0**30, float(faults),
+                         float(dev)], dtype=torch.float64, device=cdev)
+    per_rank = [mine.cpu()]
+    dev_names = [props.name]
+    if dist_on:
+        if backend == "nccl":
+            bufs = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(bufs, mine)
+            per_rank = [b.cpu() for b in bufs]
+        else:
+            bufs = [torch.zeros(mine.numel(), dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(bufs, mine.cpu())
+            per_rank = bufs
+        try:
+            names = [None] * world
+            dist.all_gather_object(names, f"{props.name} [{getattr(props, 'gcnArchName', '')}] on {HOSTNAME}")
+            dev_names = names
+        except Exception as e:      # (device names are a courtesy: the numbers above are the record)
+            dev_names = [f"{props.name} (gather failed: {e!r})"] * world
+        dt = float(all_reduce(torch.tensor([dt], dtype=torch.float64, device=cdev), dist.ReduceOp.MAX).item())
+    else:
+        dev_names = [f"{props.name} [{getattr(props, 'gcnArchName', '')}] on {HOSTNAME}"]
     fallbacks = [int((eng.info[:, 39] == v).sum().item()) for v in (1, 3, 2)]
     timed_steps = K * R
 
@@ -792,6 +814,13 @@ def main():
             "vs_baseline": None, "dtype": "f64 dynamics / f32 history ring + outputs", "data": "synthetic",
             "repeats": R, "timed_steps": timed_steps, "ranks_seen": ranks_seen,
             "dist_backend": (dist.get_backend() if dist_on else None),
+            # one entry per rank, from the rank's OWN clock around the same timed region (`value` uses the slowest: max over ranks)
+            "per_rank": [{"rank": int(t[0]), "value": round(N * timed_steps / float(t[1]), 1), "ms_per_step": round(float(t[1]) / timed_steps * 1e3, 5),
+                          "kernel_event_ms_per_step": round(float(t[2]) / timed_steps * 1e3, 5), "device": dev_names[i] if i < len(dev_names) else None,
+                          "device_index": int(t[6]), "compute_units": int(t[3]), "xcds": int(t[3]) // 32, "hbm_GiB": round(float(t[4]), 1),
+                          "envs": N, "faults": int(t[5])} for i, t in enumerate(per_rank)],
+            "slowest_rank": int(max(per_rank, key=lambda t: float(t[1]))[0]),
+            "sum_of_rank_values": round(sum(N * timed_steps / float(t[1]) for t in per_rank), 1),
             "block_ms_median": round(float(np.median(block_ms)), 5), "block_ms_min": round(float(block_ms.min()), 5),
             "block_ms_max": round(float(block_ms.max()), 5),
             "config": {"workload": ("4096 envs x mixed 16/20/25-rack dc configs" if args.mixed_racks else

@@ -40,6 +40,24 @@ def _bench(world, extra_env=None, self_launch=False):
     return json.loads(lines[0])
 
 
+def test_bench_line_of_eight_ranks_explains_itself():
+    """The SCALE record's line for N > 1: eight gloo ranks on the lease's one MI355X -- per-rank value / ms_per_step
+    from every rank's own clock, device name / compute units / XCD count, the slowest rank; `value` is the whole job at the SLOWEST
+    rank's time, so it cannot exceed the sum of the ranks' own values."""
+    d = _bench(8, {"SDC_DIST_BACKEND": "gloo"})
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and len(d["per_rank"]) == 8
+    assert sorted(r["rank"] for r in d["per_rank"]) == list(range(8))
+    for r in d["per_rank"]:
+        assert set(r) >= {"rank", "value", "ms_per_step", "device", "device_index", "compute_units", "xcds", "hbm_GiB", "envs", "faults"}
+        assert r["value"] > 0 and r["ms_per_step"] > 0 and r["envs"] == 256 and r["faults"] == 0
+        assert r["compute_units"] == 256 and r["xcds"] == 8 and "gfx950" in r["device"]
+    slow = max(d["per_rank"], key=lambda r: r["ms_per_step"])
+    assert d["slowest_rank"] == slow["rank"]
+    assert abs(d["ms_per_step"] - slow["ms_per_step"]) <= 1e-4 * slow["ms_per_step"] + 1e-5
+    assert d["value"] <= d["sum_of_rank_values"] * (1 + 1e-6)
+    assert d["config"]["parallelism"] == "env-shard x8" and d["scaling"] == "weak"
+
+
 def test_bench_two_ranks_on_one_gpu_gloo():
     one = _bench(1)
     two = _bench(2, {"SDC_DIST_BACKEND": "gloo"})
