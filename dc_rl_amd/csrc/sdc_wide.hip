@@ -90,7 +90,7 @@ struct WideHandGen {
 static_assert(sizeof(WideHandGen) <= sizeof(unsigned) * WE * 16 && SDC_WIDE_MAX_CLS >= 12, "dwords 32 WE .. 48 WE of the general form's `row`");
 // (measurement build -DSDC_WIDE_STAMPS: lane 0 of both wavefronts stamps the wall clock (100 MHz) at the marks WST(i); the reward wavefront
 // leaves them in columns 0..23 of its first env's info row -- tools/dev/wide_timeline.py, wide_entry.py, wide_tail.py; stamp 16 = the
-// workgroup's first instruction, 17 / 19 = arriving windows served / the oldest task found)
+// workgroup's first instruction, 18 / 17 / 19 = window keys requested / arriving windows served / the oldest task found)
 #ifdef SDC_WIDE_STAMPS
 #define WST(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(sh.row + WE * 16 + 896)[i] = wall_clock64(); } while (0)
 // (the first stamps are taken while the feature rows are still streaming into `row`: kept in a register, written later)
@@ -900,6 +900,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
       }
   }
 
+  WST_HOLD(wst18);
   // ---- rewards + reward-state upkeep (utils/reward_creator.py:16-130): pair_reward_fast, lane = env ---------------------------------
   const int n = n_step;         // history length after this step's append
   const bool has_old = x_old != KEY_NONE;
@@ -1047,6 +1048,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
 
   WST_PUT(8, wst8);
   WST_PUT(17, wst17);
+  WST_PUT(18, wst18);
   WST(9);
 
   // ---- oldest task: smallest step hd in [head, now] with cum[hd] > popped; it only moves when tasks were popped ----------------------
@@ -1447,9 +1449,18 @@ __device__ __forceinline__ void wide_kernel_body(const SdcDev& S, WideSharedT<GE
 #else
   constexpr unsigned long long wst_top = 0ull;
 #endif
+#ifndef WIDE_KTOUCH
+#define WIDE_KTOUCH 1
+#endif
+#if WIDE_KTOUCH
+  const KernargTouch ktouch = kernarg_touch();      // (every line of the kernel arguments behind ONE scalar-cache round trip: sdc_sweep.hpp)
+#endif
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / SDC_WAVE));
   const int lane = threadIdx.x % SDC_WAVE;
   const int bx = (int)blockIdx.x;
+#if WIDE_KTOUCH
+  kernarg_touch_done(ktouch);
+#endif
   // Issue priorities.  An env wavefront placed beside an ACTIVE sweep wavefront loses ~2 us of its ~12 us at the sweeps' raised
   // priority (the other kernels' choice; measured at 16 384 envs: the rack-model segment 5.6 instead of 3.7 us in the same 8 % of
   // the workgroups every launch -- and the launch ends with its slowest workgroup).  Up to one env workgroup per CU a sweep is ~5 us

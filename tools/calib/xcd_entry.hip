@@ -1,6 +1,6 @@
 // xcd_entry.hip -- when do the workgroups of BACK-TO-BACK launches of the lane-per-env kernel's shape (NB workgroups x 128 threads,
 // 40 KB of LDS, > 168 VGPRs: four workgroups per CU) enter, by XCD (workgroup b runs on XCD b % 8)?  Variants: no memory traffic / every
-// workgroup reads RD KB at entry / writes WR KB before it ends (plain or non-temporal), ~10 us of dependent arithmetic in between.
+// workgroup reads RD KB at entry / writes WR KB before it ends (plain, non-temporal, or system-scope = written through the L2: sc0 sc1), ~10 us of dependent arithmetic in between.
 // hipcc --offload-arch=gfx950 -O3 -o xcd_entry xcd_entry.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,7 +26,10 @@ __global__ __launch_bounds__(128) void shape(unsigned long long* out, float* buf
   const f4v w = {a, 1.0f, 2.0f, 3.0f};
   for (int k = 0; k < wr_kb * 1024 / 16 / 128; k++) {
     f4v* p = reinterpret_cast<f4v*>(buf + base + (size_t)(k * 128 + threadIdx.x) * 4);
-    if (NT) __builtin_nontemporal_store(w, p);
+    if (NT == 1) __builtin_nontemporal_store(w, p);
+    else if (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");      // system scope: written through the L2
+    else if (NT == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+    else if (NT == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(w) : "memory");
     else *p = w;
   }
   const unsigned long long t3 = wall_clock64();
@@ -46,10 +49,15 @@ int main(int argc, char** argv) {
   struct V { const char* name; int nt, rd, wr; } vs[] = {
     {"no traffic                      ", 0, 0, 0}, {"read 40 KB                      ", 0, 40, 0}, {"write 76 KB plain               ", 0, 0, 76},
     {"write 76 KB non-temporal        ", 1, 0, 76}, {"read 40 + write 76 KB plain     ", 0, 40, 76}, {"read 40 + write 76 KB nt        ", 1, 40, 76},
-    {"read 40 + write 16 KB plain     ", 0, 40, 16}};
+    {"read 40 + write 16 KB plain     ", 0, 40, 16},
+    {"write 76 KB sc0 sc1 (write-thru)", 2, 0, 76}, {"read 40 + write 76 KB sc0 sc1   ", 2, 40, 76}, {"read 40 + write 76 KB sc1       ", 3, 40, 76},
+    {"read 40 + write 76 KB sc0 sc1 nt", 4, 40, 76}};
   for (const V& v : vs) {
     for (int s = 0; s < L; s++) {
-      if (v.nt) hipLaunchKernelGGL(shape<1>, dim3(NB), dim3(128), 0, 0, d, buf, v.rd, v.wr, 3000, s);
+      if (v.nt == 1) hipLaunchKernelGGL(shape<1>, dim3(NB), dim3(128), 0, 0, d, buf, v.rd, v.wr, 3000, s);
+      else if (v.nt == 2) hipLaunchKernelGGL(shape<2>, dim3(NB), dim3(128), 0, 0, d, buf, v.rd, v.wr, 3000, s);
+      else if (v.nt == 3) hipLaunchKernelGGL(shape<3>, dim3(NB), dim3(128), 0, 0, d, buf, v.rd, v.wr, 3000, s);
+      else if (v.nt == 4) hipLaunchKernelGGL(shape<4>, dim3(NB), dim3(128), 0, 0, d, buf, v.rd, v.wr, 3000, s);
       else hipLaunchKernelGGL(shape<0>, dim3(NB), dim3(128), 0, 0, d, buf, v.rd, v.wr, 3000, s);
     }
     hipDeviceSynchronize();

@@ -22,7 +22,7 @@ end = T[15]
 last = end.argmax(1)
 L = np.arange(a.shape[0])
 segs = [("first instruction (after the launch's first)", None, 16), ("-> D entry (arguments read)", 16, 0), ("-> R headers in LDS, queue reads issued", 0, 8),
-        ("-> R arrivals served", 8, 17), ("-> R evictions applied", 17, 9), ("-> R oldest task found (at barrier 2)", 9, 19),
+        ("-> R header in registers, 16 window keys requested", 8, 18), ("-> R arrivals served", 18, 17), ("-> R evictions applied", 17, 9), ("-> R oldest task found (at barrier 2)", 9, 19),
         ("   D energy handed over (at barrier 2), after D entry", 0, 4), ("barrier 2 -> R insertions applied", 10, 11), ("-> R moments", 11, 12),
         ("-> R requests filed, committed", 12, 13), ("-> R header out, fallbacks", 13, 14), ("-> R info out", 14, 15)]
 print(f"N={N}, 200 launches x {a.shape[1]} workgroups: segment (us): all workgroups mean / p99 | the launch's LAST-ENDING workgroup mean / p90")
