@@ -1008,11 +1008,13 @@ def main():
                 sec["harl_unchanged_loop"] = {"error": repr(e)}
             scan = []
             # (2 048 / 8 192: two / four envs per wavefront; from 9 216: one lane per env -- sdc_wide.hip; counters at 8 192 and 32 768)
-            for n in (2048, 8192, 16384, 32768, 65536):
+            # (262 144 envs = four dispatch rounds of the lane-per-env kernel: the THROUGHPUT regime, where a workgroup's loads overlap
+            # other workgroups' arithmetic and the kernel's rate is set by the memory system; 39 GB of state)
+            for n in (2048, 8192, 16384, 32768, 65536, 262144):
                 try:
                     r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=8192 <= n <= 16384)
                     r["rate_vs_4096_envs"] = round(r["value"] / value, 4)
-                    if n in (8192, 32768) and not args.no_pmc:
+                    if n in (8192, 32768, 262144) and not args.no_pmc:
                         r["roofline"] = scan_roofline(n, args.episode_steps, r["us_per_step"], args, r.get("kernel"))
                     scan.append(r)
                 except Exception as e:

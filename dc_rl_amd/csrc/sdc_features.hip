@@ -16,21 +16,32 @@
 namespace {
 
 // np.polyfit(range(n), y, 1)[0]
+// (both quotients have compile-time divisors -- N and the sum of the squared abscissae, 5 / 17.5 / 227.5 / 408 for N = 4 / 6 / 14 / 17:
+// the correctly rounded 3-instruction form, sdc_device.hpp sdc_div_const, checked for these constants by tests/aux/div_const_check.c,
+// instead of two ~30-instruction IEEE division sequences per fit -- six per row, a sixth of the kernel's instructions)
+template <int N>
+constexpr double slope_sxx() {
+  double s = 0.0;
+  for (int i = 0; i < N; i++) s += ((double)i - 0.5 * (double)(N - 1)) * ((double)i - 0.5 * (double)(N - 1));
+  return s;
+}
 template <int N>
 __device__ __forceinline__ double slope_of(const double (&y)[N]) {
   const double xm = 0.5 * (double)(N - 1);
   double ym = 0.0;
 #pragma unroll
   for (int i = 0; i < N; i++) ym += y[i];
-  ym /= (double)N;
-  double sxy = 0.0, sxx = 0.0;
+  ym = SDC_DIV_CONST(ym, N);
+  double sxy = 0.0;
 #pragma unroll
   for (int i = 0; i < N; i++) {
     const double dx = (double)i - xm;
     sxy += dx * (y[i] - ym);
-    sxx += dx * dx;
   }
-  return sxy / sxx;
+  constexpr double sxx = slope_sxx<N>();      // (the same sum in the same order as the run-time loop it replaces: exact in fp64)
+  static_assert(N != 4 || sxx == 5.0, ""); static_assert(N != 6 || sxx == 17.5, ""); static_assert(N != 14 || sxx == 227.5, "");
+  static_assert(N != 17 || sxx == 408.0, "");
+  return sdc_div_const(sxy, sxx, 1.0 / sxx);
 }
 // NumPy's pairwise sum for n = 8 or 16 contiguous doubles
 template <int N>

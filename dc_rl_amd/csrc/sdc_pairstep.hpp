@@ -173,58 +173,23 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
 
   const bool lane0 = h == 0 && l == 0;
   SDC_AT(1, sh, lane0);
-  // ---- load shifting: envs/carbon_ls.py:172-324 ------------------------------------------------
-  // The reference keeps a deque of per-task enqueue timestamps and only ever removes a FIFO prefix
-  // (overdue `remove()` loop :225-226 and popleft :257-258).  Equivalent state: cum[t] = tasks ever
-  // enqueued up to step t of the episode, popped = tasks ever removed.  Tasks still queued that were
-  // enqueued at or before step t: max(0, cum[t] - popped).
+  // ---- load shifting: envs/carbon_ls.py:172-324 (sdc_physics.hpp ls_algebra) ------------------------------------------------
   if (wl < 0 || wl > 1) fault |= SDC_FAULT_WORKLOAD;
-  static_assert(1 - 0.2 == 0.8, "nonflex");
-  const double flex = KC(0.2);    // class default; make_ls_env never forwards flexible_load (make_envs_pyenv.py:37-41)
-  const double nonflex = KC(0.8); // 1 - flex
-  const int ns = (int)ceil(wl * nonflex * 100);
-  const int shf = (int)floor(wl * flex * 100);
   const uint2* qt = S.qtab + (size_t)envc * S.qstride;
   const int now = rel;
   const int popped0 = lrec_i32(rp, R_QPOPPED);
-  int popped = popped0;
   const int cum_prev = lrec_i32(rp, R_QCUM);
   const unsigned cumT_prev = (unsigned)lrec_i32(rp, R_QCUMT);
   auto cum_g = [&](int slot) -> int { return (int)(unsigned)__double2loint(g[slot]); };  // .x of the gathered uint2 (0 if t < 0)
-  // overdue: age > 24 h  <=>  enqueued at step <= now - 97  (carbon_ls.py:208)
-  const int overdue = max(0, cum_g(G_Q97) - popped);
-  int avail = 90 - (ns + shf);
-  int od_proc = 0;
-  if (avail > 0 && overdue > 0) od_proc = min(overdue, avail);
-  popped += od_proc;
-  avail = 90 - (ns + shf + od_proc);
-  // (selects, not branches: the two envs of a wavefront usually take different actions, and every divergent `if` costs
-  // the pair an exec-mask save / restore and a branch on top of both bodies)
-  const int qlen = cum_prev - popped;                                // queued after the overdue tasks have run
-  const bool defer = a_ls == 0, drain = a_ls == 2 && avail >= 1;
-  const int add = defer ? min(shf, S.queue_max - qlen) : 0;          // a = 0: enqueue what fits, the rest is dropped (:231-242)
-  const int dropped = defer ? shf - add : 0;
-  const int processed = drain ? min(min(shf, avail), qlen) : 0;      // a = 2: pop from the left (:244-264)
-  popped += processed;
-  const int util_tasks = od_proc + (defer ? shf - add : shf + processed);   // the flexible part of the utilisation, in tasks (a = 1: :266-268)
-  double util = KDIV((double)util_tasks, 100);
-  util += KDIV((double)ns, 100);
-  const int cum_now = cum_prev + add;
-  const unsigned cumT_now = cumT_prev + (unsigned)add * (unsigned)now;
-  const int total = cum_now - popped;
-  // age histogram, bins [0,6,12,18,24,inf] hours = [0,24,48,72,96,inf) steps (carbon_ls.py:63-73)
-  const int a24 = max(0, cum_g(G_Q24) - popped), a48 = max(0, cum_g(G_Q48) - popped);
-  const int a72 = max(0, cum_g(G_Q72) - popped), a96 = max(0, cum_g(G_Q96) - popped);
+  const LsStep ls = ls_algebra(kt, wl, a_ls, popped0, cum_prev, cumT_prev, now, S.queue_max, cum_g(G_Q97), cum_g(G_Q24), cum_g(G_Q48),
+                               cum_g(G_Q72), cum_g(G_Q96));
+  const int overdue = ls.overdue, popped = ls.popped, dropped = ls.dropped, processed = ls.processed;
+  const int cum_now = ls.cum_now, total = ls.total;
+  const unsigned cumT_now = ls.cumT_now;
+  const double util = ls_utilisation(kt, ls);
   double hist[5];
   const double den = (double)max(total, 1), rden = 1.0 / den;   // (an integer <= 1000: significand never all ones)
-  {
-    // four divisions by the same count: one reciprocal, then the exact 3-instruction form (sdc_div_const)
-    hist[0] = sdc_div_const((double)(total - a24), den, rden);
-    hist[1] = sdc_div_const((double)(a24 - a48), den, rden);
-    hist[2] = sdc_div_const((double)(a48 - a72), den, rden);
-    hist[3] = sdc_div_const((double)(a72 - a96), den, rden);
-    hist[4] = a96 > 0 ? 1.0 : 0.0;
-  }
+  ls_age_hist(ls, den, rden, hist);
   SDC_AT(2, sh, lane0);
   // oldest task: smallest step hd in [head, now] with cum[hd] > popped.  It only moves when tasks were popped
   // (or the queue was empty): then a 32-ary search over the half's lanes (<= 2 rounds) finds it and cum/cumT[hd-1]
@@ -322,22 +287,7 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
         }
       }
     }
-    if (total > 0) {
-      if (was_empty) {          // everything queued was enqueued now
-        head = now;
-        cum_hm1 = cum_prev;
-        cumT_hm1 = cumT_prev;
-      }
-      // sum of enqueue steps over the queued tasks = cumT[now] - cumT[h-1] - (popped - cum[h-1]) * h
-      const long long sum_t = (long long)cumT_now - (long long)cumT_hm1 - (long long)(popped - cum_hm1) * head;
-      const long long sum_age_steps = (long long)total * now - sum_t;
-      oldest = (double)(now - head) * 0.25;                  // hours, exact
-      avg = sdc_div_const((double)sum_age_steps * 0.25, den, rden);  // / total (> 0 here); sum(ages) is exact in the reference too
-    } else {
-      head = now;
-      cum_hm1 = cum_now;
-      cumT_hm1 = cumT_now;
-    }
+    ls_ages(ls, now, cum_prev, cumT_prev, was_empty, den, rden, head, cum_hm1, cumT_hm1, oldest, avg);
   }
   const double normq = sdc_div_const((double)total, S.queue_max_d, S.rc_queue_max);
   const double oldest_norm = KDIV(oldest, 24), avg_norm = KDIV(avg, 24);
@@ -359,62 +309,22 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     }
   }
   if (l == 0) {
-    float* inf = sh.info[h];
-    inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)wl;
-    inf[SDC_INFO_LS_SHIFTED_WORKLOAD] = (float)util;
-    inf[SDC_INFO_LS_TASKS_IN_QUEUE] = (float)total;
-    inf[SDC_INFO_LS_NORM_TASKS_IN_QUEUE] = (float)normq;
-    inf[SDC_INFO_LS_TASKS_DROPPED] = (float)dropped;
-    inf[SDC_INFO_LS_TASKS_PROCESSED] = (float)processed;
-    inf[SDC_INFO_LS_OLDEST_TASK_AGE] = (float)oldest_norm;
-    inf[SDC_INFO_LS_AVERAGE_TASK_AGE] = (float)avg_norm;
-    inf[SDC_INFO_LS_OVERDUE_PENALTY] = (float)overdue;
-    inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(util * 100);
-    inf[SDC_INFO_LS_CURRENT_HOUR] = (float)hour;
-    for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
-    inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)util;
+    const InfoLs il = {wl, util, normq, oldest_norm, avg_norm, hour, total, dropped, processed, overdue};
+    info_put_ls(sh.info[h], il, hist);
   }
 
   SDC_AT(3, sh, lane0);
   // ---- rule-based policies for agent_dc / agent_bat (sdc_config.policy; 0 = the caller's action) ----------------------
   int a_dc = a_dc_in, a_bat = a_bat_in;
   int tr_count = lrec_i32(rp, R_TR_COUNT);
-  if (!FAST && S.policy[1] == SDC_POLICY_TRIM_AND_RESPOND) {
-    // utils/trim_and_respond.py:28-38 on the room temperature the previous step reported (dc_int_temperature)
-    const double room = lrec_f64(rp, R_LAST_ROOM);
-    if (S.tr_limit >= room) {
-      if (tr_count > 4) {        // response_duration_limit = 4
-        tr_count = 0;
-        a_dc = 2;
-      } else {
-        tr_count += 1;
-        a_dc = 1;
-      }
-    } else {
-      a_dc = 0;
-    }
-  }
-  if (!FAST && S.policy[2] == SDC_POLICY_RBC) {
-    // utils/rbc_agents.py:21-47 (look_ahead 3, smooth_window 1) on [ci, ci_future] of the step's info: charge when the
-    // carbon intensity three steps ahead is above the current one, else discharge
-    // (on the NORMALISED values the reference's agent is given: managers.py:437)
-    const double cmin = lrec_f64(rp, R_CI_MIN), cden = lrec_f64(rp, R_CI_DEN);
-    a_bat = (g[G_C3] - cmin) / cden > (ci_i - cmin) / cden ? 0 : 1;
-  }
+  if (!FAST && S.policy[1] == SDC_POLICY_TRIM_AND_RESPOND) a_dc = trim_and_respond_action(S.tr_limit, lrec_f64(rp, R_LAST_ROOM), tr_count);
+  if (!FAST && S.policy[2] == SDC_POLICY_RBC) a_bat = rbc_battery_action(g[G_C3], ci_i, lrec_f64(rp, R_CI_MIN), lrec_f64(rp, R_CI_DEN));
 
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 ----------------------------------------
   if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
   const int delta = a_dc - 1;  // make_envs_pyenv.py:127-131
-  int last_delta = lrec_i32(rp, R_LAST_DELTA), consecutive = lrec_i32(rp, R_CONSEC), scale = lrec_i32(rp, R_SCALE);
-  if (last_delta != -2 && delta == last_delta && a_dc != 0) {
-    consecutive += 1;
-  } else {
-    consecutive = 1;
-    scale = 1;
-  }
-  if (consecutive > 3) scale += 1;
-  double stpt = lrec_f64(rp, R_STPT) + (double)(delta * scale);
-  stpt = fmax(fmin(stpt, pr[P_MAX_TEMP]), pr[P_MIN_TEMP]);
+  int consecutive = lrec_i32(rp, R_CONSEC), scale = lrec_i32(rp, R_SCALE);
+  const double stpt = setpoint_step(a_dc, lrec_i32(rp, R_LAST_DELTA), consecutive, scale, lrec_f64(rp, R_STPT), pr[P_MAX_TEMP], pr[P_MIN_TEMP]);
 
   SDC_AT(4, sh, lane0);
   // ---- rack model, lane = rack inside the half: envs/datacenter.py:250-317, :157-181 ------------------
@@ -426,9 +336,10 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   double outlet_a = 0.0, pw_a = 0.0;       // (16 lanes per env: the first rack pass)
   bool bad_delta = false;
   {
-    const double m_cpu = pr[P_M_CPU], c_cpu = pr[P_C_CPU], rs_cpu = pr[P_RS_CPU];
-    const double m_fan = pr[P_M_FAN], c_fan = pr[P_C_FAN], rs_fan = pr[P_RS_FAN];
-    const double cpu_shift = rs_cpu * KDIV(load_pct, 100), fan_shift = rs_fan * KDIV(load_pct, 20);
+    // (the rack's expressions: sdc_physics.hpp rack_point -- x^y as exp2(y log2 x), no library-function fallback: its ~50 constants would
+    // be materialised in front of this loop on every step)
+    const RackEnv E = {pr[P_M_CPU], pr[P_C_CPU], pr[P_M_FAN], pr[P_C_FAN], pr[P_RS_CPU] * KDIV(load_pct, 100), pr[P_RS_FAN] * KDIV(load_pct, 20),
+                       pr[P_ITFAN_REF_P], pr[P_RC_ITFAN_REF_V_RATIO], pr[P_IT_FAN_FULL_LOAD_V], pr[P_K_OUTLET]};
     auto rack = [&](const int rk, const bool valid) __attribute__((always_inline)) {
       // (four envs per wavefront: the rack's four parameters come from LDS, where the step's FIRST loads left them -- read
       // from the config in memory here they are a memory round trip in the middle of the dynamics, which a wavefront
@@ -441,31 +352,12 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
       } else {
         r_supply = P.rack_supply[rk]; r_idle = P.rack_idle[rk]; r_full = P.rack_full[rk]; r_n = P.rack_n[rk];
       }
-      const double sa = fmax(KC(3.8), fmin(r_supply, KC(5.3)));  // datacenter.py:209-215
-      const double inlet = sa + stpt;
-      const double ratio = ((m_cpu + KC(0.05)) * inlet + c_cpu) + cpu_shift;
-      const double cpu1 = fmax(r_idle, r_full * ratio);
-      const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
-      const double fan1 = pr[P_ITFAN_REF_P] * (v * pr[P_RC_ITFAN_REF_V_RATIO]);
-      const double vf1 = pr[P_IT_FAN_FULL_LOAD_V] * v;
-      const double n = r_n;
-      const double pc = n * cpu1, pf = n * fan1;
-      const double vtot = n * vf1;
-      // x^y as exp2(y log2 x): <= 5e-14 relative against the correctly rounded power (the reference's libm pow is
-      // <= 1.3e-16), eight orders below the fp32 outputs' resolution, at a fifth of the instructions of pow()
-      // ... and power^1.096 / airflow^0.824 as ONE exp2 of the difference of the two scaled logarithms
-      const double pw = pc + pf;
-      // (positive, normal, finite -- always, for a valid config.  Anything else has no outlet temperature in the
-      // reference either (a power of a negative number; datacenter.py:295-300 then raises): it is flagged like an outlet
-      // below the inlet and evaluated at 1.  No library-function fallback here: its ~50 constants would be materialised
-      // in front of this loop on every step.)
-      const bool plain = pw > KC(1e-300) && pw < KC(1e300) && vtot > KC(1e-300) && vtot < KC(1e300);
-      const double rise = exp2_short(KC(1.096) * log2_pos_normal(plain ? pw : 1.0, kt) - KC(0.824) * log2_pos_normal(plain ? vtot : 1.0, kt), kt);
-      const double out = inlet + pr[P_K_OUTLET] * rise + KC(-14.01);   // 1.918 power^1.096 / (c_air rho_air airflow^0.824 0.526) - 14.01
-      if (valid && (out - inlet < 2 || !plain)) bad_delta = true;
-      pcpu += valid ? pc : 0.0;
-      pfan += valid ? pf : 0.0;
-      outlet += valid ? out : 0.0;
+      double inlet;
+      const RackOut ro = rack_point(kt, E, r_n, r_supply, r_full, r_idle, stpt, inlet);
+      if (valid && (ro.out - inlet < 2 || !ro.plain)) bad_delta = true;
+      pcpu += valid ? ro.pc : 0.0;
+      pfan += valid ? ro.pf : 0.0;
+      outlet += valid ? ro.out : 0.0;
     };
     if constexpr (FAST && LPE == QL) {
       // 16 lanes per env: racks 0..15, then 16..31 (the sums of the two passes are reduced apart and added -- rows 1 + 0
@@ -497,61 +389,16 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   const double p_it = LPE == HL ? half_sum_f64(pcpu + pfan) : sdc_hw::row_sum_f64(pcpu + pfan) + sdc_hw::row_sum_f64(pw_a);
 
   SDC_AT(6, sh, lane0);
-  // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 ------------------------------------------
-  const double c_air = pr[P_C_AIR], rho_air = pr[P_RHO_AIR], ct_fan_ref_p = pr[P_CT_FAN_REF_P];
-  const double m_sys = rho_air * pr[P_CRAC_SUPPLY_PU] * p_it;
-  const double q_cool = m_sys * c_air * fmax(0.0, avg_ret - stpt);
-  const double comp = chiller_power(ct_fan_ref_p, q_cool, amb, kt);
-  double ct;
-  {
-    const double dlt = fmax(50 - (amb - stpt), 1);
-    const double m_air = sdc_div_fast(q_cool, c_air * dlt);
-    const double v_air = m_air * pr[P_RC_RHO_AIR];
-    const double x = fmin(v_air * pr[P_RC_CTAFR], 1);
-    ct = amb < 5 ? 0.0 : ct_fan_ref_p * (x * x * x);
-  }
-  double water;
-  {
-    const double range_temp = avg_ret - stpt;
-    const double y_int = KC(0.3528) * range_temp + KC(0.101);
-    double w = KC(0.044) * wet_bulb + y_int;
-    if (w < 0) w = 0;
-    w += w * KC(0.01);
-    water = k_round((w * 1000) / 4, 1e4);
-  }
-  const double total_kw = KDIV(p_it + ct + comp, 1e3);
+  // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 (sdc_physics.hpp hvac_water) ------------------------------------------
+  const HvacPrm HP = {pr[P_C_AIR], pr[P_RHO_AIR], pr[P_CT_FAN_REF_P], pr[P_CRAC_SUPPLY_PU], pr[P_RC_RHO_AIR], pr[P_RC_CTAFR]};
+  const HvacOut hv = hvac_water(kt, HP, p_it, avg_ret, stpt, amb, wet_bulb);
+  const double comp = hv.comp, ct = hv.ct, water = hv.water, total_kw = hv.total_kw;
 
   SDC_AT(7, sh, lane0);
-  // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ----------------------
-  // charge and discharge share one sigmoid and one division (selected operands, the reference's expressions)
-  const double cap = pr[P_BAT_CAP];
-  const double dcload = KDIV(total_kw, 1e3);  // MW (sustaindc_env.py:652)
+  // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 (sdc_physics.hpp battery_step) ----------------------
   double bat_load = lrec_f64(rp, R_BAT);
-  const double e_nobat = dcload * 1e3 * 0.25;
-  double energy = e_nobat, co2;
-  if (a_bat != 2) {
-    const bool chg = a_bat == 0;
-    const double soc = sdc_div_const(bat_load - 0, cap - 0, pr[P_RC_BAT_CAP]);
-    const double sg = 1 / (1 + exp_plain(-(10 * (soc - (chg ? 0.5 : 0.25))), kt));       // sigmoid (|argument| <= 10)
-    const double rate = chg ? k_round(0.5 * (1 - sg), 1e4) : fmax(0.5, 4 * sg);
-    const double tu = KDIV(rate * 15, 60);
-    // charge:    (1 * cap - bat_load) / ((1 * tu) - (-0.04))        discharge: (bat_load - 0 * cap) / (0.01 + (1 * tu))
-    const double quo = (chg ? cap - bat_load : bat_load) / (chg ? tu + KC(0.04) : KC(0.01) + tu);
-    if (chg) {
-      const double max_charge = fmin((cap / 1) * KC(0.1), quo);
-      const double charging_load = fmin(max_charge, cap) * 1 * tu;
-      bat_load = k_round(bat_load + charging_load, 1e8);
-      energy = e_nobat + charging_load * 1e3;
-    } else {
-      const double max_d = fmin(fmin((cap / 1) * 1, quo), dcload * 0.25);   // dcload / 4
-      bat_load = k_round(bat_load - (fmin(max_d, cap) * 1 * tu), 1e8);
-      const double discharge = max_d < cap ? max_d * tu : cap * tu;
-      if (!(e_nobat >= discharge * 1e3)) fault |= SDC_FAULT_BAT_DISCHARGE;
-      energy = e_nobat - discharge * 1e3;
-    }
-  }
-  co2 = (a_bat == 1 ? fmax(energy, 0.0) : energy) * ci_i;
-  const double soc_after = sdc_div_const(bat_load, cap, pr[P_RC_BAT_CAP]);
+  const BatOut bo = battery_step(kt, a_bat, bat_load, pr[P_BAT_CAP], pr[P_RC_BAT_CAP], total_kw, ci_i, fault);
+  const double e_nobat = bo.e_nobat, energy = bo.energy, co2 = bo.co2, soc_after = bo.soc_after;
 
   SDC_AT(8, sh, lane0);
   // ---- time: utils/managers.py:127-147 -------------------------------------------------------------
@@ -593,51 +440,17 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
   int hl = lrec_i32(rp, R_HIST_LEN), hpos = lrec_i32(rp, R_HIST_POS);
   const double href = hl == 0 ? energy : lrec_f64(rp, R_HIST_REF);
   const double e_off = energy - href;
-  int slot;
-  if (!append) {
-    slot = -1;
-  } else if (hl < S.hist_cap) {
-    slot = hl;
-    hl += 1;
-  } else {
-    slot = hpos;
-    hpos = hpos + 1 == S.hist_cap ? 0 : hpos + 1;
-  }
+  const int slot = append ? hist_append_slot(hl, hpos, S.hist_cap) : -1;
   const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
 
   SDC_AT(9, sh, lane0);
   wave_sync();     // every lane has read what it needs from the records: lane 0 of each half may now patch its record
   if (l == 0) {
     // ---- info block --------------------------------------------------------------------------------
-    float* inf = sh.info[h];
-    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)(p_it * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)(ct * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)(comp * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)((ct + comp) * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
-    inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
-    inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
-    inf[SDC_INFO_DC_INT_TEMPERATURE] = (float)mean_outlet;
-    inf[SDC_INFO_DC_EXTERIOR_AMBIENT_TEMP] = (float)amb;
-    inf[SDC_INFO_DC_WATER_USAGE] = (float)water;
-    inf[SDC_INFO_BAT_ACTION] = (float)a_bat;
-    inf[SDC_INFO_BAT_SOC] = (float)soc_after;
-    inf[SDC_INFO_BAT_CO2_FOOTPRINT] = (float)co2;
-    inf[SDC_INFO_BAT_AVG_CI] = (float)ci_i;
-    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH] = (float)e_nobat;
-    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH] = (float)energy;
-    inf[SDC_INFO_NORM_CI] = (float)norm_ci;
-    inf[SDC_INFO_OUTSIDE_TEMP] = (float)amb_next;
-    inf[SDC_INFO_DAY] = (float)day_n;
-    inf[SDC_INFO_HOUR] = (float)((double)hourq_n * 0.25);
     const unsigned f_all = (unsigned)lrec_i32(rp, R_FAULT) | fault;
-    inf[SDC_INFO_FAULT] = (float)f_all;
-    inf[SDC_INFO_ENERGY_Z] = 0.0f;       // the five columns below are filled by the reward part of the step
-    inf[SDC_INFO_RESERVED] = 0.0f;
-    inf[SDC_INFO_EP_RETURN_LS] = 0.0f;
-    inf[SDC_INFO_EP_RETURN_DC] = 0.0f;
-    inf[SDC_INFO_EP_RETURN_BAT] = 0.0f;
-    inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
+    const InfoDc id = {p_it, ct, comp, total_kw, stpt, mean_outlet, amb, water, soc_after, co2, ci_i, e_nobat, energy, norm_ci, amb_next,
+                       delta, a_bat, day_n, hourq_n, rel + 1, f_all};
+    info_put_dc(kt, sh.info[h], id);
 
     // ---- history append: the ring slot gets this step's key; the queue table this step's prefix counts ----------
     if (append) S.hist[(size_t)envc * SDC_HIST_STRIDE + slot] = x_new;
@@ -1145,24 +958,13 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   // rewards (step_rewards), per lane
   double r[3], ret[3];
   {
-    const double foot = -1.0 * (d.norm_ci * z / 0.50);
-    const double overdue_pen = -0.3 * sdc_rw::sqrt_count((double)d.overdue) + 0.3;
-    const double age_pen = -0.1 * d.oldest_norm;
-    double rls = foot + overdue_pen + age_pen;
-    rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
+    double foot, rls;
+    sdc_rw::reward_terms(z, d.norm_ci, (double)d.overdue, d.oldest_norm, foot, rls);
     const double ite_kw = SDC_DIV_CONST(d.p_it, 1e3), hour = (double)d.hourq_n * 0.25;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      double v;
-      switch (FAST ? (int)SDC_REWARD_DEFAULT : S.reward_method[a]) {   // wave-uniform
-        case SDC_REWARD_DEFAULT: v = a == 0 ? rls : foot; break;
-        case SDC_REWARD_FOOTPRINT: v = foot; break;
-        case SDC_REWARD_TOU: v = -1.0 * d.energy * tou_price((int)hour % 24); break;
-        case SDC_REWARD_ENERGY_EFFICIENCY: v = ite_kw / d.total_kw; break;
-        case SDC_REWARD_PUE: v = -fabs((ite_kw != 0 ? d.total_kw / ite_kw : (double)INFINITY) - 1); break;
-        case SDC_REWARD_WATER: v = -0.01 * d.water; break;
-        default: v = 0.0;   // SDC_REWARD_CUSTOM: custom_agent_reward returns 0
-      }
+      const double v = sdc_rw::agent_reward(FAST ? (int)SDC_REWARD_DEFAULT : S.reward_method[a], a == 0, rls, foot, d.energy, hour, ite_kw,
+                                            d.total_kw, d.water);
       r[a] = v;
       ret[a] = lrec_f64(hp, H_RET + 2 * a) + v;
     }

@@ -195,4 +195,325 @@ __device__ __forceinline__ double chiller_power(double max_cooling_cap, double l
   return oper > 0 ? power : 0.0;
 }
 
+// =====================================================================================================================================
+// THE STEP'S EXPRESSIONS, once: what sdc_pairstep.hpp (two / four envs per wavefront) and sdc_wide.hip (one lane per env) both
+// evaluate per env.  Which lane holds an env's values, where the operands come from (LDS broadcast, v_readlane, registers) and how the
+// racks are spread over lanes stays with the callers; the arithmetic -- and so the bits -- is here.  KT: the constant source (KLds / KLit).
+
+// ---- load shifting: envs/carbon_ls.py:172-324 -------------------------------------------------------------------------------------------
+// The reference keeps a deque of per-task enqueue timestamps and only ever removes a FIFO prefix (overdue `remove()` loop :225-226 and
+// popleft :257-258).  Equivalent state: cum[t] = tasks ever enqueued up to step t of the episode, popped = tasks ever removed.  Tasks
+// still queued that were enqueued at or before step t: max(0, cum[t] - popped).
+struct LsStep {
+  int ns, shf, overdue, od_proc, popped, add, dropped, processed, util_tasks, cum_now, total, a24, a48, a72, a96;
+  unsigned cumT_now;
+};
+// cum97 .. cum96: cum[now - 97], cum[now - 24], [now - 48], [now - 72], [now - 96] (0 before the episode's start)
+template <class KT>
+__device__ __forceinline__ LsStep ls_algebra(const KT kt, const double wl, const int a_ls, const int popped0, const int cum_prev, const unsigned cumT_prev,
+                                             const int now, const int queue_max, const int cum97, const int cum24, const int cum48, const int cum72,
+                                             const int cum96) {
+  LsStep o;
+  static_assert(1 - 0.2 == 0.8, "nonflex");
+  const double flex = KC(0.2);     // class default; make_ls_env never forwards flexible_load (make_envs_pyenv.py:37-41)
+  const double nonflex = KC(0.8);  // 1 - flex
+  o.ns = (int)ceil(wl * nonflex * 100);
+  o.shf = (int)floor(wl * flex * 100);
+  int popped = popped0;
+  o.overdue = max(0, cum97 - popped);       // overdue: age > 24 h  <=>  enqueued at step <= now - 97  (carbon_ls.py:208)
+  int avail = 90 - (o.ns + o.shf);
+  o.od_proc = 0;
+  if (avail > 0 && o.overdue > 0) o.od_proc = min(o.overdue, avail);
+  popped += o.od_proc;
+  avail = 90 - (o.ns + o.shf + o.od_proc);
+  // (selects, not branches: the envs of a wavefront usually take different actions)
+  const int qlen = cum_prev - popped;                                  // queued after the overdue tasks have run
+  const bool defer = a_ls == 0, drain = a_ls == 2 && avail >= 1;
+  o.add = defer ? min(o.shf, queue_max - qlen) : 0;                    // a = 0: enqueue what fits, the rest is dropped (:231-242)
+  o.dropped = defer ? o.shf - o.add : 0;
+  o.processed = drain ? min(min(o.shf, avail), qlen) : 0;              // a = 2: pop from the left (:244-264)
+  popped += o.processed;
+  o.popped = popped;
+  o.util_tasks = o.od_proc + (defer ? o.shf - o.add : o.shf + o.processed);   // the flexible part of the utilisation, in tasks (a = 1: :266-268)
+  o.cum_now = cum_prev + o.add;
+  o.cumT_now = cumT_prev + (unsigned)o.add * (unsigned)now;
+  o.total = o.cum_now - popped;
+  // age histogram, bins [0,6,12,18,24,inf] hours = [0,24,48,72,96,inf) steps (carbon_ls.py:63-73)
+  o.a24 = max(0, cum24 - popped); o.a48 = max(0, cum48 - popped);
+  o.a72 = max(0, cum72 - popped); o.a96 = max(0, cum96 - popped);
+  return o;
+}
+template <class KT>
+__device__ __forceinline__ double ls_utilisation(const KT kt, const LsStep& ls) {
+  double util = KDIV((double)ls.util_tasks, 100);
+  util += KDIV((double)ls.ns, 100);
+  return util;
+}
+// the five bins as fractions of the queue (four divisions by the same count: one reciprocal, then the exact 3-instruction form)
+__device__ __forceinline__ void ls_age_hist(const LsStep& ls, const double den, const double rden, double (&hist)[5]) {
+  hist[0] = sdc_div_const((double)(ls.total - ls.a24), den, rden);
+  hist[1] = sdc_div_const((double)(ls.a24 - ls.a48), den, rden);
+  hist[2] = sdc_div_const((double)(ls.a48 - ls.a72), den, rden);
+  hist[3] = sdc_div_const((double)(ls.a72 - ls.a96), den, rden);
+  hist[4] = ls.a96 > 0 ? 1.0 : 0.0;
+}
+// oldest / mean task age in hours once the oldest task's step `head` is known (the callers search for it their own way), and the
+// cached prefix counts in front of it.  sum of enqueue steps over the queued tasks = cumT[now] - cumT[h-1] - (popped - cum[h-1]) * h
+__device__ __forceinline__ void ls_ages(const LsStep& ls, const int now, const int cum_prev, const unsigned cumT_prev, const bool was_empty,
+                                        const double den, const double rden, int& head, int& cum_hm1, unsigned& cumT_hm1, double& oldest, double& avg) {
+  oldest = 0.0;
+  avg = 0.0;
+  if (ls.total > 0) {
+    if (was_empty) {          // everything queued was enqueued now
+      head = now;
+      cum_hm1 = cum_prev;
+      cumT_hm1 = cumT_prev;
+    }
+    const long long sum_t = (long long)ls.cumT_now - (long long)cumT_hm1 - (long long)(ls.popped - cum_hm1) * head;
+    const long long sum_age_steps = (long long)ls.total * now - sum_t;
+    oldest = (double)(now - head) * 0.25;                              // hours, exact
+    avg = sdc_div_const((double)sum_age_steps * 0.25, den, rden);      // / total (> 0 here); sum(ages) is exact in the reference too
+  } else {
+    head = now;
+    cum_hm1 = ls.cum_now;
+    cumT_hm1 = ls.cumT_now;
+  }
+}
+
+// ---- rule-based policies (sdc_config.policy) ---------------------------------------------------------------------------------------------
+// utils/trim_and_respond.py:28-38 on the room temperature the previous step reported (dc_int_temperature); response_duration_limit = 4
+__device__ __forceinline__ int trim_and_respond_action(const double tr_limit, const double room, int& tr_count) {
+  int a_dc;
+  if (tr_limit >= room) {
+    if (tr_count > 4) {
+      tr_count = 0;
+      a_dc = 2;
+    } else {
+      tr_count += 1;
+      a_dc = 1;
+    }
+  } else {
+    a_dc = 0;
+  }
+  return a_dc;
+}
+// utils/rbc_agents.py:21-47 (look_ahead 3, smooth_window 1) on [ci, ci_future] of the step's info: charge when the carbon intensity three
+// steps ahead is above the current one, else discharge (on the NORMALISED values the reference's agent is given: managers.py:437)
+__device__ __forceinline__ int rbc_battery_action(const double ci_3, const double ci_now, const double cmin, const double cden) {
+  return (ci_3 - cmin) / cden > (ci_now - cmin) / cden ? 0 : 1;
+}
+
+// ---- CRAC set-point integrator: envs/dc_gym.py:160-174 (delta = a_dc - 1: make_envs_pyenv.py:127-131) -----------------------------------
+__device__ __forceinline__ double setpoint_step(const int a_dc, const int last_delta, int& consecutive, int& scale, const double stpt0,
+                                                const double max_temp, const double min_temp) {
+  const int delta = a_dc - 1;
+  if (last_delta != -2 && delta == last_delta && a_dc != 0) {
+    consecutive += 1;
+  } else {
+    consecutive = 1;
+    scale = 1;
+  }
+  if (consecutive > 3) scale += 1;
+  const double stpt = stpt0 + (double)(delta * scale);
+  return fmax(fmin(stpt, max_temp), min_temp);
+}
+
+// ---- rack model: envs/datacenter.py:250-317, :157-181 -------------------------------------------------------------------------------------
+// the part of a rack that depends on (number of CPUs, supply approach temperature) and the env's set-point / load only
+struct RackAir {
+  double inlet, ratio, pf, vtot;      // inlet temperature, CPU power ratio, the rack's fan power, its air volume flow
+};
+struct RackEnv {                       // per env and step: the config's curve parameters and the load's shifts
+  double m_cpu, c_cpu, m_fan, c_fan, cpu_shift, fan_shift, itfan_ref_p, rc_itfan_ref_v_ratio, it_fan_full_load_v, k_outlet;
+};
+template <class KT>
+__device__ __forceinline__ RackAir rack_air(const KT kt, const RackEnv& E, const double r_n, const double r_supply, const double stpt) {
+  RackAir a;
+  const double sa = fmax(KC(3.8), fmin(r_supply, KC(5.3)));  // datacenter.py:209-215
+  a.inlet = sa + stpt;
+  a.ratio = ((E.m_cpu + KC(0.05)) * a.inlet + E.c_cpu) + E.cpu_shift;
+  const double v = (E.m_fan * 10 * a.inlet + E.c_fan * 5) + E.fan_shift;
+  const double fan1 = E.itfan_ref_p * (v * E.rc_itfan_ref_v_ratio);
+  const double vf1 = E.it_fan_full_load_v * v;
+  a.pf = r_n * fan1;
+  a.vtot = r_n * vf1;
+  return a;
+}
+__device__ __forceinline__ double rack_cpu_power(const RackAir& a, const double r_n, const double r_full, const double r_idle) {
+  const double cpu1 = fmax(r_idle, r_full * a.ratio);
+  return r_n * cpu1;
+}
+// positive, normal, finite -- always, for a valid config.  Anything else has no outlet temperature in the reference either (a power of a
+// negative number; datacenter.py:295-300 then raises): it is flagged like an outlet below the inlet and evaluated at 1.
+template <class KT>
+__device__ __forceinline__ bool rack_plain(const KT kt, const double x) { return x > KC(1e-300) && x < KC(1e300); }
+// outlet temperature from the two logarithms: x^y as exp2(y log2 x) (<= 5e-14 relative against the correctly rounded power, eight orders
+// below the fp32 outputs' resolution), power^1.096 / airflow^0.824 as ONE exp2 of the difference of the two scaled logarithms:
+// 1.918 power^1.096 / (c_air rho_air airflow^0.824 0.526) - 14.01
+template <class KT>
+__device__ __forceinline__ double rack_outlet(const KT kt, const RackEnv& E, const double inlet, const double l2_power, const double l2_airflow) {
+  const double rise = exp2_short(KC(1.096) * l2_power - KC(0.824) * l2_airflow, kt);
+  return inlet + E.k_outlet * rise + KC(-14.01);
+}
+// one rack, everything: {cpu power, fan power, outlet temperature, plain}
+struct RackOut {
+  double pc, pf, out;
+  bool plain;
+};
+template <class KT>
+__device__ __forceinline__ RackOut rack_point(const KT kt, const RackEnv& E, const double r_n, const double r_supply, const double r_full,
+                                              const double r_idle, const double stpt, double& inlet) {
+  const RackAir a = rack_air(kt, E, r_n, r_supply, stpt);
+  RackOut o;
+  o.pc = rack_cpu_power(a, r_n, r_full, r_idle);
+  o.pf = a.pf;
+  const double pw = o.pc + o.pf;
+  o.plain = rack_plain(kt, pw) && rack_plain(kt, a.vtot);
+  o.out = rack_outlet(kt, E, a.inlet, log2_pos_normal(o.plain ? pw : 1.0, kt), log2_pos_normal(o.plain ? a.vtot : 1.0, kt));
+  inlet = a.inlet;
+  return o;
+}
+
+// ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 -------------------------------------------------------------------------------------
+struct HvacPrm {
+  double c_air, rho_air, ct_fan_ref_p, crac_supply_pu, rc_rho_air, rc_ctafr;
+};
+struct HvacOut {
+  double comp, ct, water, total_kw;
+};
+template <class KT>
+__device__ __forceinline__ HvacOut hvac_water(const KT kt, const HvacPrm& P, const double p_it, const double avg_ret, const double stpt,
+                                              const double amb, const double wet_bulb) {
+  HvacOut o;
+  const double m_sys = P.rho_air * P.crac_supply_pu * p_it;
+  const double q_cool = m_sys * P.c_air * fmax(0.0, avg_ret - stpt);
+  o.comp = chiller_power(P.ct_fan_ref_p, q_cool, amb, kt);
+  {
+    const double dlt = fmax(50 - (amb - stpt), 1);
+    const double m_air = sdc_div_fast(q_cool, P.c_air * dlt);
+    const double v_air = m_air * P.rc_rho_air;
+    const double x = fmin(v_air * P.rc_ctafr, 1);
+    o.ct = amb < 5 ? 0.0 : P.ct_fan_ref_p * (x * x * x);
+  }
+  {
+    const double range_temp = avg_ret - stpt;
+    const double y_int = KC(0.3528) * range_temp + KC(0.101);
+    double w = KC(0.044) * wet_bulb + y_int;
+    if (w < 0) w = 0;
+    w += w * KC(0.01);
+    o.water = k_round((w * 1000) / 4, 1e4);
+  }
+  o.total_kw = KDIV(p_it + o.ct + o.comp, 1e3);
+  return o;
+}
+
+// ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 --------------------------------------------------------------
+// charge and discharge share one sigmoid and one division (selected operands, the reference's expressions)
+struct BatOut {
+  double e_nobat, energy, co2, soc_after;
+};
+template <class KT>
+__device__ __forceinline__ BatOut battery_step(const KT kt, const int a_bat, double& bat_load, const double cap, const double rc_cap,
+                                               const double total_kw, const double ci_i, unsigned& fault) {
+  BatOut o;
+  const double dcload = KDIV(total_kw, 1e3);  // MW (sustaindc_env.py:652)
+  o.e_nobat = dcload * 1e3 * 0.25;
+  o.energy = o.e_nobat;
+  if (a_bat != 2) {
+    const bool chg = a_bat == 0;
+    const double soc = sdc_div_const(bat_load - 0, cap - 0, rc_cap);
+    const double sg = 1 / (1 + exp_plain(-(10 * (soc - (chg ? 0.5 : 0.25))), kt));       // sigmoid (|argument| <= 10)
+    const double rate = chg ? k_round(0.5 * (1 - sg), 1e4) : fmax(0.5, 4 * sg);
+    const double tu = KDIV(rate * 15, 60);
+    // charge:    (1 * cap - bat_load) / ((1 * tu) - (-0.04))        discharge: (bat_load - 0 * cap) / (0.01 + (1 * tu))
+    const double quo = (chg ? cap - bat_load : bat_load) / (chg ? tu + KC(0.04) : KC(0.01) + tu);
+    if (chg) {
+      const double max_charge = fmin((cap / 1) * KC(0.1), quo);
+      const double charging_load = fmin(max_charge, cap) * 1 * tu;
+      bat_load = k_round(bat_load + charging_load, 1e8);
+      o.energy = o.e_nobat + charging_load * 1e3;
+    } else {
+      const double max_d = fmin(fmin((cap / 1) * 1, quo), dcload * 0.25);   // dcload / 4
+      bat_load = k_round(bat_load - (fmin(max_d, cap) * 1 * tu), 1e8);
+      const double discharge = max_d < cap ? max_d * tu : cap * tu;
+      if (!(o.e_nobat >= discharge * 1e3)) fault |= SDC_FAULT_BAT_DISCHARGE;
+      o.energy = o.e_nobat - discharge * 1e3;
+    }
+  }
+  o.co2 = (a_bat == 1 ? fmax(o.energy, 0.0) : o.energy) * ci_i;
+  o.soc_after = sdc_div_const(bat_load, cap, rc_cap);
+  return o;
+}
+
+// ---- history append (utils/reward_creator.py:7-14): the ring slot this step's value goes to ------------------------------------------------
+__device__ __forceinline__ int hist_append_slot(int& hl, int& hpos, const int hist_cap) {
+  int slot;
+  if (hl < hist_cap) {
+    slot = hl;
+    hl += 1;
+  } else {
+    slot = hpos;
+    hpos = hpos + 1 == hist_cap ? 0 : hpos + 1;
+  }
+  return slot;
+}
+
+// ---- the info row's entries (sustaindc_env.py:600-700 common info; SDC_INFO_*), into whatever `inf` indexes -------------------------------
+struct InfoLs {
+  double wl, util, normq, oldest_norm, avg_norm, hour;
+  int total, dropped, processed, overdue;
+};
+template <class ROW>
+__device__ __forceinline__ void info_put_ls(ROW&& inf, const InfoLs& v, const double (&hist)[5]) {
+  inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)v.wl;
+  inf[SDC_INFO_LS_SHIFTED_WORKLOAD] = (float)v.util;
+  inf[SDC_INFO_LS_TASKS_IN_QUEUE] = (float)v.total;
+  inf[SDC_INFO_LS_NORM_TASKS_IN_QUEUE] = (float)v.normq;
+  inf[SDC_INFO_LS_TASKS_DROPPED] = (float)v.dropped;
+  inf[SDC_INFO_LS_TASKS_PROCESSED] = (float)v.processed;
+  inf[SDC_INFO_LS_OLDEST_TASK_AGE] = (float)v.oldest_norm;
+  inf[SDC_INFO_LS_AVERAGE_TASK_AGE] = (float)v.avg_norm;
+  inf[SDC_INFO_LS_OVERDUE_PENALTY] = (float)v.overdue;
+  inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(v.util * 100);
+  inf[SDC_INFO_LS_CURRENT_HOUR] = (float)v.hour;
+#pragma unroll
+  for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
+  inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)v.util;
+}
+struct InfoDc {
+  double p_it, ct, comp, total_kw, stpt, mean_outlet, amb, water, soc_after, co2, ci_i, e_nobat, energy, norm_ci, amb_next;
+  int delta, a_bat, day_n, hourq_n, rel_next;
+  unsigned fault;
+};
+template <class KT, class ROW>
+__device__ __forceinline__ void info_put_dc(const KT kt, ROW&& inf, const InfoDc& v) {
+  inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)(v.p_it * KC(1.0 / 1e3));
+  inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)(v.ct * KC(1.0 / 1e3));
+  inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)(v.comp * KC(1.0 / 1e3));
+  inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)((v.ct + v.comp) * KC(1.0 / 1e3));
+  inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)v.total_kw;
+  inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)v.delta;
+  inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)v.stpt;
+  inf[SDC_INFO_DC_INT_TEMPERATURE] = (float)v.mean_outlet;
+  inf[SDC_INFO_DC_EXTERIOR_AMBIENT_TEMP] = (float)v.amb;
+  inf[SDC_INFO_DC_WATER_USAGE] = (float)v.water;
+  inf[SDC_INFO_BAT_ACTION] = (float)v.a_bat;
+  inf[SDC_INFO_BAT_SOC] = (float)v.soc_after;
+  inf[SDC_INFO_BAT_CO2_FOOTPRINT] = (float)v.co2;
+  inf[SDC_INFO_BAT_AVG_CI] = (float)v.ci_i;
+  inf[SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH] = (float)v.e_nobat;
+  inf[SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH] = (float)v.energy;
+  inf[SDC_INFO_NORM_CI] = (float)v.norm_ci;
+  inf[SDC_INFO_OUTSIDE_TEMP] = (float)v.amb_next;
+  inf[SDC_INFO_DAY] = (float)v.day_n;
+  inf[SDC_INFO_HOUR] = (float)((double)v.hourq_n * 0.25);
+  inf[SDC_INFO_FAULT] = (float)v.fault;
+  inf[SDC_INFO_ENERGY_Z] = 0.0f;       // the five columns below are filled by the reward part of the step
+  inf[SDC_INFO_RESERVED] = 0.0f;
+  inf[SDC_INFO_EP_RETURN_LS] = 0.0f;
+  inf[SDC_INFO_EP_RETURN_DC] = 0.0f;
+  inf[SDC_INFO_EP_RETURN_BAT] = 0.0f;
+  inf[SDC_INFO_EPISODE_STEP] = (float)v.rel_next;
+}
+
 }  // namespace

@@ -274,25 +274,45 @@ struct Rewards {
 __device__ __forceinline__ double tou_price(const int h) {   // reward_creator.py:166-189
   return h < 6 ? 0.25 : (h < 11 ? 0.41 : (h < 16 ? 0.30 : (h < 22 ? 0.27 : 0.25)));
 }
-__device__ __forceinline__ Rewards step_rewards(const RewardIn& in, const int (&method)[3], const unsigned hd0) {
-  const double foot = -1.0 * (in.norm_ci_next * in.z / 0.50);
-  const double overdue_pen = -0.3 * sqrt_count(in.overdue) + 0.3;
-  const double age_pen = cold_f64<0xBFB99999u, 0x9999999Au>() * in.oldest_norm;   // -0.1 (this is the whole-wavefront fallback: cold)
-  double rls = foot + overdue_pen + age_pen;
+// The agents' rewards, once for every mapping of the step (utils/reward_creator.py): the footprint term and default_ls_reward (:48-130),
+// then one agent slot's reward by its configured method (:154-334).  COLD: the whole-wavefront fallback's copy -- its two non-inline
+// literals are built where they are used instead of being held in registers across the step.
+template <bool COLD = false>
+__device__ __forceinline__ void reward_terms(const double z, const double norm_ci_next, const double overdue, const double oldest_norm,
+                                             double& foot, double& rls) {
+  foot = -1.0 * (norm_ci_next * z / 0.50);
+  const double overdue_pen = -0.3 * sqrt_count(overdue) + 0.3;
+  double age_pen;
+  if constexpr (COLD) age_pen = cold_f64<0xBFB99999u, 0x9999999Au>() * oldest_norm;   // -0.1
+  else age_pen = -0.1 * oldest_norm;
+  rls = foot + overdue_pen + age_pen;
   rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
+}
+template <bool COLD = false>
+__device__ __forceinline__ double agent_reward(const int method, const bool ls_slot, const double rls, const double foot, const double energy_kwh,
+                                               const double hour, const double ite_kw, const double total_kw, const double water) {
+  double r;
+  switch (method) {   // wave-uniform
+    case SDC_REWARD_DEFAULT: r = ls_slot ? rls : foot; break;
+    case SDC_REWARD_FOOTPRINT: r = foot; break;
+    case SDC_REWARD_TOU: r = -1.0 * energy_kwh * tou_price((int)hour % 24); break;
+    case SDC_REWARD_ENERGY_EFFICIENCY: r = ite_kw / total_kw; break;
+    case SDC_REWARD_PUE: r = -fabs((ite_kw != 0 ? total_kw / ite_kw : (double)INFINITY) - 1); break;
+    case SDC_REWARD_WATER:
+      if constexpr (COLD) r = cold_f64<0xBF847AE1u, 0x47AE147Bu>() * water;   // -0.01
+      else r = -0.01 * water;
+      break;
+    default: r = 0.0;   // SDC_REWARD_CUSTOM: custom_agent_reward returns 0
+  }
+  return r;
+}
+__device__ __forceinline__ Rewards step_rewards(const RewardIn& in, const int (&method)[3], const unsigned hd0) {
+  double foot, rls;
+  reward_terms<true>(in.z, in.norm_ci_next, in.overdue, in.oldest_norm, foot, rls);
   Rewards o;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    double r;
-    switch (method[a]) {   // wave-uniform
-      case SDC_REWARD_DEFAULT: r = a == 0 ? rls : foot; break;
-      case SDC_REWARD_FOOTPRINT: r = foot; break;
-      case SDC_REWARD_TOU: r = -1.0 * in.energy_kwh * tou_price((int)in.hour % 24); break;
-      case SDC_REWARD_ENERGY_EFFICIENCY: r = in.ite_kw / in.total_kw; break;
-      case SDC_REWARD_PUE: r = -fabs((in.ite_kw != 0 ? in.total_kw / in.ite_kw : (double)INFINITY) - 1); break;
-      case SDC_REWARD_WATER: r = cold_f64<0xBF847AE1u, 0x47AE147Bu>() * in.water; break;   // -0.01
-      default: r = 0.0;   // SDC_REWARD_CUSTOM: custom_agent_reward returns 0
-    }
+    const double r = agent_reward<true>(method[a], a == 0, rls, foot, in.energy_kwh, in.hour, in.ite_kw, in.total_kw, in.water);
     o.r[a] = r;
     o.ret[a] = rec_f64(hd0, H_RET + 2 * a) + r;
   }

@@ -220,43 +220,10 @@ struct TreeSum32 {
   }
 };
 
-// ---- load shifting, the part every consumer needs: envs/carbon_ls.py:172-324 (pair_dynamics, same expressions).  Both wavefronts of
-// an env workgroup evaluate it (integer algebra on the step's workload, the action and five queue probes): the dynamics wavefront
-// for the utilisation, the reward wavefront for the oldest-task search -- which needs a second, dependent memory round trip (the
-// queue table ahead of the oldest task) that would otherwise sit on the path to the step's energy.
-struct WideLs {
-  int ns, shf, overdue, od_proc, popped, add, dropped, processed, util_tasks, cum_now, total, a24, a48, a72, a96;
-  unsigned cumT_now;
-};
-__device__ __forceinline__ WideLs wide_ls_algebra(const SdcDev& S, const double wl, const int a_ls, const int popped0, const int cum_prev,
-                                                  const unsigned cumT_prev, const int now, const int (&cumq)[5]) {
-  KLit kt{};
-  WideLs o;
-  const double flex = KC(0.2), nonflex = KC(0.8);
-  o.ns = (int)ceil(wl * nonflex * 100);
-  o.shf = (int)floor(wl * flex * 100);
-  int popped = popped0;
-  o.overdue = max(0, cumq[0] - popped);
-  int avail = 90 - (o.ns + o.shf);
-  o.od_proc = 0;
-  if (avail > 0 && o.overdue > 0) o.od_proc = min(o.overdue, avail);
-  popped += o.od_proc;
-  avail = 90 - (o.ns + o.shf + o.od_proc);
-  const int qlen = cum_prev - popped;
-  const bool defer = a_ls == 0, drain = a_ls == 2 && avail >= 1;
-  o.add = defer ? min(o.shf, S.queue_max - qlen) : 0;
-  o.dropped = defer ? o.shf - o.add : 0;
-  o.processed = drain ? min(min(o.shf, avail), qlen) : 0;
-  popped += o.processed;
-  o.popped = popped;
-  o.util_tasks = o.od_proc + (defer ? o.shf - o.add : o.shf + o.processed);
-  o.cum_now = cum_prev + o.add;
-  o.cumT_now = cumT_prev + (unsigned)o.add * (unsigned)now;
-  o.total = o.cum_now - popped;
-  o.a24 = max(0, cumq[1] - popped); o.a48 = max(0, cumq[2] - popped);
-  o.a72 = max(0, cumq[3] - popped); o.a96 = max(0, cumq[4] - popped);
-  return o;
-}
+// ---- load shifting (sdc_physics.hpp ls_algebra: envs/carbon_ls.py:172-324).  Both wavefronts of an env workgroup evaluate it (integer
+// algebra on the step's workload, the action and five queue probes): the dynamics wavefront for the utilisation, the reward wavefront
+// for the oldest-task search -- which needs a second, dependent memory round trip (the queue table ahead of the oldest task) that would
+// otherwise sit on the path to the step's energy.
 constexpr int WIDE_QA = 16;        // table entries ahead of the oldest task's step requested up front (two per dwordx4)
 
 // ---- the DYNAMICS wavefront of an env workgroup: lane = env ---------------------------------------------------------------------------
@@ -366,19 +333,14 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   // ---- load shifting: envs/carbon_ls.py:172-324 (pair_dynamics, same expressions) ---------------------------------------------
   if (wl < 0 || wl > 1) fault |= SDC_FAULT_WORKLOAD;
   const int now = rel;
-  const WideLs ls = wide_ls_algebra(S, wl, a_ls, popped0, cum_prev, cumT_prev, now, cumq);
-  const int ns = ls.ns, overdue = ls.overdue, popped = ls.popped, dropped = ls.dropped, processed = ls.processed;
+  const LsStep ls = ls_algebra(kt, wl, a_ls, popped0, cum_prev, cumT_prev, now, S.queue_max, cumq[0], cumq[1], cumq[2], cumq[3], cumq[4]);
+  const int overdue = ls.overdue, popped = ls.popped, dropped = ls.dropped, processed = ls.processed;
   const int cum_now = ls.cum_now, total = ls.total;
   const unsigned cumT_now = ls.cumT_now;
-  double util = KDIV((double)ls.util_tasks, 100);
-  util += KDIV((double)ns, 100);
+  const double util = ls_utilisation(kt, ls);
   double hist[5];
   const double den = (double)max(total, 1), rden = 1.0 / den;
-  hist[0] = sdc_div_const((double)(total - ls.a24), den, rden);
-  hist[1] = sdc_div_const((double)(ls.a24 - ls.a48), den, rden);
-  hist[2] = sdc_div_const((double)(ls.a48 - ls.a72), den, rden);
-  hist[3] = sdc_div_const((double)(ls.a72 - ls.a96), den, rden);
-  hist[4] = ls.a96 > 0 ? 1.0 : 0.0;
+  ls_age_hist(ls, den, rden, hist);
   const double normq = sdc_div_const((double)total, S.queue_max_d, S.rc_queue_max);
   // (the oldest task's step, the cached prefix counts before it and the two ages: from the reward wavefront, behind barrier 2)
 
@@ -389,43 +351,19 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   // ---- GEN: rule-based policies choose the dc / battery actions (pair_dynamics, same expressions) ------------------------------------
   int tr_count = (int)r6.z;
   if constexpr (GEN) {
-    if (S.policy[1] == SDC_POLICY_TRIM_AND_RESPOND) {
-      // utils/trim_and_respond.py:28-38 on the room temperature the previous step reported (dc_int_temperature)
-      const double room = __hiloint2double((int)r5.w, (int)r5.z);
-      if (S.tr_limit >= room) {
-        if (tr_count > 4) {        // response_duration_limit = 4
-          tr_count = 0;
-          a_dc = 2;
-        } else {
-          tr_count += 1;
-          a_dc = 1;
-        }
-      } else {
-        a_dc = 0;
-      }
-    }
+    // (the previous step's room temperature: dc_int_temperature; the carbon intensity three steps ahead from the location's table)
+    if (S.policy[1] == SDC_POLICY_TRIM_AND_RESPOND) a_dc = trim_and_respond_action(S.tr_limit, __hiloint2double((int)r5.w, (int)r5.z), tr_count);
     if (S.policy[2] == SDC_POLICY_RBC) {
-      // utils/rbc_agents.py:21-47 (look_ahead 3, smooth_window 1): charge when the carbon intensity three steps ahead is above the
-      // current one, else discharge -- on the NORMALISED values the reference's agent is given (managers.py:437)
       const int i3 = min(max(i + 3, 0), S.table_len - 1);
       const double c3 = S.tabC[(size_t)(int)r6.y * S.table_len + i3];
-      const double cmin = __hiloint2double((int)r7.y, (int)r7.x), cden = __hiloint2double((int)r7.w, (int)r7.z);
-      a_bat = (c3 - cmin) / cden > (ci_i - cmin) / cden ? 0 : 1;
+      a_bat = rbc_battery_action(c3, ci_i, __hiloint2double((int)r7.y, (int)r7.x), __hiloint2double((int)r7.w, (int)r7.z));
     }
   }
 
   // ---- CRAC set-point integrator: envs/dc_gym.py:160-174 --------------------------------------------------------------------
   if (util < 0.0 || util > 1.0) fault |= SDC_FAULT_CPU_LOAD;
   const int delta = a_dc - 1;
-  if (last_delta != -2 && delta == last_delta && a_dc != 0) {
-    consecutive += 1;
-  } else {
-    consecutive = 1;
-    scale = 1;
-  }
-  if (consecutive > 3) scale += 1;
-  double stpt = stpt0 + (double)(delta * scale);
-  stpt = fmax(fmin(stpt, PRM(P_MAX_TEMP)), PRM(P_MIN_TEMP));
+  const double stpt = setpoint_step(a_dc, last_delta, consecutive, scale, stpt0, PRM(P_MAX_TEMP), PRM(P_MIN_TEMP));
 
   // ---- rack model: envs/datacenter.py:250-317, :157-181 -------------------------------------------------------------------------
   // A rack's power and outlet temperature depend on its four parameters (and the env's set-point and load) only, and configs
@@ -434,6 +372,8 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   // every slot's class value in slot order (the half-wave reduction's tree).  Same expressions on the same inputs as a pass over
   // all racks: the same bits.
   const double load_pct = util * 100;
+  const RackEnv E = {PRM(P_M_CPU), PRM(P_C_CPU), PRM(P_M_FAN), PRM(P_C_FAN), PRM(P_RS_CPU) * KDIV(load_pct, 100), PRM(P_RS_FAN) * KDIV(load_pct, 20),
+                     PRM(P_ITFAN_REF_P), PRM(P_RC_ITFAN_REF_V_RATIO), PRM(P_IT_FAN_FULL_LOAD_V), PRM(P_K_OUTLET)};
   bool bad_delta = false;
   TreeSum32 s_out, s_pw;
   s_out.init();
@@ -445,30 +385,14 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
     const int n_cls = (int)ncr.x, R = (int)ncr.y;
     double* cls_pw = reinterpret_cast<double*>(sh.row);                 // [class][lane]
     double* cls_out = cls_pw + SDC_WIDE_MAX_CLS * WE;
-    const double m_cpu = PRM(P_M_CPU), c_cpu = PRM(P_C_CPU), rs_cpu = PRM(P_RS_CPU);
-    const double m_fan = PRM(P_M_FAN), c_fan = PRM(P_C_FAN), rs_fan = PRM(P_RS_FAN);
-    const double cpu_shift = rs_cpu * KDIV(load_pct, 100), fan_shift = rs_fan * KDIV(load_pct, 20);
     const int max_cls = S.wide_max_cls;
 #pragma unroll 2
     for (int c = 0; c < max_cls; c++) {
-      const double r_n = wc[4 * c], r_supply = wc[4 * c + 1], r_full = wc[4 * c + 2], r_idle = wc[4 * c + 3];
-      const double sa = fmax(KC(3.8), fmin(r_supply, KC(5.3)));
-      const double inlet = sa + stpt;
-      const double ratio = ((m_cpu + KC(0.05)) * inlet + c_cpu) + cpu_shift;
-      const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
-      const double fan1 = PRM(P_ITFAN_REF_P) * (v * PRM(P_RC_ITFAN_REF_V_RATIO));
-      const double vf1 = PRM(P_IT_FAN_FULL_LOAD_V) * v;
-      const double pf = r_n * fan1;
-      const double vtot = r_n * vf1;
-      const double cpu1 = fmax(r_idle, r_full * ratio);
-      const double pc = r_n * cpu1;
-      const double pw = pc + pf;
-      const bool plain = pw > KC(1e-300) && pw < KC(1e300) && vtot > KC(1e-300) && vtot < KC(1e300);
-      const double rise = exp2_short(KC(1.096) * log2_pos_normal(plain ? pw : 1.0, kt) - KC(0.824) * log2_pos_normal(plain ? vtot : 1.0, kt), kt);
-      const double out = inlet + PRM(P_K_OUTLET) * rise + KC(-14.01);
-      if (c < n_cls && (out - inlet < 2 || !plain)) bad_delta = true;
-      cls_pw[c * WE + lane] = pw;
-      cls_out[c * WE + lane] = out;
+      double inlet;
+      const RackOut ro = rack_point(kt, E, wc[4 * c], wc[4 * c + 1], wc[4 * c + 2], wc[4 * c + 3], stpt, inlet);
+      if (c < n_cls && (ro.out - inlet < 2 || !ro.plain)) bad_delta = true;
+      cls_pw[c * WE + lane] = ro.pc + ro.pf;
+      cls_out[c * WE + lane] = ro.out;
     }
     wave_sync();
     const unsigned* wmap = reinterpret_cast<const unsigned*>(wc + WC_MAP);
@@ -498,34 +422,21 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
     const int n_grp = tab_i32(0);
     double* cls_pw = reinterpret_cast<double*>(sh.row);                 // [class][lane]
     double* cls_out = cls_pw + SDC_MAX_RACK_CLS * WE;
-    const double m_cpu = PRM(P_M_CPU), c_cpu = PRM(P_C_CPU), rs_cpu = PRM(P_RS_CPU);
-    const double m_fan = PRM(P_M_FAN), c_fan = PRM(P_C_FAN), rs_fan = PRM(P_RS_FAN);
-    const double cpu_shift = rs_cpu * KDIV(load_pct, 100), fan_shift = rs_fan * KDIV(load_pct, 20);
 #pragma unroll 1
     for (int g = 0; g < n_grp; g++) {
-      const double r_n = tab_f64(g), r_supply = tab_f64(8 + g);
-      const double sa = fmax(KC(3.8), fmin(r_supply, KC(5.3)));
-      const double inlet = sa + stpt;
-      const double ratio = ((m_cpu + KC(0.05)) * inlet + c_cpu) + cpu_shift;
-      const double v = (m_fan * 10 * inlet + c_fan * 5) + fan_shift;
-      const double fan1 = PRM(P_ITFAN_REF_P) * (v * PRM(P_RC_ITFAN_REF_V_RATIO));
-      const double vf1 = PRM(P_IT_FAN_FULL_LOAD_V) * v;
-      const double pf = r_n * fan1;
-      const double vtot = r_n * vf1;
-      const bool plain_v = vtot > KC(1e-300) && vtot < KC(1e300);
-      const double l2v = log2_pos_normal(plain_v ? vtot : 1.0, kt);
+      // what depends on (number of CPUs, supply approach) once per group (sdc_physics.hpp rack_air), the airflow's logarithm with it
+      const double r_n = tab_f64(g);
+      const RackAir ra = rack_air(kt, E, r_n, tab_f64(8 + g), stpt);
+      const bool plain_v = rack_plain(kt, ra.vtot);
+      const double l2v = log2_pos_normal(plain_v ? ra.vtot : 1.0, kt);
       const int c0 = tab_i32(2 + g), c1 = tab_i32(3 + g);
 #pragma unroll 2
       for (int c = c0; c < c1; c++) {
-        const double r_full = tab_f64(16 + c), r_idle = tab_f64(24 + c);
-        const double cpu1 = fmax(r_idle, r_full * ratio);
-        const double pc = r_n * cpu1;
-        const double pw = pc + pf;
-        const bool plain = pw > KC(1e-300) && pw < KC(1e300) && plain_v;
-        // (log2 of 1.0 is exactly 0.0: what the all-racks pass evaluates for the airflow when the power is not a plain number)
-        const double rise = exp2_short(KC(1.096) * log2_pos_normal(plain ? pw : 1.0, kt) - KC(0.824) * (plain ? l2v : 0.0), kt);
-        const double out = inlet + PRM(P_K_OUTLET) * rise + KC(-14.01);
-        if (out - inlet < 2 || !plain) bad_delta = true;
+        const double pw = rack_cpu_power(ra, r_n, tab_f64(16 + c), tab_f64(24 + c)) + ra.pf;
+        const bool plain = rack_plain(kt, pw) && plain_v;
+        // (log2 of 1.0 is exactly 0.0: what rack_point evaluates for the airflow when the power is not a plain number)
+        const double out = rack_outlet(kt, E, ra.inlet, log2_pos_normal(plain ? pw : 1.0, kt), plain ? l2v : 0.0);
+        if (out - ra.inlet < 2 || !plain) bad_delta = true;
         cls_pw[c * WE + lane] = pw;
         cls_out[c * WE + lane] = out;
       }
@@ -567,57 +478,15 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   const double avg_ret = (PCFG(WC_RET_SUM, P_RET_SUM) + sum_outlet) * rc_n_racks;
   const double mean_outlet = sum_outlet * rc_n_racks;
 
-  // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 -----------------------------------------------------------------------
-  const double c_air = PRM(P_C_AIR), rho_air = PRM(P_RHO_AIR), ct_fan_ref_p = PCFG(WC_CT_FAN_REF_P, P_CT_FAN_REF_P);
-  const double m_sys = rho_air * PRM(P_CRAC_SUPPLY_PU) * p_it;
-  const double q_cool = m_sys * c_air * fmax(0.0, avg_ret - stpt);
-  const double comp = chiller_power(ct_fan_ref_p, q_cool, amb, kt);
-  double ct;
-  {
-    const double dlt = fmax(50 - (amb - stpt), 1);
-    const double m_air = sdc_div_fast(q_cool, c_air * dlt);
-    const double v_air = m_air * PRM(P_RC_RHO_AIR);
-    const double x = fmin(v_air * PCFG(WC_RC_CTAFR, P_RC_CTAFR), 1);
-    ct = amb < 5 ? 0.0 : ct_fan_ref_p * (x * x * x);
-  }
-  double water;
-  {
-    const double range_temp = avg_ret - stpt;
-    const double y_int = KC(0.3528) * range_temp + KC(0.101);
-    double w = KC(0.044) * wet_bulb + y_int;
-    if (w < 0) w = 0;
-    w += w * KC(0.01);
-    water = k_round((w * 1000) / 4, 1e4);
-  }
-  const double total_kw = KDIV(p_it + ct + comp, 1e3);
+  // ---- HVAC: envs/datacenter.py:432-474 ; water :325-353 (sdc_physics.hpp hvac_water) ------------------------------------------------------
+  const HvacPrm HP = {PRM(P_C_AIR), PRM(P_RHO_AIR), PCFG(WC_CT_FAN_REF_P, P_CT_FAN_REF_P), PRM(P_CRAC_SUPPLY_PU), PRM(P_RC_RHO_AIR),
+                      PCFG(WC_RC_CTAFR, P_RC_CTAFR)};
+  const HvacOut hv = hvac_water(kt, HP, p_it, avg_ret, stpt, amb, wet_bulb);
+  const double comp = hv.comp, ct = hv.ct, water = hv.water, total_kw = hv.total_kw;
 
-  // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 ---------------------------------------------------
-  const double cap = PCFG(WC_BAT_CAP, P_BAT_CAP), rc_cap = PCFG(WC_RC_BAT_CAP, P_RC_BAT_CAP);
-  const double dcload = KDIV(total_kw, 1e3);
-  const double e_nobat = dcload * 1e3 * 0.25;
-  double energy = e_nobat, co2;
-  if (a_bat != 2) {
-    const bool chg = a_bat == 0;
-    const double soc = sdc_div_const(bat_load - 0, cap - 0, rc_cap);
-    const double sg = 1 / (1 + exp_plain(-(10 * (soc - (chg ? 0.5 : 0.25))), kt));
-    const double rate = chg ? k_round(0.5 * (1 - sg), 1e4) : fmax(0.5, 4 * sg);
-    const double tu = KDIV(rate * 15, 60);
-    const double quo = (chg ? cap - bat_load : bat_load) / (chg ? tu + KC(0.04) : KC(0.01) + tu);
-    if (chg) {
-      const double max_charge = fmin((cap / 1) * KC(0.1), quo);
-      const double charging_load = fmin(max_charge, cap) * 1 * tu;
-      bat_load = k_round(bat_load + charging_load, 1e8);
-      energy = e_nobat + charging_load * 1e3;
-    } else {
-      const double max_d = fmin(fmin((cap / 1) * 1, quo), dcload * 0.25);
-      bat_load = k_round(bat_load - (fmin(max_d, cap) * 1 * tu), 1e8);
-      const double discharge = max_d < cap ? max_d * tu : cap * tu;
-      if (!(e_nobat >= discharge * 1e3)) fault |= SDC_FAULT_BAT_DISCHARGE;
-      energy = e_nobat - discharge * 1e3;
-    }
-  }
-  co2 = (a_bat == 1 ? fmax(energy, 0.0) : energy) * ci_i;
-  const double soc_after = sdc_div_const(bat_load, cap, rc_cap);
+  // ---- battery: envs/bat_env_fwd_view.py:84-245, envs/battery_model.py:94-132 (sdc_physics.hpp battery_step) -----------------------------
+  const BatOut bo = battery_step(kt, a_bat, bat_load, PCFG(WC_BAT_CAP, P_BAT_CAP), PCFG(WC_RC_BAT_CAP, P_RC_BAT_CAP), total_kw, ci_i, fault);
+  const double e_nobat = bo.e_nobat, energy = bo.energy, co2 = bo.co2, soc_after = bo.soc_after;
 
   // ---- time: utils/managers.py:127-147 -------------------------------------------------------------------------------------------
   int hourq_n = hourq + 1, day_n = day;
@@ -630,14 +499,7 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   // ---- history append (utils/reward_creator.py:7-14) -------------------------------------------------------------------------------
   const double href = hl == 0 ? energy : href0;
   const double e_off = energy - href;
-  int slot;
-  if (hl < S.hist_cap) {
-    slot = hl;
-    hl += 1;
-  } else {
-    slot = hpos;
-    hpos = hpos + 1 == S.hist_cap ? 0 : hpos + 1;
-  }
+  const int slot = hist_append_slot(hl, hpos, S.hist_cap);
   const unsigned x_new = sdc_f32_key(__float_as_uint((float)e_off));
   const unsigned f_all = fault0 | fault;
 
@@ -738,47 +600,11 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   }
   {
     float inf[SDC_INFO_DIM];
-    inf[SDC_INFO_LS_ORIGINAL_WORKLOAD] = (float)wl;
-    inf[SDC_INFO_LS_SHIFTED_WORKLOAD] = (float)util;
-    inf[SDC_INFO_LS_TASKS_IN_QUEUE] = (float)total;
-    inf[SDC_INFO_LS_NORM_TASKS_IN_QUEUE] = (float)normq;
-    inf[SDC_INFO_LS_TASKS_DROPPED] = (float)dropped;
-    inf[SDC_INFO_LS_TASKS_PROCESSED] = (float)processed;
-    inf[SDC_INFO_LS_OLDEST_TASK_AGE] = (float)oldest_norm;
-    inf[SDC_INFO_LS_AVERAGE_TASK_AGE] = (float)avg_norm;
-    inf[SDC_INFO_LS_OVERDUE_PENALTY] = (float)overdue;
-    inf[SDC_INFO_LS_COMPUTED_TASKS] = (float)(int)(util * 100);
-    inf[SDC_INFO_LS_CURRENT_HOUR] = (float)hour;
-#pragma unroll
-    for (int b = 0; b < 5; b++) inf[SDC_INFO_LS_AGE_HIST0 + b] = (float)hist[b];
-    inf[SDC_INFO_DC_ITE_TOTAL_POWER_KW] = (float)(p_it * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_CT_TOTAL_POWER_KW] = (float)(ct * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_COMPRESSOR_TOTAL_POWER_KW] = (float)(comp * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_HVAC_TOTAL_POWER_KW] = (float)((ct + comp) * KC(1.0 / 1e3));
-    inf[SDC_INFO_DC_TOTAL_POWER_KW] = (float)total_kw;
-    inf[SDC_INFO_DC_CRAC_SETPOINT_DELTA] = (float)delta;
-    inf[SDC_INFO_DC_CRAC_SETPOINT] = (float)stpt;
-    inf[SDC_INFO_DC_CPU_WORKLOAD_FRACTION] = (float)util;
-    inf[SDC_INFO_DC_INT_TEMPERATURE] = (float)mean_outlet;
-    inf[SDC_INFO_DC_EXTERIOR_AMBIENT_TEMP] = (float)amb;
-    inf[SDC_INFO_DC_WATER_USAGE] = (float)water;
-    inf[SDC_INFO_BAT_ACTION] = (float)a_bat;
-    inf[SDC_INFO_BAT_SOC] = (float)soc_after;
-    inf[SDC_INFO_BAT_CO2_FOOTPRINT] = (float)co2;
-    inf[SDC_INFO_BAT_AVG_CI] = (float)ci_i;
-    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITHOUT_BATTERY_KWH] = (float)e_nobat;
-    inf[SDC_INFO_BAT_TOTAL_ENERGY_WITH_BATTERY_KWH] = (float)energy;
-    inf[SDC_INFO_NORM_CI] = (float)norm_ci;
-    inf[SDC_INFO_OUTSIDE_TEMP] = (float)amb_next;
-    inf[SDC_INFO_DAY] = (float)day_n;
-    inf[SDC_INFO_HOUR] = (float)((double)hourq_n * 0.25);
-    inf[SDC_INFO_FAULT] = (float)f_all;
-    inf[SDC_INFO_ENERGY_Z] = 0.0f;       // (the five reward-side columns: filled in by the reward wavefront, which sends the block out)
-    inf[SDC_INFO_RESERVED] = 0.0f;
-    inf[SDC_INFO_EP_RETURN_LS] = 0.0f;
-    inf[SDC_INFO_EP_RETURN_DC] = 0.0f;
-    inf[SDC_INFO_EP_RETURN_BAT] = 0.0f;
-    inf[SDC_INFO_EPISODE_STEP] = (float)(rel + 1);
+    const InfoLs il = {wl, util, normq, oldest_norm, avg_norm, hour, total, dropped, processed, overdue};
+    info_put_ls(inf, il, hist);
+    const InfoDc id = {p_it, ct, comp, total_kw, stpt, mean_outlet, amb, water, soc_after, co2, ci_i, e_nobat, energy, norm_ci, amb_next,
+                       delta, a_bat, day_n, hourq_n, rel + 1, f_all};
+    info_put_dc(kt, inf, id);      // (the five reward-side columns: zeros here, filled in by the reward wavefront, which sends the block out)
     // ... through the staging block too: the wavefront's 64 info rows are 11 KB of whole lines
     float* const stage = reinterpret_cast<float*>(&sh.rec[0]);
     wave_sync();
@@ -839,7 +665,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
   const int now = rel;
   const double wl = __hiloint2double(__float_as_int(wl2.y), __float_as_int(wl2.x));
   if ((unsigned)a_ls > 2u) a_ls = 1;
-  const WideLs ls = wide_ls_algebra(S, wl, a_ls, popped0, cum_prev, cumT_prev, now, cumq);
+  const LsStep ls = ls_algebra(kt, wl, a_ls, popped0, cum_prev, cumT_prev, now, S.queue_max, cumq[0], cumq[1], cumq[2], cumq[3], cumq[4]);
   const int overdue = ls.overdue, hourq_n = hourq + 1 >= 96 ? 0 : hourq + 1;
   constexpr int QA = WIDE_QA;
   uint4 qa[QA / 2];
@@ -1101,21 +927,7 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
         cumT_hm1 = e.y;
       }
     }
-    if (total > 0) {
-      if (was_empty) {
-        head = now;
-        cum_hm1 = cum_prev;
-        cumT_hm1 = cumT_prev;
-      }
-      const long long sum_t = (long long)cumT_now - (long long)cumT_hm1 - (long long)(popped - cum_hm1) * head;
-      const long long sum_age_steps = (long long)total * now - sum_t;
-      oldest = (double)(now - head) * 0.25;
-      avg = sdc_div_const((double)sum_age_steps * 0.25, den, rden);
-    } else {
-      head = now;
-      cum_hm1 = cum_now;
-      cumT_hm1 = cumT_now;
-    }
+    ls_ages(ls, now, cum_prev, cumT_prev, was_empty, den, rden, head, cum_hm1, cumT_hm1, oldest, avg);
     oldest_norm = KDIV(oldest, 24);
     avg_norm = KDIV(avg, 24);
     block_put<16>(sh.rec, lane, WIDE_REC_CHUNKS, make_uint4((unsigned)__double2loint(oldest_norm), (unsigned)__double2hiint(oldest_norm),
@@ -1305,31 +1117,16 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
   const double z = (e_off - mean) * inv_sd;     // (n >= SMALL_N >= 2 here)
   double r_a[3], ret_a[3];
   {
-    const double foot = -1.0 * (norm_ci * z / 0.50);
-    const double overdue_pen = -0.3 * sqrt_count((double)overdue) + 0.3;
-    const double age_pen = -0.1 * oldest_norm;
-    double rls = foot + overdue_pen + age_pen;
-    rls = rls < -10 ? -10 : (rls > 10 ? 10 : rls);
+    double foot, rls;
+    reward_terms(z, norm_ci, (double)overdue, oldest_norm, foot, rls);
     r_a[0] = rls; r_a[1] = foot; r_a[2] = foot;
     if constexpr (GEN) {
-      // the dc / battery agents' reward functions (utils/reward_creator.py:154-334; pair_reward_fast, same expressions); the ls agent
-      // keeps default_ls_reward here (wide_gen_case)
+      // the dc / battery agents' reward functions (utils/reward_creator.py:154-334: sdc_trackers.hpp agent_reward); the ls agent keeps
+      // default_ls_reward here (wide_gen_case)
       const WideHandGen& G = *reinterpret_cast<const WideHandGen*>(sh.row + WE * 32);
-      const double ite_kw = SDC_DIV_CONST(G.p_it[lane], 1e3), total_kw = G.total_kw[lane], hour = (double)hourq_n * 0.25;
+      const double ite_kw = SDC_DIV_CONST(G.p_it[lane], 1e3), hour = (double)hourq_n * 0.25;
 #pragma unroll
-      for (int a = 1; a < 3; a++) {
-        double v;
-        switch (S.reward_method[a]) {   // wave-uniform
-          case SDC_REWARD_DEFAULT: v = foot; break;
-          case SDC_REWARD_FOOTPRINT: v = foot; break;
-          case SDC_REWARD_TOU: v = -1.0 * energy * tou_price((int)hour % 24); break;
-          case SDC_REWARD_ENERGY_EFFICIENCY: v = ite_kw / total_kw; break;
-          case SDC_REWARD_PUE: v = -fabs((ite_kw != 0 ? total_kw / ite_kw : (double)INFINITY) - 1); break;
-          case SDC_REWARD_WATER: v = -0.01 * G.water[lane]; break;
-          default: v = 0.0;   // SDC_REWARD_CUSTOM: custom_agent_reward returns 0
-        }
-        r_a[a] = v;
-      }
+      for (int a = 1; a < 3; a++) r_a[a] = agent_reward(S.reward_method[a], false, rls, foot, energy, hour, ite_kw, G.total_kw[lane], G.water[lane]);
     }
 #pragma unroll
     for (int a = 0; a < 3; a++) ret_a[a] = hd_f64(H_RET + 2 * a) + r_a[a];

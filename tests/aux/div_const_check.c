@@ -14,7 +14,9 @@ int main(int argc, char **argv) {
   /* every constant divisor of sdc_dynamics.hip / sdc_device.hpp */
   const double cs[] = {100.0, 24.0, 20.0, 1e3, 60.0, 2.778, 3.0, 1e4, 1e8, 6.0, 14.0, 17.0, 0.05,
                        /* run-time divisors of the shipped configs: history / queue capacity, rack counts */
-                       1e4, 1e3, 16.0, 20.0, 25.0, 257.0};
+                       1e4, 1e3, 16.0, 20.0, 25.0, 257.0,
+                       /* sdc_features.hip slope_of: the sums of squared abscissae of the 4-, 6-, 14- and 17-point least-squares fits */
+                       5.0, 17.5, 227.5, 408.0};
   long bad = 0;
   for (unsigned k = 0; k < sizeof(cs) / sizeof(cs[0]); k++) {
     const double c = cs[k], rc = 1.0 / c;
