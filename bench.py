@@ -68,7 +68,7 @@ N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
 MAX_CLOCK_GHZ = 2.4
 HIST_CAP = 10000
 ALG_BYTES_FIXED = 1540      # B(H) = 4*H + 1540 bytes per env-step
-WIDE_MIN_ENVS = 9216        # sdc_capi.hip SDC_WIDE_MIN_ENVS: single steps of a batch this large run one lane per env (sdc_wide.hip)
+WIDE_MIN_ENVS = 7680        # sdc_capi.hip SDC_WIDE_MIN_ENVS: single steps of a batch this large run one lane per env (sdc_wide.hip)
 STEP_KERNEL = "sdc_dynamics_fast_kernel"   # the step kernel specialised for the common case, which is what this workload is
 STEP_KERNEL_PREFIX = "sdc_dynamics"            # (the general kernel sdc_dynamics_kernel serves every other case)
 MIN_REGION_S = 0.2
@@ -1007,14 +1007,14 @@ def main():
             except Exception as e:
                 sec["harl_unchanged_loop"] = {"error": repr(e)}
             scan = []
-            # (2 048 / 8 192: two / four envs per wavefront; from 9 216: one lane per env -- sdc_wide.hip; counters at 8 192 and 32 768)
+            # (2 048: two envs per wavefront; 6 144: four; from 7 680: one lane per env -- sdc_wide.hip; counters at 6 144, 32 768 and 262 144)
             # (262 144 envs = four dispatch rounds of the lane-per-env kernel: the THROUGHPUT regime, where a workgroup's loads overlap
             # other workgroups' arithmetic and the kernel's rate is set by the memory system; 39 GB of state)
-            for n in (2048, 8192, 16384, 32768, 65536, 262144):
+            for n in (2048, 6144, 8192, 16384, 32768, 65536, 262144):
                 try:
-                    r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=8192 <= n <= 16384)
+                    r = secondary_rate(n, args.episode_steps, "ny", dev, 2016, loops=n in (6144, 16384))
                     r["rate_vs_4096_envs"] = round(r["value"] / value, 4)
-                    if n in (8192, 32768, 262144) and not args.no_pmc:
+                    if n in (6144, 32768, 262144) and not args.no_pmc:
                         r["roofline"] = scan_roofline(n, args.episode_steps, r["us_per_step"], args, r.get("kernel"))
                     scan.append(r)
                 except Exception as e:

@@ -254,9 +254,13 @@ int quad_blocks(int n_envs) { return (n_envs / 4 + STEP_WPB - 1) / STEP_WPB; }
 // racks, 16-byte aligned output rows (whole-line stores through the wavefront's staging block); debug_flags bit 11 forces it
 // for any such batch, bit 12 keeps it off
 #ifndef SDC_WIDE_MIN_ENVS
-// (measured, us per step with the episode boundary inside, lane per env / four per wavefront: 7 168 envs 14.8 / 13.8, 8 192: 15.1 / 14.5,
-// 9 216: 15.6 / 15.7, 10 240: 15.9 / 16.0, 11 264: 16.2 / 16.3, 12 288: 16.4 / 21.4, 16 384: 17.6 / 24.8, 32 768: 26.2 / 40.2, 65 536: 47 / 72.6)
-#define SDC_WIDE_MIN_ENVS 9216
+// (measured, us per step with the episode boundary inside, lane per env / four per wavefront, round 6 -- after the record's one-line
+// layout and the kernel-argument touch: 6 144 envs 13.74 / 13.40, 7 168: 14.02 / 13.69, 7 680: 14.16 / 14.34, 8 192: 14.25 / 14.47,
+// 8 704: 14.63 / 15.52, 12 288: 15.6 / 21.4, 16 384: 16.5 / 24.8, 32 768: 23.6 / 40.5, 65 536: 42.7 / 73.4; round 5's crossover was 9 216)
+#define SDC_WIDE_MIN_ENVS 7680
+#endif
+#ifndef SDC_WIDE_ROLLOUT_MIN_ENVS
+#define SDC_WIDE_ROLLOUT_MIN_ENVS 12288      // sdc_rollout: K single-step launches of the lane-per-env kernel from here (below: one K-step launch)
 #endif
 // the structural conditions of the lane-per-env kernel (either form): a multiple of 64 envs, the queue table's time-major mirror,
 // whole-line stores through the workgroup's staging block (16-byte aligned output rows)
@@ -930,12 +934,16 @@ int sdc_rollout(sdc_handle* h, int n_steps, const int32_t* actions, float* obs, 
   const int N = h->cfg.n_envs;
   SdcDev d = h->d;
   d.actions_out = actions_out;
-  const bool w_common = actions && !actions_out && fast_case(h, actions, share_obs, info, false) && wide_case(h, obs, share_obs, info, final_obs);
+  // (a MULTI-STEP launch of four envs per wavefront has no launch boundary between its steps: it stays ahead of K lane-per-env
+  // launches up to SDC_WIDE_ROLLOUT_MIN_ENVS envs -- 8 192 envs: 11.6 against 14.3 us per step, 12 288: 15.4 / 15.6, 16 384: 23.4 / 17.4)
+  const bool roll_wide = N >= SDC_WIDE_ROLLOUT_MIN_ENVS || (h->d.debug_flags & 2048);
+  const bool w_common = roll_wide && actions && !actions_out && fast_case(h, actions, share_obs, info, false) &&
+                        wide_case(h, obs, share_obs, info, final_obs);
   // (the slices of step k start k * N rows in: aligned like the arrays themselves for the batches this kernel takes, N % 64 == 0)
-  const bool w_gen = !w_common && wide_gen_case(h, actions, obs, share_obs, info, final_obs, false) &&
+  const bool w_gen = roll_wide && !w_common && wide_gen_case(h, actions, obs, share_obs, info, final_obs, false) &&
                      (!actions_out || (reinterpret_cast<uintptr_t>(actions_out) & 3u) == 0);
   if (w_common || w_gen) {
-    // A batch the lane-per-env kernel serves (sdc_wide.hip: from SDC_WIDE_MIN_ENVS envs): n_steps single-step launches of it, the
+    // A batch the lane-per-env kernel serves (sdc_wide.hip), from SDC_WIDE_ROLLOUT_MIN_ENVS envs: n_steps single-step launches of it, the
     // deferred re-centrings running between them as in sdc_step -- faster than one n_steps launch of four envs per wavefront
     // (16 384 envs: 17.7 against 23.4 us per step), the same outputs to the bit.  Its general form likewise: several configs,
     // rule-based policies (a step's policy reads the state the previous launch left), other reward functions.

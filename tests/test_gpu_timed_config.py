@@ -163,9 +163,9 @@ def test_common_case_kernels_equal_the_general_kernels():
         e.close()
 
 
-@pytest.mark.parametrize("N", [8192, 8200])      # (8200: a partly filled last workgroup, a grid that is not a multiple of 8)
+@pytest.mark.parametrize("N", [7168, 7176])      # (7176: a partly filled last workgroup, a grid that is not a multiple of 8; from 7 680 envs: one lane per env)
 def test_large_batches_take_the_four_env_mapping(N):
-    """Large batches (single steps above 5632 envs, the multi-step kernels above 4096) run four envs per wavefront by default (sdc_capi.hip quad_case): same outputs
+    """Large batches (single steps above 5632 envs and below 7680, the multi-step kernels above 4096) run four envs per wavefront by default (sdc_capi.hip quad_case): same outputs
     and state, bit for bit, as the two-env mapping (debug_flags bit 9) at those sizes -- steps, a rollout, the closed loop."""
     import torch
     from tests.test_gpu_actor import _torch_actor

@@ -125,10 +125,10 @@ def test_lane_per_env_kernel_full_rings_whole_state():
 
 def test_the_host_picks_the_kernel_by_batch_size():
     """Single steps of a lock-step, single-config batch: two envs per wavefront up to 5 632 envs, four above, one lane per env from
-    9 216 (sdc_capi.hip fast_case / quad_case / wide_case); debug_flags bit 12 keeps the lane-per-env kernel off."""
+    7 680 (sdc_capi.hip fast_case / quad_case / wide_case); debug_flags bit 12 keeps the lane-per-env kernel off."""
     import torch
-    for N, flags, want in ((4096, 0, "sdc_dynamics_fast_kernel"), (8192, 0, "sdc_dynamics_quad_kernel"),
-                           (9216, 0, "sdc_dynamics_wide_kernel"), (9216, 4096, "sdc_dynamics_quad_kernel"),
+    for N, flags, want in ((4096, 0, "sdc_dynamics_fast_kernel"), (7616, 0, "sdc_dynamics_quad_kernel"),
+                           (7680, 0, "sdc_dynamics_wide_kernel"), (7680, 4096, "sdc_dynamics_quad_kernel"),
                            (9220, 0, "sdc_dynamics_quad_kernel")):
         (e,) = _engines(N, 96, flags=(flags,))
         e.step(torch.ones((N, 3), dtype=torch.int32, device="cuda"))
@@ -137,11 +137,11 @@ def test_the_host_picks_the_kernel_by_batch_size():
 
 
 def test_rollout_of_a_large_batch_is_single_step_launches_of_the_lane_per_env_kernel():
-    """`sdc_rollout` over a batch the lane-per-env kernel serves (9 216 envs and up): K launches of it inside the call, the same bits
+    """`sdc_rollout` over a batch the lane-per-env kernel serves (12 288 envs and up: sdc_capi.hip SDC_WIDE_ROLLOUT_MIN_ENVS): K launches of it inside the call, the same bits
     as K calls of step() on a twin engine and as the multi-step kernel of four envs per wavefront (debug_flags bit 12), across an
     episode end (auto-reset inside the last step)."""
     import torch
-    N, steps, K = 9216, 48, 24
+    N, steps, K = 12288, 48, 24
     a, b, c = _engines(N, steps, flags=(0, 0, 4096))
     g = torch.Generator(device="cpu").manual_seed(21)
     acts = torch.randint(0, 3, (2 * K, N, 3), dtype=torch.int32, generator=g).cuda()
@@ -213,12 +213,12 @@ def test_the_queue_tables_time_major_mirror_is_kept_by_every_kernel():
 
 
 def test_lane_per_env_kernel_in_verify_mode_from_empty_rings():
-    """9 216 envs (the smallest batch the host gives to the lane-per-env kernel by itself) from EMPTY rings for 1 300 steps with
+    """7 680 envs (the smallest batch the host gives to the lane-per-env kernel by itself) from EMPTY rings for 1 300 steps with
     debug_flags bit 0: after every step sdc_reward_verify_kernel checks every key of all four rank windows against its rank in the
     ring, the quartiles against an exact bisection and z against a direct fp64 pass.  Covers the young histories (fallback path for
     all 64 envs of a wavefront), the first rebuilds, the flood of re-centring requests around steps 64-100 and an auto-reset."""
     import torch
-    N = 9216
+    N = 7680
     (e,) = _engines(N, 672, flags=(1,))
     g = torch.Generator(device="cpu").manual_seed(12)
     pool = torch.randint(0, 3, (64, N, 3), dtype=torch.int32, generator=g).cuda()

@@ -2,7 +2,7 @@
 # One gpurun call that produces everything profiles/ and DESIGN.md quote for a round:  bash tools/profile_round.sh r2
 # (rocprofv3 passes run from /tmp with TMPDIR=/tmp; --pmc passes -- inside bench.py -- use --kernel-trace only)
 set -x
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -57,6 +57,15 @@ SDC_DEBUG_FLAGS=4096 bash tools/dev/wide_pmc.sh 32768 > $O/quad_pmc_32768.txt 2>
 for f in 0 4096 2048; do echo "debug_flags $f (4096: lane-per-env kernel off, 2048: forced)"; SDC_DBG=$f timeout 300 python tools/batch_scan.py 8192 12288 16384 20480 32768 65536; done > $O/wide_crossover.txt 2>&1
 if [ -f tools/bin/lib_wstamps.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/prod.so; cp tools/bin/lib_wstamps.so dc_rl_amd/csrc/libsustaindc_hip.so; for n in 16384 32768 65536; do timeout 200 python tools/dev/wide_timeline.py $n; done > $O/wide_timeline.txt 2>&1; cp /tmp/prod.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
 hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o /tmp/valu_rates 2>/dev/null && timeout 200 /tmp/valu_rates > $O/valu_rates.txt 2>&1
+# round 6: the general form of the lane-per-env kernel (configs[3] mix), what the episode boundary costs by batch size, the throughput regime,
+# what the last-ending workgroup of a launch did (-DSDC_WIDE_STAMPS build), how the reward normalisation was served, the boundary's kernels
+timeout 300 python tools/dev/mixed_scan.py --mixed 4096 16384 32768 65536 > $O/mixed_scan.txt 2>&1
+timeout 300 python tools/dev/boundary_share.py 4096 8192 16384 32768 65536 262144 > $O/boundary_share.txt 2>&1
+timeout 300 python tools/batch_scan.py 65536 98304 131072 262144 > $O/batch_scan_throughput.txt 2>&1
+bash tools/dev/wide_pmc.sh 262144 > $O/wide_pmc_262144.txt 2>&1
+if [ -f tools/bin/lib_wstamps.so ]; then cp dc_rl_amd/csrc/libsustaindc_hip.so /tmp/prod.so; cp tools/bin/lib_wstamps.so dc_rl_amd/csrc/libsustaindc_hip.so; for n in 16384 32768; do timeout 200 python tools/dev/wide_tail.py $n; done > $O/wide_tail.txt 2>&1; cp /tmp/prod.so dc_rl_amd/csrc/libsustaindc_hip.so; fi
+for n in 16384 32768; do SDC_N=$n SDC_DBG=2 SDC_STEPS=1500 timeout 280 python tools/path_hist.py; done > $O/path_hist.txt 2>&1
+bash tools/reset_time.sh > $O/reset_kernels.txt 2>&1
 grep -v amdgpu.ids $O/*.txt | tail -60
 cut -c1-600 $O/bench.json
 ls $O
