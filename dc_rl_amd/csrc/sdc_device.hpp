@@ -243,6 +243,12 @@ struct SdcDev {
   unsigned long long* prof_ts;  // measurement only: [3 kernels][N][2] wall-clock stamps of this launch, or nullptr
 };
 
+// TEST HOOK (debug_flags bit 13 = 8192): every 61st (env + launch) takes env_reward's "a clip bound left its window" repair whatever the
+// windows say -- the path is otherwise taken by ~4e-8 of the env-steps (tests/test_gpu_bound_repair.py runs it in verify mode)
+__device__ __forceinline__ bool bound_repair_forced(const SdcDev& S, const int env) {
+  return (S.debug_flags & 8192) != 0 && (unsigned)(env + S.step_no) % 61u == 0u;
+}
+
 // per-kernel timing without host events: one lane per workgroup stamps the constant-rate wall clock at entry and
 // exit; the host takes min(entry) / max(exit) over the workgroups of a sampled launch (sdc_profile_read)
 enum { SDC_PROF_DYNAMICS = 0, SDC_PROF_REWARD = 1, SDC_PROF_RESET = 2 };

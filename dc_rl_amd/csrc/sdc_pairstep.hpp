@@ -569,7 +569,8 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
           if (~x_new >= kbl1) { qc1 += 1; qs1_1 += vn; qs2_1 += vn * vn; }
         }
         const unsigned lo0 = min(kb0, kbl0), hi0 = max(kb0, kbl0), lo1 = min(kb1, kbl1), hi1 = max(kb1, kbl1);
-        const bool cov0 = kb0 == kbl0 || qt_spans(bu, lo0, hi0, n), cov1 = kb1 == kbl1 || qt_spans(bl, lo1, hi1, n);
+        const bool forced = bound_repair_forced(S, env);
+        const bool cov0 = (kb0 == kbl0 || qt_spans(bu, lo0, hi0, n)) && !forced, cov1 = (kb1 == kbl1 || qt_spans(bl, lo1, hi1, n)) && !forced;
         if (__builtin_expect(cov0 && cov1, 1)) {
           int dc0 = 0, dc1 = 0;
           double d1_0 = 0.0, d2_0 = 0.0, d1_1 = 0.0, d2_1 = 0.0;
@@ -593,7 +594,23 @@ __device__ __forceinline__ void env_reward(const SdcDev& S, const int env, const
           clipped_moments(n, b, A1, A2, t1, t2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap, S.hist_cap_d);
           done_eval = true;
         } else {
+          // A CLIP BOUND LEFT ITS WINDOW (the quartiles moved it further in one step than the window reaches, usually while the window's
+          // deferred re-centring is still in flight): ~4e-8 of the env-steps.  Everything else the state holds is good -- the quartile
+          // windows, the bounds they give -- and this step's moments need the bounds' TAIL SUMS, not their windows: the sums of the NEW
+          // bounds come from the ring in one pass (ring_sums; the totals fresh with them), ~10 us instead of the full rebuild's 0.4 ms
+          // (two 32-pass bisections).  The window is then moved towards the rank of the first key beyond its bound by the
+          // ahead-of-need refill below (12-45 ranks per sweep); should the bound have jumped further, the next step lands here again.
           why = cov0 ? 7 : 6;
+          const RingSums rs = ring_sums(R, lane, b);
+          A1 = rs.A1; A2 = rs.A2;
+          qc0 = rs.qc[0]; qc1 = rs.qc[1];
+          qs1_0 = rs.qs1[0]; qs1_1 = rs.qs1[1];
+          qs2_0 = rs.qs2[0]; qs2_1 = rs.qs2[1];
+          const double t1 = (qs1_0 - (double)qc0 * b.ub) + (qs1_1 - (double)qc1 * b.lb);
+          const double t2 = (qs2_0 - (double)qc0 * (b.ub * b.ub)) + (qs2_1 - (double)qc1 * (b.lb * b.lb));
+          clipped_moments(n, b, A1, A2, t1, t2, mean, sd, inv_sd, S.hist_cap, S.rc_hist_cap, S.hist_cap_d);
+          done_eval = true;
+          path = 5 + ((S.debug_flags & 2) ? why : 0);      // 5: the clip bounds' tail sums redone from the ring
         }
       } else {
         why = 4;
@@ -744,6 +761,7 @@ __device__ __forceinline__ unsigned long long pair_reward_fast(const SdcDev& S, 
   Win bl = win_from(kw, (int)hp[H_BL + T_R0], (int)hp[H_BL + T_HI]);
   double A1 = lrec_f64(hp, H_A1), A2 = lrec_f64(hp, H_A2);
   bool ok = append & (n >= SMALL_N) & (q1.hi > 0) & (q3.hi > 0) & (bu.hi > 0) & (bl.hi > 0) & ((int)hp[H_VALID] == 1);
+  if constexpr (!FAST) ok = ok & !bound_repair_forced(S, envc);     // (test hook, debug_flags bit 13: env_reward takes the step)
   // ---- deferred re-centrings (SdcRefillReq / SdcRefillRes): a window requested two steps ago arrives now --------------
   unsigned pend0 = hp[H_PEND], pend1 = hp[H_PEND + 1], pend2 = hp[H_PEND + 2], pend3 = hp[H_PEND + 3];
   // cached first / last key of every window (see below)

@@ -73,7 +73,8 @@ enum sdc_info_col {
   SDC_INFO_RESERVED, /* diagnostic: how this step's reward normalisation was served: 0 incremental state only (no
                         history read), 1 a rank window was re-centred over the history inline, 2 incremental state
                         only and a window re-centred by a spare wavefront of the previous launch was taken over,
-                        3 the state was rebuilt from the history (and, only with debug_flags bit 3: 4 incremental
+                        3 the state was rebuilt from the history, 5 a clip bound had left its window and the bounds' side
+                        (tail sums, that window) was redone from the history (and, only with debug_flags bit 3: 4 incremental
                         state only and a re-centring request was filed).  Scheduling-dependent (which requests find
                         a free slot), unlike every other output */
   /* running return of the current episode INCLUDING this step (== the episode return on the done step);
@@ -124,7 +125,9 @@ typedef struct {
                               Bits 9 / 10 (512 / 1024): the common-case kernels with two / four envs per wavefront
                               whatever the batch size (by default four when the batch is a multiple of four and
                               large: single steps above 5632 envs, the multi-step entry points above 4096; same
-                              results to the bit) */
+                              results to the bit).
+                              Bit 13 (8192): TEST HOOK -- every 61st (env + launch) redoes its clip bounds' side from the
+                              history as if a bound had left its window (a path ~4e-8 of the env-steps take by themselves) */
   int32_t reward_method[3]; /* reward function per agent slot (ls, dc, bat), utils/reward_creator.py:322-334:
                                SDC_REWARD_DEFAULT the slot's own default_*_reward, SDC_REWARD_FOOTPRINT
                                default_dc_reward = default_bat_reward, SDC_REWARD_CUSTOM custom_agent_reward (0),
