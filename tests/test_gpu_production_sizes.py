@@ -22,20 +22,20 @@ from tests.production_rig import ProductionRig
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N", [12288, 16384, 32768])
-def test_quad_step_kernel_production_vs_oracle(N):
-    """The default kernel of a large batch (debug_flags = 0) -- since round 5 ONE LANE PER ENV (sdc_wide.hip) from 9 216 envs -- at
-    12 288 / 16 384 / 32 768 envs (the largest batch a rate is quoted for): 330 single steps over two auto-resets, the first / last
+@pytest.mark.parametrize("N", [6144, 8192, 12288, 16384, 32768])
+def test_default_step_kernel_of_large_batches_production_vs_oracle(N):
+    """The default kernel of a large batch (debug_flags = 0) -- four envs per wavefront at 6 144 envs, ONE LANE PER ENV (sdc_wide.hip)
+    from 7 680 -- at the sizes rates are quoted for up to 32 768 envs: 330 single steps over two auto-resets, the first / last
     wavefronts and both sides of every occupancy round sampled, every reward-state path."""
     rig = ProductionRig(N, debug_flags=0, episode_steps=120, seed=1000 + N, envs_per_wave=4)
     assert len(rig.sample) >= 72
     obs, _ = rig.eng.reset()
     rig.begin_all(obs)
     rig.single_steps(330)
-    print(f"quad step kernel, {N} envs:", rig.worst, "reward-state paths:", rig.paths[:4], "auto-resets:", rig.resets,
-          "sampled envs:", len(rig.sample))
+    print(f"default step kernel, {N} envs:", rig.eng.last_step_kernel(), rig.worst, "reward-state paths:", rig.paths[:4],
+          "auto-resets:", rig.resets, "sampled envs:", len(rig.sample))
     assert rig.resets >= 2
-    assert rig.eng.last_step_kernel() == "sdc_dynamics_wide_kernel"
+    assert rig.eng.last_step_kernel() == ("sdc_dynamics_quad_kernel" if N < 7680 else "sdc_dynamics_wide_kernel")
     rig.assert_ok()
     rig.assert_all_reward_state_paths_seen()
     rig.eng.close()
