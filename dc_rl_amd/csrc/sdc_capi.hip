@@ -512,8 +512,19 @@ int sdc_create(const sdc_config* cfg, sdc_handle** out) {
   A(d.rec, (size_t)N * SDC_REC_DWORDS);
   A(d.qtab, (size_t)N * d.qstride);
   d.qcum_t = nullptr;
+  d.hist_t = nullptr;
   if ((N & 63) == 0 && (N >= SDC_WIDE_MIN_ENVS || (cfg->debug_flags & 2048))) {      // (batches the lane-per-env kernel can serve: wide_case)
-    A(d.qcum_t, (size_t)N * d.qstride);      // (zeroed by the allocation)
+    // ... and BEHIND it, in the same allocation, the history ring's slot-major mirror for the batches that get one (rows qstride ..
+    // qstride + hist_cap of the same [row][N] array: the lane-per-env kernel addresses it from the pointer and the strides it holds anyway)
+    const bool mirror = N >= SDC_HIST_MIRROR_MIN_ENVS;
+    A(d.qcum_t, (size_t)N * ((size_t)d.qstride + (mirror ? (size_t)d.hist_cap : 0)));      // (zeroed by the allocation)
+    if (mirror) {
+      d.hist_t = d.qcum_t + (size_t)N * d.qstride;
+      if (hipMemset(d.hist_t, 0xFF, sizeof(unsigned) * (size_t)N * d.hist_cap) != hipSuccess) {      // every slot empty
+        sdc_destroy(h);
+        return fail_msg("sdc_create: clearing the history rings' mirror failed");
+      }
+    }
   }
   A(d.t_win, (size_t)N * d.lw);
   A(d.wb_win, (size_t)N * d.lw);
@@ -1210,6 +1221,12 @@ __global__ void sdc_qcum_mirror_kernel(SdcDev S) {
   if (env < S.n_envs) S.qcum_t[(size_t)t * S.n_envs + env] = S.qtab[(size_t)env * S.qstride + t].x;
 }
 
+// ... and the history ring's slot-major mirror from the rings
+__global__ void sdc_hist_mirror_kernel(SdcDev S) {
+  const int slot = (int)blockIdx.x, env = (int)(blockIdx.y * blockDim.x + threadIdx.x);
+  if (env < S.n_envs) S.hist_t[(size_t)slot * S.n_envs + env] = S.hist[(size_t)env * SDC_HIST_STRIDE + slot];
+}
+
 int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t bytes) {
   if (!h || !field || !host_buf) return fail_msg("sdc_set_state: null argument");
   const Field* f = find_field(h, field);
@@ -1258,6 +1275,11 @@ int sdc_set_state(sdc_handle* h, const char* field, const void* host_buf, size_t
   }
   if (h->d.qcum_t && std::strcmp(field, "qtab") == 0) {
     hipLaunchKernelGGL(sdc_qcum_mirror_kernel, dim3(h->d.qstride, (h->cfg.n_envs + 255) / 256), dim3(256), 0, 0, h->d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  if (h->d.hist_t && std::strcmp(field, "hist") == 0) {
+    hipLaunchKernelGGL(sdc_hist_mirror_kernel, dim3(h->d.hist_cap, (h->cfg.n_envs + 255) / 256), dim3(256), 0, 0, h->d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
   }

@@ -241,6 +241,10 @@ struct SdcDev {
   unsigned* qwin;    // [N][SDC_WIN][4] rank windows (sdc_trackers.hpp): lane l's keys of {Q1, Q3, upper bound, lower bound}
   unsigned char* reset_mask;  // [N] device copy of the caller's mask
   unsigned long long* prof_ts;  // measurement only: [3 kernels][N][2] wall-clock stamps of this launch, or nullptr
+  unsigned* hist_t;  // [hist_cap][N] SLOT-MAJOR mirror of the history ring, or nullptr (allocated with qcum_t): the lane-per-env kernel reads
+                     // the key a step evicts from it -- 64 consecutive dwords per wavefront instead of 64 scattered 128-byte lines -- and
+                     // every kernel that appends to the ring appends here too (hist_t_append); sdc_set_state("hist") rebuilds it.  The
+                     // sweeps and rebuilds read an env's ring as a whole: they keep the ring itself
 };
 
 // TEST HOOK (debug_flags bit 13 = 8192): every 61st (env + launch) takes env_reward's "a clip bound left its window" repair whatever the
@@ -363,6 +367,14 @@ enum { SDC_P_COS = 0, SDC_P_SIN, SDC_P_NC, SDC_P_CI7 = 3, SDC_P_OLDEST = 10, SDC
 // the time-major mirror of the queue table's `cum` column (SdcDev::qcum_t), kept by whoever appends to the table
 __device__ __forceinline__ void qcum_append(const SdcDev& S, const int env, const int t, const unsigned cum) {
   if (S.qcum_t) S.qcum_t[(size_t)t * S.n_envs + env] = cum;
+}
+// ... and the slot-major mirror of the history ring (SdcDev::hist_t), kept by whoever appends to the ring.  It exists for batches of
+// SDC_HIST_MIRROR_MIN_ENVS envs and up: where the lane-per-env kernel is bound by the memory system (several dispatch rounds) the
+// evicted key's 128-byte line per env-step is worth saving (262 144 envs: 141.9 -> 137.6 us per step, 65 536: 41.6 -> 40.9); below,
+// where a launch is a latency chain, the extra store costs more than the gather (32 768 envs: 23.15 -> 23.3, 16 384: 16.5 -> 16.7)
+#define SDC_HIST_MIRROR_MIN_ENVS 49152
+__device__ __forceinline__ void hist_t_append(const SdcDev& S, const int env, const int slot, const unsigned key) {
+  if (S.hist_t) S.hist_t[(size_t)slot * S.n_envs + env] = key;
 }
 __device__ __forceinline__ size_t feat_row_offset(const SdcDev& S, const int env, const int s) {
   return ((size_t)s * (size_t)S.n_envs + (size_t)env) * SDC_FEAT_ROW;

@@ -453,7 +453,10 @@ __device__ __forceinline__ DynOut pair_dynamics(const SdcDev& S, const int envc,
     info_put_dc(kt, sh.info[h], id);
 
     // ---- history append: the ring slot gets this step's key; the queue table this step's prefix counts ----------
-    if (append) S.hist[(size_t)envc * SDC_HIST_STRIDE + slot] = x_new;
+    if (append) {
+      S.hist[(size_t)envc * SDC_HIST_STRIDE + slot] = x_new;
+      hist_t_append(S, envc, slot, x_new);
+    }
     S.qtab[(size_t)envc * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
     qcum_append(S, envc, now, (unsigned)cum_now);
 

@@ -528,6 +528,8 @@ __device__ __forceinline__ void wide_dynamics(const SdcDev& S, WideSharedT<GEN>&
   S.hist[(size_t)env * SDC_HIST_STRIDE + slot] = x_new;
   S.qtab[(size_t)env * S.qstride + now] = make_uint2((unsigned)cum_now, cumT_now);
   S.qcum_t[(size_t)now * S.n_envs + env] = (unsigned)cum_now;
+  // (the ring's slot-major mirror, SdcDev::hist_t, of the batches that have one: it lies behind qcum_t)
+  if (S.n_envs >= SDC_HIST_MIRROR_MIN_ENVS) S.qcum_t[(size_t)(S.qstride + slot) * S.n_envs + env] = x_new;
   block_put<16>(sh.rec, lane, 0, make_uint4((unsigned)ip, (unsigned)(rel + 1), (unsigned)day_n, (unsigned)hourq_n));
   block_put<16>(sh.rec, lane, 1, make_uint4((unsigned)popped, (unsigned)cum_now, cumT_now, (unsigned)head));
   block_put<16>(sh.rec, lane, 2, make_uint4((unsigned)cum_hm1, cumT_hm1, (unsigned)delta, (unsigned)consecutive));
@@ -652,7 +654,12 @@ __device__ __forceinline__ void wide_rewards(const SdcDev& S, WideSharedT<GEN>& 
   const int hpos = (int)r3g.z;
   const int slot0 = hl < S.hist_cap ? hl : hpos;
   unsigned x_old = 0xFFFFFFFFu;
-  if (hl >= S.hist_cap) x_old = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
+  // (batches with the ring's slot-major mirror read it there -- consecutive dwords instead of a 128-byte line per env; SdcDev::hist_t =
+  // rows qstride .. of the array qcum_t points to)
+  if (hl >= S.hist_cap) {
+    if (S.n_envs >= SDC_HIST_MIRROR_MIN_ENVS) x_old = S.qcum_t[(size_t)(S.qstride + slot0) * S.n_envs + env];
+    else x_old = S.hist[(size_t)env * SDC_HIST_STRIDE + slot0];
+  }
   dma_wait();
   __syncthreads();      // (1) records, feature rows and headers are in LDS
   // ---- the oldest queued task and the ages (pair_dynamics, same expressions): the load-shifting algebra once more, then the queue

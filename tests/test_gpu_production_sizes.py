@@ -41,12 +41,13 @@ def test_default_step_kernel_of_large_batches_production_vs_oracle(N):
     rig.eng.close()
 
 
-@pytest.mark.parametrize("N", [16384, 32768])
+@pytest.mark.parametrize("N", [16384, 32768, 49152])      # (49 152: the smallest batch with the ring's slot-major mirror, SdcDev::hist_t)
 def test_lane_per_env_kernel_equals_four_per_wavefront_for_every_env(N):
     """The oracle is run for a sample of the envs; EVERY env of the lane-per-env kernel is held to the four-envs-per-wavefront kernel
     here: two engines in the production configuration (full rings with duplicates, spread write positions, the same seed), 16 384
-    and 32 768 envs, 260 single steps over two auto-resets under the full load of deferred re-centrings -- every output of every env
-    the same bits (the diagnostics column aside: it says which path served the reward state)."""
+    and 32 768 envs -- and 49 152, where the lane-per-env kernel reads the key a step evicts from the ring's slot-major mirror and the
+    other kernel from the ring --, 260 single steps over two auto-resets under the full load of deferred re-centrings -- every output
+    of every env the same bits (the diagnostics column aside: it says which path served the reward state), and at the end the rings."""
     import torch
     a = ProductionRig(N, debug_flags=0, episode_steps=120, seed=515, envs_per_wave=4, n_random=0)
     b = ProductionRig(N, debug_flags=4096, episode_steps=120, seed=515, envs_per_wave=4, n_random=0)
@@ -65,6 +66,9 @@ def test_lane_per_env_kernel_equals_four_per_wavefront_for_every_env(N):
                 bad = (u != v).nonzero()
                 raise AssertionError((t, nm, bad[:6].tolist(), u[tuple(bad[0])].item(), v[tuple(bad[0])].item()))
     assert a.eng.last_step_kernel() == "sdc_dynamics_wide_kernel" and b.eng.last_step_kernel() == "sdc_dynamics_quad_kernel"
+    if N >= 49152:
+        import numpy as np
+        np.testing.assert_array_equal(a.eng.get_state("hist").view(np.uint32), b.eng.get_state("hist").view(np.uint32))
     for r in (a, b):
         assert (r.eng.info[:, L.INFO_IDX["fault"]] == 0).all()
         r.eng.close()
